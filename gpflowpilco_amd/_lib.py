@@ -1,0 +1,85 @@
+"""ctypes binding of ``libgpflowpilco_mm.so`` (include/gpflowpilco_mm.h).
+
+There is NO CPU fallback: if the HIP library is missing the import of any op
+raises, loudly.  Build it with ``gpflowpilco_amd/csrc/build.sh`` (or
+``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpflowpilco_mm.so")
+
+MM_F32, MM_F64 = 0, 1
+MM_DMAX = 32
+MM_M_ALIGN = 128
+MM_FULL_OUTPUT_COV = 1
+MM_MODEL_UNCERTAINTY = 2
+MM_FORCE_GENERIC = 4
+
+ERRORS = {
+    -1: "MM_E_ARG: NULL pointer or non-positive size",
+    -2: "MM_E_DIM: input dimension d exceeds MM_DMAX=32 or unsupported shape",
+    -3: "MM_E_DTYPE: dtype must be MM_F32 or MM_F64",
+    -4: "MM_E_WORKSPACE: workspace/packed buffer too small",
+    -5: "MM_E_NO_C: model_uncertainty requested but the model was packed without C",
+    -6: "MM_E_STATE: Euler update / closed rollout needs d == L and a full output covariance",
+}
+
+# name -> (restype, argtypes); exactly the symbols include/gpflowpilco_mm.h declares
+SIGNATURES = {
+    "mm_abi_version": (C.c_int, []),
+    "mm_packed_model_bytes": (C.c_size_t, [C.c_int] * 5),
+    "mm_pack_model": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
+                      + [C.c_void_p] * 6 + [C.c_void_p]),
+    "mm_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
+    "mm_moment_match": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                  C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                  C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "mm_q_forward": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p,
+                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "mm_Q_reduce_forward": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_double, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mm_euler_update": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 8),
+    "mm_rollout_closed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                    C.c_double, C.c_int, C.c_double,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class MomentMatchingLibraryError(RuntimeError):
+  pass
+
+
+def lib():
+  """Load the shared library once; raise if it is not built."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise MomentMatchingLibraryError(
+          f"{LIB_PATH} is missing: the HIP extension is not built and there is no CPU "
+          "fallback. Run gpflowpilco_amd/csrc/build.sh (needs hipcc).")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(handle, name)
+      fn.restype = res
+      fn.argtypes = args
+    _lib = handle
+  return _lib
+
+
+def check(rc: int, what: str):
+  if rc == 0:
+    return
+  if rc < 0:
+    raise ValueError(f"{what}: {ERRORS.get(rc, rc)}")
+  raise MomentMatchingLibraryError(f"{what}: HIP error {rc}")

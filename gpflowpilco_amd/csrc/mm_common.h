@@ -1,0 +1,98 @@
+// Shared host/device layout helpers for the moment-matching kernels (gfx950).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/gpflowpilco_mm.h"
+
+static inline size_t mm_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int mm_round_up_int(int x, int a) { return (x + a - 1) / a * a; }
+static inline size_t mm_elem_size(int dtype) { return dtype == MM_F64 ? 8 : 4; }
+
+// Number of (a, a') kernel pairs that are reduced: all a <= a' with full output
+// covariance (models.py:244-248), only a == a' otherwise (:249-252).
+static inline int mm_num_pairs(int L, int flags) {
+  return (flags & MM_FULL_OUTPUT_COV) ? L * (L + 1) / 2 : L;
+}
+
+// Packed model: byte offsets inside the caller-owned device buffer.
+struct MMModelLayout {
+  int Mp, Kz;
+  size_t Z64;     // [L][M][d]  f64 raw inducing inputs (prep stages run in f64)
+  size_t zbar;    // [L][d]     f64 per-latent centroid of Z (centres the MFMA A operand)
+  size_t ls2;     // [L][d]     f64 squared lengthscales (Lambda)
+  size_t var;     // [L]        f64 kernel variances
+  size_t meanc;   // [L]        f64 Constant mean (zeros for Zero)
+  size_t beta64;  // [L][M]     f64 Kuu^-1 u
+  size_t Zc;      // [L][Mp][Kz] T  centred inducing inputs, zero padded (rows >= M, cols >= d)
+  size_t Cm;      // [L][Mp][Mp] T  Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total)
+  size_t total;
+};
+
+static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int with_C) {
+  MMModelLayout o;
+  const size_t es = mm_elem_size(dtype), A = 256;
+  o.Mp = mm_round_up_int(M, MM_M_ALIGN);
+  o.Kz = mm_round_up_int(d, 2);
+  size_t off = 0;
+  o.Z64 = off;    off = mm_align_up(off + (size_t)L * M * d * 8, A);
+  o.zbar = off;   off = mm_align_up(off + (size_t)L * d * 8, A);
+  o.ls2 = off;    off = mm_align_up(off + (size_t)L * d * 8, A);
+  o.var = off;    off = mm_align_up(off + (size_t)L * 8, A);
+  o.meanc = off;  off = mm_align_up(off + (size_t)L * 8, A);
+  o.beta64 = off; off = mm_align_up(off + (size_t)L * M * 8, A);
+  o.Zc = off;     off = mm_align_up(off + (size_t)L * o.Mp * o.Kz * es, A);
+  o.Cm = off;
+  if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * es, A);
+  o.total = off;
+  return o;
+}
+
+// Rows per workgroup of the generic reduce kernel / columns per workgroup.
+#define MM_GEN_ROWS 64
+#define MM_GEN_COLS 256
+// MFMA kernels (f32): row panel per workgroup (4 waves x 64 rows), 128x128 diagonal tiles.
+#define MM_PANEL_ROWS 256
+#define MM_DIAG_TILE 128
+
+struct MMWorkspaceLayout {
+  int Mp, P, NS;
+  size_t pairmat;  // [B][P][3 d^2 + 1] f64: G, Drow, Dcol, const
+  size_t latmat;   // [B][L][d^2 + 1]   f64: (Sigma + Lambda_a)^-1, log-normaliser
+  size_t w;        // [B][L][Mp] T   beta_i q_i
+  size_t q;        // [B][L][Mp] T   q_i = <k_a(x, z_i)>
+  size_t rowA;     // [B][P][Mp] T   rho_i
+  size_t colB;     // [B][P][d+1][Mp] T   g_j (d rows) and gamma'_j
+  size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
+  size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i exp(delta_ij) q_j
+  size_t f1s;      // [B][L] T      rollout scratch outputs
+  size_t Sffs;     // [B][L][L] T
+  size_t crs;      // [B][d][L] T
+  size_t total;
+};
+
+static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, int dtype, int flags) {
+  MMWorkspaceLayout o;
+  const size_t es = mm_elem_size(dtype), A = 256;
+  o.Mp = mm_round_up_int(M, MM_M_ALIGN);
+  o.P = mm_num_pairs(L, flags);
+  const int nrb = (o.Mp + MM_GEN_ROWS - 1) / MM_GEN_ROWS;
+  const int ncb = (o.Mp + MM_GEN_COLS - 1) / MM_GEN_COLS;
+  const int nt = o.Mp / MM_DIAG_TILE;
+  int ns = nrb * ncb;
+  if (nt * (nt + 1) / 2 > ns) ns = nt * (nt + 1) / 2;
+  o.NS = ns;
+  size_t off = 0;
+  o.pairmat = off; off = mm_align_up(off + (size_t)B * o.P * (3 * d * d + 1) * 8, A);
+  o.latmat = off;  off = mm_align_up(off + (size_t)B * L * (d * d + 1) * 8, A);
+  o.w = off;       off = mm_align_up(off + (size_t)B * L * o.Mp * es, A);
+  o.q = off;       off = mm_align_up(off + (size_t)B * L * o.Mp * es, A);
+  o.rowA = off;    off = mm_align_up(off + (size_t)B * o.P * o.Mp * es, A);
+  o.colB = off;    off = mm_align_up(off + (size_t)B * o.P * (d + 1) * o.Mp * es, A);
+  o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
+  o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);
+  o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);
+  o.Sffs = off;    off = mm_align_up(off + (size_t)B * L * L * es, A);
+  o.crs = off;     off = mm_align_up(off + (size_t)B * d * L * es, A);
+  o.total = off;
+  return o;
+}

@@ -1,0 +1,778 @@
+// Moment-matched GP propagation for MI355X (gfx950): hand-written HIP kernels + C ABI.
+//
+// Replaces, behind include/gpflowpilco_mm.h, the per-step arithmetic of
+//   gpflow_pilco/moment_matching/models.py:200-299 (_mm_gauss_svgp_mo; _so and GPR are L == 1)
+//   gpflow_pilco/utils/kernel_expectation.py:72-247 (<K_Zx K_xZ'> pair kernel and fan-outs)
+//   gpflow <k(x,Z)> (third party)   and   gpflow_pilco/dynamics/solvers.py:110-135.
+//
+// Algorithm (DESIGN.md "Centred fused reduce"): the reference materialises
+// Q = eKuffu [B,L,M,L,M] and runs two triangular solves per step.  Here, with
+// beta_a = Kuu_a^-1 u_a and C_a = Kuu_a^-1 S_a Kuu_a^-1 - Kuu_a^-1 precomputed once,
+//   f1_a     = sum_i w_i,                          w_i = beta_i q_i
+//   Sff_aa'  = sum_ij w_i (exp(delta_ij) - 1) w'_j  + [a==a'] (sigma_a^2 + sum_ij C_ij q_i exp(delta_ij) q_j)
+//   delta_ij = log Q_ij - log q_i - log q'_j = const + rho_i + gamma_j + zeta_i^T G zeta_j
+// which is algebraically f2 - f1 f1^T (+ E[Var f]) of models.py:244-261 but never forms Q
+// and has no catastrophic cancellation (delta -> 0 as Sigma -> 0).
+//
+// Stages per moment match (all enqueue-only):
+//   k_prep      one wave per (b, pair) / (b, latent): d x d Cholesky algebra in f64 (LDS)
+//   k_qvec      one workgroup per (b, latent): q_i, w_i, f1, Sigma^-1 Cov(x,f)
+//   k_pairvec   per (b, pair, m): rho_m, g_m = G zeta_m, gamma'_m  (streamed operands of the reduce)
+//   k_qred_*    the M x M fused reduce (generic VALU kernel here; f32 MFMA kernels in mm_mfma.hip)
+//   k_finalize  deterministic sum of the partial slabs -> Sff
+//   k_euler     MomentMatchingEuler.step
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "mm_common.h"
+
+#define MM_ABI_VERSION 1
+
+// ---------------------------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mm_decode_pair(int p, int L, int& a, int& a2) {
+  // pairs [0, L) are the diagonal (a, a); the rest enumerate a < a' row by row.
+  if (p < L) { a = p; a2 = p; return; }
+  int r = p - L;
+  int i = 0;
+  while (r >= L - 1 - i) { r -= L - 1 - i; ++i; }
+  a = i; a2 = i + 1 + r;
+}
+
+__device__ __forceinline__ double mm_wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// Sum over a 256-thread workgroup; result valid in thread 0. `red` holds >= 4 doubles.
+__device__ __forceinline__ double mm_block_sum256(double v, double* red) {
+  v = mm_wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ __forceinline__ float mm_expm1(float x) { return expm1f(x); }
+__device__ __forceinline__ double mm_expm1(double x) { return expm1(x); }
+
+// In-place inverse of a symmetric positive definite d x d matrix held in LDS (row stride dp),
+// by one 64-lane workgroup.  A: in SPD (full storage) -> out inverse (full).  Y: scratch.
+// Returns log det(A) (same value in every lane); *ok is cleared if a pivot is not positive.
+__device__ double mm_spd_inverse(double* A, double* Y, int d, int dp, bool* ok) {
+  const int lane = threadIdx.x;
+  for (int k = 0; k < d; ++k) {
+    __syncthreads();
+    const double akk = A[k * dp + k];
+    if (!(akk > 0.0)) *ok = false;
+    const double lkk = sqrt(akk);
+    __syncthreads();
+    if (lane > k && lane < d) A[lane * dp + k] /= lkk;
+    if (lane == k) A[k * dp + k] = lkk;
+    __syncthreads();
+    for (int idx = lane; idx < d * d; idx += 64) {
+      const int i = idx / d, j = idx - i * d;
+      if (j > k && i >= j) A[i * dp + j] -= A[i * dp + k] * A[j * dp + k];
+    }
+  }
+  __syncthreads();
+  double logdet = 0.0;
+  for (int k = 0; k < d; ++k) logdet += log(A[k * dp + k]);
+  logdet *= 2.0;
+  // Y = L^-1 (lower): lane c owns column c.
+  if (lane < d) {
+    const int c = lane;
+    for (int i = 0; i < d; ++i) {
+      double v = 0.0;
+      if (i == c) v = 1.0 / A[i * dp + i];
+      else if (i > c) {
+        double s = 0.0;
+        for (int k = c; k < i; ++k) s += A[i * dp + k] * Y[k * dp + c];
+        v = -s / A[i * dp + i];
+      }
+      Y[i * dp + c] = v;
+    }
+  }
+  __syncthreads();
+  // A <- Y^T Y
+  for (int idx = lane; idx < d * d; idx += 64) {
+    const int i = idx / d, j = idx - i * d;
+    const int k0 = i > j ? i : j;
+    double s = 0.0;
+    for (int k = k0; k < d; ++k) s += Y[k * dp + i] * Y[k * dp + j];
+    A[i * dp + j] = s;
+  }
+  __syncthreads();
+  return logdet;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pack_model: raw f64 model -> packed buffer (centred/padded T copies for the reduce kernels)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, int d,
+                               const double* __restrict__ Z, const double* __restrict__ ls,
+                               const double* __restrict__ var, const double* __restrict__ beta,
+                               const double* __restrict__ mean_c) {
+  // one workgroup per latent a
+  const int a = blockIdx.x, tid = threadIdx.x;
+  double* Z64 = (double*)(packed + lay.Z64) + (size_t)a * M * d;
+  double* zbar = (double*)(packed + lay.zbar) + (size_t)a * d;
+  double* ls2 = (double*)(packed + lay.ls2) + (size_t)a * d;
+  double* b64 = (double*)(packed + lay.beta64) + (size_t)a * M;
+  T* Zc = (T*)(packed + lay.Zc) + (size_t)a * lay.Mp * lay.Kz;
+  __shared__ double red[4];
+  __shared__ double zb[MM_DMAX];
+  for (int k = 0; k < d; ++k) {
+    double s = 0.0;
+    for (int m = tid; m < M; m += 256) s += Z[((size_t)a * M + m) * d + k];
+    s = mm_block_sum256(s, red);
+    if (tid == 0) zb[k] = s / (double)M;
+  }
+  __syncthreads();
+  if (tid < d) { zbar[tid] = zb[tid]; const double l = ls[a * d + tid]; ls2[tid] = l * l; }
+  if (tid == 0) {
+    ((double*)(packed + lay.var))[a] = var[a];
+    ((double*)(packed + lay.meanc))[a] = mean_c ? mean_c[a] : 0.0;
+  }
+  for (int idx = tid; idx < M * d; idx += 256) Z64[idx] = Z[(size_t)a * M * d + idx];
+  for (int m = tid; m < M; m += 256) b64[m] = beta[(size_t)a * M + m];
+  for (int idx = tid; idx < lay.Mp * lay.Kz; idx += 256) {
+    const int m = idx / lay.Kz, k = idx - m * lay.Kz;
+    double v = 0.0;
+    if (m < M && k < d) v = Z[((size_t)a * M + m) * d + k] - zb[k];
+    Zc[idx] = (T)v;
+  }
+}
+
+template <typename T>
+__global__ void k_pack_C(char* packed, MMModelLayout lay, int L, int M, const double* __restrict__ C) {
+  // grid (Mp/256, Mp, L): padded, T-typed copy of C
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, a = blockIdx.z;
+  if (j >= lay.Mp) return;
+  T* Cm = (T*)(packed + lay.Cm) + ((size_t)a * lay.Mp + i) * lay.Mp;
+  double v = 0.0;
+  if (i < M && j < M) v = C[((size_t)a * M + i) * M + j];
+  Cm[j] = (T)v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_prep: per (b, pair) and per (b, latent) d x d algebra, f64, one wave each
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, const double* __restrict__ var,
+                                             int L, int d, int P,
+                                             const T* __restrict__ mu, const T* __restrict__ Sigma,
+                                             double* __restrict__ pairmat, double* __restrict__ latmat,
+                                             int32_t* status) {
+  extern __shared__ double smem[];
+  const int dp = d + 1, msz = d * dp;
+  double* Sg = smem;            // Sigma_b (symmetrised from the lower triangle)
+  double* A0 = Sg + msz;        // (Sigma + V)^-1
+  double* A1 = A0 + msz;        // (Sigma + Lambda_a)^-1
+  double* A2 = A1 + msz;        // (Sigma + Lambda_a')^-1
+  double* Tm = A2 + msz;        // T
+  double* Y = Tm + msz;         // scratch
+  const int lane = threadIdx.x, item = blockIdx.x, b = blockIdx.y;
+  bool ok = true;
+  const T* Sb = Sigma + (size_t)b * d * d;
+  for (int idx = lane; idx < d * d; idx += 64) {
+    const int i = idx / d, j = idx - i * d;
+    Sg[i * dp + j] = (double)(i >= j ? Sb[i * d + j] : Sb[j * d + i]);
+  }
+  __syncthreads();
+  if (item >= P) {
+    // latent item: P_a = (Sigma + Lambda_a)^-1, lognorm_a = log var + sum log ls - 0.5 logdet
+    const int a = item - P;
+    const double* la = ls2 + a * d;
+    for (int idx = lane; idx < d * d; idx += 64) {
+      const int i = idx / d, j = idx - i * d;
+      A1[i * dp + j] = Sg[i * dp + j] + (i == j ? la[i] : 0.0);
+    }
+    const double ld = mm_spd_inverse(A1, Y, d, dp, &ok);
+    double* out = latmat + ((size_t)b * L + a) * (d * d + 1);
+    for (int idx = lane; idx < d * d; idx += 64) { const int i = idx / d, j = idx - i * d; out[idx] = A1[i * dp + j]; }
+    if (lane == 0) {
+      double sl = 0.0;
+      for (int k = 0; k < d; ++k) sl += log(la[k]);
+      out[d * d] = log(var[a]) + 0.5 * sl - 0.5 * ld;
+    }
+  } else {
+    int a, a2;
+    mm_decode_pair(item, L, a, a2);
+    const double* la = ls2 + a * d;
+    const double* lb = ls2 + a2 * d;
+    for (int idx = lane; idx < d * d; idx += 64) {
+      const int i = idx / d, j = idx - i * d;
+      const double s = Sg[i * dp + j];
+      const double v = la[i] * lb[i] / (la[i] + lb[i]);   // kernel_expectation.py:119
+      A0[i * dp + j] = s + (i == j ? v : 0.0);
+      A1[i * dp + j] = s + (i == j ? la[i] : 0.0);
+      A2[i * dp + j] = s + (i == j ? lb[i] : 0.0);
+    }
+    const double ldS = mm_spd_inverse(A0, Y, d, dp, &ok);
+    const double ldA = mm_spd_inverse(A1, Y, d, dp, &ok);
+    const double ldB = mm_spd_inverse(A2, Y, d, dp, &ok);
+    // T = V S^-1 Sigma (product form: no cancellation), symmetrised below
+    for (int idx = lane; idx < d * d; idx += 64) {
+      const int i = idx / d, j = idx - i * d;
+      double s = 0.0;
+      for (int k = 0; k < d; ++k) s += A0[i * dp + k] * Sg[k * dp + j];
+      Y[i * dp + j] = (la[i] * lb[i] / (la[i] + lb[i])) * s;
+    }
+    __syncthreads();
+    for (int idx = lane; idx < d * d; idx += 64) {
+      const int i = idx / d, j = idx - i * d;
+      Tm[i * dp + j] = 0.5 * (Y[i * dp + j] + Y[j * dp + i]);
+    }
+    __syncthreads();
+    double* out = pairmat + ((size_t)b * P + item) * (3 * d * d + 1);
+    // G = Lambda_a^-1 T Lambda_a'^-1
+    for (int idx = lane; idx < d * d; idx += 64) {
+      const int i = idx / d, j = idx - i * d;
+      out[idx] = Tm[i * dp + j] / (la[i] * lb[j]);
+    }
+    // Drow = Lambda_a^-1 Sigma P_a - Lambda_a^-1 T Lambda_a^-1 ; Dcol likewise with a'
+    for (int idx = lane; idx < d * d; idx += 64) {
+      const int i = idx / d, j = idx - i * d;
+      double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
+      for (int k = 0; k < d; ++k) {
+        s1 += Sg[i * dp + k] * A1[k * dp + j];
+        t1 += Sg[j * dp + k] * A1[k * dp + i];
+        s2 += Sg[i * dp + k] * A2[k * dp + j];
+        t2 += Sg[j * dp + k] * A2[k * dp + i];
+      }
+      const double tij = Tm[i * dp + j];
+      out[d * d + idx] = 0.5 * (s1 / la[i] + t1 / la[j]) - tij / (la[i] * la[j]);
+      out[2 * d * d + idx] = 0.5 * (s2 / lb[i] + t2 / lb[j]) - tij / (lb[i] * lb[j]);
+    }
+    if (lane == 0) {
+      double lv = 0.0, sla = 0.0, slb = 0.0;
+      for (int k = 0; k < d; ++k) {
+        lv += log(la[k] * lb[k] / (la[k] + lb[k]));
+        sla += log(la[k]); slb += log(lb[k]);
+      }
+      // log kappa_ab - lognorm_a - lognorm_a'  (the variances cancel)
+      out[3 * d * d] = -0.5 * ldS + 0.5 * lv - 0.5 * sla - 0.5 * slb + 0.5 * ldA + 0.5 * ldB;
+    }
+  }
+  if (!ok && lane == 0 && status) {
+    atomicMax(status, (int)gridDim.y - b);   // B - b: the host decodes the smallest failing b
+    status[1] = item;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_qvec: q_i, w_i = beta_i q_i, f1, Sigma^-1 Cov(x, f).  One workgroup per (latent, b).
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DK>
+__global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, const double* __restrict__ beta64,
+                                              const double* __restrict__ meanc,
+                                              int L, int M, int Mp, int d,
+                                              const T* __restrict__ mu, const double* __restrict__ latmat,
+                                              T* __restrict__ w, T* __restrict__ q,
+                                              T* __restrict__ f1, T* __restrict__ cross, T* __restrict__ q_out) {
+  const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  __shared__ double Pa[MM_DMAX * MM_DMAX];
+  __shared__ double mub[MM_DMAX];
+  __shared__ double red[4];
+  __shared__ double sv[MM_DMAX + 1];
+  const double* lm = latmat + ((size_t)b * L + a) * (d * d + 1);
+  for (int idx = tid; idx < d * d; idx += 256) Pa[idx] = lm[idx];
+  if (tid < d) mub[tid] = (double)mu[(size_t)b * d + tid];
+  __syncthreads();
+  const double lognorm = lm[d * d];
+  double acc_f = 0.0;
+  double acc_s[DK];
+#pragma unroll
+  for (int k = 0; k < DK; ++k) acc_s[k] = 0.0;
+  T* wb = w + ((size_t)b * L + a) * Mp;
+  T* qb = q + ((size_t)b * L + a) * Mp;
+  for (int m = tid; m < Mp; m += 256) {
+    double wv = 0.0, qv = 0.0;
+    if (m < M) {
+      double z[DK];
+#pragma unroll
+      for (int k = 0; k < DK; ++k) z[k] = (k < d) ? Z64[((size_t)a * M + m) * d + k] - mub[k] : 0.0;
+      double maha = 0.0;
+#pragma unroll
+      for (int i = 0; i < DK; ++i) {
+        if (i < d) {
+          double t = 0.0;
+#pragma unroll
+          for (int k = 0; k < DK; ++k) if (k < d) t += Pa[i * d + k] * z[k];
+          maha += z[i] * t;
+        }
+      }
+      qv = exp(lognorm - 0.5 * maha);
+      wv = beta64[(size_t)a * M + m] * qv;
+      acc_f += wv;
+#pragma unroll
+      for (int k = 0; k < DK; ++k) acc_s[k] += wv * z[k];
+      if (q_out) q_out[((size_t)b * L + a) * M + m] = (T)qv;
+    }
+    wb[m] = (T)wv;
+    qb[m] = (T)qv;
+  }
+  const double f = mm_block_sum256(acc_f, red);
+  if (tid == 0) sv[DK] = f;
+#pragma unroll
+  for (int k = 0; k < DK; ++k) {
+    if (k < d) {
+      const double s = mm_block_sum256(acc_s[k], red);
+      if (tid == 0) sv[k] = s;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) f1[(size_t)b * L + a] = (T)(sv[DK] + meanc[a]);
+  if (tid < d) {
+    // Sigma^-1 Cov(x, f_a) = P_a sum_i w_i (z_i - mu)      (models.py:263-277)
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) s += Pa[tid * d + k] * sv[k];
+    cross[((size_t)b * d + tid) * L + a] = (T)s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pairvec: streamed operands of the reduce.  grid (Mp/256, P, B)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DK>
+__global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64, const double* __restrict__ zbar,
+                                                 int L, int M, int Mp, int d, int P,
+                                                 const T* __restrict__ mu, const double* __restrict__ pairmat,
+                                                 T* __restrict__ rowA, T* __restrict__ colB) {
+  const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int m = blockIdx.x * 256 + tid;
+  int a, a2;
+  mm_decode_pair(p, L, a, a2);
+  __shared__ double G[MM_DMAX * MM_DMAX], Dr[MM_DMAX * MM_DMAX], Dc[MM_DMAX * MM_DMAX];
+  __shared__ double mub[MM_DMAX], dmu[MM_DMAX];
+  const double* pm = pairmat + ((size_t)b * P + p) * (3 * d * d + 1);
+  for (int idx = tid; idx < d * d; idx += 256) { G[idx] = pm[idx]; Dr[idx] = pm[d * d + idx]; Dc[idx] = pm[2 * d * d + idx]; }
+  if (tid < d) {
+    const double mv = (double)mu[(size_t)b * d + tid];
+    mub[tid] = mv;
+    dmu[tid] = mv - zbar[a * d + tid];   // the A operand is centred at zbar_a, not at mu_b
+  }
+  __syncthreads();
+  if (m >= Mp) return;
+  const double cst = pm[3 * d * d];
+  T* ra = rowA + ((size_t)b * P + p) * Mp;
+  T* cb = colB + ((size_t)b * P + p) * (size_t)(d + 1) * Mp;
+  if (m >= M) {
+    ra[m] = (T)0;
+    for (int k = 0; k <= d; ++k) cb[(size_t)k * Mp + m] = (T)0;
+    return;
+  }
+  double zr[DK], zc[DK];
+#pragma unroll
+  for (int k = 0; k < DK; ++k) {
+    zr[k] = (k < d) ? Z64[((size_t)a * M + m) * d + k] - mub[k] : 0.0;
+    zc[k] = (k < d) ? Z64[((size_t)a2 * M + m) * d + k] - mub[k] : 0.0;
+  }
+  double rho = 0.0, gam = 0.0, corr = 0.0;
+#pragma unroll
+  for (int i = 0; i < DK; ++i) {
+    if (i < d) {
+      double tr = 0.0, tc = 0.0, g = 0.0;
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        if (k < d) {
+          tr += Dr[i * d + k] * zr[k];
+          tc += Dc[i * d + k] * zc[k];
+          g += G[i * d + k] * zc[k];
+        }
+      }
+      rho += zr[i] * tr;
+      gam += zc[i] * tc;
+      corr += dmu[i] * g;
+      cb[(size_t)i * Mp + m] = (T)g;
+    }
+  }
+  ra[m] = (T)(-0.5 * rho);
+  // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j
+  cb[(size_t)d * Mp + m] = (T)(-0.5 * gam + cst - corr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_qred_generic: portable VALU fused reduce (f64 path; f32 fallback / cross-check).
+//   thread = one column j, workgroup = 256 columns x MM_GEN_ROWS rows of one (b, pair).
+//   grid (nrb * ncb, P, B)
+// ---------------------------------------------------------------------------------------------
+template <typename T, int DK>
+__global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, int Kz, const T* __restrict__ Cm,
+                                                      int L, int Mp, int d, int P, int NS, int ncb,
+                                                      const T* __restrict__ w, const T* __restrict__ q,
+                                                      const T* __restrict__ rowA, const T* __restrict__ colB,
+                                                      double* __restrict__ partB, double* __restrict__ partC) {
+  const int cbk = blockIdx.x % ncb, rbk = blockIdx.x / ncb;
+  const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  int a, a2;
+  mm_decode_pair(p, L, a, a2);
+  const int j = cbk * MM_GEN_COLS + tid;
+  const bool jv = j < Mp;
+  const int jj = jv ? j : 0;
+  const T* cb = colB + ((size_t)b * P + p) * (size_t)(d + 1) * Mp;
+  T g[DK];
+#pragma unroll
+  for (int k = 0; k < DK; ++k) g[k] = (k < d) ? cb[(size_t)k * Mp + jj] : (T)0;
+  const T gam = cb[(size_t)d * Mp + jj];
+  const T wj = jv ? w[((size_t)b * L + a2) * Mp + jj] : (T)0;
+  const bool withC = (Cm != nullptr) && (a == a2);
+  const T qj = (withC && jv) ? q[((size_t)b * L + a2) * Mp + jj] : (T)0;
+  const T* ra = rowA + ((size_t)b * P + p) * Mp;
+  const T* wr = w + ((size_t)b * L + a) * Mp;
+  const T* qr = q + ((size_t)b * L + a) * Mp;
+  const T* zrow = Zc + (size_t)a * Mp * Kz;
+  const int i0 = rbk * MM_GEN_ROWS;
+  const int i1 = (i0 + MM_GEN_ROWS < Mp) ? i0 + MM_GEN_ROWS : Mp;
+  T accB = (T)0, accC = (T)0;
+  double sumB = 0.0, sumC = 0.0;
+  for (int i = i0; i < i1; ++i) {
+    T delta = ra[i] + gam;
+#pragma unroll
+    for (int k = 0; k < DK; ++k) if (k < d) delta += zrow[(size_t)i * Kz + k] * g[k];
+    const T e = mm_expm1(delta);
+    accB += wr[i] * e;
+    if (withC) {
+      const T cij = Cm[((size_t)a * Mp + i) * Mp + jj];
+      const T t = qr[i] * e + qr[i];          // q_i exp(delta)
+      accC += cij * t;
+    }
+    if (((i - i0) & 15) == 15) { sumB += (double)accB; accB = (T)0; sumC += (double)accC; accC = (T)0; }
+  }
+  sumB += (double)accB; sumC += (double)accC;
+  sumB *= (double)wj;
+  sumC *= (double)qj;
+  __shared__ double red[4];
+  const double tb = mm_block_sum256(sumB, red);
+  if (tid == 0) partB[((size_t)b * P + p) * NS + blockIdx.x] = tb;
+  if (withC) {
+    const double tc = mm_block_sum256(sumC, red);
+    if (tid == 0) partC[((size_t)b * L + a) * NS + blockIdx.x] = tc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_finalize: Sff from the partial slabs (fixed summation order => bitwise reproducible)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_finalize(const double* __restrict__ partB, const double* __restrict__ partC,
+                           const double* __restrict__ var, int B, int L, int P, int NS,
+                           int nsB_diag, int nsB_off, int nsC, int full, int with_unc, double jitter,
+                           T* __restrict__ Sff) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * P) return;
+  const int b = idx / P, p = idx - b * P;
+  int a, a2;
+  mm_decode_pair(p, L, a, a2);
+  const double* pb = partB + ((size_t)b * P + p) * NS;
+  const int ns = (a == a2) ? nsB_diag : nsB_off;
+  double s = 0.0;
+  for (int k = 0; k < ns; ++k) s += pb[k];
+  if (a == a2) {
+    if (with_unc) {
+      const double* pc = partC + ((size_t)b * L + a) * NS;
+      double c = 0.0;
+      for (int k = 0; k < nsC; ++k) c += pc[k];
+      s += var[a] + c;                         // models.py:254-261
+    }
+    s += jitter;                               // models.py:293-296
+    if (full) Sff[((size_t)b * L + a) * L + a] = (T)s;
+    else Sff[(size_t)b * L + a] = (T)s;
+  } else {
+    Sff[((size_t)b * L + a) * L + a2] = (T)s;
+    Sff[((size_t)b * L + a2) * L + a] = (T)s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_euler: MomentMatchingEuler.step (solvers.py:110-135), one workgroup per b, in-place safe
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_euler(int d, double dt, const T* __restrict__ mu, const T* __restrict__ Sigma,
+                                              const T* __restrict__ f1, const T* __restrict__ Sff,
+                                              const T* __restrict__ cross, T* mu_out, T* Sigma_out,
+                                              T* traj_mu, T* traj_Sigma) {
+  extern __shared__ double smem[];
+  double* Sg = smem;          // [d][d]
+  double* Cr = Sg + d * d;    // [d][d] cross_pre
+  double* Sxf = Cr + d * d;   // [d][d]
+  const int b = blockIdx.x, lane = threadIdx.x;
+  for (int idx = lane; idx < d * d; idx += 64) {
+    Sg[idx] = (double)Sigma[(size_t)b * d * d + idx];
+    Cr[idx] = (double)cross[(size_t)b * d * d + idx];
+  }
+  __syncthreads();
+  for (int idx = lane; idx < d * d; idx += 64) {
+    const int i = idx / d, j = idx - i * d;
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) s += Sg[i * d + k] * Cr[k * d + j];   // gaussian.py:38-39
+    Sxf[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = lane; idx < d * d; idx += 64) {
+    const int i = idx / d, j = idx - i * d;
+    const double v = Sg[idx] + dt * (Sxf[i * d + j] + Sxf[j * d + i]) + dt * dt * (double)Sff[(size_t)b * d * d + idx];
+    Sigma_out[(size_t)b * d * d + idx] = (T)v;
+    if (traj_Sigma) traj_Sigma[(size_t)b * d * d + idx] = (T)v;
+  }
+  if (lane < d) {
+    const double v = (double)mu[(size_t)b * d + lane] + dt * (double)f1[(size_t)b * d + lane];
+    mu_out[(size_t)b * d + lane] = (T)v;
+    if (traj_mu) traj_mu[(size_t)b * d + lane] = (T)v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+// f32 MFMA reduce kernels (mm_mfma.hip)
+extern "C" int mm_mfma_supported(int d);
+int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
+                        int B, int L, int d, int with_unc, int* nsB_diag, int* nsB_off, int* nsC,
+                        hipStream_t stream);
+
+#define MM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+static int mm_check_common(const void* packed, int L, int M, int d, int dtype, int B) {
+  if (!packed) return MM_E_ARG;
+  if (L <= 0 || M <= 0 || d <= 0 || B <= 0) return MM_E_ARG;
+  if (d > MM_DMAX) return MM_E_DIM;
+  if (dtype != MM_F32 && dtype != MM_F64) return MM_E_DTYPE;
+  return 0;
+}
+
+static inline int mm_dk(int d) { return d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : 32; }
+
+extern "C" int mm_abi_version(void) { return MM_ABI_VERSION; }
+
+extern "C" size_t mm_packed_model_bytes(int L, int M, int d, int dtype, int with_C) {
+  if (L <= 0 || M <= 0 || d <= 0 || d > MM_DMAX) return 0;
+  return mm_model_layout(L, M, d, dtype, with_C).total;
+}
+
+extern "C" size_t mm_workspace_bytes(int B, int L, int M, int d, int dtype, int flags) {
+  if (B <= 0 || L <= 0 || M <= 0 || d <= 0 || d > MM_DMAX) return 0;
+  return mm_workspace_layout(B, L, M, d, dtype, flags).total;
+}
+
+template <typename T>
+static int mm_pack_model_t(char* packed, const MMModelLayout& lay, int L, int M, int d,
+                           const double* Z, const double* ls, const double* var, const double* beta,
+                           const double* C, const double* mean_c, hipStream_t s) {
+  hipLaunchKernelGGL((k_pack_vectors<T>), dim3(L), dim3(256), 0, s, packed, lay, L, M, d, Z, ls, var, beta, mean_c);
+  MM_CHECK_LAUNCH();
+  if (C) {
+    hipLaunchKernelGGL((k_pack_C<T>), dim3((lay.Mp + 255) / 256, lay.Mp, L), dim3(256), 0, s, packed, lay, L, M, C);
+    MM_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int mm_pack_model(void* packed, size_t packed_bytes, int L, int M, int d, int dtype,
+                             const double* Z, const double* lengthscales, const double* variance,
+                             const double* beta, const double* C, const double* mean_c, void* stream) {
+  int rc = mm_check_common(packed, L, M, d, dtype, 1);
+  if (rc) return rc;
+  if (!Z || !lengthscales || !variance || !beta) return MM_E_ARG;
+  const MMModelLayout lay = mm_model_layout(L, M, d, dtype, C != nullptr);
+  if (packed_bytes < lay.total) return MM_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MM_F64) return mm_pack_model_t<double>((char*)packed, lay, L, M, d, Z, lengthscales, variance, beta, C, mean_c, s);
+  return mm_pack_model_t<float>((char*)packed, lay, L, M, d, Z, lengthscales, variance, beta, C, mean_c, s);
+}
+
+template <typename T, int DK>
+static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
+                          int L, int M, int d, int B, const T* mu, const T* Sigma,
+                          T* f1, T* cross, T* q_out, int32_t* status, hipStream_t s) {
+  const double* ls2 = (const double*)(packed + ml.ls2);
+  const double* var = (const double*)(packed + ml.var);
+  const double* Z64 = (const double*)(packed + ml.Z64);
+  double* pairmat = (double*)(ws + wl.pairmat);
+  double* latmat = (double*)(ws + wl.latmat);
+  const size_t shm = (size_t)6 * d * (d + 1) * sizeof(double);
+  hipLaunchKernelGGL((k_prep<T>), dim3(wl.P + L, B), dim3(64), shm, s,
+                     ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status);
+  MM_CHECK_LAUNCH();
+  hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
+                     Z64, (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
+                     L, M, wl.Mp, d, mu, latmat, (T*)(ws + wl.w), (T*)(ws + wl.q), f1, cross, q_out);
+  MM_CHECK_LAUNCH();
+  hipLaunchKernelGGL((k_pairvec<T, DK>), dim3((wl.Mp + 255) / 256, wl.P, B), dim3(256), 0, s,
+                     Z64, (const double*)(packed + ml.zbar), L, M, wl.Mp, d, wl.P, mu, pairmat,
+                     (T*)(ws + wl.rowA), (T*)(ws + wl.colB));
+  MM_CHECK_LAUNCH();
+  return 0;
+}
+
+template <typename T, int DK>
+static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C, char* ws, const MMWorkspaceLayout& wl,
+                         int L, int d, int B, int flags, double jitter, T* Sff, hipStream_t s) {
+  const int with_unc = (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0;
+  const int full = (flags & MM_FULL_OUTPUT_COV) ? 1 : 0;
+  if (with_unc && !has_C) return MM_E_NO_C;
+  const T* Cm = with_unc ? (const T*)(packed + ml.Cm) : nullptr;
+  double* partB = (double*)(ws + wl.partB);
+  double* partC = (double*)(ws + wl.partC);
+  int nsB_diag, nsB_off, nsC;
+  bool done = false;
+  if (sizeof(T) == 4 && !(flags & MM_FORCE_GENERIC) && mm_mfma_supported(d)) {
+    const int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, with_unc, &nsB_diag, &nsB_off, &nsC, s);
+    if (rc) return rc;
+    done = true;
+  }
+  if (!done) {
+    const int nrb = (wl.Mp + MM_GEN_ROWS - 1) / MM_GEN_ROWS, ncb = (wl.Mp + MM_GEN_COLS - 1) / MM_GEN_COLS;
+    hipLaunchKernelGGL((k_qred_generic<T, DK>), dim3(nrb * ncb, wl.P, B), dim3(256), 0, s,
+                       (const T*)(packed + ml.Zc), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS, ncb,
+                       (const T*)(ws + wl.w), (const T*)(ws + wl.q), (const T*)(ws + wl.rowA),
+                       (const T*)(ws + wl.colB), partB, partC);
+    MM_CHECK_LAUNCH();
+    nsB_diag = nsB_off = nsC = nrb * ncb;
+  }
+  const int n = B * wl.P;
+  hipLaunchKernelGGL((k_finalize<T>), dim3((n + 255) / 256), dim3(256), 0, s,
+                     partB, partC, (const double*)(packed + ml.var), B, L, wl.P, wl.NS,
+                     nsB_diag, nsB_off, nsC, full, with_unc, jitter, Sff);
+  MM_CHECK_LAUNCH();
+  return 0;
+}
+
+// Whether C is present is inferred from the size of the packed buffer (C is its last section).
+template <typename T, int DK>
+static int mm_moment_match_t(const char* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                             const T* mu, const T* Sigma, int flags, double jitter,
+                             T* f1, T* Sff, T* cross, T* q_out, char* ws, size_t ws_bytes,
+                             int32_t* status, hipStream_t s, bool do_q, bool do_Q) {
+  const int with_unc = (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0;
+  const MMModelLayout ml = mm_model_layout(L, M, d, dtype, 1);
+  if (packed_bytes < ml.Cm) return MM_E_WORKSPACE;
+  const bool has_C = packed_bytes >= ml.total;
+  if (with_unc && !has_C) return MM_E_NO_C;
+  const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
+  if (ws_bytes < wl.total) return MM_E_WORKSPACE;
+  int rc = 0;
+  if (do_q) {
+    rc = mm_q_forward_t<T, DK>(packed, ml, ws, wl, L, M, d, B, mu, Sigma, f1, cross, q_out, status, s);
+    if (rc) return rc;
+  }
+  if (do_Q) rc = mm_Q_reduce_t<T, DK>(packed, ml, has_C, ws, wl, L, d, B, flags, jitter, Sff, s);
+  return rc;
+}
+
+#define MM_DISPATCH(T_, CALL)                                             \
+  switch (mm_dk(d)) {                                                     \
+    case 4: return CALL(T_, 4);                                           \
+    case 8: return CALL(T_, 8);                                           \
+    case 16: return CALL(T_, 16);                                         \
+    default: return CALL(T_, 32);                                         \
+  }
+
+extern "C" int mm_moment_match(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                               const void* mu, const void* Sigma, int flags, double jitter,
+                               void* f1, void* Sff, void* cross_pre,
+                               void* workspace, size_t workspace_bytes, int32_t* status, void* stream) {
+  int rc = mm_check_common(packed, L, M, d, dtype, B);
+  if (rc) return rc;
+  if (!mu || !Sigma || !f1 || !Sff || !cross_pre || !workspace) return MM_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+#define CALL_MM(T_, DK_) mm_moment_match_t<T_, DK_>((const char*)packed, packed_bytes, L, M, d, dtype, B, (const T_*)mu, (const T_*)Sigma, \
+    flags, jitter, (T_*)f1, (T_*)Sff, (T_*)cross_pre, (T_*)nullptr, (char*)workspace, workspace_bytes, status, s, true, true)
+  if (dtype == MM_F64) { MM_DISPATCH(double, CALL_MM) }
+  MM_DISPATCH(float, CALL_MM)
+#undef CALL_MM
+}
+
+extern "C" int mm_q_forward(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                            const void* mu, const void* Sigma, int flags,
+                            void* f1, void* cross_pre, void* q_out,
+                            void* workspace, size_t workspace_bytes, int32_t* status, void* stream) {
+  int rc = mm_check_common(packed, L, M, d, dtype, B);
+  if (rc) return rc;
+  if (!mu || !Sigma || !f1 || !cross_pre || !workspace) return MM_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+#define CALL_Q(T_, DK_) mm_moment_match_t<T_, DK_>((const char*)packed, packed_bytes, L, M, d, dtype, B, (const T_*)mu, (const T_*)Sigma, \
+    flags, 0.0, (T_*)f1, (T_*)nullptr, (T_*)cross_pre, (T_*)q_out, (char*)workspace, workspace_bytes, status, s, true, false)
+  if (dtype == MM_F64) { MM_DISPATCH(double, CALL_Q) }
+  MM_DISPATCH(float, CALL_Q)
+#undef CALL_Q
+}
+
+extern "C" int mm_Q_reduce_forward(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                   int flags, double jitter, void* Sff,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  int rc = mm_check_common(packed, L, M, d, dtype, B);
+  if (rc) return rc;
+  if (!Sff || !workspace) return MM_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+#define CALL_QQ(T_, DK_) mm_moment_match_t<T_, DK_>((const char*)packed, packed_bytes, L, M, d, dtype, B, (const T_*)nullptr, (const T_*)nullptr, \
+    flags, jitter, (T_*)nullptr, (T_*)Sff, (T_*)nullptr, (T_*)nullptr, (char*)workspace, workspace_bytes, nullptr, s, false, true)
+  if (dtype == MM_F64) { MM_DISPATCH(double, CALL_QQ) }
+  MM_DISPATCH(float, CALL_QQ)
+#undef CALL_QQ
+}
+
+template <typename T>
+static int mm_euler_t(int B, int d, double dt, const T* mu, const T* Sigma, const T* f1, const T* Sff,
+                      const T* cross, T* mu_out, T* Sigma_out, T* tmu, T* tS, hipStream_t s) {
+  const size_t shm = (size_t)3 * d * d * sizeof(double);
+  hipLaunchKernelGGL((k_euler<T>), dim3(B), dim3(64), shm, s, d, dt, mu, Sigma, f1, Sff, cross, mu_out, Sigma_out, tmu, tS);
+  MM_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int mm_euler_update(int B, int d, int dtype, double dt, const void* mu, const void* Sigma,
+                               const void* f1, const void* Sff, const void* cross_pre,
+                               void* mu_out, void* Sigma_out, void* stream) {
+  if (B <= 0 || d <= 0) return MM_E_ARG;
+  if (d > MM_DMAX) return MM_E_DIM;
+  if (dtype != MM_F32 && dtype != MM_F64) return MM_E_DTYPE;
+  if (!mu || !Sigma || !f1 || !Sff || !cross_pre || !mu_out || !Sigma_out) return MM_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MM_F64)
+    return mm_euler_t<double>(B, d, dt, (const double*)mu, (const double*)Sigma, (const double*)f1, (const double*)Sff,
+                              (const double*)cross_pre, (double*)mu_out, (double*)Sigma_out, nullptr, nullptr, s);
+  return mm_euler_t<float>(B, d, dt, (const float*)mu, (const float*)Sigma, (const float*)f1, (const float*)Sff,
+                           (const float*)cross_pre, (float*)mu_out, (float*)Sigma_out, nullptr, nullptr, s);
+}
+
+template <typename T, int DK>
+static int mm_rollout_t(const char* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int H, double dt, int flags,
+                        double jitter, T* mu, T* Sigma, T* tmu, T* tS, char* ws, size_t ws_bytes,
+                        int32_t* status, hipStream_t s) {
+  const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
+  if (ws_bytes < wl.total) return MM_E_WORKSPACE;
+  T* f1 = (T*)(ws + wl.f1s);
+  T* Sff = (T*)(ws + wl.Sffs);
+  T* cr = (T*)(ws + wl.crs);
+  for (int h = 0; h < H; ++h) {
+    int rc = mm_moment_match_t<T, DK>(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, jitter, f1, Sff, cr, (T*)nullptr,
+                                      ws, ws_bytes, status, s, true, true);
+    if (rc) return rc;
+    rc = mm_euler_t<T>(B, d, dt, mu, Sigma, f1, Sff, cr, mu, Sigma,
+                       tmu ? tmu + (size_t)h * B * d : nullptr, tS ? tS + (size_t)h * B * d * d : nullptr, s);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+extern "C" int mm_rollout_closed(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int H,
+                                 double dt, int flags, double jitter, void* mu, void* Sigma,
+                                 void* traj_mu, void* traj_Sigma, void* workspace, size_t workspace_bytes,
+                                 int32_t* status, void* stream) {
+  int rc = mm_check_common(packed, L, M, d, dtype, B);
+  if (rc) return rc;
+  if (H <= 0 || !mu || !Sigma || !workspace) return MM_E_ARG;
+  if (d != L) return MM_E_STATE;
+  if (!(flags & MM_FULL_OUTPUT_COV)) return MM_E_STATE;
+  hipStream_t s = (hipStream_t)stream;
+#define CALL_R(T_, DK_) mm_rollout_t<T_, DK_>((const char*)packed, packed_bytes, L, M, d, dtype, B, H, dt, flags, jitter, (T_*)mu, (T_*)Sigma, \
+    (T_*)traj_mu, (T_*)traj_Sigma, (char*)workspace, workspace_bytes, status, s)
+  if (dtype == MM_F64) { MM_DISPATCH(double, CALL_R) }
+  MM_DISPATCH(float, CALL_R)
+#undef CALL_R
+}

@@ -1,0 +1,107 @@
+"""Moment-matching handlers for GP models: the drop-in boundary of the HIP kernels.
+
+Registered on ``dispatcher`` with the reference's signature
+``(x: GaussianMoments, model, /, full_output_cov=True, model_uncertainty=True, jitter=0.0)
+-> GaussianMatch`` (``gpflow_pilco/moment_matching/models.py:44-50,114-133,200-204``) and
+return contract ``GaussianMatch(x, y=GaussianMoments((f1, Sff), centered=True),
+cross=(iSxx_Sxf, True))`` (``:110-111,196-197,298-299``).
+
+The arithmetic of ``_mm_gauss_svgp_mo`` / ``_so`` / ``_mm_gauss_gpr`` runs in
+``libgpflowpilco_mm.so``; only slicing, the LinearCoregionalization mixing
+(``:279-286``) and wrapper plumbing stay here.
+"""
+from __future__ import annotations
+
+from functools import partial
+
+import torch
+
+from .. import ops
+from ..models import (GPR, SVGP, Constant, InverseLinkWrapper, KernelRegressor,
+                      LinearCoregionalization, Zero)
+from .core import Chain, LinearOperatorDiag, dispatcher
+from .gaussian import GaussianMatch, GaussianMoments
+
+
+@dispatcher.register(GaussianMoments, InverseLinkWrapper)
+def _mm_gauss_invlink(x: GaussianMoments, wrapper: InverseLinkWrapper, /, **kw):
+  """models.py:27-31."""
+  base = partial(wrapper.model, **kw)
+  chain = Chain(wrapper.invlink, base)
+  return dispatcher(x, chain)
+
+
+@dispatcher.register(GaussianMoments, KernelRegressor)
+def _mm_gauss_kr(x: GaussianMoments, regressor: KernelRegressor, /, **kwargs):
+  """models.py:34-41."""
+  uncertainty = kwargs.pop("model_uncertainty", False)
+  assert not uncertainty, ValueError("Kernel regressors have no uncertainty.")
+  return dispatcher(x, regressor.model, model_uncertainty=False, **kwargs)
+
+
+def _sliced_state(x: GaussianMoments, kernel):
+  mu = kernel.slice(x.mean())
+  Sxx = kernel.slice_cov(x.covariance(dense=True))
+  return mu.contiguous(), Sxx.contiguous()
+
+
+def _run_kernels(x: GaussianMoments, model, full_output_cov, model_uncertainty, jitter,
+                 latent_full_cov=None):
+  kernel0 = model.latent_kernels[0]
+  mu, Sxx = _sliced_state(x, kernel0)
+  if not mu.is_cuda:
+    raise RuntimeError("moment matching of GP models runs on the GPU only (no CPU fallback)")
+  pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
+  lead = mu.shape[:-1]
+  d = mu.shape[-1]
+  mu2, S2 = mu.reshape(-1, d), Sxx.reshape(-1, d, d)
+  full = full_output_cov if latent_full_cov is None else latent_full_cov
+  f1, Sff, cross = ops.moment_match(pm, mu2, S2, full_output_cov=full,
+                                    model_uncertainty=model_uncertainty, jitter=0.0)
+  f1 = f1.reshape(lead + f1.shape[1:])
+  Sff = Sff.reshape(lead + Sff.shape[1:])
+  cross = cross.reshape(lead + cross.shape[1:])
+  return f1, Sff, cross
+
+
+def _finish(x, f1, Sff, cross, full_output_cov, jitter):
+  if full_output_cov:                                            # models.py:293-296
+    if jitter:
+      Sff = Sff + jitter * torch.eye(Sff.shape[-1], dtype=Sff.dtype, device=Sff.device)
+  else:
+    Sff = LinearOperatorDiag(Sff + jitter)
+  y = GaussianMoments(moments=(f1, Sff), centered=True)
+  return GaussianMatch(x=x, y=y, cross=(cross, True))
+
+
+@dispatcher.register(GaussianMoments, GPR)
+def _mm_gauss_gpr(x: GaussianMoments, model: GPR, /, full_output_cov: bool = True,
+                  model_uncertainty: bool = True, jitter: float = 0.0):
+  """models.py:44-111."""
+  f1, Sff, cross = _run_kernels(x, model, full_output_cov, model_uncertainty, jitter)
+  return _finish(x, f1, Sff, cross, full_output_cov, jitter)
+
+
+@dispatcher.register(GaussianMoments, SVGP)
+def _mm_gauss_svgp(x: GaussianMoments, model: SVGP, /, full_output_cov: bool = True,
+                   model_uncertainty: bool = True, jitter: float = 0.0):
+  """models.py:114-126 (dispatch), :129-197 (single output), :200-299 (multi output)."""
+  kernel = model.kernel
+  if isinstance(kernel, LinearCoregionalization):
+    # the latent covariance stays full (models.py:244,258), then f = W g  (:279-286)
+    f1, Sff, cross = _run_kernels(x, model, full_output_cov, model_uncertainty, jitter,
+                                  latent_full_cov=True)
+    W = kernel.W.to(f1)
+    f1 = f1 @ W.T
+    cross = cross @ W.T
+    if full_output_cov:
+      Sff = W @ Sff @ W.T
+    else:
+      Sff = (W * (W @ Sff.transpose(-1, -2))).sum(-1)
+    if isinstance(model.mean_function, Constant):                # :288-289
+      f1 = f1 + model.mean_function.c.to(f1)
+    elif not isinstance(model.mean_function, Zero):
+      raise NotImplementedError
+    return _finish(x, f1, Sff, cross, full_output_cov, jitter)
+  f1, Sff, cross = _run_kernels(x, model, full_output_cov, model_uncertainty, jitter)
+  return _finish(x, f1, Sff, cross, full_output_cov, jitter)

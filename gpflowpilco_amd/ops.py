@@ -1,0 +1,212 @@
+"""torch-tensor front end of the C ABI (device pointers + current HIP stream).
+
+PyTorch is plumbing here: it owns the device buffers and the stream; every
+floating-point operation of the moment match happens in the HIP kernels of
+``csrc/``.  Nothing in this module runs on the CPU -- tensors must live on a
+ROCm device.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (MM_F32, MM_F64, MM_FORCE_GENERIC, MM_FULL_OUTPUT_COV,
+                   MM_MODEL_UNCERTAINTY, check, lib)
+
+_DTYPES = {torch.float32: MM_F32, torch.float64: MM_F64}
+
+
+def _dtype_code(dtype: torch.dtype) -> int:
+  try:
+    return _DTYPES[dtype]
+  except KeyError:
+    raise TypeError(f"moment matching supports float32/float64 states, got {dtype}") from None
+
+
+def _ptr(t: Optional[torch.Tensor]):
+  return None if t is None else t.data_ptr()
+
+
+def _require_device(*tensors: torch.Tensor):
+  for t in tensors:
+    if t is not None and not t.is_cuda:
+      raise RuntimeError("gpflowpilco_amd kernels run on the GPU only (no CPU fallback): "
+                         f"got a tensor on {t.device}")
+
+
+def _stream(device) -> int:
+  return torch.cuda.current_stream(device).cuda_stream
+
+
+def make_flags(full_output_cov: bool = True, model_uncertainty: bool = True,
+               force_generic: bool = False) -> int:
+  return ((MM_FULL_OUTPUT_COV if full_output_cov else 0)
+          | (MM_MODEL_UNCERTAINTY if model_uncertainty else 0)
+          | (MM_FORCE_GENERIC if force_generic else 0))
+
+
+@dataclass
+class PackedModel:
+  """Device-resident packed model (output of ``mm_pack_model``)."""
+  L: int
+  M: int
+  d: int
+  dtype: torch.dtype
+  with_C: bool
+  buf: torch.Tensor                      # uint8 [packed_bytes]
+  _workspaces: Dict[Tuple[int, int], torch.Tensor] = field(default_factory=dict, repr=False)
+  _status: Optional[torch.Tensor] = field(default=None, repr=False)
+
+  @property
+  def device(self):
+    return self.buf.device
+
+  @property
+  def nbytes(self) -> int:
+    return self.buf.numel()
+
+  def workspace(self, B: int, flags: int) -> torch.Tensor:
+    key = (B, flags & (MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY))
+    ws = self._workspaces.get(key)
+    if ws is None:
+      n = lib().mm_workspace_bytes(B, self.L, self.M, self.d, _dtype_code(self.dtype), flags)
+      if n == 0:
+        raise ValueError("mm_workspace_bytes rejected the shape")
+      ws = torch.empty(n, dtype=torch.uint8, device=self.device)
+      self._workspaces[key] = ws
+    return ws
+
+  def status(self) -> torch.Tensor:
+    if self._status is None:
+      self._status = torch.zeros(2, dtype=torch.int32, device=self.device)
+    return self._status
+
+  def check_status(self, B: int):
+    """Synchronising check of the non-PD flag (the reference raises at this point)."""
+    st = self.status().tolist()
+    if st[0] != 0:
+      self._status.zero_()
+      raise FloatingPointError(
+          f"Cholesky of (Sigma + V) failed for batch element {B - st[0]} (item {st[1]}): "
+          "the input covariance is not positive definite")
+
+
+def pack_model(Z: torch.Tensor, lengthscales: torch.Tensor, variance: torch.Tensor,
+               beta: torch.Tensor, C: Optional[torch.Tensor] = None,
+               mean_c: Optional[torch.Tensor] = None,
+               dtype: torch.dtype = torch.float32) -> PackedModel:
+  """Z [L,M,d], lengthscales [L,d], variance [L], beta [L,M], C [L,M,M]|None, mean_c [L]|None
+  (all float64 on the GPU) -> PackedModel whose reduce operands are stored as ``dtype``."""
+  _require_device(Z, lengthscales, variance, beta, C, mean_c)
+  L, M, d = Z.shape
+  f64 = lambda t: None if t is None else t.to(torch.float64).contiguous()
+  Z, lengthscales, variance, beta, C, mean_c = map(f64, (Z, lengthscales, variance, beta, C, mean_c))
+  assert lengthscales.shape == (L, d) and variance.shape == (L,) and beta.shape == (L, M)
+  assert C is None or C.shape == (L, M, M)
+  assert mean_c is None or mean_c.shape == (L,)
+  code = _dtype_code(dtype)
+  n = lib().mm_packed_model_bytes(L, M, d, code, int(C is not None))
+  if n == 0:
+    raise ValueError(f"unsupported model shape L={L} M={M} d={d} (d <= {_lib.MM_DMAX})")
+  buf = torch.empty(n, dtype=torch.uint8, device=Z.device)
+  rc = lib().mm_pack_model(buf.data_ptr(), n, L, M, d, code, _ptr(Z), _ptr(lengthscales),
+                           _ptr(variance), _ptr(beta), _ptr(C), _ptr(mean_c), _stream(Z.device))
+  check(rc, "mm_pack_model")
+  # the f64 inputs must outlive the asynchronous pack kernels
+  torch.cuda.current_stream(Z.device).synchronize()
+  return PackedModel(L=L, M=M, d=d, dtype=dtype, with_C=C is not None, buf=buf)
+
+
+def _prep_state(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor):
+  _require_device(mu, Sigma)
+  if mu.dtype != pm.dtype or Sigma.dtype != pm.dtype:
+    raise TypeError(f"state dtype {mu.dtype}/{Sigma.dtype} does not match the packed model ({pm.dtype})")
+  B, d = mu.shape
+  if d != pm.d or Sigma.shape != (B, d, d):
+    raise ValueError(f"expected mu [B,{pm.d}] and Sigma [B,{pm.d},{pm.d}], got {tuple(mu.shape)}, {tuple(Sigma.shape)}")
+  return B, mu.contiguous(), Sigma.contiguous()
+
+
+def moment_match(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor,
+                 full_output_cov: bool = True, model_uncertainty: bool = True,
+                 jitter: float = 0.0, force_generic: bool = False):
+  """(mu [B,d], Sigma [B,d,d]) -> f1 [B,L], Sff [B,L,L] | [B,L], Sigma^-1 Cov(x,f) [B,d,L]."""
+  B, mu, Sigma = _prep_state(pm, mu, Sigma)
+  flags = make_flags(full_output_cov, model_uncertainty, force_generic)
+  ws = pm.workspace(B, flags)
+  f1 = torch.empty(B, pm.L, dtype=pm.dtype, device=pm.device)
+  Sff = torch.empty((B, pm.L, pm.L) if full_output_cov else (B, pm.L), dtype=pm.dtype, device=pm.device)
+  cross = torch.empty(B, pm.d, pm.L, dtype=pm.dtype, device=pm.device)
+  rc = lib().mm_moment_match(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B,
+                             mu.data_ptr(), Sigma.data_ptr(), flags, float(jitter),
+                             f1.data_ptr(), Sff.data_ptr(), cross.data_ptr(),
+                             ws.data_ptr(), ws.numel(), pm.status().data_ptr(), _stream(pm.device))
+  check(rc, "mm_moment_match")
+  return f1, Sff, cross
+
+
+def q_forward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor, flags: int, want_q: bool = False):
+  """Stage 1: <K_xZ> terms.  Returns f1, cross_pre, q ([B,L,M] or None)."""
+  B, mu, Sigma = _prep_state(pm, mu, Sigma)
+  ws = pm.workspace(B, flags)
+  f1 = torch.empty(B, pm.L, dtype=pm.dtype, device=pm.device)
+  cross = torch.empty(B, pm.d, pm.L, dtype=pm.dtype, device=pm.device)
+  q = torch.empty(B, pm.L, pm.M, dtype=pm.dtype, device=pm.device) if want_q else None
+  rc = lib().mm_q_forward(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B,
+                          mu.data_ptr(), Sigma.data_ptr(), flags, f1.data_ptr(), cross.data_ptr(), _ptr(q),
+                          ws.data_ptr(), ws.numel(), pm.status().data_ptr(), _stream(pm.device))
+  check(rc, "mm_q_forward")
+  return f1, cross, q
+
+
+def Q_reduce_forward(pm: PackedModel, B: int, flags: int, jitter: float = 0.0):
+  """Stage 2: fused <K_Zx K_xZ'> reduce -> Sff.  Must follow ``q_forward`` with the same B/flags."""
+  ws = pm.workspace(B, flags)
+  full = bool(flags & MM_FULL_OUTPUT_COV)
+  Sff = torch.empty((B, pm.L, pm.L) if full else (B, pm.L), dtype=pm.dtype, device=pm.device)
+  rc = lib().mm_Q_reduce_forward(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B,
+                                 flags, float(jitter), Sff.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 _stream(pm.device))
+  check(rc, "mm_Q_reduce_forward")
+  return Sff
+
+
+def euler_update(mu, Sigma, f1, Sff, cross_pre, dt: float = 1.0):
+  """MomentMatchingEuler.step on the GPU (d == L)."""
+  _require_device(mu, Sigma, f1, Sff, cross_pre)
+  B, d = mu.shape
+  if f1.shape != (B, d) or Sff.shape != (B, d, d) or cross_pre.shape != (B, d, d):
+    raise ValueError("euler_update needs d == L and a full output covariance")
+  args = [t.contiguous() for t in (mu, Sigma, f1, Sff, cross_pre)]
+  mu_o, S_o = torch.empty_like(args[0]), torch.empty_like(args[1])
+  rc = lib().mm_euler_update(B, d, _dtype_code(mu.dtype), float(dt), *[t.data_ptr() for t in args],
+                             mu_o.data_ptr(), S_o.data_ptr(), _stream(mu.device))
+  check(rc, "mm_euler_update")
+  return mu_o, S_o
+
+
+def rollout_closed(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor, num_steps: int,
+                   dt: float = 1.0, model_uncertainty: bool = True, jitter: float = 0.0,
+                   keep_trajectory: bool = False, force_generic: bool = False):
+  """Drift-only moment-matched rollout, H steps enqueued back-to-back (state dim == d == L).
+
+  Returns (mu_H, Sigma_H) or (mu_H, Sigma_H, traj_mu [H,B,d], traj_Sigma [H,B,d,d]).
+  The inputs are not modified.
+  """
+  B, mu, Sigma = _prep_state(pm, mu, Sigma)
+  mu, Sigma = mu.clone(), Sigma.clone()
+  flags = make_flags(True, model_uncertainty, force_generic)
+  ws = pm.workspace(B, flags)
+  tmu = tS = None
+  if keep_trajectory:
+    tmu = torch.empty(num_steps, B, pm.d, dtype=pm.dtype, device=pm.device)
+    tS = torch.empty(num_steps, B, pm.d, pm.d, dtype=pm.dtype, device=pm.device)
+  rc = lib().mm_rollout_closed(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B,
+                               int(num_steps), float(dt), flags, float(jitter),
+                               mu.data_ptr(), Sigma.data_ptr(), _ptr(tmu), _ptr(tS),
+                               ws.data_ptr(), ws.numel(), pm.status().data_ptr(), _stream(pm.device))
+  check(rc, "mm_rollout_closed")
+  return (mu, Sigma, tmu, tS) if keep_trajectory else (mu, Sigma)

@@ -1,0 +1,124 @@
+/*
+ * gpflowpilco_mm.h -- C ABI of the MI355X (gfx950) moment-matched GP propagation.
+ *
+ * Drop-in boundary for the per-step hot path of j-wilson/GPflowPILCO:
+ *   moment_matching(GaussianMoments, SVGP|GPR)            gpflow_pilco/moment_matching/models.py:44-299
+ *   kernel_expectation  <K_xZ>, <K_Zx K_xZ'>              gpflow_pilco/utils/kernel_expectation.py:72-288
+ *   MomentMatchingEuler.step                              gpflow_pilco/dynamics/solvers.py:108-135
+ *
+ * The reference has no FFI of its own (pure Python/TF); these entry points are what a
+ * maintainer would bind from the handlers above.  Conventions:
+ *   - every pointer is a DEVICE pointer unless it says "host"; row-major contiguous; the batch
+ *     axis B is the leading axis, so a B-shard is a pointer offset;
+ *   - the caller owns every buffer including the workspace (size from *_bytes queries);
+ *   - calls only enqueue work on `stream` (a hipStream_t passed as void*); no allocation,
+ *     no synchronisation, no global state (re-entrant across streams, graph-capturable);
+ *   - return value: 0 ok, <0 bad argument (MM_E_*), >0 a hipError_t;
+ *   - `status` (device int32[2], zeroed by the caller, may be NULL): [0] = B - b for the smallest
+ *     batch index b whose (Sigma + V) Cholesky was not positive definite (0 = all fine; outputs
+ *     of that b are NaN), [1] = an item code.  The reference raises InvalidArgumentError there
+ *     (kernel_expectation.py:125-126, models.py:271).
+ *   - `packed` / `packed_bytes`: the buffer filled by mm_pack_model and its size (whether C is
+ *     present is inferred from the size).
+ *
+ * dtype selects the element type T of the state (mu, Sigma), outputs and the streaming
+ * workspace.  All d x d algebra, log-normalisers, first moments and cross terms are done in
+ * f64 regardless; T only governs the M x M inner reduction and storage.
+ */
+#ifndef GPFLOWPILCO_MM_H
+#define GPFLOWPILCO_MM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MM_F32 0
+#define MM_F64 1
+
+#define MM_DMAX 32          /* largest supported GP input dimension d            */
+#define MM_M_ALIGN 128      /* inducing-point axis is zero-padded to this multiple */
+
+/* flags */
+#define MM_FULL_OUTPUT_COV   1   /* models.py full_output_cov=True: Sff is [B,L,L]; else [B,L]     */
+#define MM_MODEL_UNCERTAINTY 2   /* models.py model_uncertainty=True: adds E[Var f] (needs C)      */
+#define MM_FORCE_GENERIC     4   /* use the portable VALU reduce kernel even where an MFMA one exists */
+
+/* error codes */
+#define MM_E_ARG      (-1)  /* NULL pointer / non-positive size                  */
+#define MM_E_DIM      (-2)  /* d > MM_DMAX or unsupported shape                  */
+#define MM_E_DTYPE    (-3)
+#define MM_E_WORKSPACE (-4) /* workspace too small                               */
+#define MM_E_NO_C     (-5)  /* MM_MODEL_UNCERTAINTY asked for but model packed without C */
+#define MM_E_STATE    (-6)  /* euler/rollout needs d == L                         */
+
+int mm_abi_version(void);
+
+/* ---- model packing (once per model; replaces the per-call Kuu Cholesky + triangular
+ *      solves of models.py:216-235 by the precomputed beta = Kuu^-1 u and
+ *      C = Kuu^-1 S Kuu^-1 - Kuu^-1) ------------------------------------ */
+size_t mm_packed_model_bytes(int L, int M, int d, int dtype, int with_C);
+
+int mm_pack_model(void* packed, size_t packed_bytes,
+                  int L, int M, int d, int dtype,
+                  const double* Z,            /* [L,M,d] inducing inputs (kernel-sliced)   */
+                  const double* lengthscales, /* [L,d]                                     */
+                  const double* variance,     /* [L]                                       */
+                  const double* beta,         /* [L,M]   Kuu^-1 u                          */
+                  const double* C,            /* [L,M,M] or NULL                           */
+                  const double* mean_c,       /* [L] Constant mean, or NULL (Zero)         */
+                  void* stream);
+
+/* ---- one moment match: (mu, Sigma) -> (f1, Sff, Sigma^-1 Cov(x,f)) --------------------
+ * Replaces _mm_gauss_svgp_mo / _so / _mm_gauss_gpr up to (not including) the
+ * LinearCoregionalization mixing (models.py:279-286), which stays on the host. */
+size_t mm_workspace_bytes(int B, int L, int M, int d, int dtype, int flags);
+
+int mm_moment_match(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype,
+                    int B,
+                    const void* mu,        /* [B,d]   T */
+                    const void* Sigma,     /* [B,d,d] T (symmetric; lower triangle is read) */
+                    int flags, double jitter,
+                    void* f1,              /* [B,L]   T  (includes the Constant mean)       */
+                    void* Sff,             /* [B,L,L] T, or [B,L] without MM_FULL_OUTPUT_COV */
+                    void* cross_pre,       /* [B,d,L] T  Sigma^-1 Cov(x,f) (preinv=True)    */
+                    void* workspace, size_t workspace_bytes,
+                    int32_t* status, void* stream);
+
+/* ---- stage-level entry points; mm_moment_match = q then Q ------- */
+/* <K_xZ> terms (kernel_expectation.py:200-214 + gpflow <k(x,Z)>): fills the workspace and
+ * writes f1, cross_pre; q_out (optional, [B,L,M] T) receives eKfu[b,m,a] transposed. */
+int mm_q_forward(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                 const void* mu, const void* Sigma, int flags,
+                 void* f1, void* cross_pre, void* q_out,
+                 void* workspace, size_t workspace_bytes, int32_t* status, void* stream);
+
+/* fused <K_Zx K_xZ'> reduce (kernel_expectation.py:72-247 + models.py:219-261) -> Sff.
+ * Must follow mm_q_forward on the same workspace/stream. */
+int mm_Q_reduce_forward(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                        int flags, double jitter, void* Sff,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* MomentMatchingEuler.step (solvers.py:110-135), requires d == L:
+ *   mu' = mu + dt f1;  Sigma' = Sigma + dt (Sxf + Sxf^T) + dt^2 Sff,  Sxf = Sigma cross_pre */
+int mm_euler_update(int B, int d, int dtype, double dt,
+                    const void* mu, const void* Sigma,
+                    const void* f1, const void* Sff, const void* cross_pre,
+                    void* mu_out, void* Sigma_out, void* stream);
+
+/* Drift-only closed rollout (Euler.__call__ fold, solvers.py:67-105, with
+ * forward_sde(x, drift, None, None, None), forward_sde.py:34-46): H steps enqueued
+ * back-to-back.  mu/Sigma are updated in place; traj_mu [H,B,d] / traj_Sigma [H,B,d,d]
+ * (optional) receive the state after every step. */
+int mm_rollout_closed(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int H,
+                      double dt, int flags, double jitter,
+                      void* mu, void* Sigma, void* traj_mu, void* traj_Sigma,
+                      void* workspace, size_t workspace_bytes,
+                      int32_t* status, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPFLOWPILCO_MM_H */
