@@ -23,8 +23,10 @@ struct MMModelLayout {
   size_t var;     // [L]        f64 kernel variances
   size_t meanc;   // [L]        f64 Constant mean (zeros for Zero)
   size_t beta64;  // [L][M]     f64 Kuu^-1 u
-  size_t Zc;      // [L][Mp][Kz] T  centred inducing inputs, zero padded (rows >= M, cols >= d)
-  size_t Cm;      // [L][Mp][Mp] T  Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total)
+  size_t Zc64;    // [L][Mp][Kz] f64 centred inducing inputs, zero padded (rows >= M, cols >= d)
+  size_t Zc;      // [L][Mp][Kz] T   same, element type T (aliases Zc64 when T is f64)
+  size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
+                  // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
 };
 
@@ -40,9 +42,11 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   o.var = off;    off = mm_align_up(off + (size_t)L * 8, A);
   o.meanc = off;  off = mm_align_up(off + (size_t)L * 8, A);
   o.beta64 = off; off = mm_align_up(off + (size_t)L * M * 8, A);
-  o.Zc = off;     off = mm_align_up(off + (size_t)L * o.Mp * o.Kz * es, A);
+  o.Zc64 = off;   off = mm_align_up(off + (size_t)L * o.Mp * o.Kz * 8, A);
+  o.Zc = o.Zc64;
+  if (dtype != MM_F64) { o.Zc = off; off = mm_align_up(off + (size_t)L * o.Mp * o.Kz * es, A); }
   o.Cm = off;
-  if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * es, A);
+  if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;
   return o;
 }
@@ -54,16 +58,21 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 #define MM_PANEL_ROWS 256
 #define MM_DIAG_TILE 128
 
+// Diagonal pairs (a == a', p < L) are always reduced in f64 (they carry the C-weighted
+// term, whose conditioning rules out f32); off-diagonal pairs (p >= L) in T.
 struct MMWorkspaceLayout {
-  int Mp, P, NS;
+  int Mp, P, Po, NS;
   size_t pairmat;  // [B][P][3 d^2 + 1] f64: G, Drow, Dcol, const
   size_t latmat;   // [B][L][d^2 + 1]   f64: (Sigma + Lambda_a)^-1, log-normaliser
-  size_t w;        // [B][L][Mp] T   beta_i q_i
-  size_t q;        // [B][L][Mp] T   q_i = <k_a(x, z_i)>
-  size_t rowA;     // [B][P][Mp] T   rho_i
-  size_t colB;     // [B][P][d+1][Mp] T   g_j (d rows) and gamma'_j
+  size_t w64;      // [B][L][Mp] f64  beta_i q_i
+  size_t q64;      // [B][L][Mp] f64  q_i = <k_a(x, z_i)>
+  size_t w;        // [B][L][Mp] T    (aliases w64 when T is f64)
+  size_t rowD;     // [B][L][Mp] f64        rho_i          diagonal pairs
+  size_t colD;     // [B][L][d+1][Mp] f64   g_j, gamma'_j  diagonal pairs
+  size_t rowO;     // [B][Po][Mp] T         off-diagonal pairs
+  size_t colO;     // [B][Po][d+1][Mp] T
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
-  size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i exp(delta_ij) q_j
+  size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i expm1(delta_ij) q_j  (+ q^T C q)
   size_t f1s;      // [B][L] T      rollout scratch outputs
   size_t Sffs;     // [B][L][L] T
   size_t crs;      // [B][d][L] T
@@ -75,6 +84,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   const size_t es = mm_elem_size(dtype), A = 256;
   o.Mp = mm_round_up_int(M, MM_M_ALIGN);
   o.P = mm_num_pairs(L, flags);
+  o.Po = o.P - L;
   const int nrb = (o.Mp + MM_GEN_ROWS - 1) / MM_GEN_ROWS;
   const int ncb = (o.Mp + MM_GEN_COLS - 1) / MM_GEN_COLS;
   const int nt = o.Mp / MM_DIAG_TILE;
@@ -84,10 +94,14 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   size_t off = 0;
   o.pairmat = off; off = mm_align_up(off + (size_t)B * o.P * (3 * d * d + 1) * 8, A);
   o.latmat = off;  off = mm_align_up(off + (size_t)B * L * (d * d + 1) * 8, A);
-  o.w = off;       off = mm_align_up(off + (size_t)B * L * o.Mp * es, A);
-  o.q = off;       off = mm_align_up(off + (size_t)B * L * o.Mp * es, A);
-  o.rowA = off;    off = mm_align_up(off + (size_t)B * o.P * o.Mp * es, A);
-  o.colB = off;    off = mm_align_up(off + (size_t)B * o.P * (d + 1) * o.Mp * es, A);
+  o.w64 = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
+  o.q64 = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
+  o.w = o.w64;
+  if (dtype != MM_F64) { o.w = off; off = mm_align_up(off + (size_t)B * L * o.Mp * es, A); }
+  o.rowD = off;    off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
+  o.colD = off;    off = mm_align_up(off + (size_t)B * L * (d + 1) * o.Mp * 8, A);
+  o.rowO = off;    off = mm_align_up(off + (size_t)B * o.Po * o.Mp * es, A);
+  o.colO = off;    off = mm_align_up(off + (size_t)B * o.Po * (d + 1) * o.Mp * es, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
   o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);
   o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);

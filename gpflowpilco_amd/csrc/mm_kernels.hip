@@ -18,7 +18,8 @@
 //   k_prep      one wave per (b, pair) / (b, latent): d x d Cholesky algebra in f64 (LDS)
 //   k_qvec      one workgroup per (b, latent): q_i, w_i, f1, Sigma^-1 Cov(x,f)
 //   k_pairvec   per (b, pair, m): rho_m, g_m = G zeta_m, gamma'_m  (streamed operands of the reduce)
-//   k_qred_*    the M x M fused reduce (generic VALU kernel here; f32 MFMA kernels in mm_mfma.hip)
+//   k_qred_*    the M x M fused reduce: diagonal pairs (a == a', incl. the C-weighted term) always in
+//               f64, off-diagonal pairs in T (generic VALU kernel here; f32 MFMA kernel in mm_mfma.hip)
 //   k_finalize  deterministic sum of the partial slabs -> Sff
 //   k_euler     MomentMatchingEuler.step
 #include <hip/hip_runtime.h>
@@ -122,6 +123,7 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
   double* zbar = (double*)(packed + lay.zbar) + (size_t)a * d;
   double* ls2 = (double*)(packed + lay.ls2) + (size_t)a * d;
   double* b64 = (double*)(packed + lay.beta64) + (size_t)a * M;
+  double* Zc64 = (double*)(packed + lay.Zc64) + (size_t)a * lay.Mp * lay.Kz;
   T* Zc = (T*)(packed + lay.Zc) + (size_t)a * lay.Mp * lay.Kz;
   __shared__ double red[4];
   __shared__ double zb[MM_DMAX];
@@ -143,19 +145,19 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
     const int m = idx / lay.Kz, k = idx - m * lay.Kz;
     double v = 0.0;
     if (m < M && k < d) v = Z[((size_t)a * M + m) * d + k] - zb[k];
-    Zc[idx] = (T)v;
+    Zc64[idx] = v;
+    if (sizeof(T) != 8) Zc[idx] = (T)v;
   }
 }
 
-template <typename T>
 __global__ void k_pack_C(char* packed, MMModelLayout lay, int L, int M, const double* __restrict__ C) {
-  // grid (Mp/256, Mp, L): padded, T-typed copy of C
+  // grid (Mp/256, Mp, L): zero-padded f64 copy of C
   const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, a = blockIdx.z;
   if (j >= lay.Mp) return;
-  T* Cm = (T*)(packed + lay.Cm) + ((size_t)a * lay.Mp + i) * lay.Mp;
+  double* Cm = (double*)(packed + lay.Cm) + ((size_t)a * lay.Mp + i) * lay.Mp;
   double v = 0.0;
   if (i < M && j < M) v = C[((size_t)a * M + i) * M + j];
-  Cm[j] = (T)v;
+  Cm[j] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
                                               const double* __restrict__ meanc,
                                               int L, int M, int Mp, int d,
                                               const T* __restrict__ mu, const double* __restrict__ latmat,
-                                              T* __restrict__ w, T* __restrict__ q,
+                                              double* __restrict__ w64, double* __restrict__ q64, T* __restrict__ w,
                                               T* __restrict__ f1, T* __restrict__ cross, T* __restrict__ q_out) {
   const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   __shared__ double Pa[MM_DMAX * MM_DMAX];
@@ -288,8 +290,9 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
   double acc_s[DK];
 #pragma unroll
   for (int k = 0; k < DK; ++k) acc_s[k] = 0.0;
+  double* wb64 = w64 + ((size_t)b * L + a) * Mp;
+  double* qb64 = q64 + ((size_t)b * L + a) * Mp;
   T* wb = w + ((size_t)b * L + a) * Mp;
-  T* qb = q + ((size_t)b * L + a) * Mp;
   for (int m = tid; m < Mp; m += 256) {
     double wv = 0.0, qv = 0.0;
     if (m < M) {
@@ -313,8 +316,9 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
       for (int k = 0; k < DK; ++k) acc_s[k] += wv * z[k];
       if (q_out) q_out[((size_t)b * L + a) * M + m] = (T)qv;
     }
-    wb[m] = (T)wv;
-    qb[m] = (T)qv;
+    wb64[m] = wv;
+    qb64[m] = qv;
+    if (sizeof(T) != 8) wb[m] = (T)wv;
   }
   const double f = mm_block_sum256(acc_f, red);
   if (tid == 0) sv[DK] = f;
@@ -342,7 +346,8 @@ template <typename T, int DK>
 __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64, const double* __restrict__ zbar,
                                                  int L, int M, int Mp, int d, int P,
                                                  const T* __restrict__ mu, const double* __restrict__ pairmat,
-                                                 T* __restrict__ rowA, T* __restrict__ colB) {
+                                                 double* __restrict__ rowD, double* __restrict__ colD,
+                                                 T* __restrict__ rowO, T* __restrict__ colO) {
   const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int m = blockIdx.x * 256 + tid;
   int a, a2;
@@ -359,11 +364,18 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
   __syncthreads();
   if (m >= Mp) return;
   const double cst = pm[3 * d * d];
-  T* ra = rowA + ((size_t)b * P + p) * Mp;
-  T* cb = colB + ((size_t)b * P + p) * (size_t)(d + 1) * Mp;
+  // diagonal pairs (p < L) stream f64 operands, off-diagonal pairs T operands
+  const bool diag = p < L;
+  const int Po = P - L;
+  double* raD = rowD + ((size_t)b * L + (diag ? p : 0)) * Mp;
+  double* cbD = colD + ((size_t)b * L + (diag ? p : 0)) * (size_t)(d + 1) * Mp;
+  T* raO = rowO + ((size_t)b * Po + (diag ? 0 : p - L)) * Mp;
+  T* cbO = colO + ((size_t)b * Po + (diag ? 0 : p - L)) * (size_t)(d + 1) * Mp;
+#define MM_PV_STORE_ROW(v_) do { if (diag) raD[m] = (v_); else raO[m] = (T)(v_); } while (0)
+#define MM_PV_STORE_COL(k_, v_) do { if (diag) cbD[(size_t)(k_) * Mp + m] = (v_); else cbO[(size_t)(k_) * Mp + m] = (T)(v_); } while (0)
   if (m >= M) {
-    ra[m] = (T)0;
-    for (int k = 0; k <= d; ++k) cb[(size_t)k * Mp + m] = (T)0;
+    MM_PV_STORE_ROW(0.0);
+    for (int k = 0; k <= d; ++k) MM_PV_STORE_COL(k, 0.0);
     return;
   }
   double zr[DK], zc[DK];
@@ -388,33 +400,38 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
       rho += zr[i] * tr;
       gam += zc[i] * tc;
       corr += dmu[i] * g;
-      cb[(size_t)i * Mp + m] = (T)g;
+      MM_PV_STORE_COL(i, g);
     }
   }
-  ra[m] = (T)(-0.5 * rho);
+  MM_PV_STORE_ROW(-0.5 * rho);
   // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j
-  cb[(size_t)d * Mp + m] = (T)(-0.5 * gam + cst - corr);
+  MM_PV_STORE_COL(d, -0.5 * gam + cst - corr);
+#undef MM_PV_STORE_ROW
+#undef MM_PV_STORE_COL
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_qred_generic: portable VALU fused reduce (f64 path; f32 fallback / cross-check).
-//   thread = one column j, workgroup = 256 columns x MM_GEN_ROWS rows of one (b, pair).
-//   grid (nrb * ncb, P, B)
+// k_qred_generic: portable VALU fused reduce over the pairs [p0, p0 + gridDim.y).
+//   f64 instantiation: the diagonal pairs of every mode (with the C-weighted term) and all
+//   pairs of the f64 mode; f32 instantiation: off-diagonal pairs (fallback / cross-check of
+//   the MFMA kernel).  thread = one column j, workgroup = 256 columns x MM_GEN_ROWS rows of
+//   one (b, pair).  grid (nrb * ncb, npairs, B); row/col operand arrays are indexed by the
+//   LOCAL pair index, the partial slabs by the global one.
 // ---------------------------------------------------------------------------------------------
 template <typename T, int DK>
-__global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, int Kz, const T* __restrict__ Cm,
-                                                      int L, int Mp, int d, int P, int NS, int ncb,
+__global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, int Kz, const double* __restrict__ Cm,
+                                                      int L, int Mp, int d, int P, int NS, int ncb, int p0,
                                                       const T* __restrict__ w, const T* __restrict__ q,
                                                       const T* __restrict__ rowA, const T* __restrict__ colB,
                                                       double* __restrict__ partB, double* __restrict__ partC) {
   const int cbk = blockIdx.x % ncb, rbk = blockIdx.x / ncb;
-  const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int lp = blockIdx.y, np = gridDim.y, p = p0 + lp, b = blockIdx.z, tid = threadIdx.x;
   int a, a2;
   mm_decode_pair(p, L, a, a2);
   const int j = cbk * MM_GEN_COLS + tid;
   const bool jv = j < Mp;
   const int jj = jv ? j : 0;
-  const T* cb = colB + ((size_t)b * P + p) * (size_t)(d + 1) * Mp;
+  const T* cb = colB + ((size_t)b * np + lp) * (size_t)(d + 1) * Mp;
   T g[DK];
 #pragma unroll
   for (int k = 0; k < DK; ++k) g[k] = (k < d) ? cb[(size_t)k * Mp + jj] : (T)0;
@@ -422,13 +439,13 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
   const T wj = jv ? w[((size_t)b * L + a2) * Mp + jj] : (T)0;
   const bool withC = (Cm != nullptr) && (a == a2);
   const T qj = (withC && jv) ? q[((size_t)b * L + a2) * Mp + jj] : (T)0;
-  const T* ra = rowA + ((size_t)b * P + p) * Mp;
+  const T* ra = rowA + ((size_t)b * np + lp) * Mp;
   const T* wr = w + ((size_t)b * L + a) * Mp;
   const T* qr = q + ((size_t)b * L + a) * Mp;
   const T* zrow = Zc + (size_t)a * Mp * Kz;
   const int i0 = rbk * MM_GEN_ROWS;
   const int i1 = (i0 + MM_GEN_ROWS < Mp) ? i0 + MM_GEN_ROWS : Mp;
-  T accB = (T)0, accC = (T)0;
+  T accB = (T)0;
   double sumB = 0.0, sumC = 0.0;
   for (int i = i0; i < i1; ++i) {
     T delta = ra[i] + gam;
@@ -437,13 +454,13 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
     const T e = mm_expm1(delta);
     accB += wr[i] * e;
     if (withC) {
-      const T cij = Cm[((size_t)a * Mp + i) * Mp + jj];
-      const T t = qr[i] * e + qr[i];          // q_i exp(delta)
-      accC += cij * t;
+      const double cij = Cm[((size_t)a * Mp + i) * Mp + jj];
+      const double qi = (double)qr[i];
+      sumC += cij * (qi * (double)e + qi);      // C_ij q_i exp(delta_ij)   (f64 only)
     }
-    if (((i - i0) & 15) == 15) { sumB += (double)accB; accB = (T)0; sumC += (double)accC; accC = (T)0; }
+    if (((i - i0) & 15) == 15) { sumB += (double)accB; accB = (T)0; }
   }
-  sumB += (double)accB; sumC += (double)accC;
+  sumB += (double)accB;
   sumB *= (double)wj;
   sumC *= (double)qj;
   __shared__ double red[4];
@@ -531,9 +548,9 @@ __global__ __launch_bounds__(64) void k_euler(int d, double dt, const T* __restr
 // ---------------------------------------------------------------------------------------------
 // f32 MFMA reduce kernels (mm_mfma.hip)
 extern "C" int mm_mfma_supported(int d);
+// off-diagonal pairs, f32: fills partB[b][p >= L][0 .. *ns_off)
 int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
-                        int B, int L, int d, int with_unc, int* nsB_diag, int* nsB_off, int* nsC,
-                        hipStream_t stream);
+                        int B, int L, int d, int* ns_off, hipStream_t stream);
 
 #define MM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -566,7 +583,7 @@ static int mm_pack_model_t(char* packed, const MMModelLayout& lay, int L, int M,
   hipLaunchKernelGGL((k_pack_vectors<T>), dim3(L), dim3(256), 0, s, packed, lay, L, M, d, Z, ls, var, beta, mean_c);
   MM_CHECK_LAUNCH();
   if (C) {
-    hipLaunchKernelGGL((k_pack_C<T>), dim3((lay.Mp + 255) / 256, lay.Mp, L), dim3(256), 0, s, packed, lay, L, M, C);
+    hipLaunchKernelGGL(k_pack_C, dim3((lay.Mp + 255) / 256, lay.Mp, L), dim3(256), 0, s, packed, lay, L, M, C);
     MM_CHECK_LAUNCH();
   }
   return 0;
@@ -600,11 +617,12 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   MM_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
                      Z64, (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
-                     L, M, wl.Mp, d, mu, latmat, (T*)(ws + wl.w), (T*)(ws + wl.q), f1, cross, q_out);
+                     L, M, wl.Mp, d, mu, latmat, (double*)(ws + wl.w64), (double*)(ws + wl.q64), (T*)(ws + wl.w),
+                     f1, cross, q_out);
   MM_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_pairvec<T, DK>), dim3((wl.Mp + 255) / 256, wl.P, B), dim3(256), 0, s,
                      Z64, (const double*)(packed + ml.zbar), L, M, wl.Mp, d, wl.P, mu, pairmat,
-                     (T*)(ws + wl.rowA), (T*)(ws + wl.colB));
+                     (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO));
   MM_CHECK_LAUNCH();
   return 0;
 }
@@ -615,24 +633,32 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
   const int with_unc = (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0;
   const int full = (flags & MM_FULL_OUTPUT_COV) ? 1 : 0;
   if (with_unc && !has_C) return MM_E_NO_C;
-  const T* Cm = with_unc ? (const T*)(packed + ml.Cm) : nullptr;
+  const double* Cm = with_unc ? (const double*)(packed + ml.Cm) : nullptr;
   double* partB = (double*)(ws + wl.partB);
   double* partC = (double*)(ws + wl.partC);
-  int nsB_diag, nsB_off, nsC;
-  bool done = false;
-  if (sizeof(T) == 4 && !(flags & MM_FORCE_GENERIC) && mm_mfma_supported(d)) {
-    const int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, with_unc, &nsB_diag, &nsB_off, &nsC, s);
-    if (rc) return rc;
-    done = true;
-  }
-  if (!done) {
-    const int nrb = (wl.Mp + MM_GEN_ROWS - 1) / MM_GEN_ROWS, ncb = (wl.Mp + MM_GEN_COLS - 1) / MM_GEN_COLS;
-    hipLaunchKernelGGL((k_qred_generic<T, DK>), dim3(nrb * ncb, wl.P, B), dim3(256), 0, s,
-                       (const T*)(packed + ml.Zc), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS, ncb,
-                       (const T*)(ws + wl.w), (const T*)(ws + wl.q), (const T*)(ws + wl.rowA),
-                       (const T*)(ws + wl.colB), partB, partC);
-    MM_CHECK_LAUNCH();
-    nsB_diag = nsB_off = nsC = nrb * ncb;
+  const int nrb = (wl.Mp + MM_GEN_ROWS - 1) / MM_GEN_ROWS, ncb = (wl.Mp + MM_GEN_COLS - 1) / MM_GEN_COLS;
+  int nsB_diag = nrb * ncb, nsB_off = nrb * ncb, nsC = nrb * ncb;
+  // (1) diagonal pairs: always f64
+  hipLaunchKernelGGL((k_qred_generic<double, DK>), dim3(nrb * ncb, L, B), dim3(256), 0, s,
+                     (const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS, ncb, 0,
+                     (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+                     (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD), partB, partC);
+  MM_CHECK_LAUNCH();
+  // (2) off-diagonal pairs in T
+  if (wl.Po > 0) {
+    bool done = false;
+    if (sizeof(T) == 4 && !(flags & MM_FORCE_GENERIC) && mm_mfma_supported(d)) {
+      const int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, &nsB_off, s);
+      if (rc) return rc;
+      done = true;
+    }
+    if (!done) {
+      hipLaunchKernelGGL((k_qred_generic<T, DK>), dim3(nrb * ncb, wl.Po, B), dim3(256), 0, s,
+                         (const T*)(packed + ml.Zc), ml.Kz, (const double*)nullptr, L, wl.Mp, d, wl.P, wl.NS, ncb, L,
+                         (const T*)(ws + wl.w), (const T*)nullptr, (const T*)(ws + wl.rowO),
+                         (const T*)(ws + wl.colO), partB, partC);
+      MM_CHECK_LAUNCH();
+    }
   }
   const int n = B * wl.P;
   hipLaunchKernelGGL((k_finalize<T>), dim3((n + 255) / 256), dim3(256), 0, s,

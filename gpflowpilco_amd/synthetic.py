@@ -1,0 +1,114 @@
+"""Seeded synthetic SVGP dynamics models and input distributions (bench + parity tests).
+
+Recipe of SURVEY.md section 8d / BASELINE.md: Z ~ U[0,1]^{M x d} shared by all L outputs,
+lengthscales log-uniform in [0.3, 3], signal variance 0.89^2, noise 1e-2 * variance, targets
+drawn from the GP prior (+ noise), q_mu / q_sqrt = the exact posterior at Z (whitened),
+mu0 ~ U[0,1]^d, Sigma0 = random correlation scaled to std 0.1 (the reference tests'
+``generate_covariance``, ``tests/utils.py:99-121``).
+
+One deviation, stated in DESIGN.md: with ``stable=True`` the targets are
+``-0.5 (z_a - 0.5) + 0.25 * prior draw`` so that a closed d == L rollout stays inside the
+data's support; with pure prior draws the state leaves [0,1]^d within a few steps, every q
+underflows to zero and the timed kernels would run on all-zero operands.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import models as gp
+
+F64 = torch.float64
+
+
+@dataclass
+class SyntheticSVGP:
+  Z: np.ndarray            # [M, d] shared inducing inputs
+  lengthscales: np.ndarray  # [L, d]
+  variance: np.ndarray     # [L]
+  noise: np.ndarray        # [L]
+  q_mu: np.ndarray         # [M, L] (whitened)
+  q_sqrt: np.ndarray       # [L, M, M] (whitened)
+  mean_c: Optional[np.ndarray] = None
+  whiten: bool = True
+
+  @property
+  def shape(self):
+    return self.lengthscales.shape[0], self.Z.shape[0], self.Z.shape[1]
+
+  def to_model(self, device="cpu") -> gp.SVGP:
+    L = self.lengthscales.shape[0]
+    kernels = [gp.SquaredExponential(variance=torch.tensor(self.variance[a], dtype=F64, device=device),
+                                     lengthscales=torch.tensor(self.lengthscales[a], dtype=F64, device=device))
+               for a in range(L)]
+    Zt = torch.tensor(self.Z, dtype=F64, device=device)
+    iv = gp.SharedIndependentInducingVariables(gp.InducingPoints(Zt))
+    mean = gp.Zero() if self.mean_c is None else gp.Constant(torch.tensor(self.mean_c, dtype=F64, device=device))
+    return gp.SVGP(kernel=gp.SeparateIndependent(kernels), inducing_variable=iv,
+                   q_mu=torch.tensor(self.q_mu, dtype=F64, device=device),
+                   q_sqrt=torch.tensor(self.q_sqrt, dtype=F64, device=device),
+                   whiten=self.whiten, mean_function=mean, num_latent_gps=L)
+
+
+def make_svgp(L: int, M: int, d: int, seed: int, stable: bool = True,
+              device: str = "cpu", mean_c: bool = False) -> SyntheticSVGP:
+  """Build the synthetic model in float64 (torch; ``device`` only speeds up the Choleskys)."""
+  rng = np.random.default_rng(seed)
+  Z = rng.uniform(size=(M, d))
+  ls = np.exp(rng.uniform(np.log(0.3), np.log(3.0), size=(L, d)))
+  var = np.full(L, 0.89 ** 2)
+  noise = 1e-2 * var
+  eps_f = rng.standard_normal((L, M))
+  eps_n = rng.standard_normal((L, M))
+  q_mu = np.empty((M, L))
+  q_sqrt = np.empty((L, M, M))
+  Zt = torch.tensor(Z, dtype=F64, device=device)
+  eye = torch.eye(M, dtype=F64, device=device)
+  for a in range(L):
+    A = Zt / torch.tensor(ls[a], dtype=F64, device=device)
+    d2 = (A * A).sum(-1)[:, None] + (A * A).sum(-1)[None, :] - 2.0 * A @ A.T
+    K = var[a] * torch.exp(-0.5 * d2.clamp_min(0.0))
+    Lk = torch.linalg.cholesky(K + gp.DEFAULT_JITTER * eye)
+    draw = Lk @ torch.tensor(eps_f[a], dtype=F64, device=device)
+    if stable:
+      col = Zt[:, a % d]
+      y = -0.5 * (col - 0.5) + 0.25 * draw
+    else:
+      y = draw
+    y = y + np.sqrt(noise[a]) * torch.tensor(eps_n[a], dtype=F64, device=device)
+    Ly = torch.linalg.cholesky(K + noise[a] * eye)
+    m = K @ torch.cholesky_solve(y[:, None], Ly)                      # posterior mean of u
+    S = K - K @ torch.cholesky_solve(K, Ly)                          # posterior cov of u
+    v = torch.linalg.solve_triangular(Lk, m, upper=False)            # whitened mean
+    T1 = torch.linalg.solve_triangular(Lk, S, upper=False)
+    Sw = torch.linalg.solve_triangular(Lk, T1.T, upper=False)
+    Sw = 0.5 * (Sw + Sw.T) + 1e-10 * eye
+    q_mu[:, a] = v[:, 0].cpu().numpy()
+    q_sqrt[a] = torch.linalg.cholesky(Sw).cpu().numpy()
+  mc = rng.standard_normal(L) * 0.1 if mean_c else None
+  return SyntheticSVGP(Z=Z, lengthscales=ls, variance=var, noise=noise, q_mu=q_mu, q_sqrt=q_sqrt, mean_c=mc)
+
+
+def generate_covariance(rng, ndims, sample_shape=(), scale=None):
+  """Random-eigen covariance prior rescaled to a marginal std (tests/utils.py:99-121)."""
+  shape = tuple(sample_shape)
+  eigen_vals = -np.log(rng.uniform(size=shape + (1, ndims)))
+  A = rng.standard_normal(shape + (ndims, ndims))
+  orthog = np.linalg.svd(A, full_matrices=True)[0]
+  sqrt_cov = np.sqrt(eigen_vals) * orthog
+  cov = sqrt_cov @ np.swapaxes(sqrt_cov, -1, -2)
+  if scale is not None:
+    istd = 1.0 / np.sqrt(np.diagonal(cov, axis1=-2, axis2=-1))
+    cov = (scale ** 2) * cov * istd[..., None] * istd[..., None, :]
+  return cov
+
+
+def make_inputs(B: int, d: int, seed: int, scale: float = 0.1, lo: float = 0.0, hi: float = 1.0):
+  """mu0 ~ U[lo,hi]^d, Sigma0 random correlation scaled to std ``scale`` -> numpy float64."""
+  rng = np.random.default_rng(seed)
+  mu = rng.uniform(lo, hi, size=(B, d))
+  Sigma = generate_covariance(rng, d, (B,), scale)
+  return mu, Sigma

@@ -1,0 +1,185 @@
+"""GPU parity: HIP path (through the C ABI) vs the fp64 CPU oracle on identical inputs.
+
+Tolerances (max abs error / max abs value of the tensor):
+  float64: 1e-9 on f1 / cross, 1e-6 on Sff -- the oracle itself carries cond(Kuu) * eps from
+           its O(M^3) triangular solves (Kuu + 1e-6 I has condition numbers ~1e7 here; the two
+           algebraically identical routes differ by ~1e-8 on the worst case), measured <= 1.3e-8.
+  float32: 1e-5 on f1 / cross, 2e-3 on Sff -- the state, outputs and the off-diagonal M x M
+           reduce are f32 (diagonal pairs stay f64, DESIGN.md "fp32 error budget");
+           measured <= 2.6e-4.
+"""
+import numpy as np
+import pytest
+import torch
+
+from gpflowpilco_amd import ops
+from gpflowpilco_amd.moment_matching import GaussianMoments, moment_matching
+from gpflowpilco_amd.synthetic import make_inputs, make_svgp
+from oracle import mm_oracle as mo
+from tests.helpers import (gp_model_from_oracle, oracle_params, random_svgp_params, scale_err, to_dev)
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float64: dict(f1=1e-9, Sff=1e-6, cross=1e-9),
+       torch.float32: dict(f1=1e-5, Sff=2e-3, cross=1e-5)}
+
+CASES = [
+    # name,        L, M,   d, B, scale
+    ("reftest_so", 1, 16, 4, 2, 0.01),
+    ("reftest_mo", 2, 16, 4, 2, 0.01),
+    ("c1_like", 4, 100, 6, 1, 0.1),
+    ("c2_cut", 4, 128, 5, 4, 0.1),
+    ("ragged_M", 3, 203, 7, 3, 0.2),
+    ("wide_sigma", 2, 64, 3, 5, 0.5),
+    ("d16", 2, 130, 16, 2, 0.1),
+    ("m512", 4, 512, 8, 2, 0.1),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_moment_match_synthetic(case, dtype, device):
+  _, L, M, d, B, scale = case
+  syn = make_svgp(L, M, d, seed=1000 + L + M, mean_c=True)
+  mu, Sigma = make_inputs(B, d, seed=7, scale=scale)
+  f1o, Sffo, cro = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
+  model = syn.to_model(device)
+  x = GaussianMoments((to_dev(mu, device, dtype), to_dev(Sigma, device, dtype)), centered=True)
+  match = moment_matching(x, model)
+  tol = TOL[dtype]
+  assert match.cross[1] is True
+  assert scale_err(match.y.mean(), f1o) < tol["f1"]
+  assert scale_err(match.y.covariance(), Sffo) < tol["Sff"]
+  assert scale_err(match.cross[0], cro) < tol["cross"]
+  # Cov(x, f) = Sigma @ cross_pre (gaussian.py:38-39)
+  assert scale_err(match.cross_covariance(), Sigma @ cro) < tol["cross"]
+
+
+@pytest.mark.parametrize("whiten", [False, True])
+@pytest.mark.parametrize("flags", [(True, True), (True, False), (False, True), (False, False)],
+                         ids=["full_unc", "full_nounc", "diag_unc", "diag_nounc"])
+def test_reference_test_design_svgp(whiten, flags, device):
+  """tests/test_moment_matching.py:199-264 design (LCM 2->3, Constant mean), all flag combos."""
+  full, unc = flags
+  p = random_svgp_params(seed=5, L=2, M=16, d=4, whiten=whiten, W_rows=3)
+  rng = np.random.default_rng(3)
+  mu = rng.uniform(size=(2, 4))
+  from gpflowpilco_amd.synthetic import generate_covariance
+  Sigma = generate_covariance(rng, 4, (2,), 0.05)
+  f1o, Sffo, cro = mo.mm_gauss_svgp_mo(mu, Sigma, p, full_output_cov=full, model_uncertainty=unc, jitter=1e-3)
+  model = gp_model_from_oracle(p, device)
+  x = GaussianMoments((to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64)), centered=True)
+  m = moment_matching(x, model, full_output_cov=full, model_uncertainty=unc, jitter=1e-3)
+  cov = m.y.covariance()
+  cov = cov.diag_part() if not full else cov
+  assert scale_err(m.y.mean(), f1o) < 1e-9
+  assert scale_err(cov, Sffo) < 1e-8
+  assert scale_err(m.cross[0], cro) < 1e-9
+
+
+def test_single_output_and_gpr(device):
+  """_mm_gauss_svgp_so (models.py:129-197) and _mm_gauss_gpr (:44-111)."""
+  from gpflowpilco_amd import models as gp
+  rng = np.random.default_rng(11)
+  d, N, B = 4, 16, 2
+  p = random_svgp_params(seed=9, L=1, M=N, d=d, whiten=False)
+  mu = rng.uniform(size=(B, d))
+  from gpflowpilco_amd.synthetic import generate_covariance
+  Sigma = generate_covariance(rng, d, (B,), 0.05)
+  f1o, Sffo, cro = mo.mm_gauss_svgp_so(mu, Sigma, p)
+  x = GaussianMoments((to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64)), centered=True)
+  m = moment_matching(x, gp_model_from_oracle(p, device))
+  assert scale_err(m.y.mean(), f1o) < 1e-9 and scale_err(m.y.covariance(), Sffo) < 1e-8
+  assert scale_err(m.cross[0], cro) < 1e-9
+
+  X = rng.uniform(size=(N, d)); Y = 0.89 * rng.standard_normal((N, 1))
+  ls = np.exp(rng.uniform(np.log(0.3), np.log(3), size=d))
+  gpr_o = mo.GPRParams(X=X, Y=Y, lengthscales=ls, variance=0.89 ** 2, noise_variance=1e-3, mean_c=1.3)
+  f1o, Sffo, cro = mo.mm_gauss_gpr(mu, Sigma, gpr_o)
+  t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=device)
+  gpr = gp.GPR(data=(t(X), t(Y)), kernel=gp.SquaredExponential(variance=t(0.89 ** 2), lengthscales=t(ls)),
+               mean_function=gp.Constant(t([1.3])), noise_variance=t(1e-3))
+  m = moment_matching(x, gpr)
+  assert scale_err(m.y.mean(), f1o) < 1e-9 and scale_err(m.y.covariance(), Sffo) < 1e-7
+  assert scale_err(m.cross[0], cro) < 1e-9
+  md = moment_matching(x, gpr, full_output_cov=False)
+  assert torch.allclose(md.y.covariance().diag_part(), torch.diagonal(m.y.covariance(), dim1=-2, dim2=-1), rtol=1e-12, atol=0)
+
+
+def test_stage_api_q_terms(device):
+  """mm_q_forward's q equals eKfu (gpflow <k(x,Z)>) and stage-wise == fused."""
+  syn = make_svgp(3, 150, 5, seed=21)
+  mu, Sigma = make_inputs(4, 5, seed=8, scale=0.15)
+  po = oracle_params(syn)
+  eKfu = mo.eKfu_list(mu, Sigma, po.Z, po.lengthscales, po.variance)          # [B,M,L]
+  model = syn.to_model(device)
+  pm = model.packed(torch.float64, True, device)
+  flags = ops.make_flags(True, True)
+  mu_t, S_t = to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64)
+  f1, cross, q = ops.q_forward(pm, mu_t, S_t, flags, want_q=True)
+  Sff = ops.Q_reduce_forward(pm, 4, flags)
+  assert scale_err(q.transpose(1, 2), eKfu) < 1e-12
+  f1b, Sffb, crossb = ops.moment_match(pm, mu_t, S_t)
+  assert torch.equal(f1, f1b) and torch.equal(Sff, Sffb) and torch.equal(cross, crossb)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_euler_and_rollout(dtype, device):
+  """MomentMatchingEuler.step and a 5-step closed rollout vs the oracle (solvers.py:67-135)."""
+  L = d = 4
+  syn = make_svgp(L, 96, d, seed=33)
+  mu, Sigma = make_inputs(3, d, seed=5, scale=0.1, lo=0.3, hi=0.7)
+  po = oracle_params(syn)
+  muH, SH, traj = mo.rollout_closed(mu, Sigma, po, 5, dt=1.0, keep=True)
+  model = syn.to_model(device)
+  pm = model.packed(dtype, True, device)
+  mu_t, S_t = to_dev(mu, device, dtype), to_dev(Sigma, device, dtype)
+  m1, S1, tmu, tS = ops.rollout_closed(pm, mu_t, S_t, 5, dt=1.0, keep_trajectory=True)
+  tol = 1e-6 if dtype == torch.float64 else 2e-3
+  for h in range(5):
+    assert scale_err(tmu[h], traj[h][0]) < tol
+    assert scale_err(tS[h], traj[h][1]) < tol
+  assert torch.equal(m1, tmu[-1]) and torch.equal(S1, tS[-1])
+  # one explicit step through the stage API
+  f1, Sff, cross = ops.moment_match(pm, mu_t, S_t)
+  m2, S2 = ops.euler_update(mu_t, S_t, f1, Sff, cross, dt=1.0)
+  assert torch.allclose(m2, tmu[0]) and torch.allclose(S2, tS[0])
+  pm.check_status(3)
+
+
+def test_sigma_to_zero_limit(device):
+  """Sigma -> 0: f1 -> GP predictive mean, Sff -> predictive variance."""
+  from oracle.pin_oracle import svgp_predict_f
+  syn = make_svgp(3, 80, 4, seed=41)
+  mu, _ = make_inputs(5, 4, seed=2)
+  Sigma = np.broadcast_to(1e-12 * np.eye(4), (5, 4, 4)).copy()
+  mean, cov = svgp_predict_f(mu, oracle_params(syn))
+  model = syn.to_model(device)
+  x = GaussianMoments((to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64)), centered=True)
+  m = moment_matching(x, model)
+  assert scale_err(m.y.mean(), mean) < 1e-8
+  assert np.abs(m.y.covariance().cpu().numpy() - cov).max() < 1e-8
+
+
+def test_non_pd_sigma_is_flagged(device):
+  syn = make_svgp(2, 32, 3, seed=2)
+  mu, Sigma = make_inputs(4, 3, seed=1)
+  Sigma[2] = -np.eye(3)
+  model = syn.to_model(device)
+  pm = model.packed(torch.float64, True, device)
+  ops.moment_match(pm, to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64))
+  with pytest.raises(FloatingPointError, match="batch element 2"):
+    pm.check_status(4)
+
+
+def test_bad_arguments_raise(device):
+  syn = make_svgp(2, 32, 3, seed=2)
+  model = syn.to_model(device)
+  pm_noC = model.packed(torch.float64, False, device)
+  mu, Sigma = make_inputs(2, 3, seed=1)
+  with pytest.raises(ValueError, match="MM_E_NO_C"):
+    ops.moment_match(pm_noC, to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64), model_uncertainty=True)
+  with pytest.raises(TypeError):
+    ops.moment_match(pm_noC, to_dev(mu, device, torch.float32), to_dev(Sigma, device, torch.float32))
+  with pytest.raises(RuntimeError, match="GPU only"):
+    ops.moment_match(pm_noC, torch.tensor(mu), torch.tensor(Sigma))
