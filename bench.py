@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""Benchmark of the moment-matched GP rollout (BASELINE.json metric) on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W [--config c3|c2|c1]
+
+One "step" = one rollout time-step of the whole local batch: q stage + fused Q reduce +
+Euler moment update for B input distributions (state resets to (mu0, Sigma0) every H steps,
+per-step expected costs are all-gathered after each H-step rollout).  value = B_total * K /
+wall time ("rollout step-elements per second", B x H per rollout time).  Weak scaling: every
+rank owns B_local = B input distributions; no data-path collective inside a rollout.
+
+The JSON line also carries
+  roofline     -- the dominant kernel (f32 MFMA off-diagonal reduce), HIP-event timed in the
+                  timed region on the launch stream; algorithmic flops per SURVEY.md section 8d;
+  cpu_baseline -- the literal fp64 CPU oracle (reference algorithm: materialised eKuffu +
+                  triangular solves) timed on this host on a bounded sample (rank 0, N=1);
+  parity       -- max abs error of one GPU step against that oracle on the same inputs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from gpflowpilco_amd import _lib, ops  # noqa: E402
+from gpflowpilco_amd.cost import expected_gaussian_cost  # noqa: E402
+from gpflowpilco_amd.synthetic import make_inputs, make_svgp  # noqa: E402
+
+CONFIGS = {
+    # name: (L, M, d, H, B_local, dtype, seed)   -- BASELINE.json configs[0..2]
+    "c1": dict(L=6, M=100, d=6, H=30, B=1, dtype=torch.float64, seed=1000,
+               label="C1-shaped closed rollout: N=100 d=6 D=6 H=30 B=1 fp64"),
+    "c2": dict(L=5, M=1000, d=5, H=40, B=64, dtype=torch.float64, seed=1001,
+               label="C2-shaped closed rollout: N=1000 d=5 D=5 H=40 B=64 fp64"),
+    "c3": dict(L=8, M=2000, d=8, H=40, B=256, dtype=torch.float32, seed=1002,
+               label="C3: N=2000 d=8 D=8 H=40 B=256 per GPU fp32 closed drift rollout"),
+}
+PEAK_TFLOPS = {torch.float32: 157.3, torch.float64: 78.6}   # MI355X_MICROARCH.md dense MFMA peaks
+
+
+def parse():
+  ap = argparse.ArgumentParser()
+  ap.add_argument("--gpus", type=int, default=1)
+  ap.add_argument("--steps", type=int, default=80)
+  ap.add_argument("--warmup", type=int, default=8)
+  ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+  ap.add_argument("--batch", type=int, default=None, help="override B per GPU")
+  ap.add_argument("--no-cpu-baseline", action="store_true")
+  ap.add_argument("--force-generic", action="store_true")
+  return ap.parse_args()
+
+
+def main():
+  args = parse()
+  rank = int(os.environ.get("RANK", "0"))
+  world = int(os.environ.get("WORLD_SIZE", "1"))
+  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if not torch.cuda.is_available():
+    raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+  torch.cuda.set_device(local_rank)
+  dev = torch.device("cuda", local_rank)
+  dist = None
+  if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("nccl", device_id=dev)
+
+  cfg = dict(CONFIGS[args.config])
+  if args.batch:
+    cfg["B"] = args.batch
+  L, M, d, H, B, dtype = cfg["L"], cfg["M"], cfg["d"], cfg["H"], cfg["B"], cfg["dtype"]
+  syn = make_svgp(L, M, d, seed=cfg["seed"], device=str(dev))
+  model = syn.to_model(dev)
+  pm = model.packed(dtype, True, dev)
+  mu0_np, S0_np = make_inputs(B, d, seed=2000 + rank, scale=0.1, lo=0.3, hi=0.7)
+  mu0 = torch.tensor(mu0_np, dtype=dtype, device=dev)
+  S0 = torch.tensor(S0_np, dtype=dtype, device=dev)
+  target = torch.full((d,), 0.5, dtype=dtype, device=dev)
+  precis = torch.eye(d, dtype=dtype, device=dev) * 4.0
+
+  base = ops.make_flags(True, True, args.force_generic)
+  F = _lib
+  traj_mu = torch.empty(H, B, d, dtype=dtype, device=dev)
+  traj_S = torch.empty(H, B, d, d, dtype=dtype, device=dev)
+  gathered = [torch.empty(B, H, dtype=dtype, device=dev) for _ in range(world)] if world > 1 else None
+  ev = []
+  state = {"mu": mu0.clone(), "S": S0.clone(), "h": 0, "cost": None}
+
+  def one_step(timed):
+    if state["h"] == 0:
+      state["mu"], state["S"] = mu0.clone(), S0.clone()
+    f1, cross, _ = ops.q_forward(pm, state["mu"], state["S"], base)
+    ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_DIAG)
+    if timed:
+      e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+      e0.record()
+    ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_OFFDIAG)
+    if timed:
+      e1.record(); ev.append((e0, e1))
+    Sff = ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_FINALIZE)
+    state["mu"], state["S"] = ops.euler_update(state["mu"], state["S"], f1, Sff, cross, 1.0)
+    traj_mu[state["h"]].copy_(state["mu"]); traj_S[state["h"]].copy_(state["S"])
+    state["h"] += 1
+    if state["h"] == H:
+      # per-step cost statistic of the finished rollout, [B_local, H] -> all ranks
+      cost = expected_gaussian_cost(traj_mu, traj_S, target, precis).T.contiguous()
+      if world > 1:
+        dist.all_gather(gathered, cost)
+        state["cost"] = torch.cat(gathered, 0)
+      else:
+        state["cost"] = cost
+      state["h"] = 0
+
+  def fence():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(args.warmup):
+    one_step(False)
+  state["h"] = 0
+  fence()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    one_step(True)
+  fence()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+  pm.check_status(B)
+  if not torch.isfinite(state["S"]).all():
+    raise SystemExit("non-finite state in the timed rollout")
+
+  # ---- roofline of the dominant kernel (off-diagonal f32 MFMA reduce) ---------------------
+  k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+  Po = L * (L - 1) // 2
+  flops = float(B) * Po * M * M * (2 * d + 12)            # E * (2d + 12), E = B*Po*M^2
+  achieved = flops / (k_ms * 1e-3) / 1e12 if Po else 0.0
+  roofline = {"bound": "mfma", "kernel": "k_qred_f32_mfma" if (dtype == torch.float32 and not args.force_generic) else "k_qred_generic",
+              "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
+              "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": None,
+              "kernel_ms": round(k_ms, 4),
+              "flops_per_launch": flops, "entries_per_launch": float(B) * Po * M * M}
+
+  out = {
+      "metric": "moment_matched_rollout_step_elements_per_sec",
+      "value": round(B * world * args.steps / elapsed, 2),
+      "unit": "rollout step-elements/s (B*H per rollout second)",
+      "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
+      "config": {"workload": cfg["label"], "N": M, "d": d, "D": L, "H": H,
+                 "B_per_gpu": B, "B_total": B * world, "parallelism": f"dp{world} over B",
+                 "diag_pairs": "f64", "offdiag_pairs": "f32" if dtype == torch.float32 else "f64"},
+      "roofline": roofline,
+  }
+
+  # ---- CPU baseline + parity (rank 0, N == 1 only) -----------------------------------------
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    from oracle import mm_oracle as mo
+    Bc = 1 if M >= 1000 else min(B, 4)
+    po = mo.SVGPParams(Z=np.broadcast_to(syn.Z, (L, M, d)).copy(), lengthscales=syn.lengthscales,
+                       variance=syn.variance, q_mu=syn.q_mu, q_sqrt=syn.q_sqrt, whiten=True)
+    mu_c, S_c = mu0_np[:Bc].copy(), S0_np[:Bc].copy()
+    t0 = time.perf_counter()
+    nst = 0
+    while True:
+      f1o, Sffo, cro = mo.mm_gauss_svgp_mo(mu_c, S_c, po)
+      nst += 1
+      if nst == 1:
+        first = (f1o, Sffo, cro)
+      Sxf = mo.cross_covariance(S_c, cro, True)
+      mu_c, S_c = mo.euler_moment_update(mu_c, S_c, f1o, Sffo, Sxf, 1.0)
+      if time.perf_counter() - t0 > 10.0 or nst >= H:
+        break
+    tc = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": round(Bc * nst / tc, 4), "unit": out["unit"],
+                           "cores": os.cpu_count(), "kind": "port",
+                           "sample": f"literal fp64 oracle (materialised eKuffu [B,L,M,L,M] + triangular solves, "
+                                     f"numpy/OpenBLAS threads), B={Bc}, {nst} step(s) of the same rollout, {tc:.1f}s"}
+    f1, Sff, cross = ops.moment_match(pm, mu0[:Bc].contiguous(), S0[:Bc].contiguous())
+    err = lambda g, w: float(np.abs(g.double().cpu().numpy() - w).max())
+    out["parity"] = {"vs": "fp64 CPU oracle, first step, same inputs", "B": Bc,
+                     "max_abs_err": {"f1": err(f1, first[0]), "Sff": err(Sff, first[1]), "cross_pre": err(cross, first[2])},
+                     "max_abs": {"f1": float(np.abs(first[0]).max()), "Sff": float(np.abs(first[1]).max()),
+                                 "cross_pre": float(np.abs(first[2]).max())}}
+  if rank == 0:
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+  main()

@@ -18,6 +18,9 @@ MM_M_ALIGN = 128
 MM_FULL_OUTPUT_COV = 1
 MM_MODEL_UNCERTAINTY = 2
 MM_FORCE_GENERIC = 4
+MM_STAGE_DIAG = 8
+MM_STAGE_OFFDIAG = 16
+MM_STAGE_FINALIZE = 32
 
 ERRORS = {
     -1: "MM_E_ARG: NULL pointer or non-positive size",
@@ -47,6 +50,7 @@ SIGNATURES = {
                                       C.c_int, C.c_double, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "mm_euler_update": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 8),
+    "mm_expected_cost": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "mm_rollout_closed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.c_double, C.c_int, C.c_double,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

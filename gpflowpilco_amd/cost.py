@@ -1,0 +1,42 @@
+"""Closed-form expected saturating cost (``GaussianObjective``, gpflow_pilco/components.py:21-41).
+
+The per-step cost statistic that the multi-GPU rollout all-gathers.
+On the GPU it runs as one HIP kernel (``mm_expected_cost``); the torch expression below is
+the host-side definition used for CPU tensors (policy evaluation off the hot path).
+"""
+from __future__ import annotations
+
+import torch
+
+from .moment_matching import GaussianMoments
+
+
+def expected_gaussian_cost(mean: torch.Tensor, cov: torch.Tensor, target: torch.Tensor,
+                           precis: torch.Tensor) -> torch.Tensor:
+  """E_{x~N(mean,cov)}[-exp(-0.5 (x-x*)^T W (x-x*))]  (components.py:29-37) -> mean.shape[:-1]."""
+  if mean.is_cuda:
+    from . import ops
+    return ops.expected_cost(mean, cov, target, precis)
+  d = mean.shape[-1]
+  eye = torch.eye(d, dtype=mean.dtype, device=mean.device)
+  IpSW = eye + cov @ precis
+  iSpW = precis @ torch.linalg.inv(IpSW)
+  err = mean - target
+  dist2 = (err * (iSpW @ err.unsqueeze(-1)).squeeze(-1)).sum(-1)
+  return -torch.rsqrt(torch.linalg.det(IpSW)) * torch.exp(-0.5 * dist2)
+
+
+class GaussianObjective:
+  """``GaussianObjective`` (components.py:21-41)."""
+
+  def __init__(self, target: torch.Tensor, precis: torch.Tensor):
+    self.target = target
+    self.precis = precis
+
+  def __call__(self, x, t=None):
+    if isinstance(x, GaussianMoments):
+      return expected_gaussian_cost(x.mean(), x.covariance(dense=True), self.target.to(x.mean()),
+                                    self.precis.to(x.mean()))
+    err = x - self.target
+    dist2 = (err * (self.precis @ err.unsqueeze(-1)).squeeze(-1)).sum(-1)
+    return -torch.exp(-0.5 * dist2)

@@ -54,9 +54,10 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 // Rows per workgroup of the generic reduce kernel / columns per workgroup.
 #define MM_GEN_ROWS 64
 #define MM_GEN_COLS 256
-// MFMA kernels (f32): row panel per workgroup (4 waves x 64 rows), 128x128 diagonal tiles.
+// f32 MFMA kernel: row panel per workgroup (4 waves x 64 rows).
 #define MM_PANEL_ROWS 256
-#define MM_DIAG_TILE 128
+// f64 MFMA kernel: 64 x 64 tiles
+#define MM_F64_TILE 64
 
 // Diagonal pairs (a == a', p < L) are always reduced in f64 (they carry the C-weighted
 // term, whose conditioning rules out f32); off-diagonal pairs (p >= L) in T.
@@ -85,11 +86,13 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.Mp = mm_round_up_int(M, MM_M_ALIGN);
   o.P = mm_num_pairs(L, flags);
   o.Po = o.P - L;
+  // partial-sum slots per (b, pair): the largest of what the reduce kernels write
   const int nrb = (o.Mp + MM_GEN_ROWS - 1) / MM_GEN_ROWS;
   const int ncb = (o.Mp + MM_GEN_COLS - 1) / MM_GEN_COLS;
-  const int nt = o.Mp / MM_DIAG_TILE;
-  int ns = nrb * ncb;
-  if (nt * (nt + 1) / 2 > ns) ns = nt * (nt + 1) / 2;
+  const int nt = o.Mp / MM_F64_TILE;
+  int ns = nrb * ncb;                                          // generic kernel
+  if (nt * (nt + 1) / 2 > ns) ns = nt * (nt + 1) / 2;          // f64 MFMA kernel, diagonal pairs
+  if (dtype == MM_F64 && o.Po > 0 && nt * nt > ns) ns = nt * nt;  // f64 MFMA kernel, off-diagonal
   o.NS = ns;
   size_t off = 0;
   o.pairmat = off; off = mm_align_up(off + (size_t)B * o.P * (3 * d * d + 1) * 8, A);

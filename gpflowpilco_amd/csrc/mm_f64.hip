@@ -1,0 +1,230 @@
+// f64 MFMA fused reduce (gfx950): the diagonal kernel pairs (a == a') of every mode, and the
+// off-diagonal pairs of the f64 mode.
+//
+// Diagonal pairs carry the C-weighted term  sum_ij C_ij q_i exp(delta_ij) q_j  of
+// models.py:254-261 (tr(W) and sum(W o q_cov)); C = Kuu^-1 S Kuu^-1 - Kuu^-1 has norm up to
+// 1/jitter = 1e6, so any per-entry f32 rounding of exp(delta) is amplified beyond use
+// (DESIGN.md "fp32 error budget") -- these pairs are reduced in f64 in both modes.
+//
+//   tile      : 64 x 64 entries per workgroup (4 waves, 32 x 32 each = 2 x 2 MFMA tiles of
+//               v_mfma_f64_16x16x4_f64; one extra k-step adds rho_i + gamma'_j)
+//   diag mode : only tile pairs it <= jt are visited (Q_aa and C_a are symmetric; strictly
+//               upper tiles count twice); the C tile is loaded ONCE into registers and the
+//               workgroup loops over its chunk of the batch -- C traffic is M^2*8 B per chunk
+//               instead of per batch element;
+//   expm1     : branch-free f64 (k ln2 + r reduction, degree-13 polynomial, ldexp), relative
+//               error ~2e-16 of expm1 itself for every argument;
+//   output    : per (b, pair, tile) partial sums -> slab (deterministic, no atomics).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "mm_common.h"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void mm_decode_pair_f(int p, int L, int& a, int& a2) {
+  if (p < L) { a = p; a2 = p; return; }
+  int r = p - L, i = 0;
+  while (r >= L - 1 - i) { r -= L - 1 - i; ++i; }
+  a = i; a2 = i + 1 + r;
+}
+
+__device__ __forceinline__ double mm_expm1_f64(double x) {
+  x = fmin(fmax(x, -800.0), 700.0);
+  const double kf = rint(x * 1.4426950408889634);
+  double r = fma(-kf, 6.93147180369123816490e-01, x);
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  double q = 1.6059043836821613e-10;            // 1/13!
+  q = fma(q, r, 2.08767569878681e-09);          // 1/12!
+  q = fma(q, r, 2.505210838544172e-08);         // 1/11!
+  q = fma(q, r, 2.755731922398589e-07);         // 1/10!
+  q = fma(q, r, 2.7557319223985893e-06);        // 1/9!
+  q = fma(q, r, 2.48015873015873e-05);          // 1/8!
+  q = fma(q, r, 1.984126984126984e-04);         // 1/7!
+  q = fma(q, r, 1.388888888888889e-03);         // 1/6!
+  q = fma(q, r, 8.333333333333333e-03);         // 1/5!
+  q = fma(q, r, 4.1666666666666664e-02);        // 1/4!
+  q = fma(q, r, 1.6666666666666666e-01);        // 1/3!
+  q = fma(q, r, 0.5);
+  q = fma(q, r, 1.0);
+  const double p = q * r;                       // expm1(r)
+  const double s = ldexp(1.0, (int)kf);
+  return fma(s, p, s - 1.0);                    // 2^k (1 + p) - 1
+}
+
+// KS4: number of K=4 MFMA steps covering the d input dimensions.
+// grid: x = tile pairs (diag: nt(nt+1)/2 upper pairs; else nt*nt), y = pairs of this launch,
+//       z = batch chunks.  Row/col operand arrays are indexed by the local pair index.
+template <int KS4, bool DIAG>
+__global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restrict__ Zc, int Kz,
+                                                          const double* __restrict__ Cm,
+                                                          int L, int Mp, int d, int P, int NS, int p0,
+                                                          int B, int bchunk,
+                                                          const double* __restrict__ w,
+                                                          const double* __restrict__ q,
+                                                          const double* __restrict__ rowA,
+                                                          const double* __restrict__ colB,
+                                                          double* __restrict__ partB,
+                                                          double* __restrict__ partC) {
+  const int nt = Mp / MM_F64_TILE;
+  int it, jt;
+  if (DIAG) {                       // blockIdx.x -> (it <= jt), row-major over the upper triangle
+    int r = blockIdx.x; it = 0;
+    while (r >= nt - it) { r -= nt - it; ++it; }
+    jt = it + r;
+  } else {
+    it = blockIdx.x / nt; jt = blockIdx.x - it * nt;
+  }
+  const int lp = blockIdx.y, np = gridDim.y, p = p0 + lp;
+  int a, a2;
+  mm_decode_pair_f(p, L, a, a2);
+  const bool withC = DIAG && (Cm != nullptr);
+  const double sym = (DIAG && it != jt) ? 2.0 : 1.0;
+
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  const int rbase = it * MM_F64_TILE + (wv >> 1) * 32;
+  const int cbase = jt * MM_F64_TILE + (wv & 1) * 32;
+
+  // b-independent A operands (centred inducing inputs of latent a)
+  const double* zr = Zc + (size_t)a * Mp * Kz;
+  double areg[2][KS4];
+#pragma unroll
+  for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+    for (int s = 0; s < KS4; ++s) {
+      const int k = 4 * s + kq;
+      const double v = zr[(size_t)(rbase + rt * 16 + l15) * Kz + (k < Kz ? k : Kz - 1)];
+      areg[rt][s] = (k < Kz) ? v : 0.0;
+    }
+  // C tile -> registers (element (row(rt, r), col(ct)) in the MFMA accumulator layout)
+  double creg[2][2][4];
+  if (withC) {
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          creg[rt][ct][r] = Cm[((size_t)a * Mp + rbase + rt * 16 + kq + 4 * r) * Mp + cbase + ct * 16 + l15];
+  }
+  size_t boff[KS4];
+#pragma unroll
+  for (int s = 0; s < KS4; ++s) {
+    const int k = 4 * s + kq;
+    boff[s] = (size_t)(k < d ? k : d) * Mp;
+  }
+  const size_t goff = (size_t)d * Mp;
+
+  __shared__ double red[8];
+  const int b0 = blockIdx.z * bchunk;
+  const int b1 = (b0 + bchunk < B) ? b0 + bchunk : B;
+  for (int b = b0; b < b1; ++b) {
+    const double* ra = rowA + ((size_t)b * np + lp) * Mp;
+    const double* cb = colB + ((size_t)b * np + lp) * (size_t)(d + 1) * Mp;
+    const double* wr = w + ((size_t)b * L + a) * Mp;
+    const double* wc = w + ((size_t)b * L + a2) * Mp;
+    const double* qr = q + ((size_t)b * L + a) * Mp;
+
+    double ax[2], bx[2], breg[2][KS4], wj[2], qj[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const double rv = ra[rbase + rt * 16 + l15];
+      ax[rt] = (kq == 0) ? rv : (kq == 1 ? 1.0 : 0.0);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int col = cbase + ct * 16 + l15;
+#pragma unroll
+      for (int s = 0; s < KS4; ++s) breg[ct][s] = cb[boff[s] + col];
+      const double gv = cb[goff + col];
+      bx[ct] = (kq == 0) ? 1.0 : (kq == 1 ? gv : 0.0);
+      wj[ct] = wc[col];
+      qj[ct] = withC ? qr[col] : 0.0;      // a == a2 on the diagonal
+    }
+    double wi[2][4], qi[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + rt * 16 + kq + 4 * r;
+        wi[rt][r] = wr[row];
+        qi[rt][r] = withC ? qr[row] : 0.0;
+      }
+
+    double sB = 0.0, sC = 0.0;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      double pB = 0.0, pC = 0.0;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        f64x4 c = {0.0, 0.0, 0.0, 0.0};
+        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[rt], bx[ct], c, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < KS4; ++s)
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[rt][s], breg[ct][s], c, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double e = mm_expm1_f64(c[r]);
+          pB = fma(wi[rt][r], e, pB);
+          if (withC) pC = fma(creg[rt][ct][r], fma(qi[rt][r], e, qi[rt][r]), pC);
+        }
+      }
+      sB = fma(pB, wj[ct], sB);
+      sC = fma(pC, qj[ct], sC);
+    }
+    // workgroup reduction of (sB, sC) for this b
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      sB += __shfl_down(sB, off, 64);
+      sC += __shfl_down(sC, off, 64);
+    }
+    __syncthreads();
+    if (lane == 0) { red[wv] = sB; red[4 + wv] = sC; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      partB[((size_t)b * P + p) * NS + blockIdx.x] = sym * (red[0] + red[1] + red[2] + red[3]);
+      if (withC) partC[((size_t)b * L + a) * NS + blockIdx.x] = sym * (red[4] + red[5] + red[6] + red[7]);
+    }
+  }
+}
+
+int mm_f64_num_slots(int Mp, int diag) {
+  const int nt = Mp / MM_F64_TILE;
+  return diag ? nt * (nt + 1) / 2 : nt * nt;
+}
+
+// Launch over `npairs` pairs starting at global pair index p0.  diag != 0: pairs are (a, a).
+int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, int L, int Mp, int d, int P, int NS,
+                       int p0, int npairs, int B, int diag,
+                       const double* w, const double* q, const double* rowA, const double* colB,
+                       double* partB, double* partC, hipStream_t stream) {
+  if (npairs <= 0) return 0;
+  const int nslots = mm_f64_num_slots(Mp, diag);
+  if (nslots > NS) return MM_E_WORKSPACE;
+  // batch chunk: enough workgroups to fill the chip (>= ~8 per CU), as few C re-reads as possible
+  long long per_chunk = (long long)nslots * npairs;
+  int nchunk = (int)((2048 + per_chunk - 1) / per_chunk);
+  if (nchunk < 1) nchunk = 1;
+  if (nchunk > B) nchunk = B;
+  if (!diag) nchunk = B < 64 ? B : 64;       // no C reuse to protect: more, shorter workgroups
+  const int bchunk = (B + nchunk - 1) / nchunk;
+  nchunk = (B + bchunk - 1) / bchunk;
+  dim3 grid(nslots, npairs, nchunk);
+  const int ks4 = (d + 3) / 4;
+#define MM_LAUNCH_F64(KS_, DG_)                                                                    \
+  hipLaunchKernelGGL((k_qred_f64_mfma<KS_, DG_>), grid, dim3(256), 0, stream, Zc, Kz, Cm, L, Mp, d, \
+                     P, NS, p0, B, bchunk, w, q, rowA, colB, partB, partC)
+#define MM_LAUNCH_F64_KS(DG_)                                   \
+  do {                                                          \
+    if (ks4 <= 1) MM_LAUNCH_F64(1, DG_);                        \
+    else if (ks4 == 2) MM_LAUNCH_F64(2, DG_);                   \
+    else if (ks4 == 3) MM_LAUNCH_F64(3, DG_);                   \
+    else if (ks4 == 4) MM_LAUNCH_F64(4, DG_);                   \
+    else if (ks4 <= 6) MM_LAUNCH_F64(6, DG_);                   \
+    else MM_LAUNCH_F64(8, DG_);                                 \
+  } while (0)
+  if (diag) MM_LAUNCH_F64_KS(true); else MM_LAUNCH_F64_KS(false);
+#undef MM_LAUNCH_F64_KS
+#undef MM_LAUNCH_F64
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

@@ -544,13 +544,90 @@ __global__ __launch_bounds__(64) void k_euler(int d, double dt, const T* __restr
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_expected_cost: closed-form expected saturating cost (GaussianObjective, components.py:26-37)
+//   cost = -det(I + S W)^-1/2 exp(-0.5 err^T W (I + S W)^-1 err),  one 64-lane workgroup per element.
+//   Gaussian elimination with partial pivoting on [I + S W | err] in LDS (f64).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_expected_cost(int d, const T* __restrict__ mean, const T* __restrict__ cov,
+                                                      const T* __restrict__ target, const T* __restrict__ precis,
+                                                      T* __restrict__ cost) {
+  extern __shared__ double smem[];
+  const int dp = d + 2;
+  double* A = smem;               // [d][d+2]: I + S W | err | (pad)
+  double* W = A + d * dp;         // [d][d]
+  double* e0 = W + d * d;         // [d] err
+  __shared__ int piv;
+  __shared__ double detv;
+  const int n = blockIdx.x, lane = threadIdx.x;
+  for (int idx = lane; idx < d * d; idx += 64) W[idx] = (double)precis[idx];
+  if (lane < d) e0[lane] = (double)mean[(size_t)n * d + lane] - (double)target[lane];
+  if (lane == 0) detv = 1.0;
+  __syncthreads();
+  for (int idx = lane; idx < d * d; idx += 64) {
+    const int i = idx / d, j = idx - i * d;
+    double s = (i == j) ? 1.0 : 0.0;
+    for (int k = 0; k < d; ++k) s += (double)cov[((size_t)n * d + i) * d + k] * W[k * d + j];
+    A[i * dp + j] = s;
+  }
+  if (lane < d) A[lane * dp + d] = e0[lane];
+  __syncthreads();
+  for (int k = 0; k < d; ++k) {
+    if (lane == 0) {
+      int p = k; double best = fabs(A[k * dp + k]);
+      for (int i = k + 1; i < d; ++i) { const double v = fabs(A[i * dp + k]); if (v > best) { best = v; p = i; } }
+      piv = p;
+    }
+    __syncthreads();
+    const int p = piv;
+    if (p != k) {
+      for (int j = lane; j <= d; j += 64) { const double t = A[k * dp + j]; A[k * dp + j] = A[p * dp + j]; A[p * dp + j] = t; }
+      if (lane == 0) detv = -detv;
+    }
+    __syncthreads();
+    const double akk = A[k * dp + k];
+    if (lane == 0) detv *= akk;
+    // eliminate rows below k: entries (i, j), i > k, j > k (incl. the rhs column)
+    const int nr = d - 1 - k, nc = d - k;       // columns k+1 .. d
+    __syncthreads();
+    for (int idx = lane; idx < nr * nc; idx += 64) {
+      const int i = k + 1 + idx / nc, j = k + 1 + idx % nc;
+      A[i * dp + j] -= (A[i * dp + k] / akk) * A[k * dp + j];
+    }
+    __syncthreads();
+  }
+  // back substitution (serial, d <= 32): y = (I + S W)^-1 err
+  if (lane == 0) {
+    for (int i = d - 1; i >= 0; --i) {
+      double s = A[i * dp + d];
+      for (int j = i + 1; j < d; ++j) s -= A[i * dp + j] * A[j * dp + d];
+      A[i * dp + d] = s / A[i * dp + i];
+    }
+    double dist2 = 0.0;
+    for (int i = 0; i < d; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < d; ++j) s += W[i * d + j] * A[j * dp + d];
+      dist2 += e0[i] * s;
+    }
+    cost[n] = (T)(-rsqrt(detv) * exp(-0.5 * dist2));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 // f32 MFMA reduce kernels (mm_mfma.hip)
 extern "C" int mm_mfma_supported(int d);
-// off-diagonal pairs, f32: fills partB[b][p >= L][0 .. *ns_off)
+// off-diagonal pairs, f32: fills partB[b][p >= L][0 .. mm_mfma_num_slots(Mp))
+int mm_mfma_num_slots(int Mp);
+// f64 MFMA reduce (mm_f64.hip): diagonal pairs of both modes, off-diagonal pairs of the f64 mode
+int mm_f64_num_slots(int Mp, int diag);
+int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, int L, int Mp, int d, int P, int NS,
+                       int p0, int npairs, int B, int diag,
+                       const double* w, const double* q, const double* rowA, const double* colB,
+                       double* partB, double* partC, hipStream_t stream);
 int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
-                        int B, int L, int d, int* ns_off, hipStream_t stream);
+                        int B, int L, int d, hipStream_t stream);
 
 #define MM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -637,22 +714,42 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
   double* partB = (double*)(ws + wl.partB);
   double* partC = (double*)(ws + wl.partC);
   const int nrb = (wl.Mp + MM_GEN_ROWS - 1) / MM_GEN_ROWS, ncb = (wl.Mp + MM_GEN_COLS - 1) / MM_GEN_COLS;
-  int nsB_diag = nrb * ncb, nsB_off = nrb * ncb, nsC = nrb * ncb;
+  const bool generic = (flags & MM_FORCE_GENERIC) != 0;
+  const bool use_mfma32 = sizeof(T) == 4 && !generic && mm_mfma_supported(d);
+  const int ns_gen = nrb * ncb;
+  const int nsB_diag = generic ? ns_gen : mm_f64_num_slots(wl.Mp, 1), nsC = nsB_diag;
+  const int nsB_off = generic ? ns_gen : (sizeof(T) == 4 ? (use_mfma32 ? mm_mfma_num_slots(wl.Mp) : ns_gen)
+                                                         : mm_f64_num_slots(wl.Mp, 0));
+  int stages = flags & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE);
+  if (!stages) stages = MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE;
   // (1) diagonal pairs: always f64
-  hipLaunchKernelGGL((k_qred_generic<double, DK>), dim3(nrb * ncb, L, B), dim3(256), 0, s,
-                     (const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS, ncb, 0,
-                     (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
-                     (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD), partB, partC);
-  MM_CHECK_LAUNCH();
-  // (2) off-diagonal pairs in T
-  if (wl.Po > 0) {
-    bool done = false;
-    if (sizeof(T) == 4 && !(flags & MM_FORCE_GENERIC) && mm_mfma_supported(d)) {
-      const int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, &nsB_off, s);
+  if (stages & MM_STAGE_DIAG) {
+    if (generic) {
+      hipLaunchKernelGGL((k_qred_generic<double, DK>), dim3(nrb * ncb, L, B), dim3(256), 0, s,
+                         (const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS, ncb, 0,
+                         (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+                         (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD), partB, partC);
+      MM_CHECK_LAUNCH();
+    } else {
+      const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS,
+                                        0, L, B, 1, (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+                                        (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD),
+                                        partB, partC, s);
       if (rc) return rc;
-      done = true;
     }
-    if (!done) {
+  }
+  // (2) off-diagonal pairs in T
+  if (wl.Po > 0 && (stages & MM_STAGE_OFFDIAG)) {
+    if (use_mfma32) {
+      const int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, s);
+      if (rc) return rc;
+    } else if (sizeof(T) == 8 && !generic) {
+      const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, nullptr, L, wl.Mp, d, wl.P, wl.NS,
+                                        L, wl.Po, B, 0, (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+                                        (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO),
+                                        partB, partC, s);
+      if (rc) return rc;
+    } else {
       hipLaunchKernelGGL((k_qred_generic<T, DK>), dim3(nrb * ncb, wl.Po, B), dim3(256), 0, s,
                          (const T*)(packed + ml.Zc), ml.Kz, (const double*)nullptr, L, wl.Mp, d, wl.P, wl.NS, ncb, L,
                          (const T*)(ws + wl.w), (const T*)nullptr, (const T*)(ws + wl.rowO),
@@ -660,11 +757,13 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
       MM_CHECK_LAUNCH();
     }
   }
-  const int n = B * wl.P;
-  hipLaunchKernelGGL((k_finalize<T>), dim3((n + 255) / 256), dim3(256), 0, s,
-                     partB, partC, (const double*)(packed + ml.var), B, L, wl.P, wl.NS,
-                     nsB_diag, nsB_off, nsC, full, with_unc, jitter, Sff);
-  MM_CHECK_LAUNCH();
+  if (stages & MM_STAGE_FINALIZE) {
+    const int n = B * wl.P;
+    hipLaunchKernelGGL((k_finalize<T>), dim3((n + 255) / 256), dim3(256), 0, s,
+                       partB, partC, (const double*)(packed + ml.var), B, L, wl.P, wl.NS,
+                       nsB_diag, nsB_off, nsC, full, with_unc, jitter, Sff);
+    MM_CHECK_LAUNCH();
+  }
   return 0;
 }
 
@@ -801,4 +900,22 @@ extern "C" int mm_rollout_closed(const void* packed, size_t packed_bytes, int L,
   if (dtype == MM_F64) { MM_DISPATCH(double, CALL_R) }
   MM_DISPATCH(float, CALL_R)
 #undef CALL_R
+}
+
+extern "C" int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
+                                const void* target, const void* precis, void* cost, void* stream) {
+  if (N <= 0 || d <= 0) return MM_E_ARG;
+  if (d > MM_DMAX) return MM_E_DIM;
+  if (dtype != MM_F32 && dtype != MM_F64) return MM_E_DTYPE;
+  if (!mean || !cov || !target || !precis || !cost) return MM_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t shm = (size_t)(d * (d + 2) + d * d + d) * sizeof(double);
+  if (dtype == MM_F64)
+    hipLaunchKernelGGL((k_expected_cost<double>), dim3(N), dim3(64), shm, s, d, (const double*)mean, (const double*)cov,
+                       (const double*)target, (const double*)precis, (double*)cost);
+  else
+    hipLaunchKernelGGL((k_expected_cost<float>), dim3(N), dim3(64), shm, s, d, (const float*)mean, (const float*)cov,
+                       (const float*)target, (const float*)precis, (float*)cost);
+  MM_CHECK_LAUNCH();
+  return 0;
 }

@@ -210,3 +210,18 @@ def rollout_closed(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor, num_s
                                ws.data_ptr(), ws.numel(), pm.status().data_ptr(), _stream(pm.device))
   check(rc, "mm_rollout_closed")
   return (mu, Sigma, tmu, tS) if keep_trajectory else (mu, Sigma)
+
+
+def expected_cost(mean: torch.Tensor, cov: torch.Tensor, target: torch.Tensor, precis: torch.Tensor):
+  """GaussianObjective expected cost on the GPU: mean [...,d], cov [...,d,d] -> [...]."""
+  _require_device(mean, cov, target, precis)
+  d = mean.shape[-1]
+  lead = mean.shape[:-1]
+  m2 = mean.reshape(-1, d).contiguous()
+  c2 = cov.reshape(-1, d, d).contiguous().to(mean.dtype)
+  out = torch.empty(m2.shape[0], dtype=mean.dtype, device=mean.device)
+  rc = lib().mm_expected_cost(m2.shape[0], d, _dtype_code(mean.dtype), m2.data_ptr(), c2.data_ptr(),
+                              target.to(mean).contiguous().data_ptr(), precis.to(mean).contiguous().data_ptr(),
+                              out.data_ptr(), _stream(mean.device))
+  check(rc, "mm_expected_cost")
+  return out.reshape(lead)

@@ -85,6 +85,9 @@ def make_svgp(L: int, M: int, d: int, seed: int, stable: bool = True,
     v = torch.linalg.solve_triangular(Lk, m, upper=False)            # whitened mean
     T1 = torch.linalg.solve_triangular(Lk, S, upper=False)
     Sw = torch.linalg.solve_triangular(Lk, T1.T, upper=False)
+    Sw = 0.5 * (Sw + Sw.T)
+    ew, ev = torch.linalg.eigh(Sw)                                   # clip rounding-negative modes
+    Sw = (ev * ew.clamp_min(1e-8)) @ ev.T
     Sw = 0.5 * (Sw + Sw.T) + 1e-10 * eye
     q_mu[:, a] = v[:, 0].cpu().numpy()
     q_sqrt[a] = torch.linalg.cholesky(Sw).cpu().numpy()

@@ -45,6 +45,11 @@ extern "C" {
 #define MM_FULL_OUTPUT_COV   1   /* models.py full_output_cov=True: Sff is [B,L,L]; else [B,L]     */
 #define MM_MODEL_UNCERTAINTY 2   /* models.py model_uncertainty=True: adds E[Var f] (needs C)      */
 #define MM_FORCE_GENERIC     4   /* use the portable VALU reduce kernel even where an MFMA one exists */
+/* mm_Q_reduce_forward only: run a subset of its launches (none of the three bits = all three);
+ * lets a caller bracket each kernel with its own events (bench.py does). */
+#define MM_STAGE_DIAG        8   /* f64 reduce of the diagonal pairs a == a' (incl. the C-weighted term) */
+#define MM_STAGE_OFFDIAG    16   /* T reduce of the off-diagonal pairs a < a'                          */
+#define MM_STAGE_FINALIZE   32   /* partial slabs -> Sff                                               */
 
 /* error codes */
 #define MM_E_ARG      (-1)  /* NULL pointer / non-positive size                  */
@@ -117,6 +122,13 @@ int mm_rollout_closed(const void* packed, size_t packed_bytes, int L, int M, int
                       void* mu, void* Sigma, void* traj_mu, void* traj_Sigma,
                       void* workspace, size_t workspace_bytes,
                       int32_t* status, void* stream);
+
+/* Closed-form expected saturating cost E[-exp(-0.5 (x - x*)^T W (x - x*))], x ~ N(mean, cov)
+ * (GaussianObjective.__call__ on GaussianMoments, gpflow_pilco/components.py:26-37): the
+ * per-step statistic the rollout accumulates (loops/pilco.py:199-205).
+ * mean [N,d], cov [N,d,d], target [d], precis [d,d] -> cost [N]  (all T). */
+int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
+                     const void* target, const void* precis, void* cost, void* stream);
 
 #ifdef __cplusplus
 }

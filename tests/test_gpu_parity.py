@@ -183,3 +183,57 @@ def test_bad_arguments_raise(device):
     ops.moment_match(pm_noC, to_dev(mu, device, torch.float32), to_dev(Sigma, device, torch.float32))
   with pytest.raises(RuntimeError, match="GPU only"):
     ops.moment_match(pm_noC, torch.tensor(mu), torch.tensor(Sigma))
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("shape", [(3, 200, 5, 3), (2, 128, 8, 2), (4, 330, 11, 2), (2, 64, 1, 2)],
+                         ids=["d5", "d8", "d11", "d1"])
+def test_mfma_kernels_match_generic(shape, dtype, device):
+  """The MFMA reduce kernels (f64 16x16x4 tiles, f32 32x32x2 panels) against the portable VALU
+  kernel (MM_FORCE_GENERIC) and the oracle; exercises every K-step template and the padding."""
+  L, M, d, B = shape
+  syn = make_svgp(L, M, d, seed=77 + d)
+  mu, Sigma = make_inputs(B, d, seed=3, scale=0.2)
+  _, Sffo, _ = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
+  pm = syn.to_model(device).packed(dtype, True, device)
+  mu_t, S_t = to_dev(mu, device, dtype), to_dev(Sigma, device, dtype)
+  _, Sff_fast, _ = ops.moment_match(pm, mu_t, S_t)
+  _, Sff_gen, _ = ops.moment_match(pm, mu_t, S_t, force_generic=True)
+  scale = np.abs(Sffo).max()
+  # the two f64 kernels sum the ill-conditioned C term (|C| up to 1/jitter) in different orders
+  tol = 1e-6 if dtype == torch.float64 else 1e-3
+  assert float((Sff_fast - Sff_gen).abs().max()) / scale < tol
+  assert scale_err(Sff_fast, Sffo) < TOL[dtype]["Sff"]
+  # diagonal-only and mean-only variants go through the same kernels
+  _, Sd, _ = ops.moment_match(pm, mu_t, S_t, full_output_cov=False)
+  assert torch.allclose(Sd, torch.diagonal(Sff_fast, dim1=-2, dim2=-1), rtol=1e-12, atol=0)
+  _, Sn, _ = ops.moment_match(pm, mu_t, S_t, model_uncertainty=False)
+  _, Sno, _ = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn), model_uncertainty=False)
+  assert scale_err(Sn, Sno) < TOL[dtype]["Sff"]
+
+
+def test_large_delta_slow_path_f32(device):
+  """Wide input covariance: |delta| > 1 takes the exp2 branch of the f32 kernel."""
+  syn = make_svgp(2, 96, 3, seed=5)
+  mu, Sigma = make_inputs(3, 3, seed=4, scale=1.5)
+  _, Sffo, _ = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
+  pm = syn.to_model(device).packed(torch.float32, True, device)
+  _, Sff, _ = ops.moment_match(pm, to_dev(mu, device, torch.float32), to_dev(Sigma, device, torch.float32))
+  assert scale_err(Sff, Sffo) < 2e-3
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_expected_cost_kernel(dtype, device):
+  """mm_expected_cost vs the closed form of components.py:26-37 evaluated in numpy."""
+  rng = np.random.default_rng(0)
+  d, N = 5, 37
+  from gpflowpilco_amd.synthetic import generate_covariance
+  mean = rng.uniform(size=(N, d)); cov = generate_covariance(rng, d, (N,), 0.3)
+  target = rng.uniform(size=d); A = rng.standard_normal((d, d)); W = A @ A.T
+  IpSW = np.eye(d) + cov @ W
+  err = mean - target
+  dist2 = np.einsum('ni,nij,nj->n', err, W @ np.linalg.inv(IpSW), err)
+  want = -np.linalg.det(IpSW) ** -0.5 * np.exp(-0.5 * dist2)
+  got = ops.expected_cost(to_dev(mean, device, dtype), to_dev(cov, device, dtype),
+                          to_dev(target, device, dtype), to_dev(W, device, dtype))
+  assert scale_err(got, want) < (1e-12 if dtype == torch.float64 else 1e-5)
