@@ -20,6 +20,12 @@
 #include "mm_common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Packed f32 FMA (v_pk_fma_f32): gfx950 issues a wave64 VALU instruction over 4 cycles, so the
+// f32 vector peak (64 FLOP/clk/SIMD) is only reached with two FMAs per lane per instruction.
+__device__ __forceinline__ f32x2 mm_pkfma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#define MM_PK(c_) ((f32x2){(c_), (c_)})
 
 __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) {
   int r = p - L, i = 0;
@@ -30,6 +36,20 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
 // expm1 on [-1, 1]: Taylor to degree 10 (truncation 1/11! relative, below f32 rounding).
 // Returns x * P(x); relative error ~1e-7 of expm1(x) itself (not of 1 + expm1(x)), which is
 // what the centred reduce needs (DESIGN.md "fp32 error budget").
+__device__ __forceinline__ f32x2 mm_expm1_small2(f32x2 x) {
+  f32x2 p = MM_PK(2.7557319e-7f);
+  p = mm_pkfma(p, x, MM_PK(2.7557319e-6f));
+  p = mm_pkfma(p, x, MM_PK(2.4801587e-5f));
+  p = mm_pkfma(p, x, MM_PK(1.9841270e-4f));
+  p = mm_pkfma(p, x, MM_PK(1.3888889e-3f));
+  p = mm_pkfma(p, x, MM_PK(8.3333333e-3f));
+  p = mm_pkfma(p, x, MM_PK(4.1666667e-2f));
+  p = mm_pkfma(p, x, MM_PK(1.6666667e-1f));
+  p = mm_pkfma(p, x, MM_PK(0.5f));
+  p = mm_pkfma(p, x, MM_PK(1.0f));
+  return p * x;
+}
+
 __device__ __forceinline__ float mm_expm1_small(float x) {
   float p = 2.7557319e-7f;             // 1/10!
   p = fmaf(p, x, 2.7557319e-6f);       // 1/9!
@@ -76,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void k_qred_f32_mfma(const float* __restric
     const float* cb = colO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;
 
     float areg[2][KS], ax[2];
-    float wrow[2][16];
+    f32x2 wrow[2][8];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int row = row0 + rt * 32 + l31;
@@ -92,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void k_qred_f32_mfma(const float* __restric
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 v = *reinterpret_cast<const float4*>(wr + row0 + rt * 32 + 8 * g + 4 * h);
-        wrow[rt][4 * g + 0] = v.x; wrow[rt][4 * g + 1] = v.y;
-        wrow[rt][4 * g + 2] = v.z; wrow[rt][4 * g + 3] = v.w;
+        wrow[rt][2 * g + 0] = (f32x2){v.x, v.y};
+        wrow[rt][2 * g + 1] = (f32x2){v.z, v.w};
       }
     }
 
@@ -145,12 +165,34 @@ __global__ __launch_bounds__(256, 2) void k_qred_f32_mfma(const float* __restric
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[rt][r]));
-      float part = 0.0f;
+      f32x2 part2 = {0.0f, 0.0f};
       if (!__any(mx > 1.0f)) {
+        // Horner steps run "vertically" over the 16 register pairs so that consecutive
+        // v_pk_fma_f32 are independent (a dependent pair costs a wait state + the FMA latency).
+        f32x2 xx[16], pp[16];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int r = 0; r < 16; ++r) {
+          xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
+          pp[r] = mm_pkfma(MM_PK(2.7557319e-7f), xx[r], MM_PK(2.7557319e-6f));
+        }
+#define MM_HORNER_STEP(c_)                                            \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(pp[r], xx[r], MM_PK(c_));
+        MM_HORNER_STEP(2.4801587e-5f)
+        MM_HORNER_STEP(1.9841270e-4f)
+        MM_HORNER_STEP(1.3888889e-3f)
+        MM_HORNER_STEP(8.3333333e-3f)
+        MM_HORNER_STEP(4.1666667e-2f)
+        MM_HORNER_STEP(1.6666667e-1f)
+        MM_HORNER_STEP(0.5f)
+        MM_HORNER_STEP(1.0f)
+#undef MM_HORNER_STEP
+        f32x2 parts[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-          for (int r = 0; r < 16; ++r) part = fmaf(wrow[rt][r], mm_expm1_small(acc[rt][r]), part);
+        for (int r = 0; r < 16; ++r) {
+          const f32x2 wx = wrow[r >> 3][r & 7] * xx[r];          // w_i * x
+          parts[r & 3] = mm_pkfma(wx, pp[r], parts[r & 3]);       // += w_i * x * P(x)
+        }
+        part2 = (parts[0] + parts[1]) + (parts[2] + parts[3]);
       } else {
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
@@ -161,10 +203,10 @@ __global__ __launch_bounds__(256, 2) void k_qred_f32_mfma(const float* __restric
             const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
             const float big = __builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f;
             const float e = (fabsf(x) <= 1.0f) ? mm_expm1_small(xs) : big;
-            part = fmaf(wrow[rt][r], e, part);
+            part2[r & 1] = fmaf(wrow[rt][r >> 1][r & 1], e, part2[r & 1]);
           }
       }
-      sum += (double)part * (double)wcc;
+      sum += (double)(part2[0] + part2[1]) * (double)wcc;
 #pragma unroll
       for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
       bxc = bxn; wcc = wcn;
