@@ -16,7 +16,7 @@ static inline int mm_num_pairs(int L, int flags) {
 
 // Packed model: byte offsets inside the caller-owned device buffer.
 struct MMModelLayout {
-  int Mp, Kz;
+  int Mp, Kz, nd8;
   size_t Z64;     // [L][M][d]  f64 raw inducing inputs (prep stages run in f64)
   size_t zbar;    // [L][d]     f64 per-latent centroid of Z (centres the MFMA A operand)
   size_t ls2;     // [L][d]     f64 squared lengthscales (Lambda)
@@ -25,6 +25,7 @@ struct MMModelLayout {
   size_t beta64;  // [L][M]     f64 Kuu^-1 u
   size_t Zc64;    // [L][Mp][Kz] f64 centred inducing inputs, zero padded (rows >= M, cols >= d)
   size_t Zc;      // [L][Mp][Kz] T   same, element type T (aliases Zc64 when T is f64)
+  size_t Zs3;     // [L][Mp][3][8 nd8] bf16: Zc split into bf16 parts (h, m, l), f32 mode only
   size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
                   // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
@@ -35,6 +36,7 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   const size_t es = mm_elem_size(dtype), A = 256;
   o.Mp = mm_round_up_int(M, MM_M_ALIGN);
   o.Kz = mm_round_up_int(d, 2);
+  o.nd8 = (d + 7) / 8;
   size_t off = 0;
   o.Z64 = off;    off = mm_align_up(off + (size_t)L * M * d * 8, A);
   o.zbar = off;   off = mm_align_up(off + (size_t)L * d * 8, A);
@@ -45,6 +47,8 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   o.Zc64 = off;   off = mm_align_up(off + (size_t)L * o.Mp * o.Kz * 8, A);
   o.Zc = o.Zc64;
   if (dtype != MM_F64) { o.Zc = off; off = mm_align_up(off + (size_t)L * o.Mp * o.Kz * es, A); }
+  o.Zs3 = off;
+  if (dtype != MM_F64) off = mm_align_up(off + (size_t)L * o.Mp * 24 * o.nd8 * 2, A);
   o.Cm = off;
   if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;
@@ -70,8 +74,8 @@ struct MMWorkspaceLayout {
   size_t w;        // [B][L][Mp] T    (aliases w64 when T is f64)
   size_t rowD;     // [B][L][Mp] f64        rho_i          diagonal pairs
   size_t colD;     // [B][L][d+1][Mp] f64   g_j, gamma'_j  diagonal pairs
-  size_t rowO;     // [B][Po][Mp] T         off-diagonal pairs
-  size_t colO;     // [B][Po][d+1][Mp] T
+  size_t rowO;     // off-diagonal pairs.  f64: [B][Po][Mp] rho_i            f32: [B][Po][d+1][Mp] A_i, rho'_i
+  size_t colO;     //                      f64: [B][Po][d+1][Mp] g_j, gamma'_j  f32: [B][Po][Mp] gamma_j
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
   size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i expm1(delta_ij) q_j  (+ q^T C q)
   size_t f1s;      // [B][L] T      rollout scratch outputs
@@ -103,8 +107,9 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   if (dtype != MM_F64) { o.w = off; off = mm_align_up(off + (size_t)B * L * o.Mp * es, A); }
   o.rowD = off;    off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.colD = off;    off = mm_align_up(off + (size_t)B * L * (d + 1) * o.Mp * 8, A);
-  o.rowO = off;    off = mm_align_up(off + (size_t)B * o.Po * o.Mp * es, A);
-  o.colO = off;    off = mm_align_up(off + (size_t)B * o.Po * (d + 1) * o.Mp * es, A);
+  const size_t nrow = dtype == MM_F64 ? 1 : (size_t)(d + 1), ncol = dtype == MM_F64 ? (size_t)(d + 1) : 1;
+  o.rowO = off;    off = mm_align_up(off + (size_t)B * o.Po * nrow * o.Mp * es, A);
+  o.colO = off;    off = mm_align_up(off + (size_t)B * o.Po * ncol * o.Mp * es, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
   o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);
   o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);

@@ -148,6 +148,25 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
     Zc64[idx] = v;
     if (sizeof(T) != 8) Zc[idx] = (T)v;
   }
+  if (sizeof(T) != 8) {
+    // bf16 3-way split of the centred inputs for the f32 MFMA kernel: [Mp][3 (h,m,l)][8 nd8]
+    unsigned short* Zs3 = (unsigned short*)(packed + lay.Zs3) + (size_t)a * lay.Mp * 24 * lay.nd8;
+    const int kw = 8 * lay.nd8;
+    for (int idx = tid; idx < lay.Mp * kw; idx += 256) {
+      const int m = idx / kw, k = idx - m * kw;
+      float v = 0.0f;
+      if (m < M && k < d) v = (float)(Z[((size_t)a * M + m) * d + k] - zb[k]);
+      const __bf16 h = (__bf16)v;
+      float r = v - (float)h;
+      const __bf16 mm = (__bf16)r;
+      r -= (float)mm;
+      const __bf16 l = (__bf16)r;
+      unsigned short* o = Zs3 + (size_t)m * 3 * kw + k;
+      o[0] = __builtin_bit_cast(unsigned short, h);
+      o[kw] = __builtin_bit_cast(unsigned short, mm);
+      o[2 * kw] = __builtin_bit_cast(unsigned short, l);
+    }
+  }
 }
 
 __global__ void k_pack_C(char* packed, MMModelLayout lay, int L, int M, const double* __restrict__ C) {
@@ -353,13 +372,14 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
   int a, a2;
   mm_decode_pair(p, L, a, a2);
   __shared__ double G[MM_DMAX * MM_DMAX], Dr[MM_DMAX * MM_DMAX], Dc[MM_DMAX * MM_DMAX];
-  __shared__ double mub[MM_DMAX], dmu[MM_DMAX];
+  __shared__ double mub[MM_DMAX], dmu[MM_DMAX], dmu2[MM_DMAX];
   const double* pm = pairmat + ((size_t)b * P + p) * (3 * d * d + 1);
   for (int idx = tid; idx < d * d; idx += 256) { G[idx] = pm[idx]; Dr[idx] = pm[d * d + idx]; Dc[idx] = pm[2 * d * d + idx]; }
   if (tid < d) {
     const double mv = (double)mu[(size_t)b * d + tid];
     mub[tid] = mv;
     dmu[tid] = mv - zbar[a * d + tid];   // the A operand is centred at zbar_a, not at mu_b
+    dmu2[tid] = mv - zbar[a2 * d + tid];
   }
   __syncthreads();
   if (m >= Mp) return;
@@ -369,11 +389,18 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
   const int Po = P - L;
   double* raD = rowD + ((size_t)b * L + (diag ? p : 0)) * Mp;
   double* cbD = colD + ((size_t)b * L + (diag ? p : 0)) * (size_t)(d + 1) * Mp;
+  // (f64 off-diagonal layout; the f32 one is handled separately below)
   T* raO = rowO + ((size_t)b * Po + (diag ? 0 : p - L)) * Mp;
   T* cbO = colO + ((size_t)b * Po + (diag ? 0 : p - L)) * (size_t)(d + 1) * Mp;
 #define MM_PV_STORE_ROW(v_) do { if (diag) raD[m] = (v_); else raO[m] = (T)(v_); } while (0)
 #define MM_PV_STORE_COL(k_, v_) do { if (diag) cbD[(size_t)(k_) * Mp + m] = (v_); else cbO[(size_t)(k_) * Mp + m] = (T)(v_); } while (0)
   if (m >= M) {
+    if (!diag && sizeof(T) == 4) {
+      T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
+      for (int k = 0; k <= d; ++k) rO[(size_t)k * Mp + m] = (T)0;
+      colO[((size_t)b * Po + (p - L)) * Mp + m] = (T)0;
+      return;
+    }
     MM_PV_STORE_ROW(0.0);
     for (int k = 0; k <= d; ++k) MM_PV_STORE_COL(k, 0.0);
     return;
@@ -383,6 +410,35 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
   for (int k = 0; k < DK; ++k) {
     zr[k] = (k < d) ? Z64[((size_t)a * M + m) * d + k] - mub[k] : 0.0;
     zc[k] = (k < d) ? Z64[((size_t)a2 * M + m) * d + k] - mub[k] : 0.0;
+  }
+  if (!diag && sizeof(T) == 4) {
+    // f32 off-diagonal format (mm_mfma.hip): the ROW side carries the transformed vector
+    //   A_i = G^T zeta_i,  rho'_i = rho_i + const - A_i . (mu - zbar_a'),   gamma_j plain,
+    // so that delta_ij = rho'_i + gamma_j + A_i . zc^{a'}_j with the b-independent zc streamed.
+    T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
+    T* cO = colO + ((size_t)b * Po + (p - L)) * Mp;
+    double rho = 0.0, gam = 0.0, corr = 0.0;
+#pragma unroll
+    for (int i = 0; i < DK; ++i) {
+      if (i < d) {
+        double tr = 0.0, tc = 0.0, av = 0.0;
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+          if (k < d) {
+            tr += Dr[i * d + k] * zr[k];
+            tc += Dc[i * d + k] * zc[k];
+            av += G[k * d + i] * zr[k];
+          }
+        }
+        rho += zr[i] * tr;
+        gam += zc[i] * tc;
+        corr += dmu2[i] * av;
+        rO[(size_t)i * Mp + m] = (T)av;
+      }
+    }
+    rO[(size_t)d * Mp + m] = (T)(-0.5 * rho + cst - corr);
+    cO[m] = (T)(-0.5 * gam);
+    return;
   }
   double rho = 0.0, gam = 0.0, corr = 0.0;
 #pragma unroll
@@ -418,7 +474,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
 //   one (b, pair).  grid (nrb * ncb, npairs, B); row/col operand arrays are indexed by the
 //   LOCAL pair index, the partial slabs by the global one.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int DK>
+template <typename T, int DK, bool ROWVEC>
 __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, int Kz, const double* __restrict__ Cm,
                                                       int L, int Mp, int d, int P, int NS, int ncb, int p0,
                                                       const T* __restrict__ w, const T* __restrict__ q,
@@ -431,15 +487,21 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
   const int j = cbk * MM_GEN_COLS + tid;
   const bool jv = j < Mp;
   const int jj = jv ? j : 0;
-  const T* cb = colB + ((size_t)b * np + lp) * (size_t)(d + 1) * Mp;
+  // ROWVEC (f32 off-diagonal layout): the row side carries the vector A_i and rho'_i, the column
+  // side is the centred inducing input zc_j of latent a' plus gamma_j.  Otherwise the column side
+  // carries g_j, gamma'_j and the row side is zc_i of latent a plus rho_i.
+  const T* cb = ROWVEC ? colB + ((size_t)b * np + lp) * Mp
+                       : colB + ((size_t)b * np + lp) * (size_t)(d + 1) * Mp;
   T g[DK];
 #pragma unroll
-  for (int k = 0; k < DK; ++k) g[k] = (k < d) ? cb[(size_t)k * Mp + jj] : (T)0;
-  const T gam = cb[(size_t)d * Mp + jj];
+  for (int k = 0; k < DK; ++k)
+    g[k] = (k < d) ? (ROWVEC ? Zc[((size_t)a2 * Mp + jj) * Kz + k] : cb[(size_t)k * Mp + jj]) : (T)0;
+  const T gam = ROWVEC ? cb[jj] : cb[(size_t)d * Mp + jj];
   const T wj = jv ? w[((size_t)b * L + a2) * Mp + jj] : (T)0;
   const bool withC = (Cm != nullptr) && (a == a2);
   const T qj = (withC && jv) ? q[((size_t)b * L + a2) * Mp + jj] : (T)0;
-  const T* ra = rowA + ((size_t)b * np + lp) * Mp;
+  const T* ra = ROWVEC ? rowA + ((size_t)b * np + lp) * (size_t)(d + 1) * Mp
+                       : rowA + ((size_t)b * np + lp) * Mp;
   const T* wr = w + ((size_t)b * L + a) * Mp;
   const T* qr = q + ((size_t)b * L + a) * Mp;
   const T* zrow = Zc + (size_t)a * Mp * Kz;
@@ -448,9 +510,10 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
   T accB = (T)0;
   double sumB = 0.0, sumC = 0.0;
   for (int i = i0; i < i1; ++i) {
-    T delta = ra[i] + gam;
+    T delta = (ROWVEC ? ra[(size_t)d * Mp + i] : ra[i]) + gam;
 #pragma unroll
-    for (int k = 0; k < DK; ++k) if (k < d) delta += zrow[(size_t)i * Kz + k] * g[k];
+    for (int k = 0; k < DK; ++k)
+      if (k < d) delta += (ROWVEC ? ra[(size_t)k * Mp + i] : zrow[(size_t)i * Kz + k]) * g[k];
     const T e = mm_expm1(delta);
     accB += wr[i] * e;
     if (withC) {
@@ -725,7 +788,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
   // (1) diagonal pairs: always f64
   if (stages & MM_STAGE_DIAG) {
     if (generic) {
-      hipLaunchKernelGGL((k_qred_generic<double, DK>), dim3(nrb * ncb, L, B), dim3(256), 0, s,
+      hipLaunchKernelGGL((k_qred_generic<double, DK, false>), dim3(nrb * ncb, L, B), dim3(256), 0, s,
                          (const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS, ncb, 0,
                          (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
                          (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD), partB, partC);
@@ -750,7 +813,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
                                         partB, partC, s);
       if (rc) return rc;
     } else {
-      hipLaunchKernelGGL((k_qred_generic<T, DK>), dim3(nrb * ncb, wl.Po, B), dim3(256), 0, s,
+      hipLaunchKernelGGL((k_qred_generic<T, DK, sizeof(T) == 4>), dim3(nrb * ncb, wl.Po, B), dim3(256), 0, s,
                          (const T*)(packed + ml.Zc), ml.Kz, (const double*)nullptr, L, wl.Mp, d, wl.P, wl.NS, ncb, L,
                          (const T*)(ws + wl.w), (const T*)nullptr, (const T*)(ws + wl.rowO),
                          (const T*)(ws + wl.colO), partB, partC);

@@ -4,17 +4,18 @@
 // (the reference's eKuffu slice, utils/kernel_expectation.py:72-187, then
 // models.py:219-248),
 //     S = sum_ij w_i * expm1(delta_ij) * w'_j ,   delta_ij = rho_i + gamma'_j + zc_i . g_j
-// The bilinear part runs on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA chain,
-// one extra k-step carries (rho_i, 1) x (1, gamma'_j)), the expm1 + weighted reduction on the
-// VALU, which runs concurrently with the MFMA pipe of the other resident waves.
+//     S = sum_ij w_i * expm1(delta_ij) * w'_j ,   delta_ij = rho'_i + gamma_j + A_i . zc_j
+// The bilinear part runs on the bf16 matrix pipe as a 3-way split product with f32 accuracy
+// (v_mfma_f32_32x32x16_bf16), the expm1 polynomial + weighted reduction on the VALU in packed
+// f32 (v_pk_fma_f32), which overlaps with the matrix pipe.
 //
 // Work decomposition: workgroup = 4 waves = 256 rows of one (b, pair); a wave owns 64 rows
-// (two 32x32 MFMA row tiles, A operands and the 32 row weights stay in registers) and sweeps
-// all columns in tiles of 32, software-prefetching the next tile's B operands from the
-// k-major colO stream ([k][Mp]: two coalesced 128-B segments per k-step).  Partial sums are
-// flushed to f64 once per column tile and written to a slab (no atomics: bitwise
-// reproducible).  The 1-D grid is remapped so that the row panels of one (b, pair) -- which
-// all stream the same colO block -- land on the same XCD and share its L2.
+// (two 32x32 MFMA row tiles; split A operands, rho' (the MFMA C operand) and the 32 row weights
+// stay in registers) and sweeps all columns in tiles of 32, software-prefetching the next
+// tile's pre-split inducing inputs (two 16-B loads per lane) and gamma_j / w_j.  Partial sums
+// are flushed to f64 once per column tile and written to a slab (no atomics: bitwise
+// reproducible).  The 1-D grid is remapped so that the row panels of one (b, pair) land on the
+// same XCD and share its L2.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
@@ -64,8 +65,55 @@ __device__ __forceinline__ float mm_expm1_small(float x) {
   return p * x;
 }
 
-template <int KS>
-__global__ __launch_bounds__(256, 2) void k_qred_f32_mfma(const float* __restrict__ Zc, int Kz,
+#ifndef MM_F32_WAVES
+#define MM_F32_WAVES 2
+#endif
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned int mm_f2bf(float x) {
+  const __bf16 b = (__bf16)x;                                  // v_cvt_pk_bf16_f32, round to nearest even
+  return (unsigned int)__builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ float mm_bf2f(unsigned int u) { return __builtin_bit_cast(float, u << 16); }
+
+// x = h + m + l with h, m, l bf16 (8 + 8 + 8 significand bits: exact to ~2^-24 |x|)
+__device__ __forceinline__ void mm_split3(float x, unsigned int& h, unsigned int& m, unsigned int& l) {
+  h = mm_f2bf(x);
+  float r = x - mm_bf2f(h);
+  m = mm_f2bf(r);
+  r -= mm_bf2f(m);
+  l = mm_f2bf(r);
+}
+
+// expm1(x) / x on [-1, 1], degree 7 (near-minimax, relative error of x * P(x) ~2e-7 in f32)
+#define MM_P7_C7 2.480045805e-05f
+#define MM_P7_C6 2.039110987e-04f
+#define MM_P7_C5 1.389508019e-03f
+#define MM_P7_C4 8.329954930e-03f
+#define MM_P7_C3 4.166625813e-02f
+#define MM_P7_C2 1.666673273e-01f
+#define MM_P7_C1 5.000000596e-01f
+#define MM_P7_C0 1.0f
+
+__device__ __forceinline__ float mm_expm1_p7(float x) {
+  float p = fmaf(MM_P7_C7, x, MM_P7_C6);
+  p = fmaf(p, x, MM_P7_C5); p = fmaf(p, x, MM_P7_C4); p = fmaf(p, x, MM_P7_C3);
+  p = fmaf(p, x, MM_P7_C2); p = fmaf(p, x, MM_P7_C1); p = fmaf(p, x, MM_P7_C0);
+  return p * x;
+}
+
+// ND8: number of 8-wide blocks of input dimensions (d <= 8 * ND8).
+//
+// The bilinear form A_i . zc_j runs on the bf16 matrix pipe as a 3-way split product
+// (h/m/l bf16 parts, six cross terms packed into three K=16 MFMAs per 8 dims: f32-equivalent
+// accuracy), because v_mfma_f32_32x32x2_f32 was measured to serialise with the VALU
+// on a SIMD (it shares the f32 FMA datapath) while the bf16 MFMA overlaps with it.
+//   stationary operand (registers, split once per sweep): A_i = G^T zeta_i of the wave's 64 rows,
+//   rho'_i enters as the MFMA C operand, streaming operand: the model's pre-split centred
+//   inducing inputs of latent a' (b-independent, L2-resident), gamma_j and w_j per column.
+template <int ND8>
+__global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsigned short* __restrict__ Zs3,
                                                           int L, int Mp, int d, int P, int Po, int NS,
                                                           int npanel, int nwork,
                                                           const float* __restrict__ w,
@@ -89,102 +137,119 @@ __global__ __launch_bounds__(256, 2) void k_qred_f32_mfma(const float* __restric
   const int row0 = panel * MM_PANEL_ROWS + wv * 64;
   double sum = 0.0;
   if (row0 < Mp) {   // Mp % 128 == 0, so a wave's 64 rows are all inside or all outside
-    const float* zr = Zc + (size_t)a * Mp * Kz;
-    const float* ra = rowO + ((size_t)b * Po + lp) * Mp;
+    const float* ra = rowO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;   // [d+1][Mp]: A_i, rho'_i
+    const float* gc = colO + ((size_t)b * Po + lp) * Mp;                     // gamma_j
     const float* wr = w + ((size_t)b * L + a) * Mp;
     const float* wc = w + ((size_t)b * L + a2) * Mp;
-    const float* cb = colO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;
+    // pre-split centred inducing inputs of latent a': [Mp][3 (h,m,l)][8 ND8] bf16
+    const unsigned short* zs = Zs3 + (size_t)a2 * Mp * (24 * ND8);
 
-    float areg[2][KS], ax[2];
+    // ---- stationary operands --------------------------------------------------------------
+    bf16x8 a1[2][ND8], a2v[2][ND8], a3[2][ND8];
+    f32x16 crho[2];
     f32x2 wrow[2][8];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int row = row0 + rt * 32 + l31;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        // unconditional load at a clamped index, then select (no branch around the load)
-        const int k = 2 * s + h;
-        const float v = zr[(size_t)row * Kz + (k < Kz ? k : Kz - 1)];
-        areg[rt][s] = (k < Kz) ? v : 0.0f;
+      for (int nb = 0; nb < ND8; ++nb) {
+        unsigned int hh[8], mm[8], ll[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = nb * 8 + j;
+          const float v = ra[(size_t)(k < d ? k : d) * Mp + row];
+          mm_split3(k < d ? v : 0.0f, hh[j], mm[j], ll[j]);
+        }
+        u32x4 ph, pm, pl;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          ph[j] = hh[2 * j] | (hh[2 * j + 1] << 16);
+          pm[j] = mm[2 * j] | (mm[2 * j + 1] << 16);
+          pl[j] = ll[2 * j] | (ll[2 * j + 1] << 16);
+        }
+        // MFMA1: (m,m) | (l,h)   MFMA2: (h,l) | (m,h)   MFMA3: (h,m) | (h,h)   [lane half 0 | 1]
+        a1[rt][nb] = __builtin_bit_cast(bf16x8, h ? pl : pm);
+        a2v[rt][nb] = __builtin_bit_cast(bf16x8, h ? pm : ph);
+        a3[rt][nb] = __builtin_bit_cast(bf16x8, ph);
       }
-      const float rv = ra[row];
-      ax[rt] = h ? 1.0f : rv;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 v = *reinterpret_cast<const float4*>(wr + row0 + rt * 32 + 8 * g + 4 * h);
+        const int rr = row0 + rt * 32 + 8 * g + 4 * h;
+        const float4 rv = *reinterpret_cast<const float4*>(ra + (size_t)d * Mp + rr);
+        crho[rt][4 * g + 0] = rv.x; crho[rt][4 * g + 1] = rv.y;
+        crho[rt][4 * g + 2] = rv.z; crho[rt][4 * g + 3] = rv.w;
+        const float4 v = *reinterpret_cast<const float4*>(wr + rr);
         wrow[rt][2 * g + 0] = (f32x2){v.x, v.y};
         wrow[rt][2 * g + 1] = (f32x2){v.z, v.w};
       }
     }
 
+    // ---- streaming operands: lane half 0 reads parts (m, l), half 1 reads (h, h) ------------
+    const int offA = (h ? 0 : 1) * 8 * ND8;      // in bf16 elements within a column's 24*ND8 block
+    const int offB = (h ? 0 : 2) * 8 * ND8;
     const int nct = Mp >> 5;
-    // B-operand row offsets: k-step s reads row min(2s + h, d) of the k-major colO block.  Rows
-    // beyond d - 1 meet a zero A operand (Zc is zero padded), so any finite value is fine there.
-    size_t boff[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const int k = 2 * s + h;
-      boff[s] = (size_t)(k < d ? k : d) * Mp;
-    }
-    const size_t goff = (size_t)d * Mp;
-    float bcur[KS], bxc, wcc;
-    // prologue: operands of column tile 0
-#pragma unroll
-    for (int s = 0; s < KS; ++s) bcur[s] = cb[boff[s] + l31];
+    u32x4 zA[ND8], zB[ND8];
+    float gcur, wcur;
     {
-      const float gv = cb[goff + l31];
-      bxc = h ? gv : 1.0f;
+      const unsigned short* zc = zs + (size_t)l31 * (24 * ND8);
+#pragma unroll
+      for (int nb = 0; nb < ND8; ++nb) {
+        zA[nb] = *reinterpret_cast<const u32x4*>(zc + offA + nb * 8);
+        zB[nb] = *reinterpret_cast<const u32x4*>(zc + offB + nb * 8);
+      }
+      gcur = gc[l31]; wcur = wc[l31];
     }
-    wcc = wc[l31];
 
     for (int ct = 0; ct < nct; ++ct) {
       // prefetch tile ct + 1 (clamped: the last iteration re-reads its own tile)
       const int cn = ((ct + 1 < nct) ? ct + 1 : ct) * 32 + l31;
-      float bnxt[KS], bxn, wcn;
+      u32x4 zAn[ND8], zBn[ND8];
+      const unsigned short* zc = zs + (size_t)cn * (24 * ND8);
 #pragma unroll
-      for (int s = 0; s < KS; ++s) bnxt[s] = cb[boff[s] + cn];
-      {
-        const float gv = cb[goff + cn];
-        bxn = h ? gv : 1.0f;
+      for (int nb = 0; nb < ND8; ++nb) {
+        zAn[nb] = *reinterpret_cast<const u32x4*>(zc + offA + nb * 8);
+        zBn[nb] = *reinterpret_cast<const u32x4*>(zc + offB + nb * 8);
       }
-      wcn = wc[cn];
+      const float gnxt = gc[cn], wnxt = wc[cn];
 
       f32x16 acc[2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        c = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[rt], bxc, c, 0, 0, 0);
+        f32x16 c = crho[rt];
 #pragma unroll
-        for (int s = 0; s < KS; ++s)
-          c = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[rt][s], bcur[s], c, 0, 0, 0);
+        for (int nb = 0; nb < ND8; ++nb) {
+          const bf16x8 bA = __builtin_bit_cast(bf16x8, zA[nb]);
+          const bf16x8 bB = __builtin_bit_cast(bf16x8, zB[nb]);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[rt][nb], bA, c, 0, 0, 0);   // smallest terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v[rt][nb], bB, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[rt][nb], bA, c, 0, 0, 0);
+        }
         acc[rt] = c;
       }
-      // range check of the tile (wave-uniform): the polynomial covers |delta| <= 1
+      // delta = acc + gamma_j ; range check of the tile (wave-uniform): P7 covers |delta| <= 1
+      f32x2 xx[16];
+      const f32x2 g2 = {gcur, gcur};
       float mx = 0.0f;
 #pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fabsf(acc[rt][r]));
-      f32x2 part2 = {0.0f, 0.0f};
+      for (int r = 0; r < 16; ++r) {
+        xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]} + g2;
+        mx = fmaxf(mx, fmaxf(fabsf(xx[r][0]), fabsf(xx[r][1])));
+      }
+      f32x2 part2;
       if (!__any(mx > 1.0f)) {
         // Horner steps run "vertically" over the 16 register pairs so that consecutive
         // v_pk_fma_f32 are independent (a dependent pair costs a wait state + the FMA latency).
-        f32x2 xx[16], pp[16];
+        f32x2 pp[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
-          pp[r] = mm_pkfma(MM_PK(2.7557319e-7f), xx[r], MM_PK(2.7557319e-6f));
-        }
+        for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(MM_PK(MM_P7_C7), xx[r], MM_PK(MM_P7_C6));
 #define MM_HORNER_STEP(c_)                                            \
         _Pragma("unroll") for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(pp[r], xx[r], MM_PK(c_));
-        MM_HORNER_STEP(2.4801587e-5f)
-        MM_HORNER_STEP(1.9841270e-4f)
-        MM_HORNER_STEP(1.3888889e-3f)
-        MM_HORNER_STEP(8.3333333e-3f)
-        MM_HORNER_STEP(4.1666667e-2f)
-        MM_HORNER_STEP(1.6666667e-1f)
-        MM_HORNER_STEP(0.5f)
-        MM_HORNER_STEP(1.0f)
+        MM_HORNER_STEP(MM_P7_C5)
+        MM_HORNER_STEP(MM_P7_C4)
+        MM_HORNER_STEP(MM_P7_C3)
+        MM_HORNER_STEP(MM_P7_C2)
+        MM_HORNER_STEP(MM_P7_C1)
+        MM_HORNER_STEP(MM_P7_C0)
 #undef MM_HORNER_STEP
         f32x2 parts[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
@@ -194,22 +259,23 @@ __global__ __launch_bounds__(256, 2) void k_qred_f32_mfma(const float* __restric
         }
         part2 = (parts[0] + parts[1]) + (parts[2] + parts[3]);
       } else {
+        part2 = (f32x2){0.0f, 0.0f};
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
+          for (int e2 = 0; e2 < 2; ++e2) {
             // |delta| > 1: exp2 on the transcendental unit (relative error ~ |x| * 6e-8)
-            const float x = acc[rt][r];
+            const float x = xx[r][e2];
             const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
             const float big = __builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f;
-            const float e = (fabsf(x) <= 1.0f) ? mm_expm1_small(xs) : big;
-            part2[r & 1] = fmaf(wrow[rt][r >> 1][r & 1], e, part2[r & 1]);
+            const float e = (fabsf(x) <= 1.0f) ? mm_expm1_p7(xs) : big;
+            part2[e2] = fmaf(wrow[r >> 3][r & 7][e2], e, part2[e2]);
           }
       }
-      sum += (double)(part2[0] + part2[1]) * (double)wcc;
+      sum += (double)(part2[0] + part2[1]) * (double)wcur;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) bcur[s] = bnxt[s];
-      bxc = bxn; wcc = wcn;
+      for (int nb = 0; nb < ND8; ++nb) { zA[nb] = zAn[nb]; zB[nb] = zBn[nb]; }
+      gcur = gnxt; wcur = wnxt;
     }
   }
   // workgroup reduction -> slab
@@ -231,24 +297,21 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
   const long long nwork_ll = (long long)npanel * wl.Po * B;
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const int nwork = (int)nwork_ll;
-  const float* Zc = (const float*)(packed + ml.Zc);
+  const unsigned short* Zs3 = (const unsigned short*)(packed + ml.Zs3);
   const float* w = (const float*)(ws + wl.w);
   const float* rowO = (const float*)(ws + wl.rowO);
   const float* colO = (const float*)(ws + wl.colO);
   double* partB = (double*)(ws + wl.partB);
-  const int ks = (d + 1) / 2;
-#define MM_LAUNCH_KS(KS_)                                                                         \
-  hipLaunchKernelGGL((k_qred_f32_mfma<KS_>), dim3(nwork), dim3(256), 0, stream, Zc, ml.Kz, L,     \
-                     wl.Mp, d, wl.P, wl.Po, wl.NS, npanel, nwork, w, rowO, colO, partB)
-  if (ks <= 1) MM_LAUNCH_KS(1);
-  else if (ks == 2) MM_LAUNCH_KS(2);
-  else if (ks == 3) MM_LAUNCH_KS(3);
-  else if (ks == 4) MM_LAUNCH_KS(4);
-  else if (ks <= 6) MM_LAUNCH_KS(6);
-  else if (ks <= 8) MM_LAUNCH_KS(8);
-  else if (ks <= 12) MM_LAUNCH_KS(12);
-  else MM_LAUNCH_KS(16);
-#undef MM_LAUNCH_KS
+#define MM_LAUNCH_ND(ND_)                                                                         \
+  hipLaunchKernelGGL((k_qred_f32_mfma<ND_>), dim3(nwork), dim3(256), 0, stream, Zs3, L, wl.Mp, d, \
+                     wl.P, wl.Po, wl.NS, npanel, nwork, w, rowO, colO, partB)
+  switch (ml.nd8) {
+    case 1: MM_LAUNCH_ND(1); break;
+    case 2: MM_LAUNCH_ND(2); break;
+    case 3: MM_LAUNCH_ND(3); break;
+    default: MM_LAUNCH_ND(4); break;
+  }
+#undef MM_LAUNCH_ND
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

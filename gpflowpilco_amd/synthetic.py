@@ -54,11 +54,12 @@ class SyntheticSVGP:
 
 
 def make_svgp(L: int, M: int, d: int, seed: int, stable: bool = True,
-              device: str = "cpu", mean_c: bool = False) -> SyntheticSVGP:
+              device: str = "cpu", mean_c: bool = False,
+              ls_bounds=(0.3, 3.0)) -> SyntheticSVGP:
   """Build the synthetic model in float64 (torch; ``device`` only speeds up the Choleskys)."""
   rng = np.random.default_rng(seed)
   Z = rng.uniform(size=(M, d))
-  ls = np.exp(rng.uniform(np.log(0.3), np.log(3.0), size=(L, d)))
+  ls = np.exp(rng.uniform(np.log(ls_bounds[0]), np.log(ls_bounds[1]), size=(L, d)))
   var = np.full(L, 0.89 ** 2)
   noise = 1e-2 * var
   eps_f = rng.standard_normal((L, M))
