@@ -1,0 +1,172 @@
+"""Host-side mirror of the reference interface on CPU tensors: dispatcher, carrier types,
+GaussianMatch algebra, chain rule, model precompute, solvers.  No GPU compute is called."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from gpflowpilco_amd import dynamics, models as gp
+from gpflowpilco_amd.moment_matching import (Chain, GaussianMatch, GaussianMoments, LinearOperatorDiag,
+                                             Moments, dispatcher, moment_matching, register_type)
+from gpflowpilco_amd.moment_matching.core import Dispatcher
+from oracle import mm_fused_ref as fr
+from oracle import mm_oracle as mo
+from tests.helpers import gp_model_from_oracle, random_svgp_params
+
+F64 = torch.float64
+
+
+class Linear:
+  """y = A x + c: exact moment match, used to exercise the composition rules."""
+  def __init__(self, A, c):
+    self.A, self.c = A, c
+
+
+@dispatcher.register(GaussianMoments, Linear)
+def _mm_linear(x, op, /, preinv=False):
+  m, S = x.mean(), x.covariance(dense=True)
+  y = GaussianMoments(((op.A @ m.unsqueeze(-1)).squeeze(-1) + op.c, op.A @ S @ op.A.T), centered=True)
+  cross = op.A.T.expand(m.shape[:-1] + op.A.T.shape) if preinv else S @ op.A.T
+  return GaussianMatch(x=x, y=y, cross=(cross.contiguous(), preinv))
+
+
+def _state(B=3, d=3, seed=0):
+  g = torch.Generator().manual_seed(seed)
+  m = torch.randn(B, d, generator=g, dtype=F64)
+  A = torch.randn(B, d, d, generator=g, dtype=F64)
+  return GaussianMoments((m, A @ A.transpose(1, 2) + 0.1 * torch.eye(d, dtype=F64)), centered=True)
+
+
+def test_dispatcher_resolution_and_errors():
+  disp = Dispatcher("t")
+
+  class A: pass
+  class B(A): pass
+
+  @disp.register(A, object)
+  def _a(x, y): return "A"
+
+  @disp.register(B, (int, float))
+  def _b(x, y): return "B"
+
+  assert disp(A(), 1) == "A" and disp(B(), 1) == "B" and disp(B(), "s") == "A" and disp(B(), 2.0) == "B"
+  with pytest.raises(NotImplementedError, match="Could not find signature"):
+    disp(1, 2)
+
+
+def test_moments_and_linear_operator_diag():
+  m = torch.tensor([[1.0, 2.0]], dtype=F64)
+  m2 = torch.tensor([[[2.0, 2.5], [2.5, 5.0]]], dtype=F64)
+  unc = Moments((m, m2), centered=False)
+  assert torch.allclose(unc.covariance(), m2 - m.unsqueeze(-1) * m.unsqueeze(-2))
+  assert Moments((m, m2), centered=True).covariance() is m2 and unc.ndim == 2 and unc.dtype == F64
+  D = LinearOperatorDiag(torch.tensor([[2.0, 4.0]], dtype=F64))
+  rhs = torch.ones(1, 2, 3, dtype=F64)
+  assert torch.allclose(D.to_dense() @ rhs, D @ rhs) and torch.allclose(D.solve(D @ rhs), rhs)
+  assert torch.equal(Moments((m, D), centered=True).covariance(dense=True), D.to_dense())
+
+
+def test_gaussian_match_cross_covariance_and_joint():
+  x = _state()
+  A = torch.randn(2, 3, dtype=F64); c = torch.randn(2, dtype=F64)
+  for preinv in (False, True):
+    mt = moment_matching(x, Linear(A, c), preinv=preinv)
+    Sxy = x.covariance() @ A.T
+    assert torch.allclose(mt.cross_covariance(), Sxy)
+    assert torch.allclose(mt.cross_covariance(preinv=True), A.T.expand(3, 3, 2))
+    j = mt.joint()
+    assert j.mean().shape == (3, 5) and torch.allclose(j.covariance()[:, :3, 3:], Sxy)
+    assert torch.allclose(j.covariance(), j.covariance().transpose(1, 2))
+    Sx = x.covariance().numpy()
+    want = mo.cross_covariance(Sx, mt.cross[0].numpy(), is_preinv=preinv, preinv=not preinv)
+    assert np.allclose(mt.cross_covariance(preinv=not preinv).numpy(), want)
+
+
+def test_chain_rule_and_partial_and_register_type():
+  x = _state(seed=1)
+  A1 = torch.randn(3, 3, dtype=F64); A2 = torch.randn(2, 3, dtype=F64)
+  mt = moment_matching(x, Chain(Linear(A2, torch.zeros(2, dtype=F64)), Linear(A1, torch.ones(3, dtype=F64))))
+  full = A2 @ A1
+  assert torch.allclose(mt.y.covariance(), full @ x.covariance() @ full.T)
+  assert torch.allclose(mt.cross_covariance(), x.covariance() @ full.T)
+  assert Chain(lambda v: v + 1, lambda v: 2 * v)(3) == 7            # applied right to left
+
+  def double(v):
+    return 2 * v
+  T = register_type(double)
+
+  @dispatcher.register(GaussianMoments, T)
+  def _mm_double(x, _):
+    return GaussianMatch(x=x, y=GaussianMoments((2 * x.mean(), 4 * x.covariance()), True),
+                         cross=(2 * x.covariance(), False))
+  assert torch.allclose(moment_matching(x, double).y.mean(), 2 * x.mean())
+  with pytest.raises(ValueError):
+    register_type(double)
+  p = partial(Linear, A1)       # a partial whose func is a type -> dispatches on (Moments, partial)
+  assert isinstance(p, partial)
+
+
+@pytest.mark.parametrize("whiten", [True, False])
+def test_model_precompute_matches_reference_algebra(whiten):
+  """models.SVGP.precompute (torch, what gets packed for the kernels) == beta, C of the restatement."""
+  p = random_svgp_params(seed=3, L=2, M=20, d=3, whiten=whiten)
+  model = gp_model_from_oracle(p, "cpu")
+  Z, ls, var, beta, C, mean_c = model.precompute(torch.device("cpu"))
+  b_ref, C_ref = fr.precompute(p)
+  assert np.abs(beta.numpy() - b_ref).max() / np.abs(b_ref).max() < 1e-9
+  assert np.abs(C.numpy() - C_ref).max() / np.abs(C_ref).max() < 1e-9
+  assert np.allclose(Z.numpy(), p.Z) and np.allclose(ls.numpy(), p.lengthscales) and np.allclose(mean_c.numpy(), p.mean_c)
+
+
+def test_gpr_precompute_and_kernel_slicing():
+  rng = np.random.default_rng(0)
+  X = rng.uniform(size=(10, 4)); Y = rng.standard_normal((10, 1))
+  k = gp.SquaredExponential(variance=0.7, lengthscales=[0.5, 0.8], active_dims=(1, 3))
+  gpr = gp.GPR(data=(X, Y), kernel=k, mean_function=gp.Constant([0.2]), noise_variance=0.1)
+  Z, ls, var, beta, C, c = gpr.precompute(torch.device("cpu"))
+  assert Z.shape == (1, 10, 2) and np.allclose(Z[0].numpy(), X[:, [1, 3]])
+  Ky = mo.se_kernel(X[:, [1, 3]], None, np.array([0.5, 0.8]), 0.7) + 0.1 * np.eye(10)
+  assert np.allclose(beta[0].numpy(), np.linalg.solve(Ky, Y - 0.2)[:, 0])
+  assert np.allclose(C[0].numpy(), -np.linalg.inv(Ky))
+  S = torch.eye(4, dtype=F64)[None]
+  assert k.slice_cov(S).shape == (1, 2, 2) and k.slice(torch.zeros(1, 4)).shape == (1, 2)
+
+
+def test_gp_handlers_refuse_cpu_tensors_and_bad_wrappers():
+  p = random_svgp_params(seed=3, L=2, M=8, d=3, whiten=True)
+  model = gp_model_from_oracle(p, "cpu")
+  with pytest.raises(RuntimeError, match="GPU only"):
+    moment_matching(_state(), model)
+  with pytest.raises(AssertionError):
+    moment_matching(_state(), gp.KernelRegressor(model), model_uncertainty=True)
+  model.mean_function = object()
+  with pytest.raises(NotImplementedError):
+    model.precompute(torch.device("cpu"))
+
+
+def test_moment_matching_euler_python_path():
+  """MomentMatchingEuler.step + Euler.__call__ fold on CPU tensors with a linear drift."""
+  x0 = _state(B=2, d=3, seed=4)
+  A = -0.3 * torch.eye(3, dtype=F64); c = torch.tensor([0.1, 0.0, -0.1], dtype=F64)
+  system = dynamics.DynamicalSystem(drift=Linear(A, c), solver=dynamics.MomentMatchingEuler())
+  losses = []
+
+  def cb(t, state, acc):
+    losses.append(float(t))
+    return acc + state[0].sum(-1)
+  out = system.solve_forward(initial_time=0.0, initial_state=(x0.mean(), x0.covariance()),
+                             solution_times=np.arange(1.0, 4.0), iterator="foldl",
+                             callbacks_and_initializers=[(cb, torch.zeros(2, dtype=F64))])
+  (m, S), acc = out[0], out[1]
+  mu, Sig = x0.mean().numpy(), x0.covariance().numpy()
+  tot = np.zeros(2)
+  for _ in range(3):
+    f1 = mu @ A.numpy().T + c.numpy()
+    Sxf = Sig @ A.numpy().T
+    mu, Sig = mo.euler_moment_update(mu, Sig, f1, A.numpy() @ Sig @ A.numpy().T, Sxf, 1.0)
+    tot += mu.sum(-1)
+  assert np.allclose(m.numpy(), mu) and np.allclose(S.numpy(), Sig) and np.allclose(acc.numpy(), tot)
+  assert losses == [1.0, 2.0, 3.0]
+  hist = system.solve_forward(0.0, (x0.mean(), x0.covariance()), [0.5, 1.0])
+  assert len(hist) == 2

@@ -1,0 +1,106 @@
+"""Deterministic identities that pin the oracle beyond Monte-Carlo noise."""
+import numpy as np
+from numpy.polynomial.hermite_e import hermegauss
+
+from gpflowpilco_amd.synthetic import generate_covariance
+from oracle import mm_fused_ref as fr
+from oracle import mm_oracle as mo
+from oracle.pin_oracle import gpr_predict_f, svgp_predict_f
+from tests.helpers import random_svgp_params
+
+
+def test_sigma_to_zero_limit_is_predict_f():
+  p = random_svgp_params(seed=2, L=3, M=24, d=3, whiten=True)
+  rng = np.random.default_rng(0)
+  mu = rng.uniform(size=(4, 3))
+  Sigma = np.broadcast_to(1e-14 * np.eye(3), (4, 3, 3)).copy()
+  f1, Sff, _ = mo.mm_gauss_svgp_mo(mu, Sigma, p)
+  mean, cov = svgp_predict_f(mu, p)
+  assert np.abs(f1 - mean).max() < 1e-9
+  assert np.abs(Sff - cov).max() < 1e-8
+
+
+def test_gauss_hermite_1d():
+  """d = 1: E[f], Var via 80-point Gauss-Hermite quadrature of the GP predictive equations."""
+  rng = np.random.default_rng(3)
+  N = 12
+  gpr = mo.GPRParams(X=rng.uniform(size=(N, 1)), Y=rng.standard_normal((N, 1)),
+                     lengthscales=np.array([0.4]), variance=0.8, noise_variance=1e-2, mean_c=0.3)
+  mu = np.array([[0.45]]); s2 = 0.2 ** 2
+  x, wq = hermegauss(80)
+  wq = wq / wq.sum()
+  xs = mu[0, 0] + np.sqrt(s2) * x
+  m, v = gpr_predict_f(xs[:, None], gpr)
+  m = m[:, 0]; v = v[:, 0, 0]
+  Ef = wq @ m
+  Vf = wq @ (m - Ef) ** 2 + wq @ v
+  Cxf = wq @ ((xs - mu[0, 0]) * m)
+  f1, Sff, pre = mo.mm_gauss_gpr(mu, np.array([[[s2]]]), gpr)
+  assert abs(f1[0, 0] - Ef) < 1e-10
+  assert abs(Sff[0, 0, 0] - Vf) < 1e-10
+  assert abs(s2 * pre[0, 0, 0] - Cxf) < 1e-10
+
+
+def test_gpr_equals_svgp_with_exact_posterior():
+  """GPR == SVGP when Z = X and (q_mu, q_sqrt) is the exact posterior (whiten=False, zero Kuu jitter)."""
+  rng = np.random.default_rng(5)
+  N, d = 14, 2
+  X = rng.uniform(size=(N, d)); Y = rng.standard_normal((N, 1))
+  ls = np.array([0.5, 0.9]); var = 0.7; noise = 0.05
+  gpr = mo.GPRParams(X=X, Y=Y, lengthscales=ls, variance=var, noise_variance=noise)
+  K = mo.se_kernel(X, None, ls, var)
+  Ky = K + noise * np.eye(N)
+  m = K @ np.linalg.solve(Ky, Y)
+  S = K - K @ np.linalg.solve(Ky, K)
+  S = 0.5 * (S + S.T) + 1e-13 * np.eye(N)
+  svgp = mo.SVGPParams(Z=X[None], lengthscales=ls[None], variance=np.array([var]), q_mu=m,
+                       q_sqrt=np.linalg.cholesky(S)[None], whiten=False, kuu_jitter=1e-10)
+  mu = rng.uniform(size=(3, d)); Sigma = generate_covariance(rng, d, (3,), 0.15)
+  a = mo.mm_gauss_gpr(mu, Sigma, gpr)
+  b = mo.mm_gauss_svgp_so(mu, Sigma, svgp)
+  for x, y in zip(a, b):
+    assert np.abs(x - y).max() < 5e-6     # limited by the 1e-10 jitter needed to factor Kuu
+
+
+def test_mo_equals_so_for_one_latent():
+  p = random_svgp_params(seed=8, L=1, M=20, d=3, whiten=False)
+  rng = np.random.default_rng(1)
+  mu = rng.uniform(size=(2, 3)); Sigma = generate_covariance(rng, 3, (2,), 0.1)
+  a = mo.mm_gauss_svgp_mo(mu, Sigma, p)
+  b = mo.mm_gauss_svgp_so(mu, Sigma, p)
+  for x, y in zip(a, b):
+    assert np.abs(x - y).max() < 1e-12
+
+
+def test_fused_reformulation_equals_literal_algorithm():
+  """The beta / C / centred-delta form used on the GPU is algebraically the reference algorithm."""
+  for whiten in (True, False):
+    p = random_svgp_params(seed=4, L=3, M=40, d=4, whiten=whiten, mean=False)
+    rng = np.random.default_rng(0)
+    mu = rng.uniform(size=(3, 4)); Sigma = generate_covariance(rng, 4, (3,), 0.25)
+    lit = mo.mm_gauss_svgp_mo(mu, Sigma, p)
+    beta, C = fr.precompute(p)
+    fus = fr.moment_match(mu, Sigma, p, beta, C)
+    # relative to the tensor's scale: with whiten=False and a random q_cov, Kuu^-1 S Kuu^-1 is
+    # large and both routes carry cond(Kuu) * eps
+    for x, y in zip(lit, fus):
+      assert np.abs(x - y).max() / np.abs(x).max() < 1e-6
+    lit = mo.mm_gauss_svgp_mo(mu, Sigma, p, model_uncertainty=False)
+    fus = fr.moment_match(mu, Sigma, p, beta, C, model_uncertainty=False)
+    assert np.abs(lit[1] - fus[1]).max() / np.abs(lit[1]).max() < 1e-6
+
+
+def test_euler_update_and_cross_covariance():
+  rng = np.random.default_rng(2)
+  d = 3
+  mu = rng.uniform(size=(2, d)); Sigma = generate_covariance(rng, d, (2,), 0.2)
+  f1 = rng.standard_normal((2, d)); A = rng.standard_normal((2, d, d)); Sff = A @ np.swapaxes(A, 1, 2)
+  pre = rng.standard_normal((2, d, d))
+  Sxf = mo.cross_covariance(Sigma, pre, is_preinv=True)
+  assert np.allclose(Sxf, Sigma @ pre)
+  assert np.allclose(mo.cross_covariance(Sigma, Sxf, is_preinv=False, preinv=True), pre)
+  m2, S2 = mo.euler_moment_update(mu, Sigma, f1, Sff, Sxf, dt=0.5)
+  assert np.allclose(m2, mu + 0.5 * f1)
+  assert np.allclose(S2, Sigma + 0.5 * (Sxf + np.swapaxes(Sxf, 1, 2)) + 0.25 * Sff)
+  jm, jS = mo.joint(mu, Sigma, f1, Sff, Sxf)
+  assert jm.shape == (2, 2 * d) and np.allclose(jS[:, :d, d:], Sxf) and np.allclose(jS, np.swapaxes(jS, 1, 2))
