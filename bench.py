@@ -39,7 +39,7 @@ CONFIGS = {
     "c2": dict(L=5, M=1000, d=5, H=40, B=64, dtype=torch.float64, seed=1001,
                label="C2-shaped closed rollout: N=1000 d=5 D=5 H=40 B=64 fp64"),
     "c3": dict(L=8, M=2000, d=8, H=40, B=256, dtype=torch.float32, seed=1002,
-               label="C3: N=2000 d=8 D=8 H=40 B=256 per GPU fp32 closed drift rollout"),
+               label="C3: N=2000 d=8 D=8 H=40 B per GPU fp32 closed drift rollout"),
 }
 PEAK_TFLOPS = {torch.float32: 157.3, torch.float64: 78.6}   # MI355X_MICROARCH.md dense MFMA peaks
 
@@ -53,6 +53,8 @@ def parse():
   ap.add_argument("--batch", type=int, default=None, help="override B per GPU")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--force-generic", action="store_true")
+  ap.add_argument("--rehearse-gloo", action="store_true",
+                  help="multi-process rehearsal on ONE GPU: gloo backend, every rank on cuda:0, costs gathered via host")
   return ap.parse_args()
 
 
@@ -63,12 +65,17 @@ def main():
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+  if args.rehearse_gloo:
+    local_rank = 0
   torch.cuda.set_device(local_rank)
   dev = torch.device("cuda", local_rank)
   dist = None
   if world > 1:
     import torch.distributed as dist
-    dist.init_process_group("nccl", device_id=dev)
+    if args.rehearse_gloo:
+      dist.init_process_group("gloo")
+    else:
+      dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
 
   cfg = dict(CONFIGS[args.config])
   if args.batch:
@@ -112,7 +119,11 @@ def main():
     if state["h"] == H:
       # per-step cost statistic of the finished rollout, [B_local, H] -> all ranks
       cost = expected_gaussian_cost(traj_mu, traj_S, target, precis).T.contiguous()
-      if world > 1:
+      if world > 1 and args.rehearse_gloo:
+        host = [torch.empty(B, H, dtype=dtype) for _ in range(world)]
+        dist.all_gather(host, cost.cpu())
+        state["cost"] = torch.cat(host, 0).to(dev)
+      elif world > 1:
         dist.all_gather(gathered, cost)
         state["cost"] = torch.cat(gathered, 0)
       else:
@@ -135,12 +146,14 @@ def main():
   fence()
   elapsed = time.perf_counter() - t0
   if world > 1:
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_gloo else dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
   pm.check_status(B)
   if not torch.isfinite(state["S"]).all():
     raise SystemExit("non-finite state in the timed rollout")
+  if state["cost"] is not None and tuple(state["cost"].shape) != (B * world, H):
+    raise SystemExit(f"gathered cost matrix has shape {tuple(state['cost'].shape)}, expected {(B * world, H)}")
 
   # ---- roofline of the dominant kernel (off-diagonal f32 MFMA reduce) ---------------------
   k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
@@ -161,7 +174,7 @@ def main():
       "ms_per_step": round(1e3 * elapsed / args.steps, 4),
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
       "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
-      "config": {"workload": cfg["label"], "N": M, "d": d, "D": L, "H": H,
+      "config": {"workload": cfg["label"].replace("B per GPU", f"B={B} per GPU"), "N": M, "d": d, "D": L, "H": H,
                  "B_per_gpu": B, "B_total": B * world, "parallelism": f"dp{world} over B",
                  "diag_pairs": "f64", "offdiag_pairs": "f32" if dtype == torch.float32 else "f64"},
       "roofline": roofline,
