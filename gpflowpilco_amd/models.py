@@ -212,9 +212,32 @@ class SVGP:
     self.prior = prior
     self._cache = _PackCache()
 
+  def predict_mean(self, x: torch.Tensor) -> torch.Tensor:
+    """Posterior mean at deterministic inputs x [..., D]: K(x, Z) Kuu^-1 u (+ mean function), i.e. the
+    mean half of gpflow's ``predict_f``; what ``KernelRegressor.__call__`` returns (models/core.py:60-62).
+    Plain torch (policy evaluation on real states; not on the moment-matching hot path)."""
+    Z, ls, var, beta, _, mean_c = self.precompute(x.device)
+    kernels = self.latent_kernels
+    xs = kernels[0].slice(x).to(DEFAULT_FLOAT)
+    lead = xs.shape[:-1]
+    xs2 = xs.reshape(-1, xs.shape[-1])
+    A = xs2[None] / ls[:, None, :]                              # [L, n, d]
+    Bz = Z / ls[:, None, :]                                     # [L, M, d]
+    d2 = (A * A).sum(-1)[:, :, None] + (Bz * Bz).sum(-1)[:, None, :] - 2.0 * A @ Bz.transpose(1, 2)
+    Kxz = var[:, None, None] * torch.exp(-0.5 * d2.clamp_min(0.0))
+    g = (Kxz @ beta.unsqueeze(-1)).squeeze(-1).T                # [n, L]
+    if isinstance(self.kernel, LinearCoregionalization):
+      g = g @ self.kernel.W.to(g).T
+      if isinstance(self.mean_function, Constant):
+        g = g + self.mean_function.c.to(g)
+    elif mean_c is not None:
+      g = g + mean_c
+    return g.reshape(lead + g.shape[-1:]).to(x.dtype)
+
   def __call__(self, x, **kwargs):
-    # predict_f (gpflow conditionals) is not on the moment-matching path
-    raise NotImplementedError("SVGP.predict_f is outside the accelerated path")
+    if isinstance(x, torch.Tensor):
+      return self.predict_mean(x)
+    raise NotImplementedError("SVGP.__call__ takes a tensor of inputs")
 
   # -- helpers used by the handlers ---------------------------------------
   def _parameters(self):
@@ -332,9 +355,15 @@ class GPModelWrapper:
 class KernelRegressor(GPModelWrapper):
   """Mean-only view of a model (no predictive uncertainty); models/core.py:60-62."""
 
+  def __call__(self, x, **kwargs):
+    return self.model.predict_mean(x)
+
 
 class InverseLinkWrapper(GPModelWrapper):
   """model followed by an inverse link (bijector chain); models/core.py:65-71."""
 
   def __init__(self, model, invlink):
     super().__init__(model=model, invlink=invlink)
+
+  def __call__(self, *args, **kwargs):
+    return self.invlink(self.model(*args, **kwargs))

@@ -15,4 +15,4 @@ __all__ = (
 from .core import (Chain, LinearOperatorDiag, MomentMatch, Moments, dispatcher,
                    moment_matching, register_type)
 from .gaussian import GaussianMatch, GaussianMoments
-from . import models  # registers the GP handlers
+from . import maths, bijectors, components, models  # registers the handlers

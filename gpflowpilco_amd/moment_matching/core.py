@@ -45,10 +45,21 @@ class LinearOperatorDiag:
   def matmul(self, x: torch.Tensor) -> torch.Tensor:
     return self.diag.unsqueeze(-1) * x
 
-  __matmul__ = matmul
+  def __matmul__(self, other):
+    if isinstance(other, LinearOperatorDiag):
+      return LinearOperatorDiag(self.diag * other.diag)
+    return self.matmul(other)
+
+  def __rmatmul__(self, other: torch.Tensor) -> torch.Tensor:
+    return other * self.diag.unsqueeze(-2)          # A @ diag(v): scale the columns
 
   def solve(self, rhs: torch.Tensor) -> torch.Tensor:
     return rhs / self.diag.unsqueeze(-1)
+
+  @classmethod
+  def identity_like(cls, mean: torch.Tensor, multiplier=1.0) -> "LinearOperatorDiag":
+    """Stand-in for LinearOperatorIdentity / LinearOperatorScaledIdentity (maths.py:43,77)."""
+    return cls(torch.ones_like(mean) * multiplier)
 
 
 ArrayTypes = (torch.Tensor, LinearOperatorDiag)
