@@ -8,8 +8,6 @@ from __future__ import annotations
 
 import torch
 
-from .moment_matching import GaussianMoments
-
 
 def expected_gaussian_cost(mean: torch.Tensor, cov: torch.Tensor, target: torch.Tensor,
                            precis: torch.Tensor) -> torch.Tensor:
@@ -34,7 +32,8 @@ class GaussianObjective:
     self.precis = precis
 
   def __call__(self, x, t=None):
-    if isinstance(x, GaussianMoments):
+    from .moment_matching.core import Moments          # lazy: moment_matching imports components
+    if isinstance(x, Moments):
       return expected_gaussian_cost(x.mean(), x.covariance(dense=True), self.target.to(x.mean()),
                                     self.precis.to(x.mean()))
     err = x - self.target

@@ -28,13 +28,14 @@ __device__ __forceinline__ void mm_decode_pair_f(int p, int L, int& a, int& a2) 
   a = i; a2 = i + 1 + r;
 }
 
+// expm1, any argument: x = k ln2 + r, degree-12 Taylor of expm1(r) on |r| <= ln2/2 (truncation
+// 0.35^12/13! = 5e-16 relative), 2^k (1 + p) - 1 = fma(2^k, p, 2^k - 1).  No clamp: v_cvt_i32_f64
+// saturates and v_ldexp_f64 over/underflows to inf/0, which is the right limit.
 __device__ __forceinline__ double mm_expm1_f64(double x) {
-  x = fmin(fmax(x, -800.0), 700.0);
   const double kf = rint(x * 1.4426950408889634);
   double r = fma(-kf, 6.93147180369123816490e-01, x);
   r = fma(-kf, 1.90821492927058770002e-10, r);
-  double q = 1.6059043836821613e-10;            // 1/13!
-  q = fma(q, r, 2.08767569878681e-09);          // 1/12!
+  double q = 2.08767569878681e-09;              // 1/12!
   q = fma(q, r, 2.505210838544172e-08);         // 1/11!
   q = fma(q, r, 2.755731922398589e-07);         // 1/10!
   q = fma(q, r, 2.7557319223985893e-06);        // 1/9!
@@ -51,14 +52,35 @@ __device__ __forceinline__ double mm_expm1_f64(double x) {
   return fma(s, p, s - 1.0);                    // 2^k (1 + p) - 1
 }
 
+// expm1 on |x| <= 0.75 without range reduction: degree-14 Taylor (truncation 0.75^14/15! = 1.4e-14
+// relative at the edge, 5e-17 at |x| <= 0.5).  Used when the whole 32x32 wave tile is in range.
+__device__ __forceinline__ double mm_expm1_f64_small(double x) {
+  double q = 7.647163731819816e-13;             // 1/15!
+  q = fma(q, x, 1.1470745597729725e-11);        // 1/14!
+  q = fma(q, x, 1.6059043836821613e-10);        // 1/13!
+  q = fma(q, x, 2.08767569878681e-09);          // 1/12!
+  q = fma(q, x, 2.505210838544172e-08);         // 1/11!
+  q = fma(q, x, 2.755731922398589e-07);         // 1/10!
+  q = fma(q, x, 2.7557319223985893e-06);        // 1/9!
+  q = fma(q, x, 2.48015873015873e-05);          // 1/8!
+  q = fma(q, x, 1.984126984126984e-04);         // 1/7!
+  q = fma(q, x, 1.388888888888889e-03);         // 1/6!
+  q = fma(q, x, 8.333333333333333e-03);         // 1/5!
+  q = fma(q, x, 4.1666666666666664e-02);        // 1/4!
+  q = fma(q, x, 1.6666666666666666e-01);        // 1/3!
+  q = fma(q, x, 0.5);
+  q = fma(q, x, 1.0);
+  return q * x;
+}
+
 // KS4: number of K=4 MFMA steps covering the d input dimensions.
 // grid: x = tile pairs (diag: nt(nt+1)/2 upper pairs; else nt*nt), y = pairs of this launch,
 //       z = batch chunks.  Row/col operand arrays are indexed by the local pair index.
-template <int KS4, bool DIAG>
+template <int KS4, bool DIAG, bool WITHC>
 __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restrict__ Zc, int Kz,
                                                           const double* __restrict__ Cm,
                                                           int L, int Mp, int d, int P, int NS, int p0,
-                                                          int B, int bchunk,
+                                                          int B, int bchunk, double small_limit,
                                                           const double* __restrict__ w,
                                                           const double* __restrict__ q,
                                                           const double* __restrict__ rowA,
@@ -77,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
   const int lp = blockIdx.y, np = gridDim.y, p = p0 + lp;
   int a, a2;
   mm_decode_pair_f(p, L, a, a2);
-  const bool withC = DIAG && (Cm != nullptr);
+  constexpr bool withC = DIAG && WITHC;
   const double sym = (DIAG && it != jt) ? 2.0 : 1.0;
 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
@@ -114,21 +136,28 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
   }
   const size_t goff = (size_t)d * Mp;
 
+  // in f64 mode only |delta| <= 0.5 takes the unreduced polynomial (full f64 accuracy there)
+  const double SMALL_LIMIT = small_limit;
   __shared__ double red[8];
   const int b0 = blockIdx.z * bchunk;
   const int b1 = (b0 + bchunk < B) ? b0 + bchunk : B;
-  for (int b = b0; b < b1; ++b) {
-    const double* ra = rowA + ((size_t)b * np + lp) * Mp;
-    const double* cb = colB + ((size_t)b * np + lp) * (size_t)(d + 1) * Mp;
-    const double* wr = w + ((size_t)b * L + a) * Mp;
-    const double* wc = w + ((size_t)b * L + a2) * Mp;
-    const double* qr = q + ((size_t)b * L + a) * Mp;
+  // per-b operand pointers advance by constant strides (no 64-bit multiplies in the loop)
+  const double* ra = rowA + ((size_t)b0 * np + lp) * Mp;
+  const double* cb = colB + ((size_t)b0 * np + lp) * (size_t)(d + 1) * Mp;
+  const double* wr = w + ((size_t)b0 * L + a) * Mp;
+  const double* wc = w + ((size_t)b0 * L + a2) * Mp;
+  const double* qr = q + ((size_t)b0 * L + a) * Mp;
+  const size_t st_ra = (size_t)np * Mp, st_cb = (size_t)np * (d + 1) * Mp, st_w = (size_t)L * Mp;
+  // lane-constant selectors of the extra k-step: A = (rho_i, 1, 0, 0), B = (1, gamma'_j, 0, 0)
+  const double selA1 = (kq == 1) ? 1.0 : 0.0, selB0 = (kq == 0) ? 1.0 : 0.0;
+  const double mA0 = (kq == 0) ? 1.0 : 0.0, mB1 = (kq == 1) ? 1.0 : 0.0;
+  for (int b = b0; b < b1; ++b, ra += st_ra, cb += st_cb, wr += st_w, wc += st_w, qr += st_w) {
 
     double ax[2], bx[2], breg[2][KS4], wj[2], qj[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const double rv = ra[rbase + rt * 16 + l15];
-      ax[rt] = (kq == 0) ? rv : (kq == 1 ? 1.0 : 0.0);
+      ax[rt] = fma(rv, mA0, selA1);
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -136,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
 #pragma unroll
       for (int s = 0; s < KS4; ++s) breg[ct][s] = cb[boff[s] + col];
       const double gv = cb[goff + col];
-      bx[ct] = (kq == 0) ? 1.0 : (kq == 1 ? gv : 0.0);
+      bx[ct] = fma(gv, mB1, selB0);
       wj[ct] = wc[col];
       qj[ct] = withC ? qr[col] : 0.0;      // a == a2 on the diagonal
     }
@@ -150,10 +179,9 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
         qi[rt][r] = withC ? qr[row] : 0.0;
       }
 
-    double sB = 0.0, sC = 0.0;
+    f64x4 cacc[2][2];
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      double pB = 0.0, pC = 0.0;
+    for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         f64x4 c = {0.0, 0.0, 0.0, 0.0};
@@ -161,24 +189,45 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
 #pragma unroll
         for (int s = 0; s < KS4; ++s)
           c = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[rt][s], breg[ct][s], c, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double e = mm_expm1_f64(c[r]);
-          pB = fma(wi[rt][r], e, pB);
-          if (withC) pC = fma(creg[rt][ct][r], fma(qi[rt][r], e, qi[rt][r]), pC);
-        }
+        cacc[rt][ct] = c;
       }
-      sB = fma(pB, wj[ct], sB);
-      sC = fma(pC, qj[ct], sC);
-    }
-    // workgroup reduction of (sB, sC) for this b
+    // wave-uniform choice of the expm1 form (the |.| test runs on the high dwords only)
+    double mx = 0.0;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      sB += __shfl_down(sB, off, 64);
-      sC += __shfl_down(sC, off, 64);
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmax(mx, fabs(cacc[rt][ct][r]));
+    const bool small = !__any(mx > SMALL_LIMIT);
+    double sB = 0.0, sC = 0.0;
+#define MM_F64_ACCUM(EXPM1_)                                                              \
+    _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                    \
+      double pB = 0.0, pC = 0.0;                                                          \
+      _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                    \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                   \
+          const double e = EXPM1_(cacc[rt][ct][r]);                                       \
+          pB = fma(wi[rt][r], e, pB);                                                     \
+          if (withC) pC = fma(creg[rt][ct][r], fma(qi[rt][r], e, qi[rt][r]), pC);         \
+        }                                                                                 \
+      sB = fma(pB, wj[ct], sB);                                                           \
+      sC = fma(pC, qj[ct], sC);                                                           \
     }
+    if (small) { MM_F64_ACCUM(mm_expm1_f64_small) } else { MM_F64_ACCUM(mm_expm1_f64) }
+#undef MM_F64_ACCUM
+    // workgroup reduction of (sB, sC) for this b.  First fold across the two lane halves so that
+    // lanes 0-31 carry sB partials and lanes 32-63 sC partials, then 5 butterfly steps on ONE value.
+    double v;
+    {
+      const bool lo = lane < 32;
+      const double keep = lo ? sB : sC, give = lo ? sC : sB;
+      v = keep + __shfl_xor(give, 32, 64);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     __syncthreads();
-    if (lane == 0) { red[wv] = sB; red[4 + wv] = sC; }
+    if (lane == 0) red[wv] = v;            // sB of this wave
+    if (lane == 32) red[4 + wv] = v;       // sC of this wave
     __syncthreads();
     if (threadIdx.x == 0) {
       partB[((size_t)b * P + p) * NS + blockIdx.x] = sym * (red[0] + red[1] + red[2] + red[3]);
@@ -194,7 +243,7 @@ int mm_f64_num_slots(int Mp, int diag) {
 
 // Launch over `npairs` pairs starting at global pair index p0.  diag != 0: pairs are (a, a).
 int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, int L, int Mp, int d, int P, int NS,
-                       int p0, int npairs, int B, int diag,
+                       int p0, int npairs, int B, int diag, double small_limit,
                        const double* w, const double* q, const double* rowA, const double* colB,
                        double* partB, double* partC, hipStream_t stream) {
   if (npairs <= 0) return 0;
@@ -211,8 +260,14 @@ int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, int L, int Mp
   dim3 grid(nslots, npairs, nchunk);
   const int ks4 = (d + 3) / 4;
 #define MM_LAUNCH_F64(KS_, DG_)                                                                    \
-  hipLaunchKernelGGL((k_qred_f64_mfma<KS_, DG_>), grid, dim3(256), 0, stream, Zc, Kz, Cm, L, Mp, d, \
-                     P, NS, p0, B, bchunk, w, q, rowA, colB, partB, partC)
+  do {                                                                                             \
+    if (DG_ && Cm != nullptr)                                                                      \
+      hipLaunchKernelGGL((k_qred_f64_mfma<KS_, DG_, true>), grid, dim3(256), 0, stream, Zc, Kz, Cm, L, Mp, d, \
+                         P, NS, p0, B, bchunk, small_limit, w, q, rowA, colB, partB, partC);      \
+    else                                                                                           \
+      hipLaunchKernelGGL((k_qred_f64_mfma<KS_, DG_, false>), grid, dim3(256), 0, stream, Zc, Kz, Cm, L, Mp, d, \
+                         P, NS, p0, B, bchunk, small_limit, w, q, rowA, colB, partB, partC);      \
+  } while (0)
 #define MM_LAUNCH_F64_KS(DG_)                                   \
   do {                                                          \
     if (ks4 <= 1) MM_LAUNCH_F64(1, DG_);                        \

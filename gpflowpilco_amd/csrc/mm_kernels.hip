@@ -686,7 +686,7 @@ int mm_mfma_num_slots(int Mp);
 // f64 MFMA reduce (mm_f64.hip): diagonal pairs of both modes, off-diagonal pairs of the f64 mode
 int mm_f64_num_slots(int Mp, int diag);
 int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, int L, int Mp, int d, int P, int NS,
-                       int p0, int npairs, int B, int diag,
+                       int p0, int npairs, int B, int diag, double small_limit,
                        const double* w, const double* q, const double* rowA, const double* colB,
                        double* partB, double* partC, hipStream_t stream);
 int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
@@ -795,7 +795,8 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
       MM_CHECK_LAUNCH();
     } else {
       const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS,
-                                        0, L, B, 1, (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+                                        0, L, B, 1, sizeof(T) == 4 ? 0.75 : 0.5,
+                                        (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
                                         (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD),
                                         partB, partC, s);
       if (rc) return rc;
@@ -808,7 +809,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
       if (rc) return rc;
     } else if (sizeof(T) == 8 && !generic) {
       const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, nullptr, L, wl.Mp, d, wl.P, wl.NS,
-                                        L, wl.Po, B, 0, (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+                                        L, wl.Po, B, 0, 0.5, (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
                                         (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO),
                                         partB, partC, s);
       if (rc) return rc;
