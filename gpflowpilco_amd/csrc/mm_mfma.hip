@@ -96,6 +96,40 @@ __device__ __forceinline__ void mm_split3(float x, unsigned int& h, unsigned int
 #define MM_P7_C1 5.000000596e-01f
 #define MM_P7_C0 1.0f
 
+// Near-minimax coefficients of expm1(x)/x by range tier (relative error of x*P(x) <= 2.3e-7 in f32):
+//   |x| <= 0.25: degree 4,  |x| <= 0.5: degree 5,  |x| <= 1: degree 7   (scratch/minimax2.py)
+template <int DEG> struct MMPoly;
+template <> struct MMPoly<4> {
+  static constexpr float c[5] = {1.000000000e+00f, 4.999983013e-01f, 1.666673869e-01f, 4.177515209e-02f, 8.333330043e-03f};
+};
+template <> struct MMPoly<5> {
+  static constexpr float c[6] = {1.000000119e+00f, 4.999998212e-01f, 1.666597426e-01f, 4.166870192e-02f,
+                                 8.407683112e-03f, 1.388882170e-03f};
+};
+template <> struct MMPoly<7> {
+  static constexpr float c[8] = {MM_P7_C0, MM_P7_C1, MM_P7_C2, MM_P7_C3, MM_P7_C4, MM_P7_C5, MM_P7_C6, MM_P7_C7};
+};
+
+// sum_r w_r * x_r * P_DEG(x_r) over the 16 register pairs of a wave tile.  The Horner steps run
+// "vertically" over the pairs so that consecutive v_pk_fma_f32 are independent.
+template <int DEG>
+__device__ __forceinline__ f32x2 mm_weighted_expm1(const f32x2 (&xx)[16], const f32x2 (&wrow)[2][8]) {
+  f32x2 pp[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(MM_PK(MMPoly<DEG>::c[DEG]), xx[r], MM_PK(MMPoly<DEG>::c[DEG - 1]));
+#pragma unroll
+  for (int k = DEG - 2; k >= 0; --k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(pp[r], xx[r], MM_PK(MMPoly<DEG>::c[k]));
+  f32x2 parts[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const f32x2 wx = wrow[r >> 3][r & 7] * xx[r];          // w_i * x
+    parts[r & 3] = mm_pkfma(wx, pp[r], parts[r & 3]);       // += w_i * x * P(x)
+  }
+  return (parts[0] + parts[1]) + (parts[2] + parts[3]);
+}
+
 __device__ __forceinline__ float mm_expm1_p7(float x) {
   float p = fmaf(MM_P7_C7, x, MM_P7_C6);
   p = fmaf(p, x, MM_P7_C5); p = fmaf(p, x, MM_P7_C4); p = fmaf(p, x, MM_P7_C3);
@@ -236,28 +270,13 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
         mx = fmaxf(mx, fmaxf(fabsf(xx[r][0]), fabsf(xx[r][1])));
       }
       f32x2 part2;
-      if (!__any(mx > 1.0f)) {
-        // Horner steps run "vertically" over the 16 register pairs so that consecutive
-        // v_pk_fma_f32 are independent (a dependent pair costs a wait state + the FMA latency).
-        f32x2 pp[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(MM_PK(MM_P7_C7), xx[r], MM_PK(MM_P7_C6));
-#define MM_HORNER_STEP(c_)                                            \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(pp[r], xx[r], MM_PK(c_));
-        MM_HORNER_STEP(MM_P7_C5)
-        MM_HORNER_STEP(MM_P7_C4)
-        MM_HORNER_STEP(MM_P7_C3)
-        MM_HORNER_STEP(MM_P7_C2)
-        MM_HORNER_STEP(MM_P7_C1)
-        MM_HORNER_STEP(MM_P7_C0)
-#undef MM_HORNER_STEP
-        f32x2 parts[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const f32x2 wx = wrow[r >> 3][r & 7] * xx[r];          // w_i * x
-          parts[r & 3] = mm_pkfma(wx, pp[r], parts[r & 3]);       // += w_i * x * P(x)
-        }
-        part2 = (parts[0] + parts[1]) + (parts[2] + parts[3]);
+      // wave-uniform tier choice (three ballots, no cross-lane reduction)
+      if (!__any(mx > 0.25f)) {
+        part2 = mm_weighted_expm1<4>(xx, wrow);
+      } else if (!__any(mx > 0.5f)) {
+        part2 = mm_weighted_expm1<5>(xx, wrow);
+      } else if (!__any(mx > 1.0f)) {
+        part2 = mm_weighted_expm1<7>(xx, wrow);
       } else {
         part2 = (f32x2){0.0f, 0.0f};
 #pragma unroll
