@@ -52,26 +52,21 @@ __device__ __forceinline__ double mm_expm1_f64(double x) {
   return fma(s, p, s - 1.0);                    // 2^k (1 + p) - 1
 }
 
-// expm1 on |x| <= 0.75 without range reduction: degree-14 Taylor (truncation 0.75^14/15! = 1.4e-14
-// relative at the edge, 5e-17 at |x| <= 0.5).  Used when the whole 32x32 wave tile is in range.
-__device__ __forceinline__ double mm_expm1_f64_small(double x) {
-  double q = 7.647163731819816e-13;             // 1/15!
-  q = fma(q, x, 1.1470745597729725e-11);        // 1/14!
-  q = fma(q, x, 1.6059043836821613e-10);        // 1/13!
-  q = fma(q, x, 2.08767569878681e-09);          // 1/12!
-  q = fma(q, x, 2.505210838544172e-08);         // 1/11!
-  q = fma(q, x, 2.755731922398589e-07);         // 1/10!
-  q = fma(q, x, 2.7557319223985893e-06);        // 1/9!
-  q = fma(q, x, 2.48015873015873e-05);          // 1/8!
-  q = fma(q, x, 1.984126984126984e-04);         // 1/7!
-  q = fma(q, x, 1.388888888888889e-03);         // 1/6!
-  q = fma(q, x, 8.333333333333333e-03);         // 1/5!
-  q = fma(q, x, 4.1666666666666664e-02);        // 1/4!
-  q = fma(q, x, 1.6666666666666666e-01);        // 1/3!
-  q = fma(q, x, 0.5);
-  q = fma(q, x, 1.0);
+// expm1 without range reduction: Taylor to degree DEG, x * (1 + x/2! + ... + x^(DEG-1)/DEG!).
+// Truncation relative to expm1(x): |x|^DEG / (DEG+1)!.  Tiers used by the kernel (wave-uniform):
+//   |x| <= 0.25: DEG 10 (2.4e-14, f32 mode) or 12 (1e-17, f64 mode);  |x| <= 0.75 / 0.5: DEG 15.
+__device__ constexpr double mm_inv_fact(int n) { double f = 1.0; for (int i = 2; i <= n; ++i) f *= i; return 1.0 / f; }
+
+template <int DEG>
+__device__ __forceinline__ double mm_expm1_f64_poly(double x) {
+  double q = mm_inv_fact(DEG);
+#pragma unroll
+  for (int k = DEG - 1; k >= 1; --k) q = fma(q, x, mm_inv_fact(k));
   return q * x;
 }
+__device__ __forceinline__ double mm_expm1_f64_p10(double x) { return mm_expm1_f64_poly<10>(x); }
+__device__ __forceinline__ double mm_expm1_f64_p12(double x) { return mm_expm1_f64_poly<12>(x); }
+__device__ __forceinline__ double mm_expm1_f64_p15(double x) { return mm_expm1_f64_poly<15>(x); }
 
 // KS4: number of K=4 MFMA steps covering the d input dimensions.
 // grid: x = tile pairs (diag: nt(nt+1)/2 upper pairs; else nt*nt), y = pairs of this launch,
@@ -199,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmax(mx, fabs(cacc[rt][ct][r]));
+    const bool tiny = !__any(mx > 0.25);
     const bool small = !__any(mx > SMALL_LIMIT);
     double sB = 0.0, sC = 0.0;
 #define MM_F64_ACCUM(EXPM1_)                                                              \
@@ -213,7 +209,13 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
       sB = fma(pB, wj[ct], sB);                                                           \
       sC = fma(pC, qj[ct], sC);                                                           \
     }
-    if (small) { MM_F64_ACCUM(mm_expm1_f64_small) } else { MM_F64_ACCUM(mm_expm1_f64) }
+    if (tiny) {
+      if (SMALL_LIMIT > 0.6) { MM_F64_ACCUM(mm_expm1_f64_p10) } else { MM_F64_ACCUM(mm_expm1_f64_p12) }
+    } else if (small) {
+      MM_F64_ACCUM(mm_expm1_f64_p15)
+    } else {
+      MM_F64_ACCUM(mm_expm1_f64)
+    }
 #undef MM_F64_ACCUM
     // workgroup reduction of (sB, sC) for this b.  First fold across the two lane halves so that
     // lanes 0-31 carry sB partials and lanes 32-63 sC partials, then 5 butterfly steps on ONE value.
