@@ -160,9 +160,14 @@ def main():
   Po = L * (L - 1) // 2
   flops = float(B) * Po * M * M * (2 * d + 12)            # E * (2d + 12), E = B*Po*M^2
   achieved = flops / (k_ms * 1e-3) / 1e12 if Po else 0.0
+  # HBM bytes per launch of the dominant kernel from the PMC passes kept in
+  # profiles/r01_pmc_hbm_traffic.csv (FETCH_SIZE x 2 per MI355X_MICROARCH.md "HBM" + WRITE_SIZE, KB):
+  # 2 * 297655 KB + 448 KB = 0.61 GB against 0.60 GB of streamed operands (rowO + colO + w).
+  # Only valid for the default C3 / B = 256 launch; other shapes report null.
+  traffic = 2 * 297655 * 1024 + 448 * 1024 if (args.config == "c3" and B == 256 and not args.force_generic) else None
   roofline = {"bound": "mfma", "kernel": "k_qred_f32_mfma" if (dtype == torch.float32 and not args.force_generic) else "k_qred_generic",
               "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-              "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": None,
+              "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": traffic,
               "kernel_ms": round(k_ms, 4),
               "flops_per_launch": flops, "entries_per_launch": float(B) * Po * M * M}
 
