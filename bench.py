@@ -41,6 +41,9 @@ CONFIGS = {
     "c3": dict(L=8, M=2000, d=8, H=40, B=256, dtype=torch.float32, seed=1002,
                label="C3: N=2000 d=8 D=8 H=40 B per GPU fp32 closed drift rollout"),
 }
+# BASELINE.json configs[4] per GPU: S = 65536 / 8 sample paths, N = 2000, K = 1024 bases, H = 50
+PATHWISE = dict(L=8, M=2000, d=8, K=1024, H=50, S=8192, dtype=torch.float32, seed=1004,
+                label="C5 per-GPU shard: pathwise sample rollout S=8192 (65536/8) N=2000 K=1024 d=D=8 H=50 fp32")
 PEAK_TFLOPS = {torch.float32: 157.3, torch.float64: 78.6}   # MI355X_MICROARCH.md dense MFMA peaks
 
 
@@ -49,7 +52,7 @@ def parse():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=80)
   ap.add_argument("--warmup", type=int, default=8)
-  ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
+  ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c5"])
   ap.add_argument("--batch", type=int, default=None, help="override B per GPU")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--force-generic", action="store_true")
@@ -77,6 +80,8 @@ def main():
     else:
       dist.init_process_group("nccl", device_id=dev)     # RCCL over xGMI
 
+  if args.config == "c5":
+    return pathwise_bench(args, rank, world, dev, dist)
   cfg = dict(CONFIGS[args.config])
   if args.batch:
     cfg["B"] = args.batch
@@ -214,6 +219,72 @@ def main():
                      "max_abs_err": {"f1": err(f1, first[0]), "Sff": err(Sff, first[1]), "cross_pre": err(cross, first[2])},
                      "max_abs": {"f1": float(np.abs(first[0]).max()), "Sff": float(np.abs(first[1]).max()),
                                  "cross_pre": float(np.abs(first[2]).max())}}
+  if rank == 0:
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def pathwise_bench(args, rank, world, dev, dist):
+  """configs[4]: one step = one Euler step of all local sample paths (HBM-bound weight stream)."""
+  from gpflowpilco_amd.pathwise import PathwiseSVGP
+  c = dict(PATHWISE)
+  if args.batch:
+    c["S"] = args.batch
+  L, M, d, K, H, S, dtype = c["L"], c["M"], c["d"], c["K"], c["H"], c["S"], c["dtype"]
+  syn = make_svgp(L, M, d, seed=c["seed"], device=str(dev), ls_bounds=(0.7, 3.0))
+  base = syn.to_model(dev)
+  model = PathwiseSVGP(kernel=base.kernel, inducing_variable=base.inducing_variable, q_mu=base.q_mu,
+                       q_sqrt=base.q_sqrt, whiten=True, num_latent_gps=L)
+  g = torch.Generator(device=dev).manual_seed(c["seed"] + rank)
+  paths = model.generate_paths(S, K, dtype=dtype, device=dev, generator=g)
+  x0 = 0.3 + 0.4 * torch.rand(S, d, dtype=dtype, device=dev, generator=g)
+  target = torch.full((d,), 0.5, dtype=dtype, device=dev)
+
+  def rollout_steps(n):
+    x, traj = paths.rollout(x0, n, dt=1.0, keep_trajectory=True)
+    err = traj - target
+    return -torch.exp(-2.0 * (err * err).sum(-1)).T.contiguous()          # [S, n] per-step sample costs
+
+  def fence():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  rollout_steps(max(1, args.warmup))
+  fence()
+  e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  done = 0
+  e0.record()
+  while done < args.steps:
+    n = min(H, args.steps - done)
+    cost = rollout_steps(n)
+    if n == H and world > 1:
+      out = [torch.empty_like(cost) for _ in range(world)]
+      dist.all_gather(out, cost)
+    done += n
+  e1.record()
+  fence()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+  k_ms = e0.elapsed_time(e1) / args.steps
+  bytes_per_launch = float(S) * L * (K + M) * 4
+  achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
+  out = {"metric": "pathwise_rollout_sample_steps_per_sec", "value": round(S * world * args.steps / elapsed, 1),
+         "unit": "sample step-elements/s (S*H per rollout second)", "n_gpus": world, "steps": args.steps,
+         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
+         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+         "config": {"workload": c["label"], "N": M, "d": d, "D": L, "K": K, "H": H, "S_per_gpu": S,
+                    "parallelism": f"dp{world} over S"},
+         "roofline": {"bound": "hbm", "kernel": "k_pathwise", "achieved": round(achieved, 1), "peak": 8000.0,
+                      "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+                      "kernel_ms": round(k_ms, 4), "bytes_per_launch": bytes_per_launch,
+                      "note": "kernel_ms includes the (small) cost kernels between launches"}}
   if rank == 0:
     print(json.dumps(out))
   if world > 1:

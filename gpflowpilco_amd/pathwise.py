@@ -32,32 +32,28 @@ def _pad_last(t: torch.Tensor, mult: int) -> torch.Tensor:
 @dataclass
 class Paths:
   """S sample paths of L latent GPs (device tensors, element type ``dtype``)."""
-  omega: torch.Tensor      # [L, Kp, d]
-  phase: torch.Tensor      # [L, Kp]
-  zs: torch.Tensor         # [L, Mp, d]   Z / lengthscales
+  omega: torch.Tensor      # [L, d, Kp]   omega^T / 2 pi  (revolutions, k-major)
+  phase: torch.Tensor      # [L, Kp]      b / 2 pi
+  zs: torch.Tensor         # [L, d, Mp]   (Z * x_scale)^T, x_scale = sqrt(log2 e) / lengthscales
   hz: torch.Tensor         # [L, Mp]      |zs|^2 / 2
-  w: torch.Tensor          # [S, L, Kp]   prior weights (zero padded)
-  v: torch.Tensor          # [S, L, Mp]   update weights (zero padded)
-  lengthscales: torch.Tensor   # [L, d] f64
+  wb: torch.Tensor         # [G, L, NB, 4, BT] blocked weight stream (prior blocks, then update blocks)
+  num_samples: int
+  lengthscales: torch.Tensor   # [L, d] f64: x_scale = sqrt(log2 e) / lengthscales
   prior_scale: torch.Tensor    # [L] f64  sqrt(2 var / K)
   variance: torch.Tensor       # [L] f64
   mean_c: Optional[torch.Tensor]  # [L] f64 or None
 
   @property
-  def num_samples(self):
-    return self.w.shape[0]
-
-  @property
   def dtype(self):
-    return self.w.dtype
+    return self.wb.dtype
 
   def _dims(self):
-    S, L, Kp = self.w.shape
-    return S, L, self.v.shape[-1], Kp, self.omega.shape[-1]
+    L, d, Kp = self.omega.shape
+    return self.num_samples, L, self.zs.shape[-1], Kp, d
 
   def __call__(self, x: torch.Tensor) -> torch.Tensor:
     """f_s(x_s): x [S, d] -> [S, L]."""
-    _require_device(x, self.w)
+    _require_device(x, self.wb)
     S, L, Mp, Kp, d = self._dims()
     if x.shape != (S, d) or x.dtype != self.dtype:
       raise ValueError(f"expected x [{S},{d}] of {self.dtype}, got {tuple(x.shape)} {x.dtype}")
@@ -66,14 +62,14 @@ class Paths:
     rc = _lib.lib().mm_pathwise_eval(S, L, Mp, Kp, d, _dtype_code(self.dtype), x.data_ptr(), self.omega.data_ptr(),
                                      self.phase.data_ptr(), self.zs.data_ptr(), self.hz.data_ptr(),
                                      self.lengthscales.data_ptr(), self.prior_scale.data_ptr(),
-                                     self.variance.data_ptr(), _ptr(self.mean_c), self.w.data_ptr(),
-                                     self.v.data_ptr(), out.data_ptr(), _stream(x.device))
+                                     self.variance.data_ptr(), _ptr(self.mean_c), self.wb.data_ptr(),
+                                     out.data_ptr(), _stream(x.device))
     check(rc, "mm_pathwise_eval")
     return out
 
   def rollout(self, x0: torch.Tensor, num_steps: int, dt: float = 1.0, keep_trajectory: bool = False):
     """Drift-only Euler rollout of all S paths (d == L): x <- x + dt f(x), H steps in one ABI call."""
-    _require_device(x0, self.w)
+    _require_device(x0, self.wb)
     S, L, Mp, Kp, d = self._dims()
     x = x0.contiguous().clone()
     tmp = torch.empty_like(x)
@@ -82,7 +78,7 @@ class Paths:
                                         x.data_ptr(), tmp.data_ptr(), self.omega.data_ptr(), self.phase.data_ptr(),
                                         self.zs.data_ptr(), self.hz.data_ptr(), self.lengthscales.data_ptr(),
                                         self.prior_scale.data_ptr(), self.variance.data_ptr(), _ptr(self.mean_c),
-                                        self.w.data_ptr(), self.v.data_ptr(), _ptr(traj), _stream(x.device))
+                                        self.wb.data_ptr(), _ptr(traj), _stream(x.device))
     check(rc, "mm_pathwise_rollout")
     return (x, traj) if keep_trajectory else x
 
@@ -91,18 +87,28 @@ def paths_from_arrays(omega, phase, w, v, Z, lengthscales, variance, mean_c=None
                       device="cuda") -> Paths:
   """Build ``Paths`` from explicit arrays (omega [L,K,d], phase [L,K], w [S,L,K], v [S,L,M], Z [L,M,d])."""
   t64 = lambda a: torch.as_tensor(a, dtype=DEFAULT_FLOAT, device=device)
-  mult = 2 if dtype == torch.float64 else 4
-  ls = t64(lengthscales)
-  zs = t64(Z) / ls[:, None, :]
+  mult = 128 if dtype == torch.float64 else 256          # BT: terms per block of the weight stream
+  xscale = math.sqrt(math.log2(math.e)) / t64(lengthscales)                    # [L, d]
+  zs = t64(Z) * xscale[:, None, :]
   hz = 0.5 * (zs * zs).sum(-1)
   K = omega.shape[1]
   tt = lambda a: a.to(dtype).contiguous()
   padk = lambda a: tt(_pad_last(t64(a), mult))
-  omega_p = tt(_pad_last(t64(omega).transpose(1, 2), mult).transpose(1, 2))
-  zs_p = tt(_pad_last(zs.transpose(1, 2), mult).transpose(1, 2))
+  two_pi = 2.0 * math.pi
+  omega_p = tt(_pad_last(t64(omega).transpose(1, 2) / two_pi, mult))           # [L, d, Kp]
+  zs_p = tt(_pad_last(zs.transpose(1, 2), mult))                                # [L, d, Mp]
   var = t64(variance)
-  return Paths(omega=omega_p, phase=padk(phase), zs=zs_p, hz=padk(hz), w=padk(w), v=padk(v),
-               lengthscales=ls.contiguous(), prior_scale=torch.sqrt(2.0 * var / K).contiguous(),
+  # blocked weight stream [G, L, NB, 4, BT]
+  wp, vp = _pad_last(t64(w), mult), _pad_last(t64(v), mult)
+  S, L = wp.shape[:2]
+  G = (S + 3) // 4
+  allw = torch.cat([wp, vp], dim=-1)                                              # [S, L, Kp + Mp]
+  if G * 4 != S:
+    allw = torch.cat([allw, torch.zeros(G * 4 - S, L, allw.shape[-1], dtype=DEFAULT_FLOAT, device=device)], 0)
+  NB = allw.shape[-1] // mult
+  wb = allw.reshape(G, 4, L, NB, mult).permute(0, 2, 3, 1, 4).to(dtype).contiguous()
+  return Paths(omega=omega_p, phase=padk(t64(phase) / two_pi), zs=zs_p, hz=padk(hz), wb=wb, num_samples=S,
+               lengthscales=xscale.contiguous(), prior_scale=torch.sqrt(2.0 * var / K).contiguous(),
                variance=var.contiguous(), mean_c=None if mean_c is None else t64(mean_c).contiguous())
 
 

@@ -131,23 +131,29 @@ int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
                      const void* target, const void* precis, void* cost, void* stream);
 
 /* ---- pathwise (decoupled-sampling) rollout: SURVEY.md row f-3, BASELINE.json configs[4] ---------
- * f[s,a] = scale_a sum_k w[s,a,k] cos(omega[a,k].x_s + phase[a,k])
- *        + var_a   sum_m v[s,a,m] k_a(x_s, z_m) + mean_a
+ * f[s,a] = scale_a sum_k w[s,a,k] cos(2 pi (omega_t[a,:,k].x_s + phase[a,k]))
+ *        + var_a   sum_m v[s,a,m] 2^(zs_t[a,:,m].(x_s * x_scale[a]) - hz[a,m] - hx) + mean_a
  * i.e. PathwiseSVGP.predict_f_samples with one input per sample path (gpflow_pilco/models/svgp.py:124-130,
  * loops/pilco.py:281-291; arithmetic in the un-vendored gpflow-sampling package -- parity unpinned).
- * zs = Z / lengthscales [L,M,d], hz = |zs|^2 / 2 [L,M]; K and M must be multiples of 4 (f32) / 2 (f64)
- * (pad with zero weights).  x [S,d], omega [L,K,d], phase [L,K], w [S,L,K], v [S,L,M], f_out [S,L]: T. */
+ * Shared operands are pre-scaled and k-major: omega_t [L,d,K] = omega^T / 2pi, phase [L,K] = b / 2pi,
+ * x_scale [L,d] = sqrt(log2 e) / lengthscales (f64), zs_t [L,d,M] = (Z * x_scale)^T, hz [L,M] = |zs|^2 / 2,
+ * hx = |x * x_scale|^2 / 2 (computed in the kernel).
+ * The per-sample weights arrive as ONE blocked stream wb[G][L][NB][4][BT]: G = ceil(S/4) sample groups,
+ * BT = 256 (f32) / 128 (f64) terms per block, NB = K/BT prior blocks followed by M/BT update blocks;
+ * element [g][a][tb][sl][t] is w[4g+sl][a][tb*BT+t] (or v[..][(tb-K/BT)*BT+t]).  K and M must be multiples
+ * of BT and S is padded to a multiple of 4 (zero weights).  Each wave then streams one contiguous region.
+ * x [S,d], f_out [S,L]: T. */
 int mm_pathwise_eval(int S, int L, int M, int K, int d, int dtype,
-                     const void* x, const void* omega, const void* phase, const void* zs, const void* hz,
-                     const double* lengthscales, const double* prior_scale, const double* variance,
-                     const double* mean_c, const void* w, const void* v, void* f_out, void* stream);
+                     const void* x, const void* omega_t, const void* phase, const void* zs_t, const void* hz,
+                     const double* x_scale, const double* prior_scale, const double* variance,
+                     const double* mean_c, const void* wb, void* f_out, void* stream);
 
 /* Euler.step folded H times on the sample paths (dynamics/solvers.py:50-65, no diffusion; d == L):
  * x <- x + dt f(x).  x is updated in place (x_tmp: scratch of the same size); traj [H,S,d] optional. */
 int mm_pathwise_rollout(int S, int L, int M, int K, int d, int dtype, int H, double dt,
-                        void* x, void* x_tmp, const void* omega, const void* phase, const void* zs,
-                        const void* hz, const double* lengthscales, const double* prior_scale,
-                        const double* variance, const double* mean_c, const void* w, const void* v,
+                        void* x, void* x_tmp, const void* omega_t, const void* phase, const void* zs_t,
+                        const void* hz, const double* x_scale, const double* prior_scale,
+                        const double* variance, const double* mean_c, const void* wb,
                         void* traj, void* stream);
 
 #ifdef __cplusplus
