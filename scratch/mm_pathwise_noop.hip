@@ -17,7 +17,7 @@
 // NS * BT contiguous elements (4 KB) and consecutive passes are consecutive in memory.
 #include <hip/hip_runtime.h>
 #include <math.h>
-#include "mm_common.h"
+#include "../gpflowpilco_amd/csrc/mm_common.h"
 
 #define MM_PW_NS 4      // samples per workgroup (and per block of the weight stream)
 #ifndef PW_COS          // overridable for ablation builds (scratch/): which part of the kernel costs what
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
         T cv[DK][W], bv[W];
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
-          if (k < d) pw_unpack<T>(*reinterpret_cast<const VT*>(om + (size_t)k * K + k0), cv[k]);
+          if (k < d) { for (int j = 0; j < W; ++j) cv[k][j] = (T)(0.001 * k); }
           else {
 #pragma unroll
             for (int j = 0; j < W; ++j) cv[k][j] = (T)0;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
         T cv[DK][W], hv[W];
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
-          if (k < d) pw_unpack<T>(*reinterpret_cast<const VT*>(zz + (size_t)k * M + m0), cv[k]);
+          if (k < d) { for (int j = 0; j < W; ++j) cv[k][j] = (T)(0.001 * k); }
           else {
 #pragma unroll
             for (int j = 0; j < W; ++j) cv[k][j] = (T)0;
@@ -191,152 +191,10 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
   }
 }
 
-// LDS-resident variant (used when the shared operands of one latent fit in LDS, C5: 108 KB):
-// one 512-thread workgroup per CU loads omega_t / phase / zs_t / hz of ITS latent into LDS once
-// and then streams many sample groups through it, so the only global traffic in the loop is the
-// weight stream itself (operand re-reads through L2 cost 39 % of the plain kernel's time).
-// grid = L * nW workgroups; wave w of workgroup (a, i) handles sample groups i*8 + w, + nW*8, ...
-template <typename T, int DK>
-__global__ __launch_bounds__(512) void k_pathwise_lds(int S, int L, int M, int K, int d, int nW,
-                                                      const T* __restrict__ x, const T* __restrict__ omega,
-                                                      const T* __restrict__ phase, const T* __restrict__ zs,
-                                                      const T* __restrict__ hz, const double* __restrict__ xscale,
-                                                      const double* __restrict__ pscale, const double* __restrict__ var,
-                                                      const double* __restrict__ meanc, const T* __restrict__ wb,
-                                                      T* __restrict__ out, T* __restrict__ traj, int euler, double dt) {
-  typedef typename PwVec<T>::type VT;
-  constexpr int W = PwVec<T>::W, NS = MM_PW_NS, BT = 64 * W, NWAVE = 8;
-  extern __shared__ __attribute__((aligned(16))) char pw_smem[];
-  T* op = reinterpret_cast<T*>(pw_smem);               // [d + 1][K + M]: rows 0..d-1 vectors, row d scalars
-  const int a = blockIdx.x % L, wgi = blockIdx.x / L;
-  const int KT = K + M, nbK = K / BT, NB = KT / BT;
-  for (int idx = threadIdx.x * W; idx < (d + 1) * KT; idx += 512 * W) {
-    const int row = idx / KT, col = idx - row * KT;     // KT % W == 0: a vector never straddles rows
-    const T* src;
-    if (row < d) src = (col < K) ? omega + ((size_t)a * d + row) * K + col : zs + ((size_t)a * d + row) * M + (col - K);
-    else src = (col < K) ? phase + (size_t)a * K + col : hz + (size_t)a * M + (col - K);
-    *reinterpret_cast<VT*>(op + idx) = *reinterpret_cast<const VT*>(src);
-  }
-  __syncthreads();
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int ngroups = (S + NS - 1) / NS;
-  T sc[DK];
-#pragma unroll
-  for (int k = 0; k < DK; ++k) sc[k] = (k < d) ? (T)xscale[a * d + k] : (T)0;
-  const double ps = pscale[a], vr = var[a], mc = meanc ? meanc[a] : 0.0;
-
-  for (int g = wgi * NWAVE + wv; g < ngroups; g += nW * NWAVE) {
-    const int s0 = g * NS;
-    T xr[NS][DK], xsc[NS][DK], hx[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int row = (s0 + s < S) ? s0 + s : S - 1;
-      T h = (T)0;
-#pragma unroll
-      for (int k = 0; k < DK; ++k) {
-        xr[s][k] = (k < d) ? x[(size_t)row * d + k] : (T)0;
-        xsc[s][k] = xr[s][k] * sc[k];
-        h += xsc[s][k] * xsc[s][k];
-      }
-      hx[s] = (T)0.5 * h;
-    }
-    T accp[NS], accu[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) { accp[s] = (T)0; accu[s] = (T)0; }
-    const T* wrow = wb + (((size_t)g * L + a) * NB) * NS * BT + lane * W;
-    VT wq[3][NS];
-#pragma unroll
-    for (int pf = 0; pf < 2; ++pf)
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-        wq[pf][s] = (pf < NB) ? *reinterpret_cast<const VT*>(wrow + ((size_t)pf * NS + s) * BT) : VT{};
-    for (int tb = 0; tb < NB; ++tb) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-        wq[2][s] = (tb + 2 < NB) ? *reinterpret_cast<const VT*>(wrow + ((size_t)(tb + 2) * NS + s) * BT) : VT{};
-      T wv4[NS][W], cv[DK][W], sv[W];
-#pragma unroll
-      for (int s = 0; s < NS; ++s) pw_unpack<T>(wq[0][s], wv4[s]);
-      const int col = tb * BT + lane * W;
-#pragma unroll
-      for (int k = 0; k < DK; ++k) {
-        if (k < d) pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)k * KT + col), cv[k]);
-        else {
-#pragma unroll
-          for (int j = 0; j < W; ++j) cv[k][j] = (T)0;
-        }
-      }
-      pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)d * KT + col), sv);
-      if (tb < nbK) {                                     // wave-uniform: prior block
-#pragma unroll
-        for (int j = 0; j < W; ++j)
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            T arg = sv[j];
-#pragma unroll
-            for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
-            accp[s] += wv4[s][j] * PW_COS(arg);
-          }
-      } else {                                            // update block
-#pragma unroll
-        for (int j = 0; j < W; ++j)
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            T arg = -sv[j] - hx[s];
-#pragma unroll
-            for (int k = 0; k < DK; ++k) arg += cv[k][j] * xsc[s][k];
-            accu[s] += wv4[s][j] * PW_EXP(arg);
-          }
-      }
-#pragma unroll
-      for (int s = 0; s < NS; ++s) { wq[0][s] = wq[1][s]; wq[1][s] = wq[2][s]; }
-    }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      double t = ps * (double)accp[s] + vr * (double)accu[s];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-      if (lane == 0 && s0 + s < S) {
-        double f = t + mc;
-        if (euler) f = (double)xr[s][a < DK ? a : 0] + dt * f;
-        out[(size_t)(s0 + s) * L + a] = (T)f;
-        if (traj) traj[(size_t)(s0 + s) * L + a] = (T)f;
-      }
-    }
-  }
-}
-
 template <typename T>
 static int pw_launch(int S, int L, int M, int K, int d, const T* x, const T* omega, const T* phase, const T* zs,
                      const T* hz, const double* xscale, const double* pscale, const double* var,
                      const double* meanc, const T* wb, T* out, T* traj, int euler, double dt, hipStream_t s) {
-  // LDS-resident operands when one latent's (d + 1) x (K + M) block fits (<= 144 KB)
-  const size_t lds_bytes = (size_t)(d + 1) * (K + M) * sizeof(T);
-  if (lds_bytes <= 144 * 1024) {
-    const int ngroups = (S + MM_PW_NS - 1) / MM_PW_NS;
-    int nW = 256 / L; if (nW < 1) nW = 1;                           // ~ one workgroup per CU
-    while (nW > 1 && (nW - 1) * 8 >= ngroups) --nW;                 // no idle workgroups on small S
-#define PW_LAUNCH_LDS(DK_)                                                                          \
-    do {                                                                                            \
-      /* raise the dynamic-LDS limit once per instantiation (the call is slow: not per launch) */  \
-      static int lds_limit = 0;                                                                     \
-      if ((int)lds_bytes > lds_limit) {                                                             \
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pathwise_lds<T, DK_>), \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
-        if (ea != hipSuccess) return (int)ea;                                                       \
-        lds_limit = 144 * 1024;                                                                     \
-      }                                                                                             \
-      hipLaunchKernelGGL((k_pathwise_lds<T, DK_>), dim3(L * nW), dim3(512), lds_bytes, s, S, L, M, K, d, nW, \
-                         x, omega, phase, zs, hz, xscale, pscale, var, meanc, wb, out, traj, euler, dt); \
-    } while (0)
-    if (d <= 4) PW_LAUNCH_LDS(4);
-    else if (d <= 8) PW_LAUNCH_LDS(8);
-    else if (d <= 16) PW_LAUNCH_LDS(16);
-    else PW_LAUNCH_LDS(32);
-#undef PW_LAUNCH_LDS
-    hipError_t el = hipGetLastError();
-    return el == hipSuccess ? 0 : (int)el;
-  }
   dim3 grid((S + MM_PW_NS - 1) / MM_PW_NS);
 #define PW_LAUNCH(DK_) hipLaunchKernelGGL((k_pathwise<T, DK_>), grid, dim3(256), 0, s, S, L, M, K, d, x, omega, phase, \
                                           zs, hz, xscale, pscale, var, meanc, wb, out, traj, euler, dt)
