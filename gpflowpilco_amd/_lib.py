@@ -51,6 +51,9 @@ SIGNATURES = {
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "mm_euler_update": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 8),
     "mm_expected_cost": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "mm_backward_bytes": (C.c_size_t, [C.c_int] * 5),
+    "mm_backward_sums": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mm_pathwise_eval": (C.c_int, [C.c_int] * 6 + [C.c_void_p] * 12),
     "mm_pathwise_rollout": (C.c_int, [C.c_int] * 7 + [C.c_double] + [C.c_void_p] * 13),
     "mm_rollout_closed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,

@@ -1,0 +1,158 @@
+"""Backward of the GP moment match w.r.t. the input moments.
+
+The reference differentiates the whole rollout with ``tf.GradientTape``
+(``gpflow_pilco/utils/optimizers.py:52-56``).  During a policy update the drift model is
+frozen, so what the rollout needs from the big GP is d(f1, Sff, cross)/d(mu, Sigma).
+
+Split of work:
+  * M x M part -- HIP (``csrc/mm_backward.hip``, ``mm_backward_sums``): with
+    Omega_ij = (w_i w'_j + [a=a'] C_ij q_i q_j) exp(delta_ij) and E = expm1(delta) the kernel
+    returns the M-sized sums Ksum_j, csum_j, cC_j, Usum_j (columns) and Rsum_i, rsum_i (rows).
+  * everything else -- torch autograd on a *surrogate*: a scalar whose gradient w.r.t.
+    (mu, Sigma) equals the true one because the M^2-derived coefficients enter it as detached
+    constants:  dSff_p = sum_i r_i dw_i + sum_j c_j dw'_j + sum_ij Omega_ij d(delta_ij)  (+ C term)
+    and  d(delta_ij) = d const + d rho_i + d gamma_j + d(zeta_i^T G zeta'_j).
+
+First version: f64 mode only; the sweep is a plain VALU kernel (correctness first).
+``MomentMatchFunction`` makes ``ops.moment_match`` differentiable w.r.t. (mu, Sigma).
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+
+from . import _lib, ops
+from ._lib import MM_FULL_OUTPUT_COV, MM_MODEL_UNCERTAINTY, check, lib
+
+
+def pair_indices(L: int, full: bool = True, device="cpu") -> Tuple[torch.Tensor, torch.Tensor]:
+  """Kernel pair order: the L diagonal pairs first, then a < a' row by row."""
+  ia, ib = list(range(L)), list(range(L))
+  if full:
+    for a in range(L):
+      for b in range(a + 1, L):
+        ia.append(a); ib.append(b)
+  return torch.tensor(ia, device=device), torch.tensor(ib, device=device)
+
+
+def _sym(A):
+  return 0.5 * (A + A.transpose(-1, -2))
+
+
+def small_algebra(Sigma: torch.Tensor, ls2: torch.Tensor, var: torch.Tensor, ia, ib):
+  """The per-(b, latent) and per-(b, pair) d x d quantities of ``k_prep`` as differentiable torch ops."""
+  B, d, _ = Sigma.shape
+  eye = torch.eye(d, dtype=Sigma.dtype, device=Sigma.device)
+  SL = Sigma[:, None] + ls2[None, :, :, None] * eye                       # [B,L,d,d]
+  Pa = torch.linalg.inv(SL)
+  ld = torch.linalg.slogdet(SL)[1]                                         # [B,L]
+  lognorm = torch.log(var)[None] + 0.5 * torch.log(ls2).sum(-1)[None] - 0.5 * ld
+  La, Lb = ls2[ia], ls2[ib]                                                # [P,d]
+  V = La * Lb / (La + Lb)
+  Sv = Sigma[:, None] + V[None, :, :, None] * eye                         # [B,P,d,d]
+  T = _sym(V[None, :, :, None] * torch.linalg.solve(Sv, Sigma[:, None].expand_as(Sv)))
+  G = T / (La[None, :, :, None] * Lb[None, :, None, :])
+  SP_a = Sigma[:, None] @ Pa[:, ia]
+  SP_b = Sigma[:, None] @ Pa[:, ib]
+  Dr = _sym(SP_a / La[None, :, :, None]) - T / (La[None, :, :, None] * La[None, :, None, :])
+  Dc = _sym(SP_b / Lb[None, :, :, None]) - T / (Lb[None, :, :, None] * Lb[None, :, None, :])
+  const = (-0.5 * torch.linalg.slogdet(Sv)[1] + 0.5 * torch.log(V).sum(-1)[None]
+           - 0.5 * torch.log(La).sum(-1)[None] - 0.5 * torch.log(Lb).sum(-1)[None]
+           + 0.5 * ld[:, ia] + 0.5 * ld[:, ib])
+  return Pa, lognorm, G, Dr, Dc, const
+
+
+def moment_match_backward(pm: ops.PackedModel, pre, mu: torch.Tensor, Sigma: torch.Tensor,
+                          full_output_cov: bool, model_uncertainty: bool,
+                          g_f1: torch.Tensor, g_Sff: torch.Tensor, g_cross: torch.Tensor):
+  """-> (dL/dmu [B,d], dL/dSigma [B,d,d] symmetrised).  Must be called right after the forward
+  ``ops.moment_match`` with the same (mu, Sigma, flags): the kernel reads that call's workspace."""
+  if pm.dtype != torch.float64:
+    raise NotImplementedError("the backward pass is built for float64 models only (first version)")
+  Z, ls, var, beta, _, mean_c = pre
+  L, M, d = Z.shape
+  B = mu.shape[0]
+  dev = mu.device
+  flags = ops.make_flags(full_output_cov, model_uncertainty)
+  ws = pm.workspace(B, flags)
+  nbytes = lib().mm_backward_bytes(B, L, M, d, flags)
+  out = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+  rc = lib().mm_backward_sums(pm.buf.data_ptr(), pm.nbytes, L, M, d, _lib.MM_F64, B, mu.contiguous().data_ptr(),
+                              flags, ws.data_ptr(), ws.numel(), out.data_ptr(), nbytes, ops._stream(dev))
+  check(rc, "mm_backward_sums")
+  Mp = (M + _lib.MM_M_ALIGN - 1) // _lib.MM_M_ALIGN * _lib.MM_M_ALIGN
+  P = L * (L + 1) // 2 if full_output_cov else L
+  Po = P - L
+  ncol = B * P * (3 + d) * Mp
+  col = out[:ncol].view(B, P, 3 + d, Mp)[..., :M]
+  Ksum, csum, cC, Usum = col[:, :, 0], col[:, :, 1], col[:, :, 2], col[:, :, 3:].transpose(2, 3)   # U [B,P,M,d]
+  if Po:
+    row = out[ncol:].view(B, Po, 2, Mp)[..., :M]
+    Rsum = torch.cat([Ksum[:, :L], row[:, :, 0]], dim=1)        # diagonal pairs are symmetric
+    rsum = torch.cat([csum[:, :L], row[:, :, 1]], dim=1)
+  else:
+    Rsum, rsum = Ksum, csum
+
+  ia, ib = pair_indices(L, full_output_cov, dev)
+  if full_output_cov:
+    g_pair = torch.cat([torch.diagonal(g_Sff, dim1=-2, dim2=-1),
+                        g_Sff[:, ia[L:], ib[L:]] + g_Sff[:, ib[L:], ia[L:]]], dim=1)       # [B,P]
+  else:
+    g_pair = g_Sff
+  with torch.enable_grad():
+    mu_ = mu.detach().clone().requires_grad_(True)
+    S_ = Sigma.detach().clone().requires_grad_(True)
+    Ssym = _sym(S_)
+    Pa, lognorm, G, Dr, Dc, const = small_algebra(Ssym, ls * ls, var, ia, ib)
+    zeta = Z[None] - mu_[:, None, None, :]                                                # [B,L,M,d]
+    maha = torch.einsum('blmi,blij,blmj->blm', zeta, Pa, zeta)
+    q = torch.exp(lognorm[..., None] - 0.5 * maha)
+    w = beta[None] * q
+    f1 = w.sum(-1) + (0.0 if mean_c is None else mean_c[None])
+    cross = torch.einsum('blde,ble->bdl', Pa, torch.einsum('blm,blmd->bld', w, zeta))
+    total = (g_f1 * f1).sum() + (g_cross * cross).sum()
+    zr, zc = zeta[:, ia], zeta[:, ib]                                                     # [B,P,M,d]
+    rho = -0.5 * torch.einsum('bpmi,bpij,bpmj->bpm', zr, Dr, zr)
+    gam = -0.5 * torch.einsum('bpmi,bpij,bpmj->bpm', zc, Dc, zc)
+    m1c = torch.einsum('bpm,bpmd->bpd', Ksum, zc.detach())
+    bil = (torch.einsum('bpmd,bpde,bpme->bp', Usum, G, zc)
+           - torch.einsum('bd,bpd->bp', mu_, torch.einsum('bpde,bpe->bpd', G.detach(), m1c)))
+    sur = (Ksum.sum(-1) * const + (Rsum * rho).sum(-1) + (Ksum * gam).sum(-1) + bil
+           + (rsum * w[:, ia]).sum(-1) + (csum * w[:, ib]).sum(-1))
+    if model_uncertainty:
+      sur_diag = 2.0 * (cC[:, :L] * q).sum(-1)
+      sur = torch.cat([sur[:, :L] + sur_diag, sur[:, L:]], dim=1)
+    total = total + (g_pair * sur).sum()
+    gmu, gS = torch.autograd.grad(total, (mu_, S_))
+  return gmu, _sym(gS)
+
+
+class MomentMatchFunction(torch.autograd.Function):
+  """``ops.moment_match`` as a differentiable function of (mu, Sigma) for a frozen packed model."""
+
+  @staticmethod
+  def forward(ctx, mu, Sigma, pm, pre, full_output_cov, model_uncertainty):
+    f1, Sff, cross = ops.moment_match(pm, mu, Sigma, full_output_cov=full_output_cov,
+                                      model_uncertainty=model_uncertainty)
+    ctx.save_for_backward(mu, Sigma)
+    ctx.pm, ctx.pre, ctx.flags = pm, pre, (full_output_cov, model_uncertainty)
+    return f1, Sff, cross
+
+  @staticmethod
+  def backward(ctx, g_f1, g_Sff, g_cross):
+    mu, Sigma = ctx.saved_tensors
+    full, unc = ctx.flags
+    # the backward kernel reads the forward's workspace: re-run the forward stages for (mu, Sigma)
+    ops.moment_match(ctx.pm, mu, Sigma, full_output_cov=full, model_uncertainty=unc)
+    gmu, gS = moment_match_backward(ctx.pm, ctx.pre, mu, Sigma, full, unc,
+                                    g_f1.contiguous(), g_Sff.contiguous(), g_cross.contiguous())
+    return gmu, gS, None, None, None, None
+
+
+def moment_match_differentiable(model, mu: torch.Tensor, Sigma: torch.Tensor, full_output_cov: bool = True,
+                                model_uncertainty: bool = True):
+  """(mu, Sigma) -> (f1, Sff, cross_pre) with gradients flowing back to (mu, Sigma)."""
+  pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
+  pre = model._cache._pre
+  return MomentMatchFunction.apply(mu, Sigma, pm, pre, full_output_cov, model_uncertainty)

@@ -130,6 +130,16 @@ int mm_rollout_closed(const void* packed, size_t packed_bytes, int L, int M, int
 int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
                      const void* target, const void* precis, void* cost, void* stream);
 
+/* ---- backward w.r.t. the input moments, stage A (f64 mode) ---------------------
+ * The M x M part of d(f1, Sff, cross)/d(mu, Sigma) reduced to M-sized sums (see csrc/mm_backward.hip);
+ * gpflowpilco_amd/autodiff.py finishes the chain rule.  Must follow mm_moment_match / mm_q_forward +
+ * mm_Q_reduce_forward with the same (mu, Sigma, flags) on the same workspace.
+ * out: [B][P][3+d][Mp] column sums (Ksum, csum, cC, Usum[d]) then [B][P-L][2][Mp] row sums (Rsum, rsum). */
+size_t mm_backward_bytes(int B, int L, int M, int d, int flags);
+int mm_backward_sums(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                     const void* mu, int flags, const void* workspace, size_t workspace_bytes,
+                     void* out, size_t out_bytes, void* stream);
+
 /* ---- pathwise (decoupled-sampling) rollout: SURVEY.md row f-3, BASELINE.json configs[4] ---------
  * f[s,a] = scale_a sum_k w[s,a,k] cos(2 pi (omega_t[a,:,k].x_s + phase[a,k]))
  *        + var_a   sum_m v[s,a,m] 2^(zs_t[a,:,m].(x_s * x_scale[a]) - hz[a,m] - hx) + mean_a
