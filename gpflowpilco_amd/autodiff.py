@@ -156,3 +156,43 @@ def moment_match_differentiable(model, mu: torch.Tensor, Sigma: torch.Tensor, fu
   pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
   pre = model._cache._pre
   return MomentMatchFunction.apply(mu, Sigma, pm, pre, full_output_cov, model_uncertainty)
+
+
+def moment_match_torch(mu, Sigma, Z, ls, var, beta, C=None, mean_c=None, full_output_cov: bool = True,
+                       model_uncertainty: bool = True):
+  """Fully differentiable torch evaluation of the same centred formulas, materialising the
+  [B, P, M, M] blocks: for SMALL models whose PARAMETERS are being trained (the policy: M = 30,
+  one output, ``loops/pilco.py:78-108``), where gradients w.r.t. (Z, lengthscales, q_mu) are needed
+  and the M^2 work is negligible.  Large frozen models go through the HIP kernels instead."""
+  L, M, d = Z.shape
+  dev = mu.device
+  ia, ib = pair_indices(L, full_output_cov, dev)
+  Ssym = _sym(Sigma)
+  Pa, lognorm, G, Dr, Dc, const = small_algebra(Ssym, ls * ls, var, ia, ib)
+  zeta = Z[None] - mu[:, None, None, :]
+  maha = torch.einsum('blmi,blij,blmj->blm', zeta, Pa, zeta)
+  q = torch.exp(lognorm[..., None] - 0.5 * maha)
+  w = beta[None] * q
+  f1 = w.sum(-1) + (0.0 if mean_c is None else mean_c[None])
+  cross = torch.einsum('blde,ble->bdl', Pa, torch.einsum('blm,blmd->bld', w, zeta))
+  zr, zc = zeta[:, ia], zeta[:, ib]
+  rho = -0.5 * torch.einsum('bpmi,bpij,bpmj->bpm', zr, Dr, zr)
+  gam = -0.5 * torch.einsum('bpmi,bpij,bpmj->bpm', zc, Dc, zc)
+  delta = (const[..., None, None] + rho[..., :, None] + gam[..., None, :]
+           + torch.einsum('bpmi,bpij,bpnj->bpmn', zr, G, zc))
+  E = torch.expm1(delta)
+  Sp = torch.einsum('bpm,bpmn,bpn->bp', w[:, ia], E, w[:, ib])
+  diag = Sp[:, :L]
+  if model_uncertainty:
+    if C is None:
+      raise ValueError("model_uncertainty needs C")
+    diag = diag + var[None] + torch.einsum('lmn,blm,blmn,bln->bl', C, q, 1.0 + E[:, :L], q)
+  if not full_output_cov:
+    return f1, diag, cross
+  Sff = torch.diag_embed(diag)
+  if L > 1:
+    off = Sp[:, L:]
+    Sff = Sff.clone()
+    Sff[:, ia[L:], ib[L:]] = off
+    Sff[:, ib[L:], ia[L:]] = off
+  return f1, Sff, cross

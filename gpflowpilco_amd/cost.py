@@ -12,7 +12,8 @@ import torch
 def expected_gaussian_cost(mean: torch.Tensor, cov: torch.Tensor, target: torch.Tensor,
                            precis: torch.Tensor) -> torch.Tensor:
   """E_{x~N(mean,cov)}[-exp(-0.5 (x-x*)^T W (x-x*))]  (components.py:29-37) -> mean.shape[:-1]."""
-  if mean.is_cuda:
+  needs_grad = torch.is_grad_enabled() and (mean.requires_grad or cov.requires_grad)
+  if mean.is_cuda and not needs_grad:     # the HIP kernel has no backward: differentiable calls use torch ops
     from . import ops
     return ops.expected_cost(mean, cov, target, precis)
   d = mean.shape[-1]

@@ -135,8 +135,10 @@ class MomentMatchingEuler(Euler):
     mf = match_drift.y.mean()
     Sff = match_drift.y.covariance(dense=True)
     cross, is_preinv = match_drift.cross
+    needs_grad = torch.is_grad_enabled() and any(
+        isinstance(t, torch.Tensor) and t.requires_grad for t in (mx, Sxx, mf, Sff, cross))
     if (is_preinv and mx.is_cuda and mf.shape == mx.shape and Sff.shape == Sxx.shape
-        and isinstance(cross, torch.Tensor) and mx.ndim == 2):
+        and isinstance(cross, torch.Tensor) and mx.ndim == 2 and not needs_grad):
       _mx, _Sxx = ops.euler_update(mx, Sxx, mf, Sff, cross, dt)       # HIP k_euler
     else:
       Sxf = match_drift.cross_covariance()

@@ -51,13 +51,26 @@ def _run_kernels(x: GaussianMoments, model, full_output_cov, model_uncertainty, 
   mu, Sxx = _sliced_state(x, kernel0)
   if not mu.is_cuda:
     raise RuntimeError("moment matching of GP models runs on the GPU only (no CPU fallback)")
-  pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
   lead = mu.shape[:-1]
   d = mu.shape[-1]
   mu2, S2 = mu.reshape(-1, d), Sxx.reshape(-1, d, d)
   full = full_output_cov if latent_full_cov is None else latent_full_cov
-  f1, Sff, cross = ops.moment_match(pm, mu2, S2, full_output_cov=full,
-                                    model_uncertainty=model_uncertainty, jitter=0.0)
+  grad_on = torch.is_grad_enabled()
+  if grad_on and any(t.requires_grad for t in model._parameters()):
+    # a model whose parameters are being trained (the policy): fully differentiable torch evaluation
+    from ..autodiff import moment_match_torch
+    Z, ls, var, beta, C, mean_c = model.precompute(mu.device)
+    f1, Sff, cross = moment_match_torch(mu2.to(Z.dtype), S2.to(Z.dtype), Z, ls, var, beta,
+                                        C if model_uncertainty else None, mean_c, full, bool(model_uncertainty))
+    f1, Sff, cross = f1.to(mu.dtype), Sff.to(mu.dtype), cross.to(mu.dtype)
+  elif grad_on and (mu2.requires_grad or S2.requires_grad):
+    # frozen model, differentiable inputs (the drift during a policy update): HIP forward + backward
+    from ..autodiff import moment_match_differentiable
+    f1, Sff, cross = moment_match_differentiable(model, mu2, S2, full, bool(model_uncertainty))
+  else:
+    pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
+    f1, Sff, cross = ops.moment_match(pm, mu2, S2, full_output_cov=full,
+                                      model_uncertainty=model_uncertainty, jitter=0.0)
   f1 = f1.reshape(lead + f1.shape[1:])
   Sff = Sff.reshape(lead + Sff.shape[1:])
   cross = cross.reshape(lead + cross.shape[1:])

@@ -78,3 +78,50 @@ def test_rollout_gradient_through_two_steps(device):
     mp, mm = mu.copy(), mu.copy(); mp[0, k] += eps; mm[0, k] -= eps
     fd = (rollout_np(mp, S) - rollout_np(mm, S)) / (2 * eps)
     assert abs(fd - mu_t.grad[0, k].item()) < 3e-5 * max(1.0, abs(fd))
+
+
+def test_torch_path_equals_hip_path_and_policy_gradient(device):
+  """(i) the parameter-differentiable torch evaluation equals the HIP kernels; (ii) d(policy loss)/d(q_mu)
+  of the composed encoder -> policy -> drift rollout (the quantity update_policy needs,
+  examples/cartpole_swingup/train_utils.py:91-105) matches finite differences of the oracle rollout."""
+  from gpflowpilco_amd import bijectors as tfb, dynamics, models as gp, ops
+  from gpflowpilco_amd.autodiff import moment_match_torch
+  from gpflowpilco_amd.components import GaussianObjective, TrigonometricEncoder
+  from gpflowpilco_amd.loops import get_state_initializer, policy_loss_closure
+  from oracle import mm_compose_oracle as co
+  from tests.test_compose import _cartpole_like
+  drift_o, pol_o, mu, S, target, precis = _cartpole_like()
+  F64 = torch.float64
+  # (i)
+  drift = gp_model_from_oracle(drift_o, device)
+  jm = np.concatenate([mu, np.zeros((2, 2))], -1); jS = np.stack([np.eye(6) * 0.02] * 2)
+  pm = drift.packed(F64, True, device)
+  a = ops.moment_match(pm, to_dev(jm, device, F64), to_dev(jS, device, F64))
+  Z, ls, var, beta, C, mc = drift.precompute(device)
+  b = moment_match_torch(to_dev(jm, device, F64), to_dev(jS, device, F64), Z, ls, var, beta, C, mc)
+  for x, y in zip(a, b):
+    assert (x - y).abs().max() < 1e-9 * max(1.0, float(y.abs().max()))
+  # (ii)
+  scale, shift, active, H = 2.0, -0.5, (1,), 3
+  def loss_np(qmu):
+    pol = mo.SVGPParams(Z=pol_o.Z, lengthscales=pol_o.lengthscales, variance=pol_o.variance, q_mu=qmu,
+                        q_sqrt=pol_o.q_sqrt, whiten=True)
+    return co.policy_rollout_loss(mu, S, drift_o, lambda s: co.mm_policy(s, pol, scale, shift), active,
+                                  target, precis, H).sum()
+  pol_model = gp_model_from_oracle(pol_o, device)
+  pol_model.q_mu = pol_model.q_mu.clone().requires_grad_(True)
+  policy = gp.InverseLinkWrapper(gp.KernelRegressor(pol_model),
+                                 invlink=tfb.Chain([tfb.Scale(scale), tfb.Shift(shift), tfb.NormalCDF()]))
+  encoder = TrigonometricEncoder(active_dims=active)
+  objective = GaussianObjective(target=to_dev(target, device, F64), precis=to_dev(precis, device, F64))
+  system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=encoder, solver=dynamics.MomentMatchingEuler())
+  closure = policy_loss_closure(system, objective, get_state_initializer(to_dev(mu, device, F64), to_dev(S, device, F64)), H)
+  loss = closure().sum()
+  assert abs(float(loss.detach()) - loss_np(pol_o.q_mu)) < 1e-7
+  loss.backward()
+  g = pol_model.q_mu.grad.cpu().numpy()
+  eps = 1e-5
+  for idx in (0, 7, 19):
+    qp, qm = pol_o.q_mu.copy(), pol_o.q_mu.copy(); qp[idx, 0] += eps; qm[idx, 0] -= eps
+    fd = (loss_np(qp) - loss_np(qm)) / (2 * eps)
+    assert abs(fd - g[idx, 0]) < 1e-5 * max(1.0, abs(fd)), (idx, fd, g[idx, 0])
