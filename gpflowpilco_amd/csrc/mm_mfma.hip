@@ -97,7 +97,7 @@ __device__ __forceinline__ void mm_split3(float x, unsigned int& h, unsigned int
 #define MM_P7_C0 1.0f
 
 // Near-minimax coefficients of expm1(x)/x by range tier (relative error of x*P(x) <= 2.3e-7 in f32):
-//   |x| <= 0.25: degree 4,  |x| <= 0.5: degree 5,  |x| <= 1: degree 7   (scratch/minimax2.py)
+//   |x| <= 0.25: degree 4,  |x| <= 0.5: degree 5,  |x| <= 1: degree 7   (tools/minimax_expm1.py)
 template <int DEG> struct MMPoly;
 template <> struct MMPoly<4> {
   static constexpr float c[5] = {1.000000000e+00f, 4.999983013e-01f, 1.666673869e-01f, 4.177515209e-02f, 8.333330043e-03f};
