@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
     if (!diag && sizeof(T) == 4) {
       T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
       for (int k = 0; k <= d; ++k) rO[(size_t)k * Mp + m] = (T)0;
-      colO[((size_t)b * Po + (p - L)) * Mp + m] = (T)0;
+      colO[((size_t)b * Po + (p - L)) * 2 * Mp + m] = (T)1;            // exp(0), expm1(0): padded w_j is 0
+      colO[((size_t)b * Po + (p - L)) * 2 * Mp + Mp + m] = (T)0;
       return;
     }
     MM_PV_STORE_ROW(0.0);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
     //   A_i = G^T zeta_i,  rho'_i = rho_i + const - A_i . (mu - zbar_a'),   gamma_j plain,
     // so that delta_ij = rho'_i + gamma_j + A_i . zc^{a'}_j with the b-independent zc streamed.
     T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
-    T* cO = colO + ((size_t)b * Po + (p - L)) * Mp;
+    T* cO = colO + ((size_t)b * Po + (p - L)) * 2 * Mp;       // [2][Mp]: exp(gamma_j), expm1(gamma_j)
     double rho = 0.0, gam = 0.0, corr = 0.0;
 #pragma unroll
     for (int i = 0; i < DK; ++i) {
@@ -437,7 +438,9 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
       }
     }
     rO[(size_t)d * Mp + m] = (T)(-0.5 * rho + cst - corr);
-    cO[m] = (T)(-0.5 * gam);
+    const double em = expm1(-0.5 * gam);
+    cO[m] = (T)(em + 1.0);
+    cO[(size_t)Mp + m] = (T)em;
     return;
   }
   double rho = 0.0, gam = 0.0, corr = 0.0;
@@ -490,13 +493,15 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
   // ROWVEC (f32 off-diagonal layout): the row side carries the vector A_i and rho'_i, the column
   // side is the centred inducing input zc_j of latent a' plus gamma_j.  Otherwise the column side
   // carries g_j, gamma'_j and the row side is zc_i of latent a plus rho_i.
-  const T* cb = ROWVEC ? colB + ((size_t)b * np + lp) * Mp
+  const T* cb = ROWVEC ? colB + ((size_t)b * np + lp) * 2 * Mp
                        : colB + ((size_t)b * np + lp) * (size_t)(d + 1) * Mp;
   T g[DK];
 #pragma unroll
   for (int k = 0; k < DK; ++k)
     g[k] = (k < d) ? (ROWVEC ? Zc[((size_t)a2 * Mp + jj) * Kz + k] : cb[(size_t)k * Mp + jj]) : (T)0;
-  const T gam = ROWVEC ? cb[jj] : cb[(size_t)d * Mp + jj];
+  // ROWVEC: the column scalars are exp(gamma_j), expm1(gamma_j) (see mm_mfma.hip); else gamma'_j
+  const T gam = ROWVEC ? (T)0 : cb[(size_t)d * Mp + jj];
+  const T egj = ROWVEC ? cb[jj] : (T)1, emj = ROWVEC ? cb[(size_t)Mp + jj] : (T)0;
   const T wj = jv ? w[((size_t)b * L + a2) * Mp + jj] : (T)0;
   const bool withC = (Cm != nullptr) && (a == a2);
   const T qj = (withC && jv) ? q[((size_t)b * L + a2) * Mp + jj] : (T)0;
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
 #pragma unroll
     for (int k = 0; k < DK; ++k)
       if (k < d) delta += (ROWVEC ? ra[(size_t)k * Mp + i] : zrow[(size_t)i * Kz + k]) * g[k];
-    const T e = mm_expm1(delta);
+    const T e = ROWVEC ? egj * mm_expm1(delta) + emj : mm_expm1(delta);
     accB += wr[i] * e;
     if (withC) {
       const double cij = Cm[((size_t)a * Mp + i) * Mp + jj];
@@ -539,11 +544,12 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
 // k_finalize: Sff from the partial slabs (fixed summation order => bitwise reproducible)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void k_finalize(const double* __restrict__ partB, const double* __restrict__ partC,
-                           const double* __restrict__ var, int B, int L, int P, int NS,
-                           int nsB_diag, int nsB_off, int nsC, int full, int with_unc, double jitter,
-                           T* __restrict__ Sff) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partB, const double* __restrict__ partC,
+                                                  const double* __restrict__ var, int B, int L, int P, int NS,
+                                                  int nsB_diag, int nsB_off, int nsC, int full, int with_unc,
+                                                  double jitter, T* __restrict__ Sff) {
+  // one wave per (b, pair): lanes stride over the slab (coalesced), fixed butterfly => reproducible
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (idx >= B * P) return;
   const int b = idx / P, p = idx - b * P;
   int a, a2;
@@ -551,14 +557,16 @@ __global__ void k_finalize(const double* __restrict__ partB, const double* __res
   const double* pb = partB + ((size_t)b * P + p) * NS;
   const int ns = (a == a2) ? nsB_diag : nsB_off;
   double s = 0.0;
-  for (int k = 0; k < ns; ++k) s += pb[k];
+  for (int k = lane; k < ns; k += 64) s += pb[k];
+  if (a == a2 && with_unc) {
+    const double* pc = partC + ((size_t)b * L + a) * NS;
+    for (int k = lane; k < nsC; k += 64) s += pc[k];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane != 0) return;
   if (a == a2) {
-    if (with_unc) {
-      const double* pc = partC + ((size_t)b * L + a) * NS;
-      double c = 0.0;
-      for (int k = 0; k < nsC; ++k) c += pc[k];
-      s += var[a] + c;                         // models.py:254-261
-    }
+    if (with_unc) s += var[a];                 // models.py:254-261
     s += jitter;                               // models.py:293-296
     if (full) Sff[((size_t)b * L + a) * L + a] = (T)s;
     else Sff[(size_t)b * L + a] = (T)s;
@@ -823,7 +831,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
   }
   if (stages & MM_STAGE_FINALIZE) {
     const int n = B * wl.P;
-    hipLaunchKernelGGL((k_finalize<T>), dim3((n + 255) / 256), dim3(256), 0, s,
+    hipLaunchKernelGGL((k_finalize<T>), dim3((n + 3) / 4), dim3(256), 0, s,
                        partB, partC, (const double*)(packed + ml.var), B, L, wl.P, wl.NS,
                        nsB_diag, nsB_off, nsC, full, with_unc, jitter, Sff);
     MM_CHECK_LAUNCH();

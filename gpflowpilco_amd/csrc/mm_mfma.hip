@@ -4,7 +4,7 @@
 // (the reference's eKuffu slice, utils/kernel_expectation.py:72-187, then
 // models.py:219-248),
 //     S = sum_ij w_i * expm1(delta_ij) * w'_j ,   delta_ij = rho_i + gamma'_j + zc_i . g_j
-//     S = sum_ij w_i * expm1(delta_ij) * w'_j ,   delta_ij = rho'_i + gamma_j + A_i . zc_j
+//     S = sum_ij w_i * expm1(delta_ij) * w'_j ,   delta_ij = a_ij + gamma_j,  a_ij = rho'_i + A_i . zc_j
 // The bilinear part runs on the bf16 matrix pipe as a 3-way split product with f32 accuracy
 // (v_mfma_f32_32x32x16_bf16), the expm1 polynomial + weighted reduction on the VALU in packed
 // f32 (v_pk_fma_f32), which overlaps with the matrix pipe.
@@ -172,7 +172,11 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
   double sum = 0.0;
   if (row0 < Mp) {   // Mp % 128 == 0, so a wave's 64 rows are all inside or all outside
     const float* ra = rowO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;   // [d+1][Mp]: A_i, rho'_i
-    const float* gc = colO + ((size_t)b * Po + lp) * Mp;                     // gamma_j
+    // column scalars: exp(gamma_j) and expm1(gamma_j).  exp(delta) - 1 with delta = a + gamma factors as
+    // exp(gamma) expm1(a) + expm1(gamma), so gamma_j never has to be added to the 2048 tile entries:
+    // sum_i w_i E_ij = exp(gamma_j) sum_i w_i expm1(a_ij) + expm1(gamma_j) sum_i w_i.
+    const float* gce = colO + ((size_t)b * Po + lp) * 2 * Mp;                // [2][Mp]
+    const float* gcm = gce + Mp;
     const float* wr = w + ((size_t)b * L + a) * Mp;
     const float* wc = w + ((size_t)b * L + a2) * Mp;
     // pre-split centred inducing inputs of latent a': [Mp][3 (h,m,l)][8 ND8] bf16
@@ -222,8 +226,13 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
     const int offA = (h ? 0 : 1) * 8 * ND8;      // in bf16 elements within a column's 24*ND8 block
     const int offB = (h ? 0 : 2) * 8 * ND8;
     const int nct = Mp >> 5;
+    double Wlane = 0.0;                        // sum of this lane's 32 row weights (for the expm1(gamma_j) term)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 8; ++r) Wlane += (double)wrow[rt][r][0] + (double)wrow[rt][r][1];
     u32x4 zA[ND8], zB[ND8];
-    float gcur, wcur;
+    float gcur, mcur, wcur;
     {
       const unsigned short* zc = zs + (size_t)l31 * (24 * ND8);
 #pragma unroll
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
         zA[nb] = *reinterpret_cast<const u32x4*>(zc + offA + nb * 8);
         zB[nb] = *reinterpret_cast<const u32x4*>(zc + offB + nb * 8);
       }
-      gcur = gc[l31]; wcur = wc[l31];
+      gcur = gce[l31]; mcur = gcm[l31]; wcur = wc[l31];
     }
 
     for (int ct = 0; ct < nct; ++ct) {
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
         zAn[nb] = *reinterpret_cast<const u32x4*>(zc + offA + nb * 8);
         zBn[nb] = *reinterpret_cast<const u32x4*>(zc + offB + nb * 8);
       }
-      const float gnxt = gc[cn], wnxt = wc[cn];
+      const float gnxt = gce[cn], mnxt = gcm[cn], wnxt = wc[cn];
 
       f32x16 acc[2];
 #pragma unroll
@@ -260,13 +269,12 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
         }
         acc[rt] = c;
       }
-      // delta = acc + gamma_j ; range check of the tile (wave-uniform): P7 covers |delta| <= 1
+      // a_ij = acc (gamma_j is factored out, see above); range of the tile (wave-uniform tiers)
       f32x2 xx[16];
-      const f32x2 g2 = {gcur, gcur};
       float mx = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]} + g2;
+        xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
         mx = fmaxf(mx, fmaxf(fabsf(xx[r][0]), fabsf(xx[r][1])));
       }
       f32x2 part2;
@@ -291,10 +299,10 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
             part2[e2] = fmaf(wrow[r >> 3][r & 7][e2], e, part2[e2]);
           }
       }
-      sum += (double)(part2[0] + part2[1]) * (double)wcur;
+      sum += (double)wcur * ((double)gcur * (double)(part2[0] + part2[1]) + (double)mcur * Wlane);
 #pragma unroll
       for (int nb = 0; nb < ND8; ++nb) { zA[nb] = zAn[nb]; zB[nb] = zBn[nb]; }
-      gcur = gnxt; wcur = wnxt;
+      gcur = gnxt; mcur = mnxt; wcur = wnxt;
     }
   }
   // workgroup reduction -> slab
