@@ -74,8 +74,10 @@ struct MMWorkspaceLayout {
   size_t w;        // [B][L][Mp] T    (aliases w64 when T is f64)
   size_t rowD;     // [B][L][Mp] f64        rho_i          diagonal pairs
   size_t colD;     // [B][L][d+1][Mp] f64   g_j, gamma'_j  diagonal pairs
-  size_t rowO;     // off-diagonal pairs.  f64: [B][Po][Mp] rho_i            f32: [B][Po][d+1][Mp] A_i, rho'_i
-  size_t colO;     //                      f64: [B][Po][d+1][Mp] g_j, gamma'_j  f32: [B][Po][2][Mp] exp(gamma_j), expm1(gamma_j)
+  size_t rowO;     // off-diagonal pairs.  f64: [B][Po][Mp] rho_i            f32: [B][Po][d+1][Mp] A_i, what_i
+  size_t colO;     //                      f64: [B][Po][d+1][Mp] g_j, gamma'_j  f32: [B][Po][Mp] what'_j
+  size_t f1raw;    // [B][L] f64      sum_i w_i (f1 without the mean)
+  size_t wsum;     // [B][Po][2][Mp/256] f64  block partials of sum_i what_i, sum_j what'_j (f32 mode)
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
   size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i expm1(delta_ij) q_j  (+ q^T C q)
   size_t f1s;      // [B][L] T      rollout scratch outputs
@@ -107,9 +109,11 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   if (dtype != MM_F64) { o.w = off; off = mm_align_up(off + (size_t)B * L * o.Mp * es, A); }
   o.rowD = off;    off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.colD = off;    off = mm_align_up(off + (size_t)B * L * (d + 1) * o.Mp * 8, A);
-  const size_t nrow = dtype == MM_F64 ? 1 : (size_t)(d + 1), ncol = dtype == MM_F64 ? (size_t)(d + 1) : 2;
+  const size_t nrow = dtype == MM_F64 ? 1 : (size_t)(d + 1), ncol = dtype == MM_F64 ? (size_t)(d + 1) : 1;
   o.rowO = off;    off = mm_align_up(off + (size_t)B * o.Po * nrow * o.Mp * es, A);
   o.colO = off;    off = mm_align_up(off + (size_t)B * o.Po * ncol * o.Mp * es, A);
+  o.f1raw = off;   off = mm_align_up(off + (size_t)B * L * 8, A);
+  o.wsum = off;    off = mm_align_up(off + (size_t)B * o.Po * 2 * ((o.Mp + 255) / 256) * 8, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
   o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);
   o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);

@@ -294,6 +294,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
                                               int L, int M, int Mp, int d,
                                               const T* __restrict__ mu, const double* __restrict__ latmat,
                                               double* __restrict__ w64, double* __restrict__ q64, T* __restrict__ w,
+                                              double* __restrict__ f1raw,
                                               T* __restrict__ f1, T* __restrict__ cross, T* __restrict__ q_out) {
   const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   __shared__ double Pa[MM_DMAX * MM_DMAX];
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
     }
   }
   __syncthreads();
-  if (tid == 0) f1[(size_t)b * L + a] = (T)(sv[DK] + meanc[a]);
+  if (tid == 0) { f1[(size_t)b * L + a] = (T)(sv[DK] + meanc[a]); f1raw[(size_t)b * L + a] = sv[DK]; }
   if (tid < d) {
     // Sigma^-1 Cov(x, f_a) = P_a sum_i w_i (z_i - mu)      (models.py:263-277)
     double s = 0.0;
@@ -366,7 +367,8 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
                                                  int L, int M, int Mp, int d, int P,
                                                  const T* __restrict__ mu, const double* __restrict__ pairmat,
                                                  double* __restrict__ rowD, double* __restrict__ colD,
-                                                 T* __restrict__ rowO, T* __restrict__ colO) {
+                                                 T* __restrict__ rowO, T* __restrict__ colO,
+                                                 const double* __restrict__ w64, double* __restrict__ wsum) {
   const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int m = blockIdx.x * 256 + tid;
   int a, a2;
@@ -382,26 +384,73 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
     dmu2[tid] = mv - zbar[a2 * d + tid];
   }
   __syncthreads();
-  if (m >= Mp) return;
   const double cst = pm[3 * d * d];
-  // diagonal pairs (p < L) stream f64 operands, off-diagonal pairs T operands
   const bool diag = p < L;
   const int Po = P - L;
+  if (!diag && sizeof(T) == 4) {
+    // f32 off-diagonal format (mm_mfma.hip).  With A_i = G^T zeta_i and b_ij = A_i . zc^{a'}_j,
+    //   delta_ij = rho'_i + gamma_j + b_ij,  rho'_i = rho_i + const - A_i . (mu - zbar_a'),
+    // exp(delta) - 1 = e^{rho'_i} e^{gamma_j} (expm1(b_ij) + 1) - 1, hence
+    //   S = sum_ij what_i what'_j expm1(b_ij) + (sum_i what_i)(sum_j what'_j) - (sum_i w_i)(sum_j w'_j)
+    // with what_i = w_i e^{rho'_i}, what'_j = w'_j e^{gamma_j}: the M x M tile is a pure bilinear form.
+    // The two O(M) sums are reduced here in f64 (k_finalize adds the correction).
+    T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
+    T* cO = colO + ((size_t)b * Po + (p - L)) * Mp;
+    double whr = 0.0, whc = 0.0;
+    if (m < Mp) {
+      if (m < M) {
+        double zr[DK], zc[DK];
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+          zr[k] = (k < d) ? Z64[((size_t)a * M + m) * d + k] - mub[k] : 0.0;
+          zc[k] = (k < d) ? Z64[((size_t)a2 * M + m) * d + k] - mub[k] : 0.0;
+        }
+        double rho = 0.0, gam = 0.0, corr = 0.0;
+#pragma unroll
+        for (int i = 0; i < DK; ++i) {
+          if (i < d) {
+            double tr = 0.0, tc = 0.0, av = 0.0;
+#pragma unroll
+            for (int k = 0; k < DK; ++k) {
+              if (k < d) {
+                tr += Dr[i * d + k] * zr[k];
+                tc += Dc[i * d + k] * zc[k];
+                av += G[k * d + i] * zr[k];
+              }
+            }
+            rho += zr[i] * tr;
+            gam += zc[i] * tc;
+            corr += dmu2[i] * av;
+            rO[(size_t)i * Mp + m] = (T)av;
+          }
+        }
+        whr = w64[((size_t)b * L + a) * Mp + m] * exp(-0.5 * rho + cst - corr);
+        whc = w64[((size_t)b * L + a2) * Mp + m] * exp(-0.5 * gam);
+      } else {
+        for (int k = 0; k < d; ++k) rO[(size_t)k * Mp + m] = (T)0;
+      }
+      rO[(size_t)d * Mp + m] = (T)whr;
+      cO[m] = (T)whc;
+    }
+    __shared__ double red[4];
+    const double sr = mm_block_sum256(whr, red);
+    const double sc = mm_block_sum256(whc, red);
+    if (tid == 0) {
+      const int nblk = gridDim.x;
+      wsum[(((size_t)b * Po + (p - L)) * 2 + 0) * nblk + blockIdx.x] = sr;
+      wsum[(((size_t)b * Po + (p - L)) * 2 + 1) * nblk + blockIdx.x] = sc;
+    }
+    return;
+  }
+  if (m >= Mp) return;
+  // diagonal pairs (p < L) stream f64 operands, off-diagonal pairs of the f64 mode likewise
   double* raD = rowD + ((size_t)b * L + (diag ? p : 0)) * Mp;
   double* cbD = colD + ((size_t)b * L + (diag ? p : 0)) * (size_t)(d + 1) * Mp;
-  // (f64 off-diagonal layout; the f32 one is handled separately below)
   T* raO = rowO + ((size_t)b * Po + (diag ? 0 : p - L)) * Mp;
   T* cbO = colO + ((size_t)b * Po + (diag ? 0 : p - L)) * (size_t)(d + 1) * Mp;
 #define MM_PV_STORE_ROW(v_) do { if (diag) raD[m] = (v_); else raO[m] = (T)(v_); } while (0)
 #define MM_PV_STORE_COL(k_, v_) do { if (diag) cbD[(size_t)(k_) * Mp + m] = (v_); else cbO[(size_t)(k_) * Mp + m] = (T)(v_); } while (0)
   if (m >= M) {
-    if (!diag && sizeof(T) == 4) {
-      T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
-      for (int k = 0; k <= d; ++k) rO[(size_t)k * Mp + m] = (T)0;
-      colO[((size_t)b * Po + (p - L)) * 2 * Mp + m] = (T)1;            // exp(0), expm1(0): padded w_j is 0
-      colO[((size_t)b * Po + (p - L)) * 2 * Mp + Mp + m] = (T)0;
-      return;
-    }
     MM_PV_STORE_ROW(0.0);
     for (int k = 0; k <= d; ++k) MM_PV_STORE_COL(k, 0.0);
     return;
@@ -411,37 +460,6 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
   for (int k = 0; k < DK; ++k) {
     zr[k] = (k < d) ? Z64[((size_t)a * M + m) * d + k] - mub[k] : 0.0;
     zc[k] = (k < d) ? Z64[((size_t)a2 * M + m) * d + k] - mub[k] : 0.0;
-  }
-  if (!diag && sizeof(T) == 4) {
-    // f32 off-diagonal format (mm_mfma.hip): the ROW side carries the transformed vector
-    //   A_i = G^T zeta_i,  rho'_i = rho_i + const - A_i . (mu - zbar_a'),   gamma_j plain,
-    // so that delta_ij = rho'_i + gamma_j + A_i . zc^{a'}_j with the b-independent zc streamed.
-    T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
-    T* cO = colO + ((size_t)b * Po + (p - L)) * 2 * Mp;       // [2][Mp]: exp(gamma_j), expm1(gamma_j)
-    double rho = 0.0, gam = 0.0, corr = 0.0;
-#pragma unroll
-    for (int i = 0; i < DK; ++i) {
-      if (i < d) {
-        double tr = 0.0, tc = 0.0, av = 0.0;
-#pragma unroll
-        for (int k = 0; k < DK; ++k) {
-          if (k < d) {
-            tr += Dr[i * d + k] * zr[k];
-            tc += Dc[i * d + k] * zc[k];
-            av += G[k * d + i] * zr[k];
-          }
-        }
-        rho += zr[i] * tr;
-        gam += zc[i] * tc;
-        corr += dmu2[i] * av;
-        rO[(size_t)i * Mp + m] = (T)av;
-      }
-    }
-    rO[(size_t)d * Mp + m] = (T)(-0.5 * rho + cst - corr);
-    const double em = expm1(-0.5 * gam);
-    cO[m] = (T)(em + 1.0);
-    cO[(size_t)Mp + m] = (T)em;
-    return;
   }
   double rho = 0.0, gam = 0.0, corr = 0.0;
 #pragma unroll
@@ -493,16 +511,16 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
   // ROWVEC (f32 off-diagonal layout): the row side carries the vector A_i and rho'_i, the column
   // side is the centred inducing input zc_j of latent a' plus gamma_j.  Otherwise the column side
   // carries g_j, gamma'_j and the row side is zc_i of latent a plus rho_i.
-  const T* cb = ROWVEC ? colB + ((size_t)b * np + lp) * 2 * Mp
+  const T* cb = ROWVEC ? colB + ((size_t)b * np + lp) * Mp
                        : colB + ((size_t)b * np + lp) * (size_t)(d + 1) * Mp;
   T g[DK];
 #pragma unroll
   for (int k = 0; k < DK; ++k)
     g[k] = (k < d) ? (ROWVEC ? Zc[((size_t)a2 * Mp + jj) * Kz + k] : cb[(size_t)k * Mp + jj]) : (T)0;
-  // ROWVEC: the column scalars are exp(gamma_j), expm1(gamma_j) (see mm_mfma.hip); else gamma'_j
+  // ROWVEC: pure bilinear tile b_ij = A_i . zc_j with the factored weights what_i (row A, entry d)
+  // and what'_j (colB), see k_pairvec / mm_mfma.hip; else delta = rho_i + gamma'_j + zc_i . g_j
   const T gam = ROWVEC ? (T)0 : cb[(size_t)d * Mp + jj];
-  const T egj = ROWVEC ? cb[jj] : (T)1, emj = ROWVEC ? cb[(size_t)Mp + jj] : (T)0;
-  const T wj = jv ? w[((size_t)b * L + a2) * Mp + jj] : (T)0;
+  const T wj = jv ? (ROWVEC ? cb[jj] : w[((size_t)b * L + a2) * Mp + jj]) : (T)0;
   const bool withC = (Cm != nullptr) && (a == a2);
   const T qj = (withC && jv) ? q[((size_t)b * L + a2) * Mp + jj] : (T)0;
   const T* ra = ROWVEC ? rowA + ((size_t)b * np + lp) * (size_t)(d + 1) * Mp
@@ -515,12 +533,12 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
   T accB = (T)0;
   double sumB = 0.0, sumC = 0.0;
   for (int i = i0; i < i1; ++i) {
-    T delta = (ROWVEC ? ra[(size_t)d * Mp + i] : ra[i]) + gam;
+    T delta = ROWVEC ? (T)0 : ra[i] + gam;
 #pragma unroll
     for (int k = 0; k < DK; ++k)
       if (k < d) delta += (ROWVEC ? ra[(size_t)k * Mp + i] : zrow[(size_t)i * Kz + k]) * g[k];
-    const T e = ROWVEC ? egj * mm_expm1(delta) + emj : mm_expm1(delta);
-    accB += wr[i] * e;
+    const T e = mm_expm1(delta);
+    accB += (ROWVEC ? ra[(size_t)d * Mp + i] : wr[i]) * e;
     if (withC) {
       const double cij = Cm[((size_t)a * Mp + i) * Mp + jj];
       const double qi = (double)qr[i];
@@ -547,7 +565,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partB, const double* __restrict__ partC,
                                                   const double* __restrict__ var, int B, int L, int P, int NS,
                                                   int nsB_diag, int nsB_off, int nsC, int full, int with_unc,
-                                                  double jitter, T* __restrict__ Sff) {
+                                                  double jitter, const double* __restrict__ f1raw,
+                                                  const double* __restrict__ wsum, int nblk,
+                                                  T* __restrict__ Sff) {
   // one wave per (b, pair): lanes stride over the slab (coalesced), fixed butterfly => reproducible
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (idx >= B * P) return;
@@ -562,9 +582,19 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
     const double* pc = partC + ((size_t)b * L + a) * NS;
     for (int k = lane; k < nsC; k += 64) s += pc[k];
   }
+  double sr = 0.0, sc = 0.0;
+  if (a != a2 && wsum) {       // f32 mode: factored weights (k_pairvec), O(M) correction term
+    const double* wr = wsum + ((size_t)b * (P - L) + (p - L)) * 2 * nblk;
+    for (int k = lane; k < nblk; k += 64) { sr += wr[k]; sc += wr[nblk + k]; }
+  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  for (int off = 32; off > 0; off >>= 1) {
+    s += __shfl_xor(s, off, 64);
+    sr += __shfl_xor(sr, off, 64);
+    sc += __shfl_xor(sc, off, 64);
+  }
   if (lane != 0) return;
+  if (a != a2 && wsum) s += sr * sc - f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a2];
   if (a == a2) {
     if (with_unc) s += var[a];                 // models.py:254-261
     s += jitter;                               // models.py:293-296
@@ -766,11 +796,12 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
                      Z64, (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
                      L, M, wl.Mp, d, mu, latmat, (double*)(ws + wl.w64), (double*)(ws + wl.q64), (T*)(ws + wl.w),
-                     f1, cross, q_out);
+                     (double*)(ws + wl.f1raw), f1, cross, q_out);
   MM_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_pairvec<T, DK>), dim3((wl.Mp + 255) / 256, wl.P, B), dim3(256), 0, s,
                      Z64, (const double*)(packed + ml.zbar), L, M, wl.Mp, d, wl.P, mu, pairmat,
-                     (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO));
+                     (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO),
+                     (const double*)(ws + wl.w64), (double*)(ws + wl.wsum));
   MM_CHECK_LAUNCH();
   return 0;
 }
@@ -833,7 +864,8 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
     const int n = B * wl.P;
     hipLaunchKernelGGL((k_finalize<T>), dim3((n + 3) / 4), dim3(256), 0, s,
                        partB, partC, (const double*)(packed + ml.var), B, L, wl.P, wl.NS,
-                       nsB_diag, nsB_off, nsC, full, with_unc, jitter, Sff);
+                       nsB_diag, nsB_off, nsC, full, with_unc, jitter, (const double*)(ws + wl.f1raw),
+                       sizeof(T) == 4 ? (const double*)(ws + wl.wsum) : (const double*)nullptr, (wl.Mp + 255) / 256, Sff);
     MM_CHECK_LAUNCH();
   }
   return 0;

@@ -4,7 +4,9 @@
 // (the reference's eKuffu slice, utils/kernel_expectation.py:72-187, then
 // models.py:219-248),
 //     S = sum_ij w_i * expm1(delta_ij) * w'_j ,   delta_ij = rho_i + gamma'_j + zc_i . g_j
-//     S = sum_ij w_i * expm1(delta_ij) * w'_j ,   delta_ij = a_ij + gamma_j,  a_ij = rho'_i + A_i . zc_j
+//     S = sum_ij w_i expm1(delta_ij) w'_j,  delta_ij = rho'_i + gamma_j + b_ij,  b_ij = A_i . zc_j
+//       = sum_ij what_i expm1(b_ij) what'_j + (sum what)(sum what') - (sum w)(sum w'),
+//         what_i = w_i e^{rho'_i}, what'_j = w'_j e^{gamma_j}   (O(M) terms: k_pairvec / k_finalize)
 // The bilinear part runs on the bf16 matrix pipe as a 3-way split product with f32 accuracy
 // (v_mfma_f32_32x32x16_bf16), the expm1 polynomial + weighted reduction on the VALU in packed
 // f32 (v_pk_fma_f32), which overlaps with the matrix pipe.
@@ -143,14 +145,13 @@ __device__ __forceinline__ float mm_expm1_p7(float x) {
 // (h/m/l bf16 parts, six cross terms packed into three K=16 MFMAs per 8 dims: f32-equivalent
 // accuracy), because v_mfma_f32_32x32x2_f32 was measured to serialise with the VALU
 // on a SIMD (it shares the f32 FMA datapath) while the bf16 MFMA overlaps with it.
-//   stationary operand (registers, split once per sweep): A_i = G^T zeta_i of the wave's 64 rows,
-//   rho'_i enters as the MFMA C operand, streaming operand: the model's pre-split centred
-//   inducing inputs of latent a' (b-independent, L2-resident), gamma_j and w_j per column.
+//   stationary operand (registers, split once per sweep): A_i = G^T zeta_i of the wave's 64 rows and
+//   their factored weights what_i; streaming operand: the model's pre-split centred inducing inputs
+//   of latent a' (b-independent, L2-resident) and what'_j per column.
 template <int ND8>
 __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsigned short* __restrict__ Zs3,
                                                           int L, int Mp, int d, int P, int Po, int NS,
                                                           int npanel, int nwork,
-                                                          const float* __restrict__ w,
                                                           const float* __restrict__ rowO,
                                                           const float* __restrict__ colO,
                                                           double* __restrict__ partB) {
@@ -171,20 +172,13 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
   const int row0 = panel * MM_PANEL_ROWS + wv * 64;
   double sum = 0.0;
   if (row0 < Mp) {   // Mp % 128 == 0, so a wave's 64 rows are all inside or all outside
-    const float* ra = rowO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;   // [d+1][Mp]: A_i, rho'_i
-    // column scalars: exp(gamma_j) and expm1(gamma_j).  exp(delta) - 1 with delta = a + gamma factors as
-    // exp(gamma) expm1(a) + expm1(gamma), so gamma_j never has to be added to the 2048 tile entries:
-    // sum_i w_i E_ij = exp(gamma_j) sum_i w_i expm1(a_ij) + expm1(gamma_j) sum_i w_i.
-    const float* gce = colO + ((size_t)b * Po + lp) * 2 * Mp;                // [2][Mp]
-    const float* gcm = gce + Mp;
-    const float* wr = w + ((size_t)b * L + a) * Mp;
-    const float* wc = w + ((size_t)b * L + a2) * Mp;
+    const float* ra = rowO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;   // [d+1][Mp]: A_i, what_i
+    const float* wcf = colO + ((size_t)b * Po + lp) * Mp;                    // what'_j
     // pre-split centred inducing inputs of latent a': [Mp][3 (h,m,l)][8 ND8] bf16
     const unsigned short* zs = Zs3 + (size_t)a2 * Mp * (24 * ND8);
 
     // ---- stationary operands --------------------------------------------------------------
     bf16x8 a1[2][ND8], a2v[2][ND8], a3[2][ND8];
-    f32x16 crho[2];
     f32x2 wrow[2][8];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
@@ -213,10 +207,7 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int rr = row0 + rt * 32 + 8 * g + 4 * h;
-        const float4 rv = *reinterpret_cast<const float4*>(ra + (size_t)d * Mp + rr);
-        crho[rt][4 * g + 0] = rv.x; crho[rt][4 * g + 1] = rv.y;
-        crho[rt][4 * g + 2] = rv.z; crho[rt][4 * g + 3] = rv.w;
-        const float4 v = *reinterpret_cast<const float4*>(wr + rr);
+        const float4 v = *reinterpret_cast<const float4*>(ra + (size_t)d * Mp + rr);   // factored row weights
         wrow[rt][2 * g + 0] = (f32x2){v.x, v.y};
         wrow[rt][2 * g + 1] = (f32x2){v.z, v.w};
       }
@@ -226,13 +217,8 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
     const int offA = (h ? 0 : 1) * 8 * ND8;      // in bf16 elements within a column's 24*ND8 block
     const int offB = (h ? 0 : 2) * 8 * ND8;
     const int nct = Mp >> 5;
-    double Wlane = 0.0;                        // sum of this lane's 32 row weights (for the expm1(gamma_j) term)
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int r = 0; r < 8; ++r) Wlane += (double)wrow[rt][r][0] + (double)wrow[rt][r][1];
     u32x4 zA[ND8], zB[ND8];
-    float gcur, mcur, wcur;
+    float wcur;
     {
       const unsigned short* zc = zs + (size_t)l31 * (24 * ND8);
 #pragma unroll
@@ -240,7 +226,7 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
         zA[nb] = *reinterpret_cast<const u32x4*>(zc + offA + nb * 8);
         zB[nb] = *reinterpret_cast<const u32x4*>(zc + offB + nb * 8);
       }
-      gcur = gce[l31]; mcur = gcm[l31]; wcur = wc[l31];
+      wcur = wcf[l31];
     }
 
     for (int ct = 0; ct < nct; ++ct) {
@@ -253,12 +239,12 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
         zAn[nb] = *reinterpret_cast<const u32x4*>(zc + offA + nb * 8);
         zBn[nb] = *reinterpret_cast<const u32x4*>(zc + offB + nb * 8);
       }
-      const float gnxt = gce[cn], mnxt = gcm[cn], wnxt = wc[cn];
+      const float wnxt = wcf[cn];
 
       f32x16 acc[2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        f32x16 c = crho[rt];
+        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nb = 0; nb < ND8; ++nb) {
           const bf16x8 bA = __builtin_bit_cast(bf16x8, zA[nb]);
@@ -269,7 +255,7 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
         }
         acc[rt] = c;
       }
-      // a_ij = acc (gamma_j is factored out, see above); range of the tile (wave-uniform tiers)
+      // b_ij = acc: a pure bilinear form (rho'_i, gamma_j live in the weights); tile range -> tier
       f32x2 xx[16];
       float mx = 0.0f;
 #pragma unroll
@@ -299,10 +285,10 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
             part2[e2] = fmaf(wrow[r >> 3][r & 7][e2], e, part2[e2]);
           }
       }
-      sum += (double)wcur * ((double)gcur * (double)(part2[0] + part2[1]) + (double)mcur * Wlane);
+      sum += (double)wcur * (double)(part2[0] + part2[1]);
 #pragma unroll
       for (int nb = 0; nb < ND8; ++nb) { zA[nb] = zAn[nb]; zB[nb] = zBn[nb]; }
-      gcur = gnxt; mcur = mnxt; wcur = wnxt;
+      wcur = wnxt;
     }
   }
   // workgroup reduction -> slab
@@ -325,13 +311,12 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const int nwork = (int)nwork_ll;
   const unsigned short* Zs3 = (const unsigned short*)(packed + ml.Zs3);
-  const float* w = (const float*)(ws + wl.w);
   const float* rowO = (const float*)(ws + wl.rowO);
   const float* colO = (const float*)(ws + wl.colO);
   double* partB = (double*)(ws + wl.partB);
 #define MM_LAUNCH_ND(ND_)                                                                         \
   hipLaunchKernelGGL((k_qred_f32_mfma<ND_>), dim3(nwork), dim3(256), 0, stream, Zs3, L, wl.Mp, d, \
-                     wl.P, wl.Po, wl.NS, npanel, nwork, w, rowO, colO, partB)
+                     wl.P, wl.Po, wl.NS, npanel, nwork, rowO, colO, partB)
   switch (ml.nd8) {
     case 1: MM_LAUNCH_ND(1); break;
     case 2: MM_LAUNCH_ND(2); break;
