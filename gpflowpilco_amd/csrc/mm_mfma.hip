@@ -99,8 +99,16 @@ __device__ __forceinline__ void mm_split3(float x, unsigned int& h, unsigned int
 #define MM_P7_C0 1.0f
 
 // Near-minimax coefficients of expm1(x)/x by range tier (relative error of x*P(x) <= 2.3e-7 in f32):
-//   |x| <= 0.25: degree 4,  |x| <= 0.5: degree 5,  |x| <= 1: degree 7   (tools/minimax_expm1.py)
+//   |x| <= 1/64: degree 2,  |x| <= 1/16: degree 3,  |x| <= 0.25: degree 4,  |x| <= 0.5: degree 5,
+//   |x| <= 1: degree 7   (tools/minimax_expm1.py).  Along the C3 rollout 90-100 % of the 64 x 32 wave
+//   tiles fall into the first two tiers (tools/tier_stats.py).
 template <int DEG> struct MMPoly;
+template <> struct MMPoly<2> {
+  static constexpr float c[3] = {1.000000000e+00f, 5.000076294e-01f, 1.666666716e-01f};
+};
+template <> struct MMPoly<3> {
+  static constexpr float c[4] = {1.000000000e+00f, 5.000000000e-01f, 1.666992158e-01f, 4.166666791e-02f};
+};
 template <> struct MMPoly<4> {
   static constexpr float c[5] = {1.000000000e+00f, 4.999983013e-01f, 1.666673869e-01f, 4.177515209e-02f, 8.333330043e-03f};
 };
@@ -214,33 +222,24 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
     }
 
     // ---- streaming operands: lane half 0 reads parts (m, l), half 1 reads (h, h) ------------
-    const int offA = (h ? 0 : 1) * 8 * ND8;      // in bf16 elements within a column's 24*ND8 block
-    const int offB = (h ? 0 : 2) * 8 * ND8;
-    const int nct = Mp >> 5;
-    u32x4 zA[ND8], zB[ND8];
-    float wcur;
-    {
-      const unsigned short* zc = zs + (size_t)l31 * (24 * ND8);
+    // lane byte offsets inside the latent's [Mp][3][8 ND8] bf16 block; the tile offset is wave-uniform
+    const unsigned int tile_bytes = 32u * 48u * ND8;
+    const unsigned int offA = (unsigned int)l31 * (48u * ND8) + (h ? 0u : 1u) * 16u * ND8;
+    const unsigned int offB = (unsigned int)l31 * (48u * ND8) + (h ? 0u : 2u) * 16u * ND8;
+    const char* zbase = reinterpret_cast<const char*>(zs);
+    const int nct = Mp >> 5;                     // Mp % 128 == 0: nct is a multiple of 4
+
+    auto load_tile = [&](int ct, u32x4 (&zA)[ND8], u32x4 (&zB)[ND8], float& wc) {
+      const char* tb = zbase + (size_t)ct * tile_bytes;
 #pragma unroll
       for (int nb = 0; nb < ND8; ++nb) {
-        zA[nb] = *reinterpret_cast<const u32x4*>(zc + offA + nb * 8);
-        zB[nb] = *reinterpret_cast<const u32x4*>(zc + offB + nb * 8);
+        zA[nb] = *reinterpret_cast<const u32x4*>(tb + offA + nb * 16);
+        zB[nb] = *reinterpret_cast<const u32x4*>(tb + offB + nb * 16);
       }
-      wcur = wcf[l31];
-    }
+      wc = wcf[ct * 32 + l31];
+    };
 
-    for (int ct = 0; ct < nct; ++ct) {
-      // prefetch tile ct + 1 (clamped: the last iteration re-reads its own tile)
-      const int cn = ((ct + 1 < nct) ? ct + 1 : ct) * 32 + l31;
-      u32x4 zAn[ND8], zBn[ND8];
-      const unsigned short* zc = zs + (size_t)cn * (24 * ND8);
-#pragma unroll
-      for (int nb = 0; nb < ND8; ++nb) {
-        zAn[nb] = *reinterpret_cast<const u32x4*>(zc + offA + nb * 8);
-        zBn[nb] = *reinterpret_cast<const u32x4*>(zc + offB + nb * 8);
-      }
-      const float wnxt = wcf[cn];
-
+    auto do_tile = [&](const u32x4 (&zA)[ND8], const u32x4 (&zB)[ND8], float wc) {
       f32x16 acc[2];
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
@@ -261,11 +260,15 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
-        mx = fmaxf(mx, fmaxf(fabsf(xx[r][0]), fabsf(xx[r][1])));
+        mx = fmaxf(fmaxf(mx, fabsf(xx[r][0])), fabsf(xx[r][1]));   // one v_max3_f32 |a|, |b| (needs -fno-honor-nans)
       }
       f32x2 part2;
-      // wave-uniform tier choice (three ballots, no cross-lane reduction)
-      if (!__any(mx > 0.25f)) {
+      // wave-uniform tier choice (ballots, no cross-lane reduction)
+      if (!__any(mx > 0.015625f)) {
+        part2 = mm_weighted_expm1<2>(xx, wrow);
+      } else if (!__any(mx > 0.0625f)) {
+        part2 = mm_weighted_expm1<3>(xx, wrow);
+      } else if (!__any(mx > 0.25f)) {
         part2 = mm_weighted_expm1<4>(xx, wrow);
       } else if (!__any(mx > 0.5f)) {
         part2 = mm_weighted_expm1<5>(xx, wrow);
@@ -285,10 +288,18 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
             part2[e2] = fmaf(wrow[r >> 3][r & 7][e2], e, part2[e2]);
           }
       }
-      sum += (double)wcur * (double)(part2[0] + part2[1]);
-#pragma unroll
-      for (int nb = 0; nb < ND8; ++nb) { zA[nb] = zAn[nb]; zB[nb] = zBn[nb]; }
-      wcur = wnxt;
+      sum += (double)wc * (double)(part2[0] + part2[1]);
+    };
+
+    // two-stage register ping-pong: tile ct + 1 is in flight while tile ct is reduced
+    u32x4 zA0[ND8], zB0[ND8], zA1[ND8], zB1[ND8];
+    float w0, w1;
+    load_tile(0, zA0, zB0, w0);
+    for (int ct = 0; ct < nct; ct += 2) {
+      load_tile(ct + 1, zA1, zB1, w1);
+      do_tile(zA0, zB0, w0);
+      load_tile(ct + 2 < nct ? ct + 2 : ct, zA0, zB0, w0);      // clamped: the last pass re-reads its own tile
+      do_tile(zA1, zB1, w1);
     }
   }
   // workgroup reduction -> slab

@@ -22,7 +22,7 @@ def test_fused(coef,R):
     ref=np.expm1(x)
     m=np.abs(ref)>0
     return (np.abs(y-ref)[m]/np.abs(ref)[m]).max()
-for R,deg in [(0.25,3),(0.25,4),(0.5,4),(0.5,5),(0.75,6),(1.0,7)]:
+for R,deg in [(1/64,1),(1/64,2),(1/32,2),(1/16,2),(1/16,3),(1/8,3),(0.25,3),(0.25,4),(0.5,4),(0.5,5),(0.75,6),(1.0,7)]:
     coef,e=remez_like(R,deg)
     print(f"R={R} deg={deg} fit-err={e:.2e} fused-f32 max rel err={test_fused(coef,R):.2e}")
     print('   ',', '.join(f'{v:.9e}f' for v in coef.astype(np.float32)))
