@@ -20,6 +20,7 @@
 #include "mm_common.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+#define MM_F64_NB 16      // batch elements whose partial sums are staged in LDS between workgroup reductions
 
 __device__ __forceinline__ void mm_decode_pair_f(int p, int L, int& a, int& a2) {
   if (p < L) { a = p; a2 = p; return; }
@@ -64,18 +65,33 @@ __device__ __forceinline__ double mm_expm1_f64_poly(double x) {
   for (int k = DEG - 1; k >= 1; --k) q = fma(q, x, mm_inv_fact(k));
   return q * x;
 }
-__device__ __forceinline__ double mm_expm1_f64_p10(double x) { return mm_expm1_f64_poly<10>(x); }
-__device__ __forceinline__ double mm_expm1_f64_p12(double x) { return mm_expm1_f64_poly<12>(x); }
-__device__ __forceinline__ double mm_expm1_f64_p15(double x) { return mm_expm1_f64_poly<15>(x); }
 
-// KS4: number of K=4 MFMA steps covering the d input dimensions.
+// Per-b operands of one wave's 32 x 32 sub-tile (prefetched one batch element ahead).
+template <int KS4>
+struct MMF64Operands {
+  double rho[2][4];      // rho_i of the rows (rt, kq + 4 r)
+  double rw[2][4];       // row weight: q_i (C-weighted diagonal) or w_i
+  double breg[2][KS4];   // MFMA B operand: g_j components of column (ct, l15)
+  double gam[2];         // gamma'_j
+  double cw[2];          // column weight: q_j or w'_j
+};
+
+// KS4: number of K=4 MFMA steps covering the d input dimensions.  LOWP: f32 mode (the diagonal pairs
+// of an f32 model: expm1 to ~1e-14 relative instead of ~1e-17).
 // grid: x = tile pairs (diag: nt(nt+1)/2 upper pairs; else nt*nt), y = pairs of this launch,
 //       z = batch chunks.  Row/col operand arrays are indexed by the local pair index.
-template <int KS4, bool DIAG, bool WITHC>
+//
+// Diagonal pairs with model uncertainty reduce ONE fused sum
+//     sum_ij q_i q_j (D_ij expm1(delta_ij) + C_ij),   D = C + beta beta^T   (w_i = beta_i q_i),
+// i.e. sum w expm1 w' + sum C q exp(delta) q' with two FMAs per entry instead of three; D is formed
+// once per workgroup from the C tile.  delta_ij = rho_i + gamma'_j + zc_i . g_j: the two O(1) terms
+// initialise the MFMA accumulator (one add per entry; an extra K step would cost a whole MFMA).
+template <int KS4, bool DIAG, bool WITHC, bool LOWP>
 __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restrict__ Zc, int Kz,
                                                           const double* __restrict__ Cm,
+                                                          const double* __restrict__ beta, int M,
                                                           int L, int Mp, int d, int P, int NS, int p0,
-                                                          int B, int bchunk, double small_limit,
+                                                          int B, int bchunk,
                                                           const double* __restrict__ w,
                                                           const double* __restrict__ q,
                                                           const double* __restrict__ rowA,
@@ -112,16 +128,30 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
       const double v = zr[(size_t)(rbase + rt * 16 + l15) * Kz + (k < Kz ? k : Kz - 1)];
       areg[rt][s] = (k < Kz) ? v : 0.0;
     }
-  // C tile -> registers (element (row(rt, r), col(ct)) in the MFMA accumulator layout)
-  double creg[2][2][4];
+  // C and D = C + beta beta^T tiles -> registers (element (row(rt, r), col(ct)) in the MFMA accumulator layout)
+  double creg[2][2][4], dreg[2][2][4];
   if (withC) {
+    double bcol[2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int col = cbase + ct * 16 + l15;
+      bcol[ct] = beta[(size_t)a * M + (col < M ? col : M - 1)];
+      if (col >= M) bcol[ct] = 0.0;
+    }
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + rt * 16 + kq + 4 * r;
+        double brow = beta[(size_t)a * M + (row < M ? row : M - 1)];
+        if (row >= M) brow = 0.0;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          creg[rt][ct][r] = Cm[((size_t)a * Mp + rbase + rt * 16 + kq + 4 * r) * Mp + cbase + ct * 16 + l15];
+        for (int ct = 0; ct < 2; ++ct) {
+          const double cv = Cm[((size_t)a * Mp + row) * Mp + cbase + ct * 16 + l15];
+          creg[rt][ct][r] = cv;
+          dreg[rt][ct][r] = fma(brow, bcol[ct], cv);
+        }
+      }
   }
   size_t boff[KS4];
 #pragma unroll
@@ -131,110 +161,162 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
   }
   const size_t goff = (size_t)d * Mp;
 
-  // in f64 mode only |delta| <= 0.5 takes the unreduced polynomial (full f64 accuracy there)
-  const double SMALL_LIMIT = small_limit;
-  __shared__ double red[8];
+  __shared__ double stage[MM_F64_NB][256];
+  __shared__ double part16[MM_F64_NB][16];
   const int b0 = blockIdx.z * bchunk;
   const int b1 = (b0 + bchunk < B) ? b0 + bchunk : B;
   // per-b operand pointers advance by constant strides (no 64-bit multiplies in the loop)
   const double* ra = rowA + ((size_t)b0 * np + lp) * Mp;
   const double* cb = colB + ((size_t)b0 * np + lp) * (size_t)(d + 1) * Mp;
-  const double* wr = w + ((size_t)b0 * L + a) * Mp;
-  const double* wc = w + ((size_t)b0 * L + a2) * Mp;
-  const double* qr = q + ((size_t)b0 * L + a) * Mp;
+  const double* rwp = (withC ? q : w) + ((size_t)b0 * L + a) * Mp;
+  const double* cwp = (withC ? q : w) + ((size_t)b0 * L + a2) * Mp;
   const size_t st_ra = (size_t)np * Mp, st_cb = (size_t)np * (d + 1) * Mp, st_w = (size_t)L * Mp;
-  // lane-constant selectors of the extra k-step: A = (rho_i, 1, 0, 0), B = (1, gamma'_j, 0, 0)
-  const double selA1 = (kq == 1) ? 1.0 : 0.0, selB0 = (kq == 0) ? 1.0 : 0.0;
-  const double mA0 = (kq == 0) ? 1.0 : 0.0, mB1 = (kq == 1) ? 1.0 : 0.0;
-  for (int b = b0; b < b1; ++b, ra += st_ra, cb += st_cb, wr += st_w, wc += st_w, qr += st_w) {
 
-    double ax[2], bx[2], breg[2][KS4], wj[2], qj[2];
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt) {
-      const double rv = ra[rbase + rt * 16 + l15];
-      ax[rt] = fma(rv, mA0, selA1);
-    }
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct) {
-      const int col = cbase + ct * 16 + l15;
-#pragma unroll
-      for (int s = 0; s < KS4; ++s) breg[ct][s] = cb[boff[s] + col];
-      const double gv = cb[goff + col];
-      bx[ct] = fma(gv, mB1, selB0);
-      wj[ct] = wc[col];
-      qj[ct] = withC ? qr[col] : 0.0;      // a == a2 on the diagonal
-    }
-    double wi[2][4], qi[2][4];
+  auto load_ops = [&](MMF64Operands<KS4>& o) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + rt * 16 + kq + 4 * r;
-        wi[rt][r] = wr[row];
-        qi[rt][r] = withC ? qr[row] : 0.0;
+        o.rho[rt][r] = ra[row];
+        o.rw[rt][r] = rwp[row];
       }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const int col = cbase + ct * 16 + l15;
+#pragma unroll
+      for (int s = 0; s < KS4; ++s) {
+        o.breg[ct][s] = cb[boff[s] + col];     // k >= d reads the (finite) gamma row against a zero A operand
+      }
+      o.gam[ct] = cb[goff + col];
+      o.cw[ct] = cwp[col];
+    }
+  };
 
+  // sum the staged partials of batch elements [bs, bs + nb): 16 threads per element sum 16 values
+  // each (rotated start: LDS bank spread), then one thread per element sums the 16 partials.
+  // Fixed order => bitwise reproducible.
+  auto flush = [&](int bs, int nb) {
+    __syncthreads();
+    const int bl = threadIdx.x >> 4, j = threadIdx.x & 15;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc += stage[bl][j * 16 + ((k + j) & 15)];
+    part16[bl][j] = acc;
+    __syncthreads();
+    if (threadIdx.x < nb) {
+      double tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tot += part16[threadIdx.x][k];
+      const int b = bs + threadIdx.x;
+      partB[((size_t)b * P + p) * NS + blockIdx.x] = sym * tot;
+      if (withC) partC[((size_t)b * L + a) * NS + blockIdx.x] = 0.0;    // fused into partB
+    }
+  };
+
+  auto reduce_b = [&](int b, const MMF64Operands<KS4>& o) {
     f64x4 cacc[2][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        f64x4 c = {0.0, 0.0, 0.0, 0.0};
-        c = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[rt], bx[ct], c, 0, 0, 0);
+        f64x4 c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = o.rho[rt][r] + o.gam[ct];
 #pragma unroll
         for (int s = 0; s < KS4; ++s)
-          c = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[rt][s], breg[ct][s], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[rt][s], o.breg[ct][s], c, 0, 0, 0);
         cacc[rt][ct] = c;
       }
-    // wave-uniform choice of the expm1 form (the |.| test runs on the high dwords only)
-    double mx = 0.0;
+    // wave-uniform choice of the expm1 form.  |x| is ordered like its high dword (sign cleared) as an
+    // unsigned integer, so the range test runs on 32-bit integer max; comparing against the high
+    // dword of the (power-of-two) limits with >= errs to the higher-degree side at the boundary.
+    unsigned int mxh = 0u;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmax(mx, fabs(cacc[rt][ct][r]));
-    const bool tiny = !__any(mx > 0.25);
-    const bool small = !__any(mx > SMALL_LIMIT);
-    double sB = 0.0, sC = 0.0;
+        for (int r = 0; r < 4; ++r) {
+          const unsigned int hi = (unsigned int)(__builtin_bit_cast(unsigned long long, cacc[rt][ct][r]) >> 32);
+          const unsigned int ah = hi & 0x7fffffffu;
+          mxh = ah > mxh ? ah : mxh;
+        }
+#define MM_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))
+    double sv = 0.0;
 #define MM_F64_ACCUM(EXPM1_)                                                              \
     _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                    \
-      double pB = 0.0, pC = 0.0;                                                          \
+      double pv = 0.0;                                                                    \
       _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                    \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                   \
           const double e = EXPM1_(cacc[rt][ct][r]);                                       \
-          pB = fma(wi[rt][r], e, pB);                                                     \
-          if (withC) pC = fma(creg[rt][ct][r], fma(qi[rt][r], e, qi[rt][r]), pC);         \
+          if (withC) pv = fma(fma(dreg[rt][ct][r], e, creg[rt][ct][r]), o.rw[rt][r], pv); \
+          else pv = fma(o.rw[rt][r], e, pv);                                              \
         }                                                                                 \
-      sB = fma(pB, wj[ct], sB);                                                           \
-      sC = fma(pC, qj[ct], sC);                                                           \
+      sv = fma(pv, o.cw[ct], sv);                                                         \
     }
-    if (tiny) {
-      if (SMALL_LIMIT > 0.6) { MM_F64_ACCUM(mm_expm1_f64_p10) } else { MM_F64_ACCUM(mm_expm1_f64_p12) }
-    } else if (small) {
-      MM_F64_ACCUM(mm_expm1_f64_p15)
+    // Taylor tiers: the Horner steps run "vertically" over the 8 entries of a column block, so
+    // consecutive v_fma_f64 are independent (a per-entry chain stalls on the f64 FMA latency with
+    // only two waves per SIMD to cover it).
+#define MM_F64_ACCUM_POLY(DEG_)                                                           \
+    _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                    \
+      double pp[8], xv[8];                                                                \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                     \
+        xv[i] = cacc[i >> 2][ct][i & 3];                                                  \
+        pp[i] = fma(mm_inv_fact(DEG_), xv[i], mm_inv_fact(DEG_ - 1));                     \
+      }                                                                                   \
+      _Pragma("unroll") for (int k = DEG_ - 2; k >= 1; --k)                               \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] = fma(pp[i], xv[i], mm_inv_fact(k)); \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] *= xv[i];                       \
+      double pa = 0.0, pb = 0.0;                                                          \
+      if (withC) {                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] = fma(dreg[i >> 2][ct][i & 3], pp[i], creg[i >> 2][ct][i & 3]); \
+      }                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 8; i += 2) {                                  \
+        pa = fma(pp[i], o.rw[i >> 2][i & 3], pa);                                         \
+        pb = fma(pp[i + 1], o.rw[(i + 1) >> 2][(i + 1) & 3], pb);                         \
+      }                                                                                   \
+      sv = fma(pa + pb, o.cw[ct], sv);                                                    \
+    }
+    // Taylor degree by range: truncation |x|^DEG / (DEG+1)! relative to expm1(x)
+    //   LOWP (f32 model): 1/64 -> 6 (3e-15), 1/16 -> 8 (6e-16), 1/4 -> 10 (2e-14), 3/4 -> 15
+    //   f64 model       : 1/64 -> 7 (6e-18), 1/16 -> 9 (4e-18), 1/4 -> 12 (1e-17), 1/2 -> 15
+    if (!__any(mxh >= MM_HI32(0.015625))) {
+      if (LOWP) { MM_F64_ACCUM_POLY(6) } else { MM_F64_ACCUM_POLY(7) }
+    } else if (!__any(mxh >= MM_HI32(0.0625))) {
+      if (LOWP) { MM_F64_ACCUM_POLY(8) } else { MM_F64_ACCUM_POLY(9) }
+    } else if (!__any(mxh >= MM_HI32(0.25))) {
+      if (LOWP) { MM_F64_ACCUM_POLY(10) } else { MM_F64_ACCUM_POLY(12) }
+    } else if (!__any(mxh >= (LOWP ? MM_HI32(0.75) : MM_HI32(0.5)))) {
+      MM_F64_ACCUM_POLY(15)
     } else {
       MM_F64_ACCUM(mm_expm1_f64)
     }
 #undef MM_F64_ACCUM
-    // workgroup reduction of (sB, sC) for this b.  First fold across the two lane halves so that
-    // lanes 0-31 carry sB partials and lanes 32-63 sC partials, then 5 butterfly steps on ONE value.
-    double v;
-    {
-      const bool lo = lane < 32;
-      const double keep = lo ? sB : sC, give = lo ? sC : sB;
-      v = keep + __shfl_xor(give, 32, 64);
-    }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    __syncthreads();
-    if (lane == 0) red[wv] = v;            // sB of this wave
-    if (lane == 32) red[4 + wv] = v;       // sC of this wave
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      partB[((size_t)b * P + p) * NS + blockIdx.x] = sym * (red[0] + red[1] + red[2] + red[3]);
-      if (withC) partC[((size_t)b * L + a) * NS + blockIdx.x] = sym * (red[4] + red[5] + red[6] + red[7]);
-    }
+#undef MM_F64_ACCUM_POLY
+#undef MM_HI32
+    // the workgroup reduction is deferred: per-thread partials of MM_F64_NB batch elements are
+    // staged in LDS and reduced together (no cross-lane traffic or barrier per batch element)
+    stage[(b - b0) % MM_F64_NB][threadIdx.x] = sv;
+    if ((b - b0) % MM_F64_NB == MM_F64_NB - 1 || b == b1 - 1) flush(b - (b - b0) % MM_F64_NB, (b - b0) % MM_F64_NB + 1);
+  };
+
+  // two operand sets in registers: batch element b + 1 is in flight while b is reduced
+  // (the prefetch is unconditional -- past the end it re-reads the last element -- so that the
+  // compiler's s_waitcnt for the current set does not have to cover a maybe-not-issued prefetch)
+  MMF64Operands<KS4> o0, o1;
+  auto advance = [&](bool more) {
+    const size_t m = more ? 1 : 0;
+    ra += m * st_ra; cb += m * st_cb; rwp += m * st_w; cwp += m * st_w;
+  };
+  load_ops(o0);
+  for (int b = b0; b < b1; b += 2) {
+    advance(b + 1 < b1);
+    load_ops(o1);
+    reduce_b(b, o0);
+    advance(b + 2 < b1);
+    load_ops(o0);
+    if (b + 1 < b1) reduce_b(b + 1, o1);
   }
 }
 
@@ -244,8 +326,9 @@ int mm_f64_num_slots(int Mp, int diag) {
 }
 
 // Launch over `npairs` pairs starting at global pair index p0.  diag != 0: pairs are (a, a).
-int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, int L, int Mp, int d, int P, int NS,
-                       int p0, int npairs, int B, int diag, double small_limit,
+// lowp != 0: the model is f32 (diagonal pairs only need ~1e-14 relative accuracy of expm1).
+int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double* beta, int M, int L, int Mp, int d,
+                       int P, int NS, int p0, int npairs, int B, int diag, int lowp,
                        const double* w, const double* q, const double* rowA, const double* colB,
                        double* partB, double* partC, hipStream_t stream) {
   if (npairs <= 0) return 0;
@@ -256,19 +339,26 @@ int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, int L, int Mp
   int nchunk = (int)((2048 + per_chunk - 1) / per_chunk);
   if (nchunk < 1) nchunk = 1;
   if (nchunk > B) nchunk = B;
-  if (!diag) nchunk = B < 64 ? B : 64;       // no C reuse to protect: more, shorter workgroups
+  if (!diag) {                               // no C reuse to protect: ~24 workgroups per CU, but chunks long
+    nchunk = (int)((6144 + per_chunk - 1) / per_chunk);   // enough (>= 4) for the operand prefetch to pay
+    const int cap = (B + 3) / 4;
+    if (nchunk > cap) nchunk = cap;
+    if (nchunk < 1) nchunk = 1;
+  }
   const int bchunk = (B + nchunk - 1) / nchunk;
   nchunk = (B + bchunk - 1) / bchunk;
   dim3 grid(nslots, npairs, nchunk);
   const int ks4 = (d + 3) / 4;
-#define MM_LAUNCH_F64(KS_, DG_)                                                                    \
-  do {                                                                                             \
-    if (DG_ && Cm != nullptr)                                                                      \
-      hipLaunchKernelGGL((k_qred_f64_mfma<KS_, DG_, true>), grid, dim3(256), 0, stream, Zc, Kz, Cm, L, Mp, d, \
-                         P, NS, p0, B, bchunk, small_limit, w, q, rowA, colB, partB, partC);      \
-    else                                                                                           \
-      hipLaunchKernelGGL((k_qred_f64_mfma<KS_, DG_, false>), grid, dim3(256), 0, stream, Zc, Kz, Cm, L, Mp, d, \
-                         P, NS, p0, B, bchunk, small_limit, w, q, rowA, colB, partB, partC);      \
+#define MM_LAUNCH_F64_(KS_, DG_, WC_, LP_)                                                                  \
+  hipLaunchKernelGGL((k_qred_f64_mfma<KS_, DG_, WC_, LP_>), grid, dim3(256), 0, stream, Zc, Kz, Cm, beta, M, \
+                     L, Mp, d, P, NS, p0, B, bchunk, w, q, rowA, colB, partB, partC)
+#define MM_LAUNCH_F64(KS_, DG_)                                                  \
+  do {                                                                           \
+    const bool wc = DG_ && Cm != nullptr;                                        \
+    if (wc && lowp) MM_LAUNCH_F64_(KS_, DG_, true, true);                        \
+    else if (wc) MM_LAUNCH_F64_(KS_, DG_, true, false);                          \
+    else if (lowp) MM_LAUNCH_F64_(KS_, DG_, false, true);                        \
+    else MM_LAUNCH_F64_(KS_, DG_, false, false);                                 \
   } while (0)
 #define MM_LAUNCH_F64_KS(DG_)                                   \
   do {                                                          \
@@ -282,6 +372,7 @@ int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, int L, int Mp
   if (diag) MM_LAUNCH_F64_KS(true); else MM_LAUNCH_F64_KS(false);
 #undef MM_LAUNCH_F64_KS
 #undef MM_LAUNCH_F64
+#undef MM_LAUNCH_F64_
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

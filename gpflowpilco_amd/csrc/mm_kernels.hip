@@ -723,8 +723,8 @@ extern "C" int mm_mfma_supported(int d);
 int mm_mfma_num_slots(int Mp);
 // f64 MFMA reduce (mm_f64.hip): diagonal pairs of both modes, off-diagonal pairs of the f64 mode
 int mm_f64_num_slots(int Mp, int diag);
-int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, int L, int Mp, int d, int P, int NS,
-                       int p0, int npairs, int B, int diag, double small_limit,
+int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double* beta, int M, int L, int Mp, int d,
+                       int P, int NS, int p0, int npairs, int B, int diag, int lowp,
                        const double* w, const double* q, const double* rowA, const double* colB,
                        double* partB, double* partC, hipStream_t stream);
 int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
@@ -808,7 +808,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
 
 template <typename T, int DK>
 static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C, char* ws, const MMWorkspaceLayout& wl,
-                         int L, int d, int B, int flags, double jitter, T* Sff, hipStream_t s) {
+                         int L, int M, int d, int B, int flags, double jitter, T* Sff, hipStream_t s) {
   const int with_unc = (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0;
   const int full = (flags & MM_FULL_OUTPUT_COV) ? 1 : 0;
   if (with_unc && !has_C) return MM_E_NO_C;
@@ -833,8 +833,9 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
                          (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD), partB, partC);
       MM_CHECK_LAUNCH();
     } else {
-      const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS,
-                                        0, L, B, 1, sizeof(T) == 4 ? 0.75 : 0.5,
+      const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, Cm,
+                                        (const double*)(packed + ml.beta64), M, L, wl.Mp, d, wl.P, wl.NS,
+                                        0, L, B, 1, sizeof(T) == 4 ? 1 : 0,
                                         (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
                                         (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD),
                                         partB, partC, s);
@@ -847,8 +848,9 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
       const int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, s);
       if (rc) return rc;
     } else if (sizeof(T) == 8 && !generic) {
-      const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, nullptr, L, wl.Mp, d, wl.P, wl.NS,
-                                        L, wl.Po, B, 0, 0.5, (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+      const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, nullptr,
+                                        (const double*)(packed + ml.beta64), M, L, wl.Mp, d, wl.P, wl.NS,
+                                        L, wl.Po, B, 0, 0, (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
                                         (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO),
                                         partB, partC, s);
       if (rc) return rc;
@@ -889,7 +891,7 @@ static int mm_moment_match_t(const char* packed, size_t packed_bytes, int L, int
     rc = mm_q_forward_t<T, DK>(packed, ml, ws, wl, L, M, d, B, mu, Sigma, f1, cross, q_out, status, s);
     if (rc) return rc;
   }
-  if (do_Q) rc = mm_Q_reduce_t<T, DK>(packed, ml, has_C, ws, wl, L, d, B, flags, jitter, Sff, s);
+  if (do_Q) rc = mm_Q_reduce_t<T, DK>(packed, ml, has_C, ws, wl, L, M, d, B, flags, jitter, Sff, s);
   return rc;
 }
 
