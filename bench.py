@@ -103,20 +103,23 @@ def main():
   traj_mu = torch.empty(H, B, d, dtype=dtype, device=dev)
   traj_S = torch.empty(H, B, d, d, dtype=dtype, device=dev)
   gathered = [torch.empty(B, H, dtype=dtype, device=dev) for _ in range(world)] if world > 1 else None
-  ev = []
+  ev, evd = [], []
   state = {"mu": mu0.clone(), "S": S0.clone(), "h": 0, "cost": None}
 
   def one_step(timed):
     if state["h"] == 0:
       state["mu"], state["S"] = mu0.clone(), S0.clone()
     f1, cross, _ = ops.q_forward(pm, state["mu"], state["S"], base)
+    if timed:
+      d0 = torch.cuda.Event(enable_timing=True); d1 = torch.cuda.Event(enable_timing=True)
+      e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+      d0.record()
     ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_DIAG)
     if timed:
-      e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-      e0.record()
+      d1.record(); e0.record()
     ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_OFFDIAG)
     if timed:
-      e1.record(); ev.append((e0, e1))
+      e1.record(); ev.append((e0, e1)); evd.append((d0, d1))
     Sff = ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_FINALIZE)
     state["mu"], state["S"] = ops.euler_update(state["mu"], state["S"], f1, Sff, cross, 1.0)
     traj_mu[state["h"]].copy_(state["mu"]); traj_S[state["h"]].copy_(state["S"])
@@ -160,21 +163,42 @@ def main():
   if state["cost"] is not None and tuple(state["cost"].shape) != (B * world, H):
     raise SystemExit(f"gathered cost matrix has shape {tuple(state['cost'].shape)}, expected {(B * world, H)}")
 
-  # ---- roofline of the dominant kernel (off-diagonal f32 MFMA reduce) ---------------------
+  # ---- roofline of the dominant kernel (the off-diagonal reduce) ----------------------------
   k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
+  kd_ms = float(np.mean([a.elapsed_time(b) for a, b in evd])) if evd else float("nan")
   Po = L * (L - 1) // 2
-  flops = float(B) * Po * M * M * (2 * d + 12)            # E * (2d + 12), E = B*Po*M^2
+  entries = float(B) * Po * M * M
+  flops = entries * (2 * d + 12)                           # E * (2d + 12), E = B*Po*M^2
   achieved = flops / (k_ms * 1e-3) / 1e12 if Po else 0.0
+  f32_mfma = dtype == torch.float32 and not args.force_generic
+  kname = "k_qred_generic" if args.force_generic else ("k_qred_f32_mfma" if f32_mfma else "k_qred_f64_mfma")
   # HBM bytes per launch of the dominant kernel from the PMC passes kept in
-  # profiles/r01_pmc_hbm_traffic.csv (FETCH_SIZE x 2 per MI355X_MICROARCH.md "HBM" + WRITE_SIZE, KB):
-  # 2 * 297655 KB + 448 KB = 0.61 GB against 0.60 GB of streamed operands (rowO + colO + w).
+  # profiles/r01_pmc_counters.csv (FETCH_SIZE x 2 per MI355X_MICROARCH.md "HBM" + WRITE_SIZE, KB):
+  # 2 * 289494 KB + 448 KB = 0.59 GB against 0.59 GB of streamed operands (rowO + colO).
   # Only valid for the default C3 / B = 256 launch; other shapes report null.
-  traffic = 2 * 297655 * 1024 + 448 * 1024 if (args.config == "c3" and B == 256 and not args.force_generic) else None
-  roofline = {"bound": "mfma", "kernel": "k_qred_f32_mfma" if (dtype == torch.float32 and not args.force_generic) else "k_qred_generic",
+  traffic = 2 * 289494 * 1024 + 448 * 1024 if (args.config == "c3" and B == 256 and f32_mfma) else None
+  roofline = {"bound": "mfma", "kernel": kname,
               "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
               "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": traffic,
               "kernel_ms": round(k_ms, 4),
-              "flops_per_launch": flops, "entries_per_launch": float(B) * Po * M * M}
+              "flops_per_launch": flops, "entries_per_launch": entries}
+  if f32_mfma:
+    # executed work (DESIGN.md "f32 reduce roofline"): the bilinear form runs as a 3-way bf16 split
+    # product, 6 v_mfma_f32_32x32x16_bf16 per 64 x 32 wave tile and 8 input dims
+    nd8 = (d + 7) // 8
+    mfma_flops = entries / 2048.0 * 6 * nd8 * 32768.0
+    roofline["executed_mfma_bf16"] = {"achieved": round(mfma_flops / (k_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
+                                      "unit": "TFLOP/s", "frac": round(mfma_flops / (k_ms * 1e-3) / 2.5e15, 4)}
+    roofline["note"] = ("achieved = algorithmic f32 flops, E*(2d+12); the 2d part executes on the bf16 matrix pipe "
+                        "(3 MFMAs per 8 dims, f32-equivalent accuracy) and the expm1 degree adapts to the tile range "
+                        "(2..7 instead of a fixed 12-flop budget), so the fraction of the f32 peak can exceed 1; "
+                        "MFMA and f32 FMA VALU time add on a SIMD (tools/ubench_overlap.hip)")
+  # second kernel of the step: the diagonal pairs, always f64 (upper-triangular tiles)
+  ed = float(B) * L * M * (M + 1) / 2
+  roofline_diag = {"bound": "mfma", "kernel": "k_qred_generic" if args.force_generic else "k_qred_f64_mfma",
+                   "achieved": round(ed * (2 * d + 12) / (kd_ms * 1e-3) / 1e12, 3), "peak": PEAK_TFLOPS[torch.float64],
+                   "unit": "TFLOP/s", "frac": round(ed * (2 * d + 12) / (kd_ms * 1e-3) / 1e12 / PEAK_TFLOPS[torch.float64], 4),
+                   "kernel_ms": round(kd_ms, 4), "entries_per_launch": ed}
 
   out = {
       "metric": "moment_matched_rollout_step_elements_per_sec",
@@ -188,6 +212,7 @@ def main():
                  "B_per_gpu": B, "B_total": B * world, "parallelism": f"dp{world} over B",
                  "diag_pairs": "f64", "offdiag_pairs": "f32" if dtype == torch.float32 else "f64"},
       "roofline": roofline,
+      "roofline_diag": roofline_diag,
   }
 
   # ---- CPU baseline + parity (rank 0, N == 1 only) -----------------------------------------

@@ -78,8 +78,8 @@ struct MMF64Operands {
 
 // KS4: number of K=4 MFMA steps covering the d input dimensions.  LOWP: f32 mode (the diagonal pairs
 // of an f32 model: expm1 to ~1e-14 relative instead of ~1e-17).
-// grid: x = tile pairs (diag: nt(nt+1)/2 upper pairs; else nt*nt), y = pairs of this launch,
-//       z = batch chunks.  Row/col operand arrays are indexed by the local pair index.
+// grid: 1-D over (pair of this launch, batch chunk, tile pair); tile pairs: nt(nt+1)/2 upper pairs on
+//       the diagonal, else nt*nt.  Row/col operand arrays are indexed by the local pair index.
 //
 // Diagonal pairs with model uncertainty reduce ONE fused sum
 //     sum_ij q_i q_j (D_ij expm1(delta_ij) + C_ij),   D = C + beta beta^T   (w_i = beta_i q_i),
@@ -91,23 +91,33 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
                                                           const double* __restrict__ Cm,
                                                           const double* __restrict__ beta, int M,
                                                           int L, int Mp, int d, int P, int NS, int p0,
-                                                          int B, int bchunk,
+                                                          int B, int bchunk, int np, int nslots, int nchunk, int nwork,
                                                           const double* __restrict__ w,
                                                           const double* __restrict__ q,
                                                           const double* __restrict__ rowA,
                                                           const double* __restrict__ colB,
                                                           double* __restrict__ partB,
                                                           double* __restrict__ partC) {
+  // 1-D grid, XCD-aware: workgroups b and b + 8 share an XCD (round-robin dispatch), so the remap
+  // hands every XCD one contiguous range of work items ordered (pair, batch chunk, tile): the
+  // per-batch-element operands of one latent stay in ONE XCD's L2.  Bijective for any nwork.
   const int nt = Mp / MM_F64_TILE;
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, slot = orig >> 3;
+  const int qn = nwork >> 3, rn = nwork & 7;
+  const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  const int tile = wi % nslots;
+  const int chunk = (wi / nslots) % nchunk;
+  const int lp = wi / (nslots * nchunk);
+  const int p = p0 + lp;
   int it, jt;
-  if (DIAG) {                       // blockIdx.x -> (it <= jt), row-major over the upper triangle
-    int r = blockIdx.x; it = 0;
+  if (DIAG) {                       // tile -> (it <= jt), row-major over the upper triangle
+    int r = tile; it = 0;
     while (r >= nt - it) { r -= nt - it; ++it; }
     jt = it + r;
   } else {
-    it = blockIdx.x / nt; jt = blockIdx.x - it * nt;
+    it = tile / nt; jt = tile - it * nt;
   }
-  const int lp = blockIdx.y, np = gridDim.y, p = p0 + lp;
   int a, a2;
   mm_decode_pair_f(p, L, a, a2);
   constexpr bool withC = DIAG && WITHC;
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
 
   __shared__ double stage[MM_F64_NB][256];
   __shared__ double part16[MM_F64_NB][16];
-  const int b0 = blockIdx.z * bchunk;
+  const int b0 = chunk * bchunk;
   const int b1 = (b0 + bchunk < B) ? b0 + bchunk : B;
   // per-b operand pointers advance by constant strides (no 64-bit multiplies in the loop)
   const double* ra = rowA + ((size_t)b0 * np + lp) * Mp;
@@ -209,8 +219,8 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
 #pragma unroll
       for (int k = 0; k < 16; ++k) tot += part16[threadIdx.x][k];
       const int b = bs + threadIdx.x;
-      partB[((size_t)b * P + p) * NS + blockIdx.x] = sym * tot;
-      if (withC) partC[((size_t)b * L + a) * NS + blockIdx.x] = 0.0;    // fused into partB
+      partB[((size_t)b * P + p) * NS + tile] = sym * tot;
+      if (withC) partC[((size_t)b * L + a) * NS + tile] = 0.0;    // fused into partB
     }
   };
 
@@ -334,11 +344,11 @@ int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double*
   if (npairs <= 0) return 0;
   const int nslots = mm_f64_num_slots(Mp, diag);
   if (nslots > NS) return MM_E_WORKSPACE;
-  // batch chunk: enough workgroups to fill the chip (>= ~8 per CU), as few C re-reads as possible
+  // batch chunk: enough workgroups to fill the chip evenly (>= ~32 per CU), as few C re-reads as possible
   long long per_chunk = (long long)nslots * npairs;
-  int nchunk = (int)((2048 + per_chunk - 1) / per_chunk);
+  int nchunk = (int)((8192 + per_chunk - 1) / per_chunk);    // >= 16 rounds of 512 resident workgroups: short tail
+  if (nchunk > B / 16) nchunk = B / 16;      // keep >= 16 batch elements per C tile load
   if (nchunk < 1) nchunk = 1;
-  if (nchunk > B) nchunk = B;
   if (!diag) {                               // no C reuse to protect: ~24 workgroups per CU, but chunks long
     nchunk = (int)((6144 + per_chunk - 1) / per_chunk);   // enough (>= 4) for the operand prefetch to pay
     const int cap = (B + 3) / 4;
@@ -347,11 +357,14 @@ int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double*
   }
   const int bchunk = (B + nchunk - 1) / nchunk;
   nchunk = (B + bchunk - 1) / bchunk;
-  dim3 grid(nslots, npairs, nchunk);
+  const long long nwork_ll = (long long)nslots * npairs * nchunk;
+  if (nwork_ll > 0x7fffffffLL) return MM_E_DIM;
+  const int nwork = (int)nwork_ll;
+  dim3 grid(nwork);
   const int ks4 = (d + 3) / 4;
 #define MM_LAUNCH_F64_(KS_, DG_, WC_, LP_)                                                                  \
   hipLaunchKernelGGL((k_qred_f64_mfma<KS_, DG_, WC_, LP_>), grid, dim3(256), 0, stream, Zc, Kz, Cm, beta, M, \
-                     L, Mp, d, P, NS, p0, B, bchunk, w, q, rowA, colB, partB, partC)
+                     L, Mp, d, P, NS, p0, B, bchunk, npairs, nslots, nchunk, nwork, w, q, rowA, colB, partB, partC)
 #define MM_LAUNCH_F64(KS_, DG_)                                                  \
   do {                                                                           \
     const bool wc = DG_ && Cm != nullptr;                                        \
