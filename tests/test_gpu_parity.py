@@ -147,6 +147,25 @@ def test_euler_and_rollout(dtype, device):
   pm.check_status(3)
 
 
+def test_graphed_rollout_replays_bitwise(device):
+  """The HIP-graph capture of the closed rollout replays to the eager result, for new inputs too."""
+  L = d = 4
+  syn = make_svgp(L, 96, d, seed=34)
+  pm = syn.to_model(device).packed(torch.float64, True, device)
+  g = ops.GraphedRollout(pm, 3, 6, dt=1.0, keep_trajectory=True)
+  for seed in (5, 6):
+    mu, Sigma = make_inputs(3, d, seed=seed, scale=0.1, lo=0.3, hi=0.7)
+    mu_t, S_t = to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64)
+    ref = ops.rollout_closed(pm, mu_t, S_t, 6, dt=1.0, keep_trajectory=True)
+    out = g(mu_t, S_t)
+    for a, b in zip(out, ref):
+      assert torch.equal(a, b)
+  pm.check_status(3)
+  with pytest.raises(ValueError):
+    g(mu_t[:2], S_t[:2])
+
+
+
 def test_sigma_to_zero_limit(device):
   """Sigma -> 0: f1 -> GP predictive mean, Sff -> predictive variance."""
   from oracle.pin_oracle import svgp_predict_f

@@ -38,3 +38,4 @@ for _ in range(a.reps):
     e0.record(); f(); e1.record(); torch.cuda.synchronize()
     tot[n] += e0.elapsed_time(e1)
 print(" ".join(f"{n}={tot[n] / a.reps:.3f}ms" for n in tot), f"sum={sum(tot.values()) / a.reps:.3f}ms")
+
