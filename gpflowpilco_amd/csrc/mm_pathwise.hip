@@ -40,6 +40,26 @@ __device__ __forceinline__ void pw_unpack(const float4& v, T (&o)[4]) { o[0] = v
 template <typename T>
 __device__ __forceinline__ void pw_unpack(const double2& v, T (&o)[2]) { o[0] = v.x; o[1] = v.y; }
 
+// Sum over the 64 lanes of a wave by DPP row operations (no LDS crossbar round trips): result valid
+// in lane 63.  Fixed order => bitwise reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double pw_dpp_add(double v) {
+  const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)u, CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(u >> 32), CTRL, ROW_MASK, 0xf, false);
+  const unsigned long long w = ((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo;
+  return v + __builtin_bit_cast(double, w);          // lanes outside ROW_MASK / without a source add +0.0
+}
+__device__ __forceinline__ double pw_wave_sum63(double v) {
+  v = pw_dpp_add<0xB1, 0xf>(v);      // quad_perm [1,0,3,2]
+  v = pw_dpp_add<0x4E, 0xf>(v);      // quad_perm [2,3,0,1]
+  v = pw_dpp_add<0x141, 0xf>(v);     // row_half_mirror
+  v = pw_dpp_add<0x140, 0xf>(v);     // row_mirror: every lane of a row holds the row sum
+  v = pw_dpp_add<0x142, 0xa>(v);     // row_bcast:15 into rows 1 and 3
+  v = pw_dpp_add<0x143, 0xc>(v);     // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+  return v;
+}
+
 // grid: ceil(S / NS) workgroups of 256 threads = 4 waves.  Wave wv of a workgroup owns the latents
 // wv, wv + 4, ... of the workgroup's NS samples and streams their K + M weights alone: the only
 // cross-lane step is one shuffle reduction per (latent, sample) -- no LDS, no barriers.  The weight
@@ -207,36 +227,55 @@ __global__ __launch_bounds__(512) void k_pathwise_lds(int S, int L, int M, int K
   typedef typename PwVec<T>::type VT;
   constexpr int W = PwVec<T>::W, NS = MM_PW_NS, BT = 64 * W, NWAVE = 8;
   extern __shared__ __attribute__((aligned(16))) char pw_smem[];
-  T* op = reinterpret_cast<T*>(pw_smem);               // [d + 1][K + M]: rows 0..d-1 vectors, row d scalars
+  // [DK + 1][K + M]: rows 0..d-1 vectors (rows d..DK-1 zero: the k loops below are unconditional),
+  // row DK the scalars (phase | hz)
+  T* op = reinterpret_cast<T*>(pw_smem);
   const int a = blockIdx.x % L, wgi = blockIdx.x / L;
   const int KT = K + M, nbK = K / BT, NB = KT / BT;
-  for (int idx = threadIdx.x * W; idx < (d + 1) * KT; idx += 512 * W) {
+  for (int idx = threadIdx.x * W; idx < (DK + 1) * KT; idx += 512 * W) {
     const int row = idx / KT, col = idx - row * KT;     // KT % W == 0: a vector never straddles rows
-    const T* src;
-    if (row < d) src = (col < K) ? omega + ((size_t)a * d + row) * K + col : zs + ((size_t)a * d + row) * M + (col - K);
-    else src = (col < K) ? phase + (size_t)a * K + col : hz + (size_t)a * M + (col - K);
-    *reinterpret_cast<VT*>(op + idx) = *reinterpret_cast<const VT*>(src);
+    T v[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) v[j] = (T)0;
+    if (row < d) {
+      pw_unpack<T>(*reinterpret_cast<const VT*>((col < K) ? omega + ((size_t)a * d + row) * K + col
+                                                          : zs + ((size_t)a * d + row) * M + (col - K)), v);
+      // update rows carry z * x_scale^2, so that both halves of the stream use the raw x_s
+      const T f = (col < K) ? (T)1 : (T)xscale[a * d + row];
+#pragma unroll
+      for (int j = 0; j < W; ++j) v[j] *= f;
+    } else if (row == DK) {
+      pw_unpack<T>(*reinterpret_cast<const VT*>((col < K) ? phase + (size_t)a * K + col
+                                                          : hz + (size_t)a * M + (col - K)), v);
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) op[idx + j] = v[j];
   }
   __syncthreads();
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // the wave index as a scalar: everything derived from it (sample group, x_s, stream base) is wave-uniform
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int ngroups = (S + NS - 1) / NS;
   T sc[DK];
 #pragma unroll
-  for (int k = 0; k < DK; ++k) sc[k] = (k < d) ? (T)xscale[a * d + k] : (T)0;
+  for (int k = 0; k < DK; ++k) {
+    const T v = (T)xscale[a * d + (k < d ? k : 0)];
+    sc[k] = (k < d) ? v : (T)0;
+  }
   const double ps = pscale[a], vr = var[a], mc = meanc ? meanc[a] : 0.0;
 
   for (int g = wgi * NWAVE + wv; g < ngroups; g += nW * NWAVE) {
     const int s0 = g * NS;
-    T xr[NS][DK], xsc[NS][DK], hx[NS];
+    T xr[NS][DK], hx[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int row = (s0 + s < S) ? s0 + s : S - 1;
       T h = (T)0;
 #pragma unroll
       for (int k = 0; k < DK; ++k) {
-        xr[s][k] = (k < d) ? x[(size_t)row * d + k] : (T)0;
-        xsc[s][k] = xr[s][k] * sc[k];
-        h += xsc[s][k] * xsc[s][k];
+        const T v = x[(size_t)row * d + (k < d ? k : 0)];      // uniform address: unconditional load, then select
+        xr[s][k] = (k < d) ? v : (T)0;
+        const T xs = xr[s][k] * sc[k];
+        h += xs * xs;
       }
       hx[s] = (T)0.5 * h;
     }
@@ -244,29 +283,22 @@ __global__ __launch_bounds__(512) void k_pathwise_lds(int S, int L, int M, int K
 #pragma unroll
     for (int s = 0; s < NS; ++s) { accp[s] = (T)0; accu[s] = (T)0; }
     const T* wrow = wb + (((size_t)g * L + a) * NB) * NS * BT + lane * W;
-    VT wq[3][NS];
+
+    // unconditional, index-clamped loads: the compiler's s_waitcnt for block tb then only has to
+    // cover the loads issued up to block tb (a conditional prefetch forces vmcnt(0) at the join)
+    auto load_blk = [&](int tb, VT (&q)[NS]) {
+      const int t = tb < NB ? tb : NB - 1;
 #pragma unroll
-    for (int pf = 0; pf < 2; ++pf)
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-        wq[pf][s] = (pf < NB) ? *reinterpret_cast<const VT*>(wrow + ((size_t)pf * NS + s) * BT) : VT{};
-    for (int tb = 0; tb < NB; ++tb) {
-#pragma unroll
-      for (int s = 0; s < NS; ++s)
-        wq[2][s] = (tb + 2 < NB) ? *reinterpret_cast<const VT*>(wrow + ((size_t)(tb + 2) * NS + s) * BT) : VT{};
+      for (int s = 0; s < NS; ++s) q[s] = *reinterpret_cast<const VT*>(wrow + ((size_t)t * NS + s) * BT);
+    };
+    auto compute_blk = [&](int tb, const VT (&q)[NS]) {
       T wv4[NS][W], cv[DK][W], sv[W];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) pw_unpack<T>(wq[0][s], wv4[s]);
+      for (int s = 0; s < NS; ++s) pw_unpack<T>(q[s], wv4[s]);
       const int col = tb * BT + lane * W;
 #pragma unroll
-      for (int k = 0; k < DK; ++k) {
-        if (k < d) pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)k * KT + col), cv[k]);
-        else {
-#pragma unroll
-          for (int j = 0; j < W; ++j) cv[k][j] = (T)0;
-        }
-      }
-      pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)d * KT + col), sv);
+      for (int k = 0; k < DK; ++k) pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)k * KT + col), cv[k]);
+      pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)DK * KT + col), sv);
       if (tb < nbK) {                                     // wave-uniform: prior block
 #pragma unroll
         for (int j = 0; j < W; ++j)
@@ -284,19 +316,27 @@ __global__ __launch_bounds__(512) void k_pathwise_lds(int S, int L, int M, int K
           for (int s = 0; s < NS; ++s) {
             T arg = -sv[j] - hx[s];
 #pragma unroll
-            for (int k = 0; k < DK; ++k) arg += cv[k][j] * xsc[s][k];
+            for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
             accu[s] += wv4[s][j] * PW_EXP(arg);
           }
       }
-#pragma unroll
-      for (int s = 0; s < NS; ++s) { wq[0][s] = wq[1][s]; wq[1][s] = wq[2][s]; }
+    };
+    // three register sets in rotation: blocks tb + 1 and tb + 2 are in flight while tb is consumed
+    VT q0[NS], q1[NS], q2[NS];
+    load_blk(0, q0);
+    load_blk(1, q1);
+    for (int tb = 0; tb < NB; tb += 3) {
+      load_blk(tb + 2, q2);
+      compute_blk(tb, q0);
+      load_blk(tb + 3, q0);
+      if (tb + 1 < NB) compute_blk(tb + 1, q1);
+      load_blk(tb + 4, q1);
+      if (tb + 2 < NB) compute_blk(tb + 2, q2);
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      double t = ps * (double)accp[s] + vr * (double)accu[s];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-      if (lane == 0 && s0 + s < S) {
+      const double t = pw_wave_sum63(ps * (double)accp[s] + vr * (double)accu[s]);
+      if (lane == 63 && s0 + s < S) {
         double f = t + mc;
         if (euler) f = (double)xr[s][a < DK ? a : 0] + dt * f;
         out[(size_t)(s0 + s) * L + a] = (T)f;
@@ -311,7 +351,8 @@ static int pw_launch(int S, int L, int M, int K, int d, const T* x, const T* ome
                      const T* hz, const double* xscale, const double* pscale, const double* var,
                      const double* meanc, const T* wb, T* out, T* traj, int euler, double dt, hipStream_t s) {
   // LDS-resident operands when one latent's (d + 1) x (K + M) block fits (<= 144 KB)
-  const size_t lds_bytes = (size_t)(d + 1) * (K + M) * sizeof(T);
+  const int dk = d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : 32;
+  const size_t lds_bytes = (size_t)(dk + 1) * (K + M) * sizeof(T);      // rows d..dk-1 are zero padding
   if (lds_bytes <= 144 * 1024) {
     const int ngroups = (S + MM_PW_NS - 1) / MM_PW_NS;
     int nW = 256 / L; if (nW < 1) nW = 1;                           // ~ one workgroup per CU
