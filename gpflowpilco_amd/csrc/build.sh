@@ -14,6 +14,10 @@ for src in mm_kernels mm_mfma mm_f64 mm_pathwise mm_backward; do
   # into one v_max3_f32 per two entries (no canonicalising v_max x, x); inputs are finite by the
   # time they reach that kernel (k_prep's status word rejects non-PD / non-finite states).
   [[ "${src}" == mm_mfma ]] && extra=(-fno-honor-nans)
+  # mm_pathwise.hip without the SLP vectoriser: it pairs elements of different 16-byte loads into
+  # v_pk_fma_f32 operands, and the shuffles it places on the loop back edge wait for the prefetched
+  # (still in flight) weight blocks -- s_waitcnt vmcnt(0) per iteration instead of vmcnt(8)
+  [[ "${src}" == mm_pathwise ]] && extra=(-fno-slp-vectorize)
   hipcc "${common[@]}" "${extra[@]}" -c "${here}/${src}.hip" -o "${obj}/${src}.o" "$@" &
   pids+=($!)
   objs+=("${obj}/${src}.o")

@@ -20,6 +20,12 @@
 #include "mm_common.h"
 
 #define MM_PW_NS 4      // samples per workgroup (and per block of the weight stream)
+#ifndef PW_RING
+#define PW_RING 3       // register sets of the weight stream: PW_RING - 1 blocks in flight per wave
+#endif
+#ifndef PW_LDS_WAVES
+#define PW_LDS_WAVES 8   // waves per workgroup of the LDS-resident kernel (one workgroup per CU)
+#endif
 #ifndef PW_COS          // overridable for ablation builds (scratch/): which part of the kernel costs what
 #define PW_COS(x_) pw_cos(x_)
 #define PW_EXP(x_) pw_exp(x_)
@@ -217,7 +223,7 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
 // weight stream itself (operand re-reads through L2 cost 39 % of the plain kernel's time).
 // grid = L * nW workgroups; wave w of workgroup (a, i) handles sample groups i*8 + w, + nW*8, ...
 template <typename T, int DK>
-__global__ __launch_bounds__(512) void k_pathwise_lds(int S, int L, int M, int K, int d, int nW,
+__global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L, int M, int K, int d, int nW,
                                                       const T* __restrict__ x, const T* __restrict__ omega,
                                                       const T* __restrict__ phase, const T* __restrict__ zs,
                                                       const T* __restrict__ hz, const double* __restrict__ xscale,
@@ -225,14 +231,14 @@ __global__ __launch_bounds__(512) void k_pathwise_lds(int S, int L, int M, int K
                                                       const double* __restrict__ meanc, const T* __restrict__ wb,
                                                       T* __restrict__ out, T* __restrict__ traj, int euler, double dt) {
   typedef typename PwVec<T>::type VT;
-  constexpr int W = PwVec<T>::W, NS = MM_PW_NS, BT = 64 * W, NWAVE = 8;
+  constexpr int W = PwVec<T>::W, NS = MM_PW_NS, BT = 64 * W, NWAVE = PW_LDS_WAVES;
   extern __shared__ __attribute__((aligned(16))) char pw_smem[];
   // [DK + 1][K + M]: rows 0..d-1 vectors (rows d..DK-1 zero: the k loops below are unconditional),
   // row DK the scalars (phase | hz)
   T* op = reinterpret_cast<T*>(pw_smem);
   const int a = blockIdx.x % L, wgi = blockIdx.x / L;
   const int KT = K + M, nbK = K / BT, NB = KT / BT;
-  for (int idx = threadIdx.x * W; idx < (DK + 1) * KT; idx += 512 * W) {
+  for (int idx = threadIdx.x * W; idx < (DK + 1) * KT; idx += 64 * PW_LDS_WAVES * W) {
     const int row = idx / KT, col = idx - row * KT;     // KT % W == 0: a vector never straddles rows
     T v[W];
 #pragma unroll
@@ -263,85 +269,95 @@ __global__ __launch_bounds__(512) void k_pathwise_lds(int S, int L, int M, int K
   }
   const double ps = pscale[a], vr = var[a], mc = meanc ? meanc[a] : 0.0;
 
-  for (int g = wgi * NWAVE + wv; g < ngroups; g += nW * NWAVE) {
-    const int s0 = g * NS;
-    T xr[NS][DK], hx[NS];
+  // The wave's work is ONE flat sequence of weight blocks (its groups back to back, NB blocks each),
+  // consumed through PW_RING register sets in rotation: blocks i + 1 .. i + PW_RING - 1 are in flight
+  // while block i is reduced -- across group boundaries too, so a new group does not start with an empty pipeline.
+  // All loads are unconditional (past the end the last block is re-read): the compiler's s_waitcnt
+  // for a block then covers exactly the loads issued up to it.
+  const int g_first = wgi * NWAVE + wv, g_stride = nW * NWAVE;
+  if (g_first >= ngroups) return;
+  const int n_mine = (ngroups - g_first + g_stride - 1) / g_stride;
+  const int total = n_mine * NB;
+  int ld_g = g_first, ld_tb = 0;                        // next block to load
+  auto load_next = [&](VT (&q)[NS]) {
+    const T* ptr = wb + (((size_t)ld_g * L + a) * NB + ld_tb) * NS * BT + lane * W;
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const int row = (s0 + s < S) ? s0 + s : S - 1;
-      T h = (T)0;
+    for (int s = 0; s < NS; ++s) q[s] = *reinterpret_cast<const VT*>(ptr + (size_t)s * BT);
+    if (ld_tb + 1 < NB) ++ld_tb;
+    else if (ld_g + g_stride < ngroups) { ld_g += g_stride; ld_tb = 0; }
+  };
+  int cg = g_first, ctb = 0;                            // block being consumed
+  T xr[NS][DK], hx[NS], accp[NS], accu[NS];
+  auto consume = [&](const VT (&q)[NS]) {
+    const int s0 = cg * NS;
+    if (ctb == 0) {                                     // new group: its NS states (wave-uniform loads)
 #pragma unroll
-      for (int k = 0; k < DK; ++k) {
-        const T v = x[(size_t)row * d + (k < d ? k : 0)];      // uniform address: unconditional load, then select
-        xr[s][k] = (k < d) ? v : (T)0;
-        const T xs = xr[s][k] * sc[k];
-        h += xs * xs;
+      for (int s = 0; s < NS; ++s) {
+        const int row = (s0 + s < S) ? s0 + s : S - 1;
+        T h = (T)0;
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+          const T v = x[(size_t)row * d + (k < d ? k : 0)];
+          xr[s][k] = (k < d) ? v : (T)0;
+          const T xs = xr[s][k] * sc[k];
+          h += xs * xs;
+        }
+        hx[s] = (T)0.5 * h;
+        accp[s] = (T)0; accu[s] = (T)0;
       }
-      hx[s] = (T)0.5 * h;
     }
-    T accp[NS], accu[NS];
+    T wv4[NS][W], cv[DK][W], sv[W];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { accp[s] = (T)0; accu[s] = (T)0; }
-    const T* wrow = wb + (((size_t)g * L + a) * NB) * NS * BT + lane * W;
-
-    // unconditional, index-clamped loads: the compiler's s_waitcnt for block tb then only has to
-    // cover the loads issued up to block tb (a conditional prefetch forces vmcnt(0) at the join)
-    auto load_blk = [&](int tb, VT (&q)[NS]) {
-      const int t = tb < NB ? tb : NB - 1;
+    for (int s = 0; s < NS; ++s) pw_unpack<T>(q[s], wv4[s]);
+    const int col = ctb * BT + lane * W;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) q[s] = *reinterpret_cast<const VT*>(wrow + ((size_t)t * NS + s) * BT);
-    };
-    auto compute_blk = [&](int tb, const VT (&q)[NS]) {
-      T wv4[NS][W], cv[DK][W], sv[W];
+    for (int k = 0; k < DK; ++k) pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)k * KT + col), cv[k]);
+    pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)DK * KT + col), sv);
+    if (ctb < nbK) {                                    // wave-uniform: prior block
 #pragma unroll
-      for (int s = 0; s < NS; ++s) pw_unpack<T>(q[s], wv4[s]);
-      const int col = tb * BT + lane * W;
+      for (int j = 0; j < W; ++j)
 #pragma unroll
-      for (int k = 0; k < DK; ++k) pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)k * KT + col), cv[k]);
-      pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)DK * KT + col), sv);
-      if (tb < nbK) {                                     // wave-uniform: prior block
+        for (int s = 0; s < NS; ++s) {
+          T arg = sv[j];
 #pragma unroll
-        for (int j = 0; j < W; ++j)
+          for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
+          accp[s] += wv4[s][j] * PW_COS(arg);
+        }
+    } else {                                            // update block
 #pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            T arg = sv[j];
+      for (int j = 0; j < W; ++j)
 #pragma unroll
-            for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
-            accp[s] += wv4[s][j] * PW_COS(arg);
-          }
-      } else {                                            // update block
+        for (int s = 0; s < NS; ++s) {
+          T arg = -sv[j] - hx[s];
 #pragma unroll
-        for (int j = 0; j < W; ++j)
-#pragma unroll
-          for (int s = 0; s < NS; ++s) {
-            T arg = -sv[j] - hx[s];
-#pragma unroll
-            for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
-            accu[s] += wv4[s][j] * PW_EXP(arg);
-          }
-      }
-    };
-    // three register sets in rotation: blocks tb + 1 and tb + 2 are in flight while tb is consumed
-    VT q0[NS], q1[NS], q2[NS];
-    load_blk(0, q0);
-    load_blk(1, q1);
-    for (int tb = 0; tb < NB; tb += 3) {
-      load_blk(tb + 2, q2);
-      compute_blk(tb, q0);
-      load_blk(tb + 3, q0);
-      if (tb + 1 < NB) compute_blk(tb + 1, q1);
-      load_blk(tb + 4, q1);
-      if (tb + 2 < NB) compute_blk(tb + 2, q2);
+          for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
+          accu[s] += wv4[s][j] * PW_EXP(arg);
+        }
     }
+    if (ctb == NB - 1) {                                // group done: reduce, Euler update, store
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const double t = pw_wave_sum63(ps * (double)accp[s] + vr * (double)accu[s]);
-      if (lane == 63 && s0 + s < S) {
-        double f = t + mc;
-        if (euler) f = (double)xr[s][a < DK ? a : 0] + dt * f;
-        out[(size_t)(s0 + s) * L + a] = (T)f;
-        if (traj) traj[(size_t)(s0 + s) * L + a] = (T)f;
+      for (int s = 0; s < NS; ++s) {
+        const double t = pw_wave_sum63(ps * (double)accp[s] + vr * (double)accu[s]);
+        if (lane == 63 && s0 + s < S) {
+          double f = t + mc;
+          if (euler) f = (double)xr[s][a < DK ? a : 0] + dt * f;
+          out[(size_t)(s0 + s) * L + a] = (T)f;
+          if (traj) traj[(size_t)(s0 + s) * L + a] = (T)f;
+        }
       }
+      ctb = 0; cg += g_stride;
+    } else {
+      ++ctb;
+    }
+  };
+  VT q[PW_RING][NS];
+#pragma unroll
+  for (int r = 0; r < PW_RING - 1; ++r) load_next(q[r]);
+  for (int i = 0; i < total; i += PW_RING) {
+#pragma unroll
+    for (int r = 0; r < PW_RING; ++r) {
+      load_next(q[(r + PW_RING - 1) % PW_RING]);
+      if (r == 0 || i + r < total) consume(q[r]);
     }
   }
 }
@@ -356,7 +372,7 @@ static int pw_launch(int S, int L, int M, int K, int d, const T* x, const T* ome
   if (lds_bytes <= 144 * 1024) {
     const int ngroups = (S + MM_PW_NS - 1) / MM_PW_NS;
     int nW = 256 / L; if (nW < 1) nW = 1;                           // ~ one workgroup per CU
-    while (nW > 1 && (nW - 1) * 8 >= ngroups) --nW;                 // no idle workgroups on small S
+    while (nW > 1 && (nW - 1) * PW_LDS_WAVES >= ngroups) --nW;                 // no idle workgroups on small S
 #define PW_LAUNCH_LDS(DK_)                                                                          \
     do {                                                                                            \
       /* raise the dynamic-LDS limit once per instantiation (the call is slow: not per launch) */  \
@@ -367,7 +383,7 @@ static int pw_launch(int S, int L, int M, int K, int d, const T* x, const T* ome
         if (ea != hipSuccess) return (int)ea;                                                       \
         lds_limit = 144 * 1024;                                                                     \
       }                                                                                             \
-      hipLaunchKernelGGL((k_pathwise_lds<T, DK_>), dim3(L * nW), dim3(512), lds_bytes, s, S, L, M, K, d, nW, \
+      hipLaunchKernelGGL((k_pathwise_lds<T, DK_>), dim3(L * nW), dim3(64 * PW_LDS_WAVES), lds_bytes, s, S, L, M, K, d, nW, \
                          x, omega, phase, zs, hz, xscale, pscale, var, meanc, wb, out, traj, euler, dt); \
     } while (0)
     if (d <= 4) PW_LAUNCH_LDS(4);
