@@ -97,7 +97,10 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
   for (int s = 0; s < NS; ++s) {
     const int row = (s0 + s < S) ? s0 + s : S - 1;
 #pragma unroll
-    for (int k = 0; k < DK; ++k) xr[s][k] = (k < d) ? x[(size_t)row * d + k] : (T)0;
+    for (int k = 0; k < DK; ++k) {
+      const T v = x[(size_t)row * d + (k < d ? k : 0)];      // unconditional load, then select
+      xr[s][k] = (k < d) ? v : (T)0;
+    }
   }
 
   for (int a = wv; a < L; a += 4) {
@@ -115,20 +118,20 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
       for (int pf = 0; pf < 2; ++pf)
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-          wq[pf][s] = (pf < nbK) ? *reinterpret_cast<const VT*>(wrow + ((size_t)pf * NS + s) * BT) : VT{};
+          wq[pf][s] = *reinterpret_cast<const VT*>(wrow + ((size_t)(pf < nbK ? pf : nbK - 1) * NS + s) * BT);
       for (int pidx = 0; pidx < nbK; ++pidx) {
         const int k0 = lane * W + pidx * BT;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-          wq[2][s] = (pidx + 2 < nbK) ? *reinterpret_cast<const VT*>(wrow + ((size_t)(pidx + 2) * NS + s) * BT) : VT{};
+          wq[2][s] = *reinterpret_cast<const VT*>(wrow + ((size_t)(pidx + 2 < nbK ? pidx + 2 : nbK - 1) * NS + s) * BT);
         T wv4[NS][W];
 #pragma unroll
         for (int s = 0; s < NS; ++s) pw_unpack<T>(wq[0][s], wv4[s]);
         T cv[DK][W], bv[W];
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
-          if (k < d) pw_unpack<T>(*reinterpret_cast<const VT*>(om + (size_t)k * K + k0), cv[k]);
-          else {
+          pw_unpack<T>(*reinterpret_cast<const VT*>(om + (size_t)(k < d ? k : 0) * K + k0), cv[k]);
+          if (k >= d) {
 #pragma unroll
             for (int j = 0; j < W; ++j) cv[k][j] = (T)0;
           }
@@ -155,7 +158,8 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
         T h = (T)0;
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
-          const T sc = (k < d) ? (T)xscale[a * d + k] : (T)0;
+          const T scv = (T)xscale[a * d + (k < d ? k : 0)];
+          const T sc = (k < d) ? scv : (T)0;
           xsc[s][k] = xr[s][k] * sc; h += xsc[s][k] * xsc[s][k];
         }
         hx[s] = (T)0.5 * h;
@@ -168,20 +172,20 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
       for (int pf = 0; pf < 2; ++pf)
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-          vq[pf][s] = (pf < nbM) ? *reinterpret_cast<const VT*>(vrow + ((size_t)pf * NS + s) * BT) : VT{};
+          vq[pf][s] = *reinterpret_cast<const VT*>(vrow + ((size_t)(pf < nbM ? pf : nbM - 1) * NS + s) * BT);
       for (int pidx = 0; pidx < nbM; ++pidx) {
         const int m0 = lane * W + pidx * BT;
 #pragma unroll
         for (int s = 0; s < NS; ++s)
-          vq[2][s] = (pidx + 2 < nbM) ? *reinterpret_cast<const VT*>(vrow + ((size_t)(pidx + 2) * NS + s) * BT) : VT{};
+          vq[2][s] = *reinterpret_cast<const VT*>(vrow + ((size_t)(pidx + 2 < nbM ? pidx + 2 : nbM - 1) * NS + s) * BT);
         T vv[NS][W];
 #pragma unroll
         for (int s = 0; s < NS; ++s) pw_unpack<T>(vq[0][s], vv[s]);
         T cv[DK][W], hv[W];
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
-          if (k < d) pw_unpack<T>(*reinterpret_cast<const VT*>(zz + (size_t)k * M + m0), cv[k]);
-          else {
+          pw_unpack<T>(*reinterpret_cast<const VT*>(zz + (size_t)(k < d ? k : 0) * M + m0), cv[k]);
+          if (k >= d) {
 #pragma unroll
             for (int j = 0; j < W; ++j) cv[k][j] = (T)0;
           }
@@ -204,10 +208,8 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
     const double ps = pscale[a], vr = var[a], mc = meanc ? meanc[a] : 0.0;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      double t = ps * (double)accp[s] + vr * (double)accu[s];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-      if (lane == 0 && s0 + s < S) {
+      const double t = pw_wave_sum63(ps * (double)accp[s] + vr * (double)accu[s]);
+      if (lane == 63 && s0 + s < S) {
         double f = t + mc;
         if (euler) f = (double)xr[s][a < DK ? a : 0] + dt * f;
         out[(size_t)(s0 + s) * L + a] = (T)f;

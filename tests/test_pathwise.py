@@ -31,8 +31,9 @@ def test_oracle_paths_match_predictive_moments():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("shape", [(3, 50, 3, 37, 130), (8, 203, 8, 9, 1024), (2, 64, 16, 5, 66)],
-                         ids=["small", "d8", "d16"])
+@pytest.mark.parametrize("shape", [(3, 50, 3, 37, 130), (8, 203, 8, 9, 1024), (2, 64, 16, 5, 66),
+                                   (2, 1100, 16, 6, 1500)],      # operands beyond 144 KB of LDS: streaming kernel
+                         ids=["small", "d8", "d16", "d16_no_lds"])
 def test_gpu_eval_and_rollout_match_oracle(shape, dtype, device):
   from gpflowpilco_amd.pathwise import paths_from_arrays
   L, M, d, S, K = shape
