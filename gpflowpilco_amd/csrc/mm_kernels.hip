@@ -368,20 +368,32 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
                                                  const T* __restrict__ mu, const double* __restrict__ pairmat,
                                                  double* __restrict__ rowD, double* __restrict__ colD,
                                                  T* __restrict__ rowO, T* __restrict__ colO,
-                                                 const double* __restrict__ w64, double* __restrict__ wsum) {
+                                                 const double* __restrict__ w64, double* __restrict__ wsum, int nblk) {
+  // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
+  // pair's matrices are fetched and staged once per workgroup, not once per chunk (at one chunk per
+  // workgroup the kernel was bound by that fetch -> barrier -> fetch Z latency chain)
   const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
-  const int m = blockIdx.x * 256 + tid;
   int a, a2;
   mm_decode_pair(p, L, a, a2);
-  __shared__ double G[MM_DMAX * MM_DMAX], Dr[MM_DMAX * MM_DMAX], Dc[MM_DMAX * MM_DMAX];
-  __shared__ double mub[MM_DMAX], dmu[MM_DMAX], dmu2[MM_DMAX];
+  // the per-(b, pair) matrices zero-padded to DK x DK (row stride DK) and the vectors to DK: every k loop
+  // below is unconditional straight-line code (with `if (k < d)` inside, the loops stay rolled and
+  // each LDS read is followed by its own s_waitcnt)
+  __shared__ double G[DK * DK], Dr[DK * DK], Dc[DK * DK];
+  __shared__ double mub[DK], dmu[DK], dmu2[DK];
   const double* pm = pairmat + ((size_t)b * P + p) * (3 * d * d + 1);
-  for (int idx = tid; idx < d * d; idx += 256) { G[idx] = pm[idx]; Dr[idx] = pm[d * d + idx]; Dc[idx] = pm[2 * d * d + idx]; }
-  if (tid < d) {
-    const double mv = (double)mu[(size_t)b * d + tid];
-    mub[tid] = mv;
-    dmu[tid] = mv - zbar[a * d + tid];   // the A operand is centred at zbar_a, not at mu_b
-    dmu2[tid] = mv - zbar[a2 * d + tid];
+  for (int idx = tid; idx < DK * DK; idx += 256) {
+    const int i = idx / DK, k = idx - i * DK;
+    const bool in = i < d && k < d;
+    const int src = in ? i * d + k : 0;
+    const double g = pm[src], dr = pm[d * d + src], dc = pm[2 * d * d + src];
+    G[idx] = in ? g : 0.0; Dr[idx] = in ? dr : 0.0; Dc[idx] = in ? dc : 0.0;
+  }
+  if (tid < DK) {
+    const int k = tid < d ? tid : 0;
+    const double mv = (double)mu[(size_t)b * d + k];
+    mub[tid] = tid < d ? mv : 0.0;
+    dmu[tid] = tid < d ? mv - zbar[a * d + k] : 0.0;     // the A operand is centred at zbar_a, not at mu_b
+    dmu2[tid] = tid < d ? mv - zbar[a2 * d + k] : 0.0;
   }
   __syncthreads();
   const double cst = pm[3 * d * d];
@@ -396,53 +408,59 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
     // The two O(M) sums are reduced here in f64 (k_finalize adds the correction).
     T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
     T* cO = colO + ((size_t)b * Po + (p - L)) * Mp;
-    double whr = 0.0, whc = 0.0;
-    if (m < Mp) {
-      if (m < M) {
-        double zr[DK], zc[DK];
+    double sr = 0.0, sc = 0.0;
+    for (int mblk = blockIdx.x; mblk < nblk; mblk += gridDim.x) {
+      const int m = mblk * 256 + tid;
+      if (m >= Mp) continue;
+      // centred inducing inputs of row / column index m (clamped loads, zero beyond d or M)
+      const int mm = m < M ? m : M - 1;
+      double zr[DK], zc[DK];
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        const int kk = k < d ? k : 0;
+        const double vr = Z64[((size_t)a * M + mm) * d + kk] - mub[k];
+        const double vc = Z64[((size_t)a2 * M + mm) * d + kk] - mub[k];
+        zr[k] = (k < d && m < M) ? vr : 0.0;
+        zc[k] = (k < d && m < M) ? vc : 0.0;
+      }
+      double rho = 0.0, gam = 0.0, corr = 0.0;
+#pragma unroll 2      // not fully: the compiler would hoist all 3 DK^2 LDS reads (> 256 VGPRs at DK = 8)
+      for (int i = 0; i < DK; ++i) {
+        double tr = 0.0, tc = 0.0, av = 0.0;
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
-          zr[k] = (k < d) ? Z64[((size_t)a * M + m) * d + k] - mub[k] : 0.0;
-          zc[k] = (k < d) ? Z64[((size_t)a2 * M + m) * d + k] - mub[k] : 0.0;
+          tr = fma(Dr[i * DK + k], zr[k], tr);
+          tc = fma(Dc[i * DK + k], zc[k], tc);
+          av = fma(G[k * DK + i], zr[k], av);
         }
-        double rho = 0.0, gam = 0.0, corr = 0.0;
-#pragma unroll
-        for (int i = 0; i < DK; ++i) {
-          if (i < d) {
-            double tr = 0.0, tc = 0.0, av = 0.0;
-#pragma unroll
-            for (int k = 0; k < DK; ++k) {
-              if (k < d) {
-                tr += Dr[i * d + k] * zr[k];
-                tc += Dc[i * d + k] * zc[k];
-                av += G[k * d + i] * zr[k];
-              }
-            }
-            rho += zr[i] * tr;
-            gam += zc[i] * tc;
-            corr += dmu2[i] * av;
-            rO[(size_t)i * Mp + m] = (T)av;
-          }
-        }
+        rho = fma(zr[i], tr, rho);
+        gam = fma(zc[i], tc, gam);
+        corr = fma(dmu2[i], av, corr);
+        if (i < d) rO[(size_t)i * Mp + m] = (T)av;          // zero for the padding rows m >= M
+      }
+      double whr = 0.0, whc = 0.0;
+      if (m < M) {
         whr = w64[((size_t)b * L + a) * Mp + m] * exp(-0.5 * rho + cst - corr);
         whc = w64[((size_t)b * L + a2) * Mp + m] * exp(-0.5 * gam);
-      } else {
-        for (int k = 0; k < d; ++k) rO[(size_t)k * Mp + m] = (T)0;
       }
       rO[(size_t)d * Mp + m] = (T)whr;
       cO[m] = (T)whc;
+      sr += whr; sc += whc;
     }
-    __shared__ double red[4];
-    const double sr = mm_block_sum256(whr, red);
-    const double sc = mm_block_sum256(whc, red);
-    if (tid == 0) {
-      const int nblk = gridDim.x;
-      wsum[(((size_t)b * Po + (p - L)) * 2 + 0) * nblk + blockIdx.x] = sr;
-      wsum[(((size_t)b * Po + (p - L)) * 2 + 1) * nblk + blockIdx.x] = sc;
+    // both block sums through one pass: wave butterflies interleaved, one LDS slot pair per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sr += __shfl_down(sr, off, 64); sc += __shfl_down(sc, off, 64); }
+    __shared__ double red[8];
+    if ((tid & 63) == 0) { red[tid >> 6] = sr; red[4 + (tid >> 6)] = sc; }
+    __syncthreads();
+    // slot blockIdx.x carries this workgroup's sums; the other slots it covers are zeroed (k_finalize sums nblk slots)
+    for (int sl = blockIdx.x + tid * gridDim.x; sl < nblk; sl += 256 * gridDim.x) {
+      const bool own = sl == (int)blockIdx.x;
+      wsum[(((size_t)b * Po + (p - L)) * 2 + 0) * nblk + sl] = own ? red[0] + red[1] + red[2] + red[3] : 0.0;
+      wsum[(((size_t)b * Po + (p - L)) * 2 + 1) * nblk + sl] = own ? red[4] + red[5] + red[6] + red[7] : 0.0;
     }
     return;
   }
-  if (m >= Mp) return;
   // diagonal pairs (p < L) stream f64 operands, off-diagonal pairs of the f64 mode likewise
   double* raD = rowD + ((size_t)b * L + (diag ? p : 0)) * Mp;
   double* cbD = colD + ((size_t)b * L + (diag ? p : 0)) * (size_t)(d + 1) * Mp;
@@ -450,39 +468,39 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
   T* cbO = colO + ((size_t)b * Po + (diag ? 0 : p - L)) * (size_t)(d + 1) * Mp;
 #define MM_PV_STORE_ROW(v_) do { if (diag) raD[m] = (v_); else raO[m] = (T)(v_); } while (0)
 #define MM_PV_STORE_COL(k_, v_) do { if (diag) cbD[(size_t)(k_) * Mp + m] = (v_); else cbO[(size_t)(k_) * Mp + m] = (T)(v_); } while (0)
-  if (m >= M) {
-    MM_PV_STORE_ROW(0.0);
-    for (int k = 0; k <= d; ++k) MM_PV_STORE_COL(k, 0.0);
-    return;
-  }
-  double zr[DK], zc[DK];
+  for (int mblk = blockIdx.x; mblk < nblk; mblk += gridDim.x) {
+    const int m = mblk * 256 + tid;
+    if (m >= Mp) continue;
+    // centred inducing inputs of row / column index m (clamped loads, zero beyond d or M)
+    const int mm = m < M ? m : M - 1;
+    double zr[DK], zc[DK];
 #pragma unroll
-  for (int k = 0; k < DK; ++k) {
-    zr[k] = (k < d) ? Z64[((size_t)a * M + m) * d + k] - mub[k] : 0.0;
-    zc[k] = (k < d) ? Z64[((size_t)a2 * M + m) * d + k] - mub[k] : 0.0;
-  }
-  double rho = 0.0, gam = 0.0, corr = 0.0;
-#pragma unroll
-  for (int i = 0; i < DK; ++i) {
-    if (i < d) {
+    for (int k = 0; k < DK; ++k) {
+      const int kk = k < d ? k : 0;
+      const double vr = Z64[((size_t)a * M + mm) * d + kk] - mub[k];
+      const double vc = Z64[((size_t)a2 * M + mm) * d + kk] - mub[k];
+      zr[k] = (k < d && m < M) ? vr : 0.0;
+      zc[k] = (k < d && m < M) ? vc : 0.0;
+    }
+    double rho = 0.0, gam = 0.0, corr = 0.0;
+#pragma unroll 2
+    for (int i = 0; i < DK; ++i) {
       double tr = 0.0, tc = 0.0, g = 0.0;
 #pragma unroll
       for (int k = 0; k < DK; ++k) {
-        if (k < d) {
-          tr += Dr[i * d + k] * zr[k];
-          tc += Dc[i * d + k] * zc[k];
-          g += G[i * d + k] * zc[k];
-        }
+        tr = fma(Dr[i * DK + k], zr[k], tr);
+        tc = fma(Dc[i * DK + k], zc[k], tc);
+        g = fma(G[i * DK + k], zc[k], g);
       }
-      rho += zr[i] * tr;
-      gam += zc[i] * tc;
-      corr += dmu[i] * g;
-      MM_PV_STORE_COL(i, g);
+      rho = fma(zr[i], tr, rho);
+      gam = fma(zc[i], tc, gam);
+      corr = fma(dmu[i], g, corr);
+      if (i < d) MM_PV_STORE_COL(i, g);                       // zero for the padding rows m >= M
     }
+    MM_PV_STORE_ROW(m < M ? -0.5 * rho : 0.0);
+    // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j
+    MM_PV_STORE_COL(d, m < M ? -0.5 * gam + cst - corr : 0.0);
   }
-  MM_PV_STORE_ROW(-0.5 * rho);
-  // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j
-  MM_PV_STORE_COL(d, -0.5 * gam + cst - corr);
 #undef MM_PV_STORE_ROW
 #undef MM_PV_STORE_COL
 }
@@ -798,10 +816,17 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
                      L, M, wl.Mp, d, mu, latmat, (double*)(ws + wl.w64), (double*)(ws + wl.q64), (T*)(ws + wl.w),
                      (double*)(ws + wl.f1raw), f1, cross, q_out);
   MM_CHECK_LAUNCH();
-  hipLaunchKernelGGL((k_pairvec<T, DK>), dim3((wl.Mp + 255) / 256, wl.P, B), dim3(256), 0, s,
-                     Z64, (const double*)(packed + ml.zbar), L, M, wl.Mp, d, wl.P, mu, pairmat,
-                     (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO),
-                     (const double*)(ws + wl.w64), (double*)(ws + wl.wsum));
+  {
+    const int nblk = (wl.Mp + 255) / 256;                  // 256-row chunks = wsum slots per (b, pair)
+    long long per = (long long)wl.P * B;                   // workgroups per chunk split
+    int nsplit = (int)((4096 + per - 1) / per);            // >= 16 workgroups per CU, else one per (b, pair)
+    if (nsplit > nblk) nsplit = nblk;
+    if (nsplit < 1) nsplit = 1;
+    hipLaunchKernelGGL((k_pairvec<T, DK>), dim3(nsplit, wl.P, B), dim3(256), 0, s,
+                       Z64, (const double*)(packed + ml.zbar), L, M, wl.Mp, d, wl.P, mu, pairmat,
+                       (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO),
+                       (const double*)(ws + wl.w64), (double*)(ws + wl.wsum), nblk);
+  }
   MM_CHECK_LAUNCH();
   return 0;
 }
