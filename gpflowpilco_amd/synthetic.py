@@ -19,6 +19,8 @@ from typing import Optional
 import numpy as np
 import torch
 
+from .linalg import cholesky as robust_cholesky
+
 from . import models as gp
 
 F64 = torch.float64
@@ -72,7 +74,7 @@ def make_svgp(L: int, M: int, d: int, seed: int, stable: bool = True,
     A = Zt / torch.tensor(ls[a], dtype=F64, device=device)
     d2 = (A * A).sum(-1)[:, None] + (A * A).sum(-1)[None, :] - 2.0 * A @ A.T
     K = var[a] * torch.exp(-0.5 * d2.clamp_min(0.0))
-    Lk = torch.linalg.cholesky(K + gp.DEFAULT_JITTER * eye)
+    Lk = robust_cholesky(K + gp.DEFAULT_JITTER * eye)
     draw = Lk @ torch.tensor(eps_f[a], dtype=F64, device=device)
     if stable:
       col = Zt[:, a % d]
@@ -80,7 +82,7 @@ def make_svgp(L: int, M: int, d: int, seed: int, stable: bool = True,
     else:
       y = draw
     y = y + np.sqrt(noise[a]) * torch.tensor(eps_n[a], dtype=F64, device=device)
-    Ly = torch.linalg.cholesky(K + noise[a] * eye)
+    Ly = robust_cholesky(K + noise[a] * eye)
     m = K @ torch.cholesky_solve(y[:, None], Ly)                      # posterior mean of u
     S = K - K @ torch.cholesky_solve(K, Ly)                          # posterior cov of u
     v = torch.linalg.solve_triangular(Lk, m, upper=False)            # whitened mean
@@ -91,7 +93,7 @@ def make_svgp(L: int, M: int, d: int, seed: int, stable: bool = True,
     Sw = (ev * ew.clamp_min(1e-8)) @ ev.T
     Sw = 0.5 * (Sw + Sw.T) + 1e-10 * eye
     q_mu[:, a] = v[:, 0].cpu().numpy()
-    q_sqrt[a] = torch.linalg.cholesky(Sw).cpu().numpy()
+    q_sqrt[a] = robust_cholesky(Sw).cpu().numpy()
   mc = rng.standard_normal(L) * 0.1 if mean_c else None
   return SyntheticSVGP(Z=Z, lengthscales=ls, variance=var, noise=noise, q_mu=q_mu, q_sqrt=q_sqrt, mean_c=mc)
 

@@ -170,3 +170,14 @@ def test_moment_matching_euler_python_path():
   assert losses == [1.0, 2.0, 3.0]
   hist = system.solve_forward(0.0, (x0.mean(), x0.covariance()), [0.5, 1.0])
   assert len(hist) == 2
+
+
+def test_robust_cholesky_matches_torch_and_raises_on_non_pd():
+  import torch
+  from gpflowpilco_amd.linalg import cholesky
+  g = torch.Generator().manual_seed(0)
+  A = torch.randn(3, 6, 6, generator=g, dtype=torch.float64)
+  A = A @ A.transpose(1, 2) + 1e-3 * torch.eye(6, dtype=torch.float64)
+  assert torch.equal(cholesky(A), torch.linalg.cholesky(A))
+  with pytest.raises(torch.linalg.LinAlgError):
+    cholesky(-A)
