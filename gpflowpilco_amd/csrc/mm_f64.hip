@@ -20,6 +20,12 @@
 #include "mm_common.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
+// Taylor degrees of the f32-mode (LOWP) tiers |x| <= 1/64, 1/16, 1/4
+#ifndef MM_LOWP_D0
+#define MM_LOWP_D0 6
+#define MM_LOWP_D1 8
+#define MM_LOWP_D2 10
+#endif
 #define MM_F64_NB 16      // batch elements whose partial sums are staged in LDS between workgroup reductions
 
 __device__ __forceinline__ void mm_decode_pair_f(int p, int L, int& a, int& a2) {
@@ -292,11 +298,11 @@ __global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restri
     //   LOWP (f32 model): 1/64 -> 6 (3e-15), 1/16 -> 8 (6e-16), 1/4 -> 10 (2e-14), 3/4 -> 15
     //   f64 model       : 1/64 -> 7 (6e-18), 1/16 -> 9 (4e-18), 1/4 -> 12 (1e-17), 1/2 -> 15
     if (!__any(mxh >= MM_HI32(0.015625))) {
-      if (LOWP) { MM_F64_ACCUM_POLY(6) } else { MM_F64_ACCUM_POLY(7) }
+      if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D0) } else { MM_F64_ACCUM_POLY(7) }
     } else if (!__any(mxh >= MM_HI32(0.0625))) {
-      if (LOWP) { MM_F64_ACCUM_POLY(8) } else { MM_F64_ACCUM_POLY(9) }
+      if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D1) } else { MM_F64_ACCUM_POLY(9) }
     } else if (!__any(mxh >= MM_HI32(0.25))) {
-      if (LOWP) { MM_F64_ACCUM_POLY(10) } else { MM_F64_ACCUM_POLY(12) }
+      if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D2) } else { MM_F64_ACCUM_POLY(12) }
     } else if (!__any(mxh >= (LOWP ? MM_HI32(0.75) : MM_HI32(0.5)))) {
       MM_F64_ACCUM_POLY(15)
     } else {
