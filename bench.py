@@ -256,6 +256,17 @@ def main():
                      "max_abs_err": {"f1": err(f1, first[0]), "Sff": err(Sff, first[1]), "cross_pre": err(cross, first[2])},
                      "max_abs": {"f1": float(np.abs(first[0]).max()), "Sff": float(np.abs(first[1]).max()),
                                  "cross_pre": float(np.abs(first[2]).max())}}
+    # rollout-level agreement (final mu_H, Sigma_H): the same kernels in f64 mode on 8 elements
+    if dtype == torch.float32:
+      Br = min(B, 8)
+      pm64 = model.packed(torch.float64, True, dev)
+      m32, S32 = ops.rollout_closed(pm, mu0[:Br].contiguous(), S0[:Br].contiguous(), H)
+      m64, S64 = ops.rollout_closed(pm64, mu0[:Br].double().contiguous(), S0[:Br].double().contiguous(), H)
+      pm64.check_status(Br)
+      out["parity"]["rollout_f32_vs_f64_mode"] = {
+          "B": Br, "H": H, "max_abs_diff": {"mu_H": float((m32.double() - m64).abs().max()),
+                                            "Sigma_H": float((S32.double() - S64).abs().max())},
+          "max_abs": {"mu_H": float(m64.abs().max()), "Sigma_H": float(S64.abs().max())}}
   if rank == 0:
     print(json.dumps(out))
   if world > 1:
