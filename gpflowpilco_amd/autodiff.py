@@ -13,7 +13,8 @@ Split of work:
     constants:  dSff_p = sum_i r_i dw_i + sum_j c_j dw'_j + sum_ij Omega_ij d(delta_ij)  (+ C term)
     and  d(delta_ij) = d const + d rho_i + d gamma_j + d(zeta_i^T G zeta'_j).
 
-First version: f64 mode only; the sweep is a plain VALU kernel (correctness first).
+The sums are taken in f64 (an f32 model's backward runs on the f64 pack of the same model); the
+sweep is a plain VALU kernel (correctness first).
 ``MomentMatchFunction`` makes ``ops.moment_match`` differentiable w.r.t. (mu, Sigma).
 """
 from __future__ import annotations
@@ -129,33 +130,43 @@ def moment_match_backward(pm: ops.PackedModel, pre, mu: torch.Tensor, Sigma: tor
 
 
 class MomentMatchFunction(torch.autograd.Function):
-  """``ops.moment_match`` as a differentiable function of (mu, Sigma) for a frozen packed model."""
+  """``ops.moment_match`` as a differentiable function of (mu, Sigma) for a frozen packed model.
+
+  ``pm`` runs the forward in the inputs' dtype; ``pm_bwd`` is the float64 pack of the same model the
+  backward sums are taken on (the same object for a float64 model: an f32 model's gradients are
+  computed in f64 from the f32 state and cast back)."""
 
   @staticmethod
-  def forward(ctx, mu, Sigma, pm, pre, full_output_cov, model_uncertainty):
+  def forward(ctx, mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty):
     f1, Sff, cross = ops.moment_match(pm, mu, Sigma, full_output_cov=full_output_cov,
                                       model_uncertainty=model_uncertainty)
     ctx.save_for_backward(mu, Sigma)
-    ctx.pm, ctx.pre, ctx.flags = pm, pre, (full_output_cov, model_uncertainty)
+    ctx.pm_bwd, ctx.pre, ctx.flags = pm_bwd, pre, (full_output_cov, model_uncertainty)
     return f1, Sff, cross
 
   @staticmethod
   def backward(ctx, g_f1, g_Sff, g_cross):
     mu, Sigma = ctx.saved_tensors
     full, unc = ctx.flags
-    # the backward kernel reads the forward's workspace: re-run the forward stages for (mu, Sigma)
-    ops.moment_match(ctx.pm, mu, Sigma, full_output_cov=full, model_uncertainty=unc)
-    gmu, gS = moment_match_backward(ctx.pm, ctx.pre, mu, Sigma, full, unc,
-                                    g_f1.contiguous(), g_Sff.contiguous(), g_cross.contiguous())
-    return gmu, gS, None, None, None, None
+    pmb = ctx.pm_bwd
+    mu64, S64 = mu.to(torch.float64), Sigma.to(torch.float64)
+    # the backward kernel reads the q-stage operands (w, q, rho / g / gamma) from the workspace:
+    # re-run that stage for (mu, Sigma) -- the M^2 forward reduce itself is not needed again
+    ops.q_forward(pmb, mu64, S64, ops.make_flags(full, unc))
+    gmu, gS = moment_match_backward(pmb, ctx.pre, mu64, S64, full, unc,
+                                    g_f1.to(torch.float64).contiguous(), g_Sff.to(torch.float64).contiguous(),
+                                    g_cross.to(torch.float64).contiguous())
+    return gmu.to(mu.dtype), gS.to(Sigma.dtype), None, None, None, None, None
 
 
 def moment_match_differentiable(model, mu: torch.Tensor, Sigma: torch.Tensor, full_output_cov: bool = True,
                                 model_uncertainty: bool = True):
   """(mu, Sigma) -> (f1, Sff, cross_pre) with gradients flowing back to (mu, Sigma)."""
   pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
+  pm_bwd = pm if mu.dtype == torch.float64 else model.packed(dtype=torch.float64, with_C=bool(model_uncertainty),
+                                                              device=mu.device)
   pre = model._cache._pre
-  return MomentMatchFunction.apply(mu, Sigma, pm, pre, full_output_cov, model_uncertainty)
+  return MomentMatchFunction.apply(mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty)
 
 
 def moment_match_torch(mu, Sigma, Z, ls, var, beta, C=None, mean_c=None, full_output_cov: bool = True,

@@ -50,6 +50,27 @@ def test_gradients_match_finite_differences(shape, unc, device):
         assert abs(fd - an) < 3e-5 * max(1.0, abs(fd)), (b, i, j, fd, an)
 
 
+def test_f32_model_gradients_track_f64(device):
+  """An f32 model's backward (taken on the f64 pack of the same model) agrees with the f64 model's."""
+  L, M, d, B = 3, 40, 4, 3
+  p = random_svgp_params(seed=21, L=L, M=M, d=d, whiten=True, ls_bounds=(0.5, 2.0), mean=False)
+  rng = np.random.default_rng(2)
+  mu = rng.uniform(size=(B, d)); S = generate_covariance(rng, d, (B,), 0.3)
+  A2 = to_dev(rng.standard_normal((B, L, L)), device, torch.float64)
+  model = gp_model_from_oracle(p, device)
+  grads = {}
+  for dtype in (torch.float64, torch.float32):
+    mu_t = to_dev(mu, device, dtype).requires_grad_(True)
+    S_t = to_dev(S, device, dtype).requires_grad_(True)
+    f1, Sff, cr = moment_match_differentiable(model, mu_t, S_t, True, True)
+    assert f1.dtype == dtype and Sff.dtype == dtype
+    (f1.sum() + (A2.to(dtype) * Sff).sum() + cr.sum()).backward()
+    assert mu_t.grad.dtype == dtype and S_t.grad.dtype == dtype
+    grads[dtype] = (mu_t.grad.double(), S_t.grad.double())
+  for g64, g32 in zip(grads[torch.float64], grads[torch.float32]):
+    assert (g64 - g32).abs().max() < 1e-4 * max(1.0, float(g64.abs().max()))
+
+
 def test_rollout_gradient_through_two_steps(device):
   """d loss / d (mu0, Sigma0) through two Euler steps of the differentiable match (torch glue)."""
   L = d = 3
