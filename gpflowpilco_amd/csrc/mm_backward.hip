@@ -24,6 +24,8 @@ __device__ __forceinline__ void mmb_decode_pair(int p, int L, int& a, int& a2) {
   a = i; a2 = i + 1 + r;
 }
 
+__device__ constexpr double mmb_inv_fact(int n) { double f = 1.0; for (int i = 2; i <= n; ++i) f *= i; return 1.0 / f; }
+
 // ROWS == false: grid (Mp/256, P, B), thread owns column j.  out_col [B][P][3 + d][Mp]: K, c, cC, U.
 // ROWS == true : grid (Mp/256, Po, B), thread owns row i of pair L + blockIdx.y.  out_row [B][Po][2][Mp].
 template <int DK, bool ROWS>
@@ -106,6 +108,259 @@ __global__ __launch_bounds__(256) void k_bwd_sums(const double* __restrict__ Z64
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA version of the same sums (d <= 31).  Structure of the forward k_qred_f64_mfma, turned into a
+// COLUMN-OWNER sweep: a workgroup owns 64 columns of one (b, pair) and loops over all 64-row tiles,
+// so every column sum stays in registers and nothing is reduced across workgroups (no atomics:
+// bitwise reproducible).  Per wave and iteration a 32 x 32 sub-tile:
+//   delta  : v_mfma_f64_16x16x4_f64, accumulator initialised with rho_i + gamma'_j (as in the forward);
+//   expm1  : wave-uniform Taylor tiers of the forward's f64 mode;
+//   U, K   : U_j[k] = sum_i Omega_ij zc_i[k] and K_j = sum_i Omega_ij are ONE more MFMA product,
+//            Omega^T (zc | 1): the forward accumulator layout (lane = column, registers = rows
+//            kq + 4 r) is exactly the A-operand layout of the transposed product, K step r -- no data
+//            movement; zeta_i = zc_i + (zbar_a - mu_b) is corrected from K at the end;
+//   c, cC  : one FMA per entry each, reduced over the row groups through LDS at the end.
+// SWAP: the row sums of an off-diagonal pair are the column sums of the transposed tile; the same
+// kernel runs with the operand roles exchanged (A operand = g_j of latent a', B operand = zc_i of
+// latent a) and only the two scalar sums.
+// ---------------------------------------------------------------------------------------------
+typedef double f64x4b __attribute__((ext_vector_type(4)));
+
+template <int DEG>
+__device__ __forceinline__ void mmb_expm1_poly8(const double (&x)[8], double (&e)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] = fma(mmb_inv_fact(DEG), x[i], mmb_inv_fact(DEG - 1));
+#pragma unroll
+  for (int k = DEG - 2; k >= 1; --k)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = fma(e[i], x[i], mmb_inv_fact(k));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) e[i] *= x[i];
+}
+
+// expm1 for any argument (k ln2 + r reduction), the forward's general path
+__device__ __forceinline__ double mmb_expm1_any(double x) {
+  const double kf = rint(x * 1.4426950408889634);
+  double r = fma(-kf, 6.93147180369123816490e-01, x);
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  double q = mmb_inv_fact(12);
+#pragma unroll
+  for (int k = 11; k >= 1; --k) q = fma(q, r, mmb_inv_fact(k));
+  const double p = q * r;
+  const double s = ldexp(1.0, (int)kf);
+  return fma(s, p, s - 1.0);
+}
+
+// KS4: K = 4 steps covering d; NU: 16-wide blocks of the U product ((d + 1) <= 16 NU).
+// grid (Mp / 64, npairs, B).  SWAP == false: pairs [0, P), out_col [B][P][3 + d][Mp].
+//                             SWAP == true : pairs L + blockIdx.y, out_row [B][Po][2][Mp].
+template <int KS4, int NU, bool SWAP>
+__global__ __launch_bounds__(256, 2) void k_bwd_mfma(const double* __restrict__ Zc, int Kz,
+                                                     const double* __restrict__ zbar, const double* __restrict__ Cm,
+                                                     const double* __restrict__ mu, int L, int Mp, int d, int P,
+                                                     const double* __restrict__ w, const double* __restrict__ q,
+                                                     const double* __restrict__ rowD, const double* __restrict__ colD,
+                                                     const double* __restrict__ rowO, const double* __restrict__ colO,
+                                                     double* __restrict__ out) {
+  const int Po = P - L;
+  const int jt = blockIdx.x, lp = blockIdx.y, b = blockIdx.z;
+  const int p = SWAP ? L + lp : lp;
+  int a, a2;
+  mmb_decode_pair(p, L, a, a2);
+  const bool diag = p < L;
+  const bool withC = !SWAP && diag && (Cm != nullptr);
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  const int rh = wv >> 1, cw = wv & 1;                 // row half / column half of the 64 x 64 tile
+  const int cbase = jt * 64 + cw * 32;
+  const int nt = Mp / 64;
+
+  // delta_ij = rho_i + gamma'_j + zc_i . g_j   (rho, zc: latent a, row index i;  g, gamma': latent a', column j)
+  const double* rho = diag ? rowD + ((size_t)b * L + p) * Mp : rowO + ((size_t)b * Po + (p - L)) * Mp;
+  const double* gcol = diag ? colD + ((size_t)b * L + p) * (size_t)(d + 1) * Mp
+                            : colO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
+  const double* zc_a = Zc + (size_t)a * Mp * Kz;
+  const double* w_a = w + ((size_t)b * L + a) * Mp;
+  const double* w_a2 = w + ((size_t)b * L + a2) * Mp;
+  const double* q_a = q + ((size_t)b * L + a) * Mp;
+
+  // ---- the workgroup's fixed side: its 32 "columns" per wave ---------------------------------
+  // !SWAP: columns = j (latent a'):  B operand g_j, init gamma'_j, weights w'_j, q_j
+  //  SWAP: columns = i (latent a) :  B operand zc_i, init rho_i, weight w_i
+  double bfix[2][KS4], cinit[2], cwt[2], cq[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = cbase + ct * 16 + l15;
+#pragma unroll
+    for (int s = 0; s < KS4; ++s) {
+      const int k = 4 * s + kq;
+      const double v = SWAP ? zc_a[(size_t)col * Kz + (k < Kz ? k : Kz - 1)] : gcol[(size_t)(k < d ? k : d) * Mp + col];
+      bfix[ct][s] = (SWAP ? k < Kz : k < d) ? v : 0.0;
+    }
+    cinit[ct] = SWAP ? rho[col] : gcol[(size_t)d * Mp + col];
+    cwt[ct] = SWAP ? w_a[col] : w_a2[col];
+    cq[ct] = withC ? q_a[col] : 0.0;
+  }
+
+  f64x4b Uacc[2][NU];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int u = 0; u < NU; ++u) Uacc[ct][u] = (f64x4b){0.0, 0.0, 0.0, 0.0};
+  double pc[2] = {0.0, 0.0}, pC[2] = {0.0, 0.0}, pK[2] = {0.0, 0.0};
+
+  for (int it = 0; it < nt; ++it) {
+    const int rbase = it * 64 + rh * 32;
+    // ---- this iteration's 32 "rows" -------------------------------------------------------------
+    double arow[2][KS4], rinit[2][4], rwt[2][4], rq[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+      for (int s = 0; s < KS4; ++s) {
+        const int k = 4 * s + kq, row = rbase + rt * 16 + l15;
+        const double v = SWAP ? gcol[(size_t)(k < d ? k : d) * Mp + row] : zc_a[(size_t)row * Kz + (k < Kz ? k : Kz - 1)];
+        arow[rt][s] = (SWAP ? k < d : k < Kz) ? v : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + rt * 16 + kq + 4 * r;
+        rinit[rt][r] = SWAP ? gcol[(size_t)d * Mp + row] : rho[row];
+        rwt[rt][r] = SWAP ? w_a2[row] : w_a[row];
+        rq[rt][r] = withC ? q_a[row] : 0.0;
+      }
+    }
+    // ---- delta tiles ------------------------------------------------------------------------------
+    f64x4b acc[2][2];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        f64x4b c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = rinit[rt][r] + cinit[ct];
+#pragma unroll
+        for (int s = 0; s < KS4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[rt][s], bfix[ct][s], c, 0, 0, 0);
+        acc[rt][ct] = c;
+      }
+    unsigned int mxh = 0u;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const unsigned int ah = (unsigned int)(__builtin_bit_cast(unsigned long long, acc[rt][ct][r]) >> 32) & 0x7fffffffu;
+          mxh = ah > mxh ? ah : mxh;
+        }
+#define MMB_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))
+    const int tier = !__any(mxh >= MMB_HI32(0.015625)) ? 0 : !__any(mxh >= MMB_HI32(0.0625)) ? 1
+                   : !__any(mxh >= MMB_HI32(0.25)) ? 2 : !__any(mxh >= MMB_HI32(0.5)) ? 3 : 4;
+#undef MMB_HI32
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      double x[8], E[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = acc[i >> 2][ct][i & 3];
+      if (tier == 0) mmb_expm1_poly8<7>(x, E);
+      else if (tier == 1) mmb_expm1_poly8<9>(x, E);
+      else if (tier == 2) mmb_expm1_poly8<12>(x, E);
+      else if (tier == 3) mmb_expm1_poly8<15>(x, E);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) E[i] = mmb_expm1_any(x[i]);
+      }
+      double om[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double e = E[i] + 1.0;
+        const double wi = rwt[i >> 2][i & 3];
+        pc[ct] = fma(wi, E[i], pc[ct]);                       // sum_i w_i E_ij      (SWAP: sum_j w'_j E_ij)
+        if (SWAP) {
+          pK[ct] = fma(wi, e, pK[ct]);                        // sum_j w'_j e_ij
+        } else {
+          double o = wi * cwt[ct];                            // w_i w'_j
+          if (withC) {
+            const int row = rbase + (i >> 2) * 16 + kq + 4 * (i & 3);
+            const double cqi = Cm[((size_t)a * Mp + row) * Mp + cbase + ct * 16 + l15] * rq[i >> 2][i & 3];
+            pC[ct] = fma(cqi, e, pC[ct]);                     // sum_i C_ij q_i e_ij
+            o = fma(cqi, cq[ct], o);
+          }
+          om[i] = o * e;                                      // Omega_ij
+        }
+      }
+      if (!SWAP) {
+        // U_j[k] += sum_i Omega_ij zc_i[k], K_j in column k == d:  A = Omega^T (register r = K step r)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const int k = 16 * u + l15;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int row = rbase + (i >> 2) * 16 + 4 * (i & 3) + kq;
+            const double zv = zc_a[(size_t)row * Kz + (k < Kz ? k : Kz - 1)];
+            const double bop = (k < d) ? (k < Kz ? zv : 0.0) : (k == d ? 1.0 : 0.0);
+            Uacc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(om[i], bop, Uacc[ct][u], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- finish: combine the row groups / row halves through LDS, write this workgroup's 64 columns ----
+  __shared__ double Us[2][2][2][NU][4][64];      // [rh][cw][ct][u][r][lane]
+  __shared__ double Ps[3][2][2][2][64];          // [which][rh][cw][ct][lane]
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Us[rh][cw][ct][u][r][lane] = SWAP ? 0.0 : Uacc[ct][u][r];
+    Ps[0][rh][cw][ct][lane] = pc[ct];
+    Ps[1][rh][cw][ct][lane] = pC[ct];
+    Ps[2][rh][cw][ct][lane] = pK[ct];
+  }
+  __syncthreads();
+  // scalar sums: thread t < 64 owns column t of the tile
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x, ccw = c >> 5, cct = (c >> 4) & 1, cl = c & 15;
+    double sc = 0.0, sC = 0.0, sK = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        sc += Ps[0][h][ccw][cct][16 * g + cl];
+        sC += Ps[1][h][ccw][cct][16 * g + cl];
+        sK += Ps[2][h][ccw][cct][16 * g + cl];
+      }
+    const int col = jt * 64 + c;
+    if (SWAP) {
+      double* o = out + ((size_t)b * Po + lp) * (size_t)2 * Mp;
+      o[col] = sK * w_a[col];                  // R_i = w_i sum_j w'_j e_ij
+      o[(size_t)Mp + col] = sc;                // r_i = sum_j w'_j E_ij
+    } else {
+      double* o = out + ((size_t)b * P + p) * (size_t)(3 + d) * Mp;
+      o[(size_t)Mp + col] = sc;
+      o[(size_t)2 * Mp + col] = sC;
+    }
+  }
+  if (!SWAP) {
+    // U / K: D layout of the transposed product: lane (l15 = k, kq), register r  <->  column kq + 4 r
+    double* o = out + ((size_t)b * P + p) * (size_t)(3 + d) * Mp;
+    for (int idx = threadIdx.x; idx < 64 * (d + 1); idx += 256) {
+      const int c = idx & 63, k = idx >> 6;                   // k == d: K_j
+      const int ccw = c >> 5, cct = (c >> 4) & 1, j16 = c & 15, ckq = j16 & 3, cr = j16 >> 2;
+      const int u = k >> 4, kl = k & 15;
+      const int ln = 16 * ckq + kl, lnK = 16 * ckq + (d & 15), uK = d >> 4;
+      const double val = Us[0][ccw][cct][u][cr][ln] + Us[1][ccw][cct][u][cr][ln];
+      const int col = jt * 64 + c;
+      if (k == d) {
+        o[col] = val;
+      } else {
+        const double Kj = Us[0][ccw][cct][uK][cr][lnK] + Us[1][ccw][cct][uK][cr][lnK];
+        o[(size_t)(3 + k) * Mp + col] = fma(zbar[a * d + k] - mu[(size_t)b * d + k], Kj, val);
+      }
+    }
+  }
+}
+
 extern "C" size_t mm_backward_bytes(int B, int L, int M, int d, int flags) {
   if (B <= 0 || L <= 0 || M <= 0 || d <= 0 || d > MM_DMAX) return 0;
   const int Mp = mm_round_up_int(M, MM_M_ALIGN), P = mm_num_pairs(L, flags), Po = P - L;
@@ -133,6 +388,30 @@ extern "C" int mm_backward_sums(const void* packed, size_t packed_bytes, int L, 
   const double* Cm = with_unc ? (const double*)(pk + ml.Cm) : nullptr;
   double* out_col = (double*)out;
   double* out_row = out_col + (size_t)B * wl.P * (3 + d) * wl.Mp;
+  if (!(flags & MM_FORCE_GENERIC) && d <= 31) {
+    const double* Zc = (const double*)(pk + ml.Zc64);
+    const double* zb = (const double*)(pk + ml.zbar);
+    const int ks4 = (d + 3) / 4, nu = (d + 16) / 16;          // (d + 1) <= 16 nu
+#define MMB_M_ARGS Zc, ml.Kz, zb, Cm, (const double*)mu, L, wl.Mp, d, wl.P, (const double*)(ws + wl.w64),          \
+                   (const double*)(ws + wl.q64), (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD),       \
+                   (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO)
+#define MMB_M_LAUNCH(KS_, NU_)                                                                                      \
+    do {                                                                                                            \
+      hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, false>), dim3(wl.Mp / 64, wl.P, B), dim3(256), 0, s, MMB_M_ARGS, out_col); \
+      if (wl.Po > 0)                                                                                                \
+        hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, true>), dim3(wl.Mp / 64, wl.Po, B), dim3(256), 0, s, MMB_M_ARGS, out_row); \
+    } while (0)
+    if (ks4 <= 1) MMB_M_LAUNCH(1, 1);
+    else if (ks4 == 2) MMB_M_LAUNCH(2, 1);
+    else if (ks4 == 3) MMB_M_LAUNCH(3, 1);
+    else if (ks4 == 4) { if (nu == 1) MMB_M_LAUNCH(4, 1); else MMB_M_LAUNCH(4, 2); }
+    else if (ks4 <= 6) MMB_M_LAUNCH(6, 2);
+    else MMB_M_LAUNCH(8, 2);
+#undef MMB_M_LAUNCH
+#undef MMB_M_ARGS
+    hipError_t em = hipGetLastError();
+    return em == hipSuccess ? 0 : (int)em;
+  }
 #define MMB_ARGS (const double*)(pk + ml.Z64), (const double*)(pk + ml.Zc64), ml.Kz, Cm, (const double*)mu, L, M, wl.Mp, d, wl.P, \
                  (const double*)(ws + wl.w64), (const double*)(ws + wl.q64), (const double*)(ws + wl.rowD),                 \
                  (const double*)(ws + wl.colD), (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO)

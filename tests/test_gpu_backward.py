@@ -50,6 +50,39 @@ def test_gradients_match_finite_differences(shape, unc, device):
         assert abs(fd - an) < 3e-5 * max(1.0, abs(fd)), (b, i, j, fd, an)
 
 
+@pytest.mark.parametrize("shape", [(3, 300, 5, 2), (2, 130, 16, 1), (4, 70, 3, 3), (1, 200, 8, 2)],
+                         ids=["L3d5", "L2d16", "L4d3", "L1d8"])
+@pytest.mark.parametrize("unc", [True, False], ids=["unc", "nounc"])
+def test_mfma_backward_sums_match_portable_kernel(shape, unc, device):
+  """k_bwd_mfma (column-owner MFMA sweep) against k_bwd_sums (plain VALU) on the same workspace."""
+  from gpflowpilco_amd import _lib, ops
+  from gpflowpilco_amd.synthetic import make_inputs, make_svgp
+  L, M, d, B = shape
+  syn = make_svgp(L, M, d, seed=40 + L, device=str(device), ls_bounds=(0.7, 3.0))
+  pm = syn.to_model(device).packed(torch.float64, True, device)
+  mu, S = make_inputs(B, d, seed=7, scale=0.2, lo=0.3, hi=0.7)
+  mu_t, S_t = to_dev(mu, device, torch.float64), to_dev(S, device, torch.float64)
+  flags = ops.make_flags(True, unc)
+  ops.q_forward(pm, mu_t, S_t, flags)
+  ws = pm.workspace(B, flags)
+  n = _lib.lib().mm_backward_bytes(B, L, M, d, flags)
+  outs = []
+  for fl in (flags, flags | _lib.MM_FORCE_GENERIC):
+    out = torch.zeros(n // 8, dtype=torch.float64, device=device)
+    rc = _lib.lib().mm_backward_sums(pm.buf.data_ptr(), pm.nbytes, L, M, d, _lib.MM_F64, B, mu_t.data_ptr(), fl,
+                                     ws.data_ptr(), ws.numel(), out.data_ptr(), n, ops._stream(device))
+    _lib.check(rc, "mm_backward_sums")
+    outs.append(out)
+  Mp = (M + _lib.MM_M_ALIGN - 1) // _lib.MM_M_ALIGN * _lib.MM_M_ALIGN
+  P = L * (L + 1) // 2
+  ncol = B * P * (3 + d) * Mp
+  for lo, hi, shp in ((0, ncol, (B, P, 3 + d, Mp)), (ncol, n // 8, (B, P - L, 2, Mp))):
+    if hi > lo:
+      a_, b_ = outs[0][lo:hi].view(shp)[..., :M], outs[1][lo:hi].view(shp)[..., :M]
+      scale = float(b_.abs().amax())
+      assert float((a_ - b_).abs().amax()) < 1e-10 * max(scale, 1.0), (float((a_ - b_).abs().amax()), scale)
+
+
 def test_f32_model_gradients_track_f64(device):
   """An f32 model's backward (taken on the f64 pack of the same model) agrees with the f64 model's."""
   L, M, d, B = 3, 40, 4, 3
