@@ -64,11 +64,120 @@ def small_algebra(Sigma: torch.Tensor, ls2: torch.Tensor, var: torch.Tensor, ia,
   return Pa, lognorm, G, Dr, Dc, const
 
 
+def _backward_sums(pm: ops.PackedModel, mu: torch.Tensor, L: int, M: int, d: int, B: int, flags: int,
+                   full_output_cov: bool):
+  """``mm_backward_sums`` -> Ksum, csum, cC [B,P,M], Usum [B,P,M,d], Rsum, rsum [B,P,M]."""
+  dev = mu.device
+  ws = pm.workspace(B, flags)
+  nbytes = lib().mm_backward_bytes(B, L, M, d, flags)
+  out = torch.empty(nbytes // 8, dtype=torch.float64, device=dev)
+  rc = lib().mm_backward_sums(pm.buf.data_ptr(), pm.nbytes, L, M, d, _lib.MM_F64, B, mu.contiguous().data_ptr(),
+                              flags, ws.data_ptr(), ws.numel(), out.data_ptr(), nbytes, ops._stream(dev))
+  check(rc, "mm_backward_sums")
+  Mp = (M + _lib.MM_M_ALIGN - 1) // _lib.MM_M_ALIGN * _lib.MM_M_ALIGN
+  P = L * (L + 1) // 2 if full_output_cov else L
+  Po = P - L
+  ncol = B * P * (3 + d) * Mp
+  col = out[:ncol].view(B, P, 3 + d, Mp)[..., :M]
+  Ksum, csum, cC, Usum = col[:, :, 0], col[:, :, 1], col[:, :, 2], col[:, :, 3:].transpose(2, 3)   # U [B,P,M,d]
+  if Po:
+    row = out[ncol:].view(B, Po, 2, Mp)[..., :M]
+    Rsum = torch.cat([Ksum[:, :L], row[:, :, 0]], dim=1)        # diagonal pairs are symmetric
+    rsum = torch.cat([csum[:, :L], row[:, :, 1]], dim=1)
+  else:
+    Rsum, rsum = Ksum, csum
+  return Ksum, csum, cC, Usum, Rsum, rsum
+
+
+def _quad_moment(Mat: torch.Tensor, mom: torch.Tensor, mu: torch.Tensor, d: int):
+  """<Mat, sum_m c_m (z_m - mu)(z_m - mu)^T> from the raw moments mom = (sum c, sum c z, sum c z z^T)."""
+  m0, m1, m2 = mom[..., 0], mom[..., 1:1 + d], mom[..., 1 + d:].reshape(mom.shape[:-1] + (d, d))
+  Mm = torch.einsum('...ij,...j->...i', Mat, mu)
+  return ((Mat * m2).sum((-1, -2)) - (Mm * m1).sum(-1) - torch.einsum('...ij,...i,...j->...', Mat, mu, m1)
+          + m0 * (Mm * mu).sum(-1))
+
+
 def moment_match_backward(pm: ops.PackedModel, pre, mu: torch.Tensor, Sigma: torch.Tensor,
                           full_output_cov: bool, model_uncertainty: bool,
                           g_f1: torch.Tensor, g_Sff: torch.Tensor, g_cross: torch.Tensor):
-  """-> (dL/dmu [B,d], dL/dSigma [B,d,d] symmetrised).  Must be called right after the forward
-  ``ops.moment_match`` with the same (mu, Sigma, flags): the kernel reads that call's workspace."""
+  """-> (dL/dmu [B,d], dL/dSigma [B,d,d] symmetrised).  Re-runs the q stage for (mu, Sigma) (the backward
+  kernel reads its operands from the workspace; the M^2 forward reduce is not needed again).
+
+  Moment form of the surrogate: every M-sized factor enters through a *detached* coefficient vector
+  c_m (d w_m = w_m d log q_m, and the pair terms are linear in rho, gamma, G), so the sums over m
+  collapse to the raw moments  sum_m c_m (1, z_m, z_m z_m^T)  -- one GEMM over M -- and autograd only
+  sees the d x d algebra of ``small_algebra`` ([B,P,d,d] tensors): its cost does not grow with M."""
+  if pm.dtype != torch.float64:
+    raise NotImplementedError("the backward sums are taken on a float64 pack (see MomentMatchFunction)")
+  Z, ls, var, beta, _, mean_c = pre
+  L, M, d = Z.shape
+  B = mu.shape[0]
+  dev = mu.device
+  flags = ops.make_flags(full_output_cov, model_uncertainty)
+  with torch.no_grad():
+    _, _, q = ops.q_forward(pm, mu, Sigma, flags, want_q=True)              # [B,L,M]; fills the workspace the sums read
+  Ksum, csum, cC, Usum, Rsum, rsum = _backward_sums(pm, mu, L, M, d, B, flags, full_output_cov)
+  ia, ib = pair_indices(L, full_output_cov, dev)
+  if full_output_cov:
+    g_pair = torch.cat([torch.diagonal(g_Sff, dim1=-2, dim2=-1),
+                        g_Sff[:, ia[L:], ib[L:]] + g_Sff[:, ib[L:], ia[L:]]], dim=1)       # [B,P]
+  else:
+    g_pair = g_Sff
+  with torch.no_grad():
+    # ---- detached M-sized pieces -------------------------------------------------------------
+    w = beta[None] * q
+    Za = torch.cat([torch.ones(L, M, 1, dtype=Z.dtype, device=dev), Z,
+                    (Z[..., :, None] * Z[..., None, :]).reshape(L, M, d * d)], dim=-1)      # [L,M,1+d+d^2]
+    mom = lambda coef, idx: torch.einsum('bpm,pmk->bpk', coef, Za[idx])      # one GEMM over M per pair side
+    eye_idx = torch.arange(L, device=dev)
+    Ssym0 = _sym(Sigma)
+    SL0 = Ssym0[:, None] + (ls * ls)[None, :, :, None] * torch.eye(d, dtype=Sigma.dtype, device=dev)
+    Pa0 = torch.linalg.inv(SL0)                                             # [B,L,d,d]
+    pv = torch.einsum('blij,bil->blj', Pa0, g_cross)                        # Pa v, v = g_cross[b,:,a]   [B,L,d]
+    e_m = (torch.einsum('lmd,bld->blm', Z, pv) - torch.einsum('bd,bld->bl', mu, pv)[..., None]) * w
+    gp = g_pair[:, :, None]
+    c_m = g_f1[:, :, None] * w + e_m
+    pair_w = torch.zeros(B, L, M, dtype=w.dtype, device=dev)
+    pair_w.index_add_(1, ia, gp * rsum)
+    pair_w.index_add_(1, ib, gp * csum)
+    c_m = c_m + pair_w * w
+    if model_uncertainty:
+      c_m = c_m + 2.0 * g_pair[:, :L, None] * cC[:, :L] * q
+    cmom = mom(c_m, eye_idx)                                                # [B,L,1+d+d^2]
+    wmom = mom(w, eye_idx)
+    w0, w1 = wmom[..., 0], wmom[..., 1:1 + d]
+    s_det = w1 - w0[..., None] * mu[:, None, :]                             # sum_m w_m zeta_m          [B,L,d]
+    Rmom = mom(Rsum, ia)                                                    # zeta^a   side  [B,P,...]
+    Kmom = mom(Ksum, ib)                                                    # zeta^a'  side
+    K0, K1 = Kmom[..., 0], Kmom[..., 1:1 + d]
+    u = Usum.sum(2)                                                         # sum_j U_j                 [B,P,d]
+    X = torch.einsum('bpmd,pme->bpde', Usum, Z[ib])                         # sum_j U_j z'_j^T          [B,P,d,d]
+    m1c = K1 - K0[..., None] * mu[:, None, :]                               # sum_j K_j zeta'_j (detached)
+  with torch.enable_grad():
+    mu_ = mu.detach().clone().requires_grad_(True)
+    S_ = Sigma.detach().clone().requires_grad_(True)
+    Ssym = _sym(S_)
+    Pa, lognorm, G, Dr, Dc, const = small_algebra(Ssym, ls * ls, var, ia, ib)
+    muL = mu_[:, None, :]
+    # per-latent part: sum_m c_m log q_m  +  v^T Pa s  -  (sum_m w_m) v^T Pa mu
+    total = (cmom[..., 0] * lognorm).sum() - 0.5 * _quad_moment(Pa, cmom, muL, d).sum()
+    total = total + torch.einsum('bil,blij,blj->', g_cross, Pa, s_det)
+    total = total - (w0 * torch.einsum('bld,bd->bl', pv, mu_)).sum()
+    # per-pair part: sum_ij Omega_ij d(delta_ij)
+    sur = (K0 * const - 0.5 * _quad_moment(Dr, Rmom, muL, d) - 0.5 * _quad_moment(Dc, Kmom, muL, d)
+           + (G * (X - u[..., :, None] * muL[..., None, :])).sum((-1, -2))
+           - torch.einsum('bd,bpd->bp', mu_, torch.einsum('bpde,bpe->bpd', G.detach(), m1c)))
+    total = total + (g_pair * sur).sum()
+    gmu, gS = torch.autograd.grad(total, (mu_, S_))
+  return gmu, _sym(gS)
+
+
+def moment_match_backward_reference(pm: ops.PackedModel, pre, mu: torch.Tensor, Sigma: torch.Tensor,
+                          full_output_cov: bool, model_uncertainty: bool,
+                          g_f1: torch.Tensor, g_Sff: torch.Tensor, g_cross: torch.Tensor):
+  """First version of ``moment_match_backward`` (kept as the cross-check of the moment form): the
+  surrogate is evaluated on [B,P,M,d]-sized tensors, so autograd runs over M-sized graphs."""
+  ops.q_forward(pm, mu, Sigma, ops.make_flags(full_output_cov, model_uncertainty))
   if pm.dtype != torch.float64:
     raise NotImplementedError("the backward pass is built for float64 models only (first version)")
   Z, ls, var, beta, _, mean_c = pre
@@ -150,9 +259,6 @@ class MomentMatchFunction(torch.autograd.Function):
     full, unc = ctx.flags
     pmb = ctx.pm_bwd
     mu64, S64 = mu.to(torch.float64), Sigma.to(torch.float64)
-    # the backward kernel reads the q-stage operands (w, q, rho / g / gamma) from the workspace:
-    # re-run that stage for (mu, Sigma) -- the M^2 forward reduce itself is not needed again
-    ops.q_forward(pmb, mu64, S64, ops.make_flags(full, unc))
     gmu, gS = moment_match_backward(pmb, ctx.pre, mu64, S64, full, unc,
                                     g_f1.to(torch.float64).contiguous(), g_Sff.to(torch.float64).contiguous(),
                                     g_cross.to(torch.float64).contiguous())

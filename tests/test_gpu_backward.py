@@ -83,6 +83,31 @@ def test_mfma_backward_sums_match_portable_kernel(shape, unc, device):
       assert float((a_ - b_).abs().amax()) < 1e-10 * max(scale, 1.0), (float((a_ - b_).abs().amax()), scale)
 
 
+@pytest.mark.parametrize("full", [True, False], ids=["full", "diagcov"])
+@pytest.mark.parametrize("unc", [True, False], ids=["unc", "nounc"])
+def test_moment_form_backward_equals_reference_surrogate(full, unc, device):
+  """The moment form of the surrogate (autograd over d x d algebra only) against the first version
+  (autograd over [B,P,M,d] tensors), same HIP sums."""
+  from gpflowpilco_amd import autodiff as ad
+  from gpflowpilco_amd.synthetic import make_inputs, make_svgp
+  L, M, d, B = 3, 90, 4, 3
+  syn = make_svgp(L, M, d, seed=50, device=str(device), ls_bounds=(0.7, 3.0), mean_c=True)
+  model = syn.to_model(device)
+  pm = model.packed(torch.float64, True, device)
+  pre = model._cache._pre
+  mu, S = make_inputs(B, d, seed=8, scale=0.2, lo=0.3, hi=0.7)
+  mu_t, S_t = to_dev(mu, device, torch.float64), to_dev(S, device, torch.float64)
+  g = torch.Generator(device="cpu").manual_seed(1)
+  g1 = torch.randn(B, L, generator=g, dtype=torch.float64).to(device)
+  g2 = (torch.randn(B, L, L, generator=g, dtype=torch.float64) if full
+        else torch.randn(B, L, generator=g, dtype=torch.float64)).to(device)
+  g3 = torch.randn(B, d, L, generator=g, dtype=torch.float64).to(device)
+  new = ad.moment_match_backward(pm, pre, mu_t, S_t, full, unc, g1, g2, g3)
+  ref = ad.moment_match_backward_reference(pm, pre, mu_t, S_t, full, unc, g1, g2, g3)
+  for a_, b_ in zip(new, ref):
+    assert float((a_ - b_).abs().max()) < 1e-9 * max(1.0, float(b_.abs().max()))
+
+
 def test_f32_model_gradients_track_f64(device):
   """An f32 model's backward (taken on the f64 pack of the same model) agrees with the f64 model's."""
   L, M, d, B = 3, 40, 4, 3
