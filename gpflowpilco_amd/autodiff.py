@@ -89,24 +89,17 @@ def _backward_sums(pm: ops.PackedModel, mu: torch.Tensor, L: int, M: int, d: int
   return Ksum, csum, cC, Usum, Rsum, rsum
 
 
-def _quad_moment(Mat: torch.Tensor, mom: torch.Tensor, mu: torch.Tensor, d: int):
-  """<Mat, sum_m c_m (z_m - mu)(z_m - mu)^T> from the raw moments mom = (sum c, sum c z, sum c z z^T)."""
-  m0, m1, m2 = mom[..., 0], mom[..., 1:1 + d], mom[..., 1 + d:].reshape(mom.shape[:-1] + (d, d))
-  Mm = torch.einsum('...ij,...j->...i', Mat, mu)
-  return ((Mat * m2).sum((-1, -2)) - (Mm * m1).sum(-1) - torch.einsum('...ij,...i,...j->...', Mat, mu, m1)
-          + m0 * (Mm * mu).sum(-1))
-
-
 def moment_match_backward(pm: ops.PackedModel, pre, mu: torch.Tensor, Sigma: torch.Tensor,
                           full_output_cov: bool, model_uncertainty: bool,
                           g_f1: torch.Tensor, g_Sff: torch.Tensor, g_cross: torch.Tensor):
   """-> (dL/dmu [B,d], dL/dSigma [B,d,d] symmetrised).  Re-runs the q stage for (mu, Sigma) (the backward
   kernel reads its operands from the workspace; the M^2 forward reduce is not needed again).
 
-  Moment form of the surrogate: every M-sized factor enters through a *detached* coefficient vector
-  c_m (d w_m = w_m d log q_m, and the pair terms are linear in rho, gamma, G), so the sums over m
-  collapse to the raw moments  sum_m c_m (1, z_m, z_m z_m^T)  -- one GEMM over M -- and autograd only
-  sees the d x d algebra of ``small_algebra`` ([B,P,d,d] tensors): its cost does not grow with M."""
+  Moment form: every M-sized factor enters through a coefficient vector c_m (d w_m = w_m d log q_m,
+  and the pair terms are linear in rho, gamma, G), so the sums over m collapse to the raw moments
+  sum_m c_m (1, z_m, z_m z_m^T) -- one GEMM over M -- and what is left is the chain rule through the
+  d x d algebra of ``k_prep``, written out in closed form on [B,P,d,d] tensors (no autograd graph;
+  ``moment_match_backward_reference`` is the autograd version it is tested against)."""
   if pm.dtype != torch.float64:
     raise NotImplementedError("the backward sums are taken on a float64 pack (see MomentMatchFunction)")
   Z, ls, var, beta, _, mean_c = pre
@@ -153,22 +146,51 @@ def moment_match_backward(pm: ops.PackedModel, pre, mu: torch.Tensor, Sigma: tor
     u = Usum.sum(2)                                                         # sum_j U_j                 [B,P,d]
     X = torch.einsum('bpmd,pme->bpde', Usum, Z[ib])                         # sum_j U_j z'_j^T          [B,P,d,d]
     m1c = K1 - K0[..., None] * mu[:, None, :]                               # sum_j K_j zeta'_j (detached)
-  with torch.enable_grad():
-    mu_ = mu.detach().clone().requires_grad_(True)
-    S_ = Sigma.detach().clone().requires_grad_(True)
-    Ssym = _sym(S_)
-    Pa, lognorm, G, Dr, Dc, const = small_algebra(Ssym, ls * ls, var, ia, ib)
-    muL = mu_[:, None, :]
-    # per-latent part: sum_m c_m log q_m  +  v^T Pa s  -  (sum_m w_m) v^T Pa mu
-    total = (cmom[..., 0] * lognorm).sum() - 0.5 * _quad_moment(Pa, cmom, muL, d).sum()
-    total = total + torch.einsum('bil,blij,blj->', g_cross, Pa, s_det)
-    total = total - (w0 * torch.einsum('bld,bd->bl', pv, mu_)).sum()
-    # per-pair part: sum_ij Omega_ij d(delta_ij)
-    sur = (K0 * const - 0.5 * _quad_moment(Dr, Rmom, muL, d) - 0.5 * _quad_moment(Dc, Kmom, muL, d)
-           + (G * (X - u[..., :, None] * muL[..., None, :])).sum((-1, -2))
-           - torch.einsum('bd,bpd->bp', mu_, torch.einsum('bpde,bpe->bpd', G.detach(), m1c)))
-    total = total + (g_pair * sur).sum()
-    gmu, gS = torch.autograd.grad(total, (mu_, S_))
+    # ---- closed-form chain rule through the d x d algebra (no autograd graph) ---------------------
+    # per latent:  F_a = c0 lognorm - 1/2 <Pa, C2(mu)> + v^T Pa s - w0 (Pa v)^T mu,   Pa = (Sigma + Lam_a)^-1
+    #   dPa = -Pa dSigma Pa,  d logdet(Sigma + Lam_a) = tr(Pa dSigma),  C2(mu) = sum_m c_m zeta_m zeta_m^T
+    # per pair:    F_p = g [K0 const - 1/2 <Dr, R2(mu)> - 1/2 <Dc, K2(mu)> + <G, X - u mu^T> - mu^T G m1c]
+    #   T = V - V Sv^-1 V,  Sv = Sigma + V:  dT = W dSigma W^T, W = V Sv^-1;   G = Lam_a^-1 T Lam_b^-1,
+    #   Dr = Lam_a^-1 - Pa - Lam_a^-1 T Lam_a^-1,  Dc likewise with b,
+    #   const = -1/2 logdet Sv + 1/2 logdet(Sigma + Lam_a) + 1/2 logdet(Sigma + Lam_b) + ...
+    def second_moment(m, muv):                            # sum_m c_m (z - mu)(z - mu)^T from raw moments
+      m0, m1, m2 = m[..., 0], m[..., 1:1 + d], m[..., 1 + d:].reshape(m.shape[:-1] + (d, d))
+      o = m1[..., :, None] * muv[..., None, :]
+      return m2 - o - o.transpose(-1, -2) + m0[..., None, None] * (muv[..., :, None] * muv[..., None, :])
+    muL = mu[:, None, :]                                                    # [B,1,d]
+    v = g_cross.transpose(1, 2)                                             # [B,L,d]
+    c0, c1 = cmom[..., 0], cmom[..., 1:1 + d]
+    C2 = second_moment(cmom, muL)
+    vs = v[..., :, None] * s_det[..., None, :]
+    Abar = -0.5 * C2 + 0.5 * (vs + vs.transpose(-1, -2))
+    gS = -(Pa0 @ Abar @ Pa0) - 0.5 * c0[..., None, None] * Pa0              # [B,L,d,d]
+    gmu = (torch.einsum('blij,blj->bli', Pa0, c1 - c0[..., None] * muL) - w0[..., None] * pv)
+    gS, gmu = gS.sum(1), gmu.sum(1)
+    ls2 = ls * ls
+    La, Lb = ls2[ia], ls2[ib]                                               # [P,d]
+    V = La * Lb / (La + Lb)
+    eye = torch.eye(d, dtype=Sigma.dtype, device=dev)
+    Svi = torch.linalg.inv(Ssym0[:, None] + V[None, :, :, None] * eye)      # [B,P,d,d]
+    Wm = V[None, :, :, None] * Svi                                          # V Sv^-1
+    T = V[None, :, :, None] * eye - Wm * V[None, :, None, :]
+    iab = 1.0 / (La[:, :, None] * Lb[:, None, :])
+    iaa = 1.0 / (La[:, :, None] * La[:, None, :])
+    ibb = 1.0 / (Lb[:, :, None] * Lb[:, None, :])
+    G = T * iab[None]
+    Pa_p, Pb_p = Pa0[:, ia], Pa0[:, ib]
+    Dr = (1.0 / La)[None, :, :, None] * eye - Pa_p - T * iaa[None]
+    Dc = (1.0 / Lb)[None, :, :, None] * eye - Pb_p - T * ibb[None]
+    R0, R1 = Rmom[..., 0], Rmom[..., 1:1 + d]
+    R2, K2 = second_moment(Rmom, muL), second_moment(Kmom, muL)
+    XG = (X - u[..., :, None] * muL[..., None, :]) * iab[None]
+    Tbar = 0.5 * (XG + XG.transpose(-1, -2)) + 0.5 * R2 * iaa[None] + 0.5 * K2 * ibb[None]
+    gS_p = (Wm.transpose(-1, -2) @ Tbar @ Wm - 0.5 * (Pa_p @ R2 @ Pa_p) - 0.5 * (Pb_p @ K2 @ Pb_p)
+            + K0[..., None, None] * (0.5 * (Pa_p + Pb_p) - 0.5 * Svi))
+    gmu_p = (torch.einsum('bpij,bpj->bpi', Dr, R1 - R0[..., None] * muL)
+             + torch.einsum('bpij,bpj->bpi', Dc, K1 - K0[..., None] * muL)
+             - torch.einsum('bpji,bpj->bpi', G, u) - torch.einsum('bpij,bpj->bpi', G, m1c))
+    gS = gS + (g_pair[..., None, None] * gS_p).sum(1)
+    gmu = gmu + (g_pair[..., None] * gmu_p).sum(1)
   return gmu, _sym(gS)
 
 
