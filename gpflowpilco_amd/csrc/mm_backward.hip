@@ -228,6 +228,31 @@ __global__ __launch_bounds__(256, 2) void k_bwd_mfma(const double* __restrict__ 
         rq[rt][r] = withC ? q_a[row] : 0.0;
       }
     }
+    // C tile and the B operand of the U product: issued here, consumed after the polynomial (their
+    // latency overlaps with the delta MFMAs and the expm1 evaluation)
+    double creg[2][2][4], zB[NU][8];
+    if (withC) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rbase + rt * 16 + kq + 4 * r;
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) creg[rt][ct][r] = Cm[((size_t)a * Mp + row) * Mp + cbase + ct * 16 + l15];
+        }
+    }
+    if (!SWAP) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const int k = 16 * u + l15;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int row = rbase + (i >> 2) * 16 + 4 * (i & 3) + kq;
+          const double zv = zc_a[(size_t)row * Kz + (k < Kz ? k : Kz - 1)];
+          zB[u][i] = (k < d) ? (k < Kz ? zv : 0.0) : (k == d ? 1.0 : 0.0);
+        }
+      }
+    }
     // ---- delta tiles ------------------------------------------------------------------------------
     f64x4b acc[2][2];
 #pragma unroll
@@ -279,8 +304,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_mfma(const double* __restrict__ 
         } else {
           double o = wi * cwt[ct];                            // w_i w'_j
           if (withC) {
-            const int row = rbase + (i >> 2) * 16 + kq + 4 * (i & 3);
-            const double cqi = Cm[((size_t)a * Mp + row) * Mp + cbase + ct * 16 + l15] * rq[i >> 2][i & 3];
+            const double cqi = creg[i >> 2][ct][i & 3] * rq[i >> 2][i & 3];
             pC[ct] = fma(cqi, e, pC[ct]);                     // sum_i C_ij q_i e_ij
             o = fma(cqi, cq[ct], o);
           }
@@ -290,16 +314,10 @@ __global__ __launch_bounds__(256, 2) void k_bwd_mfma(const double* __restrict__ 
       if (!SWAP) {
         // U_j[k] += sum_i Omega_ij zc_i[k], K_j in column k == d:  A = Omega^T (register r = K step r)
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-          const int k = 16 * u + l15;
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int row = rbase + (i >> 2) * 16 + 4 * (i & 3) + kq;
-            const double zv = zc_a[(size_t)row * Kz + (k < Kz ? k : Kz - 1)];
-            const double bop = (k < d) ? (k < Kz ? zv : 0.0) : (k == d ? 1.0 : 0.0);
-            Uacc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(om[i], bop, Uacc[ct][u], 0, 0, 0);
-          }
-        }
+          for (int i = 0; i < 8; ++i)
+            Uacc[ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(om[i], zB[u][i], Uacc[ct][u], 0, 0, 0);
       }
     }
   }
