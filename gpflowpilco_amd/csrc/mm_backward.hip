@@ -10,9 +10,10 @@
 //     cC_j   = sum_i C_ij q_i exp(delta_ij)                    (diagonal pairs only)
 //   row sums (thread = row i, columns uniform; off-diagonal pairs only -- diagonal pairs are symmetric):
 //     Rsum_i = sum_j Omega_ij     rsum_i = sum_j E_ij w'_j
-// f64 mode only (first version; a plain VALU sweep like k_qred_generic: correctness first, the
-// MFMA treatment of the forward kernels is the next step).  Must follow mm_q_forward /
-// mm_moment_match on the same workspace (it reads w, q and the streamed operands from it).
+// The sums are taken in f64 on an f64 pack (f32 models differentiate through the f64 pack of the same
+// model, autodiff.py).  Two kernels: k_bwd_mfma (below; f64 matrix pipe, d <= 31) and the first version
+// k_bwd_sums (one thread per column, kept as the cross-check behind MM_FORCE_GENERIC and for d = 32).
+// Must follow mm_q_forward / mm_moment_match on the same workspace (w, q and the streamed operands).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
