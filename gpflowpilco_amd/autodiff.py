@@ -27,14 +27,21 @@ from . import _lib, ops
 from ._lib import MM_FULL_OUTPUT_COV, MM_MODEL_UNCERTAINTY, check, lib
 
 
+_PAIR_CACHE = {}
+
+
 def pair_indices(L: int, full: bool = True, device="cpu") -> Tuple[torch.Tensor, torch.Tensor]:
-  """Kernel pair order: the L diagonal pairs first, then a < a' row by row."""
+  """Kernel pair order: the L diagonal pairs first, then a < a' row by row (cached per device)."""
+  key = (int(L), bool(full), str(device))
+  if key in _PAIR_CACHE:
+    return _PAIR_CACHE[key]
   ia, ib = list(range(L)), list(range(L))
   if full:
     for a in range(L):
       for b in range(a + 1, L):
         ia.append(a); ib.append(b)
-  return torch.tensor(ia, device=device), torch.tensor(ib, device=device)
+  _PAIR_CACHE[key] = (torch.tensor(ia, device=device), torch.tensor(ib, device=device))
+  return _PAIR_CACHE[key]
 
 
 def _sym(A):
@@ -42,17 +49,19 @@ def _sym(A):
 
 
 def small_algebra(Sigma: torch.Tensor, ls2: torch.Tensor, var: torch.Tensor, ia, ib):
-  """The per-(b, latent) and per-(b, pair) d x d quantities of ``k_prep`` as differentiable torch ops."""
+  """The per-(b, latent) and per-(b, pair) d x d quantities of ``k_prep`` as differentiable torch ops.
+  (``inv_ex`` / ``solve_ex``: the checked variants synchronise the stream once per call; a non-PD state
+  is reported by the kernels' status word, here it propagates as inf / nan.)"""
   B, d, _ = Sigma.shape
   eye = torch.eye(d, dtype=Sigma.dtype, device=Sigma.device)
   SL = Sigma[:, None] + ls2[None, :, :, None] * eye                       # [B,L,d,d]
-  Pa = torch.linalg.inv(SL)
+  Pa = torch.linalg.inv_ex(SL).inverse
   ld = torch.linalg.slogdet(SL)[1]                                         # [B,L]
   lognorm = torch.log(var)[None] + 0.5 * torch.log(ls2).sum(-1)[None] - 0.5 * ld
   La, Lb = ls2[ia], ls2[ib]                                                # [P,d]
   V = La * Lb / (La + Lb)
   Sv = Sigma[:, None] + V[None, :, :, None] * eye                         # [B,P,d,d]
-  T = _sym(V[None, :, :, None] * torch.linalg.solve(Sv, Sigma[:, None].expand_as(Sv)))
+  T = _sym(V[None, :, :, None] * torch.linalg.solve_ex(Sv, Sigma[:, None].expand_as(Sv)).result)
   G = T / (La[None, :, :, None] * Lb[None, :, None, :])
   SP_a = Sigma[:, None] @ Pa[:, ia]
   SP_b = Sigma[:, None] @ Pa[:, ib]
@@ -125,7 +134,7 @@ def moment_match_backward(pm: ops.PackedModel, pre, mu: torch.Tensor, Sigma: tor
     eye_idx = torch.arange(L, device=dev)
     Ssym0 = _sym(Sigma)
     SL0 = Ssym0[:, None] + (ls * ls)[None, :, :, None] * torch.eye(d, dtype=Sigma.dtype, device=dev)
-    Pa0 = torch.linalg.inv(SL0)                                             # [B,L,d,d]
+    Pa0 = torch.linalg.inv_ex(SL0).inverse                                             # [B,L,d,d]
     pv = torch.einsum('blij,bil->blj', Pa0, g_cross)                        # Pa v, v = g_cross[b,:,a]   [B,L,d]
     e_m = (torch.einsum('lmd,bld->blm', Z, pv) - torch.einsum('bd,bld->bl', mu, pv)[..., None]) * w
     gp = g_pair[:, :, None]
@@ -170,7 +179,7 @@ def moment_match_backward(pm: ops.PackedModel, pre, mu: torch.Tensor, Sigma: tor
     La, Lb = ls2[ia], ls2[ib]                                               # [P,d]
     V = La * Lb / (La + Lb)
     eye = torch.eye(d, dtype=Sigma.dtype, device=dev)
-    Svi = torch.linalg.inv(Ssym0[:, None] + V[None, :, :, None] * eye)      # [B,P,d,d]
+    Svi = torch.linalg.inv_ex(Ssym0[:, None] + V[None, :, :, None] * eye).inverse      # [B,P,d,d]
     Wm = V[None, :, :, None] * Svi                                          # V Sv^-1
     T = V[None, :, :, None] * eye - Wm * V[None, :, None, :]
     iab = 1.0 / (La[:, :, None] * Lb[:, None, :])

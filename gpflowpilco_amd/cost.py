@@ -19,7 +19,7 @@ def expected_gaussian_cost(mean: torch.Tensor, cov: torch.Tensor, target: torch.
   d = mean.shape[-1]
   eye = torch.eye(d, dtype=mean.dtype, device=mean.device)
   IpSW = eye + cov @ precis
-  iSpW = precis @ torch.linalg.inv(IpSW)
+  iSpW = precis @ torch.linalg.inv_ex(IpSW).inverse
   err = mean - target
   dist2 = (err * (iSpW @ err.unsqueeze(-1)).squeeze(-1)).sum(-1)
   return -torch.rsqrt(torch.linalg.det(IpSW)) * torch.exp(-0.5 * dist2)

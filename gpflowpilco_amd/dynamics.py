@@ -12,6 +12,7 @@ from typing import Any, Callable, List, Optional, Sequence, Tuple
 import torch
 
 from . import ops
+from .linalg import index_tensor
 from .moment_matching import GaussianMatch, GaussianMoments, moment_matching
 
 __all__ = ("forward_sde", "Euler", "MomentMatchingEuler", "DynamicalSystem", "closed_rollout")
@@ -62,18 +63,18 @@ def forward_sde(x, drift, noise=None, policy=None, encoder=None):
   ndims_b = ndims_x - len(encoder.active_dims)
   active, inactive = encoder.get_partition_indices(ndims_x)
   if match_encoder.cross[1]:
-    Sax = x.covariance(dense=True)[..., list(active), :]
+    Sax = x.covariance(dense=True).index_select(-2, index_tensor(active, x.mean().device))
     Sae = Sax @ match_encoder.cross_covariance(preinv=True)
   else:
     Sxe = match_encoder.cross_covariance(dense=True)
-    Sae = Sxe[..., list(active), :]
+    Sae = Sxe.index_select(-2, index_tensor(active, Sxe.device))
   Sau = Sae @ match_policy.cross_covariance(preinv=True)
   _, perm = zip(*sorted(zip(tuple(active) + tuple(inactive), range(ndims_x))))
   Sad = torch.cat([Sae, Sau], dim=-1)
   Sdd = match_drift.x.covariance()
   nd = Sdd.shape[-2]
   Sbd = Sdd[..., nd - ndims_b - ndims_u: nd - ndims_u, :]
-  Sxd = torch.cat([Sad, Sbd], dim=-2)[..., list(perm), :]
+  Sxd = torch.cat([Sad, Sbd], dim=-2).index_select(-2, index_tensor(perm, Sad.device))
   Sxf = Sxd @ match_drift.cross_covariance(preinv=True)
   chain = GaussianMatch(x=x, y=match_drift.y, cross=(Sxf, False))
   if noise is None:

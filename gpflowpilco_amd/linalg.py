@@ -22,3 +22,17 @@ def cholesky(A: torch.Tensor) -> torch.Tensor:
     if not bool((info_h != 0).any()):
       return Lh.to(A.device)
   return torch.linalg.cholesky(A)          # raises torch.linalg.LinAlgError with the usual message
+
+
+_INDEX_CACHE = {}
+
+
+def index_tensor(indices, device) -> "torch.Tensor":
+  """Device index tensor for a (short) Python index list, cached: ``x[..., [1, 3]]`` builds and uploads
+  an index tensor on every call (a host->device copy and a stream synchronisation per use)."""
+  key = (tuple(int(i) for i in indices), str(device))
+  t = _INDEX_CACHE.get(key)
+  if t is None:
+    t = torch.tensor(key[0], dtype=torch.long, device=device)
+    _INDEX_CACHE[key] = t
+  return t

@@ -48,7 +48,8 @@ def _mm_gauss_sub(x: GaussianMoments, _, c):
 @dispatcher.register(GaussianMoments, _type_mul, NumericalTypes)
 def _mm_gauss_mul(x: GaussianMoments, _, c):
   """maths.py:62-79."""
-  c = torch.as_tensor(c, dtype=x.dtype, device=x.mean().device)
+  if isinstance(c, torch.Tensor):              # Python scalars stay scalars (no host->device upload per call)
+    c = c.to(dtype=x.dtype, device=x.mean().device)
   y2 = LinearOperatorDiag((c ** 2) * x[1].diag) if isinstance(x[1], LinearOperatorDiag) else (c ** 2) * x[1]
   y = GaussianMoments(moments=(c * x[0], y2), centered=x.centered)
   return GaussianMatch(x=x, y=y, cross=(LinearOperatorDiag.identity_like(x.mean(), c), True))
