@@ -15,6 +15,8 @@ def cholesky(A: torch.Tensor) -> torch.Tensor:
   therefore retried once on the host (LAPACK, same dtype) before the error is raised.
   """
   L, info = torch.linalg.cholesky_ex(A)
+  if A.is_cuda and torch.cuda.is_current_stream_capturing():
+    return L                                 # inside a HIP-graph capture no host check is possible
   if not bool((info != 0).any()):
     return L
   if A.is_cuda:

@@ -44,3 +44,66 @@ def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_init
     return loss
 
   return _closure
+
+
+class GraphedPolicyLoss:
+  """The policy loss closure -- and its gradient w.r.t. the policy parameters -- captured once into HIP
+  graphs (``torch.cuda.CUDAGraph``) and replayed.
+
+  The reference traces the closure once under ``tf.function`` (pilco.py:219-220); here the equivalent
+  is a graph capture: at cartpole sizes one composed rollout step is several hundred small kernels
+  and the eager path is bound by the host launching them (measured: 10.7 ms/step forward+backward
+  eager, 2.4 ms/step replayed; 1.36 -> 0.39 ms/step forward only).
+
+  Everything the closure reads must live in fixed tensors: the state initializer has to return the SAME
+  tensors on every call (``get_state_initializer`` does; write a new initial state into them with
+  ``copy_``), parameters are updated in place (optimisers do), shapes are frozen.  Replays read the
+  current values of the TRAINABLE models (they are evaluated from their parameters inside the graph);
+  frozen models (the drift) enter through their packed snapshot -- rebuild the object after refitting them.
+  ``loss()`` / ``loss_and_grad()`` return static tensors that the next replay
+  overwrites; gradients are also left in ``p.grad`` (overwritten, not accumulated).  No host-side
+  checks run inside a replay: a non-PD state shows up as nan in the loss and in the packed models'
+  status words (``PackedModel.check_status``).
+  """
+
+  def __init__(self, closure: Callable, parameters: Sequence[torch.Tensor], warmup: int = 2):
+    self.closure = closure
+    self.parameters = [p for p in parameters if p.requires_grad]
+    if not self.parameters:
+      raise ValueError("GraphedPolicyLoss needs at least one parameter with requires_grad=True")
+    dev = self.parameters[0].device
+    side = torch.cuda.Stream(device=dev)                 # warm-up off the capturing stream (lazy init, caches)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+      for _ in range(max(1, warmup)):
+        with torch.no_grad():
+          closure()
+        for p in self.parameters:
+          p.grad = None
+        closure().sum().backward()
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    self._fwd = torch.cuda.CUDAGraph()
+    with torch.no_grad():
+      with torch.cuda.graph(self._fwd):
+        self._loss_fwd = closure()
+    for p in self.parameters:
+      p.grad = None
+    self._bwd = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self._bwd):
+      self._loss_bwd = closure()
+      self._loss_bwd.sum().backward()
+    self._grads = [p.grad for p in self.parameters]
+    self._loss_bwd = self._loss_bwd.detach()
+
+  def loss(self) -> torch.Tensor:
+    """Forward only: the per-batch-element loss [B]."""
+    self._fwd.replay()
+    return self._loss_fwd
+
+  def loss_and_grad(self):
+    """-> (loss [B], [d sum(loss) / d p for p in parameters]); the gradients are also in ``p.grad``."""
+    self._bwd.replay()
+    for p, g in zip(self.parameters, self._grads):
+      p.grad = g
+    return self._loss_bwd, self._grads

@@ -56,7 +56,11 @@ def _run_kernels(x: GaussianMoments, model, full_output_cov, model_uncertainty, 
   mu2, S2 = mu.reshape(-1, d), Sxx.reshape(-1, d, d)
   full = full_output_cov if latent_full_cov is None else latent_full_cov
   grad_on = torch.is_grad_enabled()
-  if grad_on and any(t.requires_grad for t in model._parameters()):
+  trainable = any(t.requires_grad for t in model._parameters())
+  # inside a HIP-graph capture a trainable model must be evaluated FROM its parameters: the packed
+  # device model is a snapshot taken outside the graph and would go stale at the next optimiser step
+  capturing = mu.is_cuda and torch.cuda.is_current_stream_capturing()
+  if trainable and (grad_on or capturing):
     # a model whose parameters are being trained (the policy): fully differentiable torch evaluation
     from ..autodiff import moment_match_torch
     Z, ls, var, beta, C, mean_c = model.precompute(mu.device)

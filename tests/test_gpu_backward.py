@@ -204,3 +204,40 @@ def test_torch_path_equals_hip_path_and_policy_gradient(device):
     qp, qm = pol_o.q_mu.copy(), pol_o.q_mu.copy(); qp[idx, 0] += eps; qm[idx, 0] -= eps
     fd = (loss_np(qp) - loss_np(qm)) / (2 * eps)
     assert abs(fd - g[idx, 0]) < 1e-5 * max(1.0, abs(fd)), (idx, fd, g[idx, 0])
+
+
+def test_graphed_policy_loss_replays_eager_values_and_gradients(device):
+  """HIP-graph capture of the composed policy loss (forward, and forward+backward) against eager."""
+  from gpflowpilco_amd import bijectors as tfb, dynamics, models as gp
+  from gpflowpilco_amd.components import GaussianObjective, TrigonometricEncoder
+  from gpflowpilco_amd.loops import GraphedPolicyLoss, get_state_initializer, policy_loss_closure
+  from tests.test_compose import _cartpole_like
+  drift_o, pol_o, mu, S, target, precis = _cartpole_like()
+  F64 = torch.float64
+  drift = gp_model_from_oracle(drift_o, device)
+  pol_model = gp_model_from_oracle(pol_o, device)
+  pol_model.q_mu = pol_model.q_mu.clone().requires_grad_(True)
+  policy = gp.InverseLinkWrapper(gp.KernelRegressor(pol_model),
+                                 invlink=tfb.Chain([tfb.Scale(2.0), tfb.Shift(-0.5), tfb.NormalCDF()]))
+  system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=TrigonometricEncoder(active_dims=(1,)),
+                                    solver=dynamics.MomentMatchingEuler())
+  objective = GaussianObjective(target=to_dev(target, device, F64), precis=to_dev(precis, device, F64))
+  m0, S0 = to_dev(mu, device, F64), to_dev(S, device, F64)
+  closure = policy_loss_closure(system, objective, get_state_initializer(m0, S0), 3)
+
+  def eager():
+    pol_model.q_mu.grad = None
+    loss = closure()
+    loss.sum().backward()
+    return loss.detach().clone(), pol_model.q_mu.grad.clone()
+
+  graphed = GraphedPolicyLoss(closure, [pol_model.q_mu])
+  for trial in range(2):
+    le, ge = eager()
+    lg, (gg,) = graphed.loss_and_grad()
+    assert torch.allclose(lg, le, rtol=1e-12, atol=1e-14) and torch.allclose(gg, ge, rtol=1e-10, atol=1e-13)
+    assert torch.allclose(graphed.loss(), le, rtol=1e-12, atol=1e-14)
+    assert pol_model.q_mu.grad is gg
+    with torch.no_grad():                      # an in-place parameter update and a new initial state
+      pol_model.q_mu.mul_(0.9)
+      m0.add_(0.01)
