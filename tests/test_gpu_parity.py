@@ -33,14 +33,22 @@ CASES = [
     ("wide_sigma", 2, 64, 3, 5, 0.5),
     ("d16", 2, 130, 16, 2, 0.1),
     ("m512", 4, 512, 8, 2, 0.1),
+    # edges of the dispatch tables: d = 1, the maximum d = 32 (4 blocks of 8 / 8 K-steps), d = 9 and 24
+    # (partly filled blocks), fewer points than one tile, a batch that is not a multiple of anything
+    ("d1", 2, 40, 1, 3, 0.1),
+    ("d9", 3, 64, 9, 2, 0.1, (1.0, 3.0)),
+    ("d24", 2, 70, 24, 1, 0.1, (2.0, 4.0)),
+    ("d32_max", 2, 96, 32, 2, 0.1, (2.5, 5.0)),
+    ("tiny_M", 2, 3, 2, 2, 0.1),
+    ("b33", 2, 48, 4, 33, 0.15),
 ]
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_moment_match_synthetic(case, dtype, device):
-  _, L, M, d, B, scale = case
-  syn = make_svgp(L, M, d, seed=1000 + L + M, mean_c=True)
+  _, L, M, d, B, scale = case[:6]
+  syn = make_svgp(L, M, d, seed=1000 + L + M, mean_c=True, **({"ls_bounds": case[6]} if len(case) > 6 else {}))
   mu, Sigma = make_inputs(B, d, seed=7, scale=scale)
   f1o, Sffo, cro = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
   model = syn.to_model(device)
