@@ -239,8 +239,7 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
       wc = wcf[ct * 32 + l31];
     };
 
-    auto do_tile = [&](const u32x4 (&zA)[ND8], const u32x4 (&zB)[ND8], float wc) {
-      f32x16 acc[2];
+    auto mfma_tile = [&](const u32x4 (&zA)[ND8], const u32x4 (&zB)[ND8], f32x16 (&acc)[2]) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -254,14 +253,20 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
         }
         acc[rt] = c;
       }
-      // b_ij = acc: a pure bilinear form (rho'_i, gamma_j live in the weights); tile range -> tier
-      f32x2 xx[16];
+    };
+    // max |b| of a finished tile: one v_max3_f32 |a|, |b|, m per entry pair (needs -fno-honor-nans)
+    auto tile_max = [&](const f32x16 (&acc)[2]) {
       float mx = 0.0f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
-        mx = fmaxf(fmaxf(mx, fabsf(xx[r][0])), fabsf(xx[r][1]));   // one v_max3_f32 |a|, |b| (needs -fno-honor-nans)
-      }
+      for (int r = 0; r < 16; ++r)
+        mx = fmaxf(fmaxf(mx, fabsf(acc[r >> 3][2 * (r & 7)])), fabsf(acc[r >> 3][2 * (r & 7) + 1]));
+      return mx;
+    };
+    // b_ij = acc: a pure bilinear form (rho'_i, gamma_j live in the weights); tile range -> tier
+    auto reduce_tile = [&](const f32x16 (&acc)[2], float mx, float wc) {
+      f32x2 xx[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
       f32x2 part2;
       // wave-uniform tier choice (ballots, no cross-lane reduction)
       if (!__any(mx > 0.015625f)) {
@@ -291,15 +296,20 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
       sum += (double)wc * (double)(part2[0] + part2[1]);
     };
 
-    // two-stage register ping-pong: tile ct + 1 is in flight while tile ct is reduced
+    // two-stage register ping-pong: tile ct + 1 is in flight while tile ct is reduced.  (Issuing the MFMAs
+    // of tile ct + 1 interleaved with the v_max3 range check of tile ct -- a second accumulator set,
+    // 182 VGPRs -- was measured: 4.27 ms against 4.25 ms; three waves per SIMD already overlap the two.)
     u32x4 zA0[ND8], zB0[ND8], zA1[ND8], zB1[ND8];
     float w0, w1;
+    f32x16 acc[2];
     load_tile(0, zA0, zB0, w0);
     for (int ct = 0; ct < nct; ct += 2) {
       load_tile(ct + 1, zA1, zB1, w1);
-      do_tile(zA0, zB0, w0);
+      mfma_tile(zA0, zB0, acc);
+      reduce_tile(acc, tile_max(acc), w0);
       load_tile(ct + 2 < nct ? ct + 2 : ct, zA0, zB0, w0);      // clamped: the last pass re-reads its own tile
-      do_tile(zA1, zB1, w1);
+      mfma_tile(zA1, zB1, acc);
+      reduce_tile(acc, tile_max(acc), w1);
     }
   }
   // workgroup reduction -> slab
