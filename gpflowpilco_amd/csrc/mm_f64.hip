@@ -7,13 +7,18 @@
 // (DESIGN.md "fp32 error budget") -- these pairs are reduced in f64 in both modes.
 //
 //   tile      : 64 x 64 entries per workgroup (4 waves, 32 x 32 each = 2 x 2 MFMA tiles of
-//               v_mfma_f64_16x16x4_f64; one extra k-step adds rho_i + gamma'_j)
+//               v_mfma_f64_16x16x4_f64; rho_i + gamma'_j initialises the accumulator)
 //   diag mode : only tile pairs it <= jt are visited (Q_aa and C_a are symmetric; strictly
 //               upper tiles count twice); the C tile is loaded ONCE into registers and the
 //               workgroup loops over its chunk of the batch -- C traffic is M^2*8 B per chunk
-//               instead of per batch element;
-//   expm1     : branch-free f64 (k ln2 + r reduction, degree-13 polynomial, ldexp), relative
-//               error ~2e-16 of expm1 itself for every argument;
+//               instead of per batch element; with model uncertainty ONE fused sum
+//               sum_ij q_i q_j (D_ij expm1(delta_ij) + C_ij), D = C + beta beta^T;
+//   expm1     : wave-uniform Taylor tiers by the tile's range (degree 6/8/10/15 for an f32 model,
+//               7/9/12/15 for an f64 model), Horner steps vertical over 8 entries; beyond the last
+//               tier k ln2 + r reduction + v_ldexp_f64 (relative error ~2e-16 for every argument);
+//   pipeline  : operands of batch element b + 1 prefetched into a second register set; per-thread
+//               partials of 16 batch elements staged in LDS and reduced together;
+//   grid      : 1-D, remapped so that an XCD owns a contiguous (pair, chunk, tile) range;
 //   output    : per (b, pair, tile) partial sums -> slab (deterministic, no atomics).
 #include <hip/hip_runtime.h>
 #include <math.h>
