@@ -14,9 +14,12 @@ static inline int mm_num_pairs(int L, int flags) {
   return (flags & MM_FULL_OUTPUT_COV) ? L * (L + 1) / 2 : L;
 }
 
+// Columns of the moment table: 1 + d + d (d + 1) / 2, rounded up to the 16-wide MFMA tile.
+static inline int mm_moment_cols(int d) { return mm_round_up_int(1 + d + d * (d + 1) / 2, 16); }
+
 // Packed model: byte offsets inside the caller-owned device buffer.
 struct MMModelLayout {
-  int Mp, Kz, nd8;
+  int Mp, Kz, nd8, KMp;
   size_t Z64;     // [L][M][d]  f64 raw inducing inputs (prep stages run in f64)
   size_t zbar;    // [L][d]     f64 per-latent centroid of Z (centres the MFMA A operand)
   size_t ls2;     // [L][d]     f64 squared lengthscales (Lambda)
@@ -26,6 +29,8 @@ struct MMModelLayout {
   size_t Zc64;    // [L][Mp][Kz] f64 centred inducing inputs, zero padded (rows >= M, cols >= d)
   size_t Zc;      // [L][Mp][Kz] T   same, element type T (aliases Zc64 when T is f64)
   size_t Zs3;     // [L][Mp][3][8 nd8] bf16: Zc split into bf16 parts (h, m, l), f32 mode only
+  size_t Zm;      // [L][Mp][KMp] f64: (1, zc_k, zc_k zc_l (k <= l)) per inducing point, zero padded -- the
+                  // table the weight moments sum_m what_m (1, zc, zc zc^T) are taken against (f32 mode only)
   size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
                   // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
@@ -37,6 +42,7 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   o.Mp = mm_round_up_int(M, MM_M_ALIGN);
   o.Kz = mm_round_up_int(d, 2);
   o.nd8 = (d + 7) / 8;
+  o.KMp = mm_moment_cols(d);
   size_t off = 0;
   o.Z64 = off;    off = mm_align_up(off + (size_t)L * M * d * 8, A);
   o.zbar = off;   off = mm_align_up(off + (size_t)L * d * 8, A);
@@ -49,6 +55,8 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   if (dtype != MM_F64) { o.Zc = off; off = mm_align_up(off + (size_t)L * o.Mp * o.Kz * es, A); }
   o.Zs3 = off;
   if (dtype != MM_F64) off = mm_align_up(off + (size_t)L * o.Mp * 24 * o.nd8 * 2, A);
+  o.Zm = off;
+  if (dtype != MM_F64) off = mm_align_up(off + (size_t)L * o.Mp * o.KMp * 8, A);
   o.Cm = off;
   if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;
@@ -77,7 +85,10 @@ struct MMWorkspaceLayout {
   size_t rowO;     // off-diagonal pairs.  f64: [B][Po][Mp] rho_i            f32: [B][Po][d+1][Mp] A_i, what_i
   size_t colO;     //                      f64: [B][Po][d+1][Mp] g_j, gamma'_j  f32: [B][Po][Mp] what'_j
   size_t f1raw;    // [B][L] f64      sum_i w_i (f1 without the mean)
-  size_t wsum;     // [B][Po][2][Mp/256] f64  block partials of sum_i what_i, sum_j what'_j (f32 mode)
+  size_t whR;      // [B][Po][Mp] f64  what_i  = w_i e^{rho'_i}   (f32 mode: row weights, unrounded)
+  size_t whC;      // [B][Po][Mp] f64  what'_j = w'_j e^{gamma_j}
+  size_t mom;      // [B][Po][2][KMp] f64  sum_m what_m (1, zc_m, zc_m zc_m^T): row side, column side
+  size_t s12;      // [B][Po] f64  linear + quadratic part of the off-diagonal sums (+ the O(M) correction)
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
   size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i expm1(delta_ij) q_j  (+ q^T C q)
   size_t f1s;      // [B][L] T      rollout scratch outputs
@@ -113,7 +124,11 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.rowO = off;    off = mm_align_up(off + (size_t)B * o.Po * nrow * o.Mp * es, A);
   o.colO = off;    off = mm_align_up(off + (size_t)B * o.Po * ncol * o.Mp * es, A);
   o.f1raw = off;   off = mm_align_up(off + (size_t)B * L * 8, A);
-  o.wsum = off;    off = mm_align_up(off + (size_t)B * o.Po * 2 * ((o.Mp + 255) / 256) * 8, A);
+  const size_t nwh = dtype == MM_F64 ? 0 : (size_t)B * o.Po * o.Mp;
+  o.whR = off;     off = mm_align_up(off + nwh * 8, A);
+  o.whC = off;     off = mm_align_up(off + nwh * 8, A);
+  o.mom = off;     off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * 2 * mm_moment_cols(d) * 8), A);
+  o.s12 = off;     off = mm_align_up(off + (size_t)B * o.Po * 8, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
   o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);
   o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);

@@ -149,6 +149,27 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
     if (sizeof(T) != 8) Zc[idx] = (T)v;
   }
   if (sizeof(T) != 8) {
+    // moment table (1, zc_k, zc_k zc_l for k <= l), zero beyond M and beyond the last column
+    double* Zm = (double*)(packed + lay.Zm) + (size_t)a * lay.Mp * lay.KMp;
+    for (int idx = tid; idx < lay.Mp * lay.KMp; idx += 256) {
+      const int m = idx / lay.KMp, c = idx - m * lay.KMp;
+      double v = 0.0;
+      if (m < M) {
+        if (c == 0) v = 1.0;
+        else if (c <= d) v = Z[((size_t)a * M + m) * d + (c - 1)] - zb[c - 1];
+        else {
+          int r = c - 1 - d, k = 0;                      // packed upper triangle, row k: entries (k, k..d-1)
+          while (k < d && r >= d - k) { r -= d - k; ++k; }
+          if (k < d) {
+            const int l = k + r;
+            v = (Z[((size_t)a * M + m) * d + k] - zb[k]) * (Z[((size_t)a * M + m) * d + l] - zb[l]);
+          }
+        }
+      }
+      Zm[idx] = v;
+    }
+  }
+  if (sizeof(T) != 8) {
     // bf16 3-way split of the centred inputs for the f32 MFMA kernel: [Mp][3 (h,m,l)][8 nd8]
     unsigned short* Zs3 = (unsigned short*)(packed + lay.Zs3) + (size_t)a * lay.Mp * 24 * lay.nd8;
     const int kw = 8 * lay.nd8;
@@ -368,7 +389,8 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
                                                  const T* __restrict__ mu, const double* __restrict__ pairmat,
                                                  double* __restrict__ rowD, double* __restrict__ colD,
                                                  T* __restrict__ rowO, T* __restrict__ colO,
-                                                 const double* __restrict__ w64, double* __restrict__ wsum, int nblk) {
+                                                 const double* __restrict__ w64, double* __restrict__ whR,
+                                                 double* __restrict__ whC, int nblk) {
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
   // pair's matrices are fetched and staged once per workgroup, not once per chunk (at one chunk per
   // workgroup the kernel was bound by that fetch -> barrier -> fetch Z latency chain)
@@ -405,10 +427,13 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
     // exp(delta) - 1 = e^{rho'_i} e^{gamma_j} (expm1(b_ij) + 1) - 1, hence
     //   S = sum_ij what_i what'_j expm1(b_ij) + (sum_i what_i)(sum_j what'_j) - (sum_i w_i)(sum_j w'_j)
     // with what_i = w_i e^{rho'_i}, what'_j = w'_j e^{gamma_j}: the M x M tile is a pure bilinear form.
-    // The two O(M) sums are reduced here in f64 (k_finalize adds the correction).
+    // The f64 weights are kept as well: their moments against (1, zc, zc zc^T) give the O(M) correction
+    // and the linear + quadratic part of the sum exactly (k_wmoments / k_s12); the tile kernel only
+    // reduces the remainder expm1(b) - b - b^2/2 in f32.
     T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
     T* cO = colO + ((size_t)b * Po + (p - L)) * Mp;
-    double sr = 0.0, sc = 0.0;
+    double* hR = whR + ((size_t)b * Po + (p - L)) * Mp;
+    double* hC = whC + ((size_t)b * Po + (p - L)) * Mp;
     for (int mblk = blockIdx.x; mblk < nblk; mblk += gridDim.x) {
       const int m = mblk * 256 + tid;
       if (m >= Mp) continue;
@@ -445,19 +470,8 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
       }
       rO[(size_t)d * Mp + m] = (T)whr;
       cO[m] = (T)whc;
-      sr += whr; sc += whc;
-    }
-    // both block sums through one pass: wave butterflies interleaved, one LDS slot pair per wave
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { sr += __shfl_down(sr, off, 64); sc += __shfl_down(sc, off, 64); }
-    __shared__ double red[8];
-    if ((tid & 63) == 0) { red[tid >> 6] = sr; red[4 + (tid >> 6)] = sc; }
-    __syncthreads();
-    // slot blockIdx.x carries this workgroup's sums; the other slots it covers are zeroed (k_finalize sums nblk slots)
-    for (int sl = blockIdx.x + tid * gridDim.x; sl < nblk; sl += 256 * gridDim.x) {
-      const bool own = sl == (int)blockIdx.x;
-      wsum[(((size_t)b * Po + (p - L)) * 2 + 0) * nblk + sl] = own ? red[0] + red[1] + red[2] + red[3] : 0.0;
-      wsum[(((size_t)b * Po + (p - L)) * 2 + 1) * nblk + sl] = own ? red[4] + red[5] + red[6] + red[7] : 0.0;
+      hR[m] = whr;
+      hC[m] = whc;
     }
     return;
   }
@@ -503,6 +517,129 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64,
   }
 #undef MM_PV_STORE_ROW
 #undef MM_PV_STORE_COL
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_wmoments: raw moments of the factored f64 weights of every off-diagonal pair (f32 mode),
+//     mom[b][po][side][:] = sum_m what_side[b][po][m] * Zm[latent(side)][m][:],   Zm = (1, zc, zc zc^T),
+// a skinny GEMM over M on the f64 matrix pipe (v_mfma_f64_16x16x4_f64: 16 batch elements x 16 table
+// columns per tile).  grid (ceil(B/16) * ncg, Po, 2); a workgroup = 4 waves splitting the m range, NC
+// (<= 4) column tiles each; the waves' partial tiles are combined through LDS in a fixed order.
+// ---------------------------------------------------------------------------------------------
+typedef double f64x4k __attribute__((ext_vector_type(4)));
+
+template <int NC>
+__global__ __launch_bounds__(256) void k_wmoments(const double* __restrict__ whR, const double* __restrict__ whC,
+                                                  const double* __restrict__ Zm, int KMp, int ncg,
+                                                  int L, int Mp, int B, int Po, double* __restrict__ mom) {
+  const int side = blockIdx.z, po = blockIdx.y;
+  const int bt = blockIdx.x / ncg, cg = blockIdx.x - bt * ncg;
+  int a, a2;
+  mm_decode_pair(L + po, L, a, a2);
+  const double* W = side ? whC : whR;
+  const double* tab = Zm + (size_t)(side ? a2 : a) * Mp * KMp;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  const int brow = bt * 16 + l15;
+  const double* wrow = W + ((size_t)(brow < B ? brow : B - 1) * Po + po) * Mp;
+  const int nct = KMp / 16;
+  int coff[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int t = cg * NC + c;
+    coff[c] = (t < nct ? t : nct - 1) * 16 + l15;       // tiles past the end recompute the last one (not stored)
+  }
+  f64x4k acc[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) acc[c] = (f64x4k){0.0, 0.0, 0.0, 0.0};
+  const int mq = Mp / 4;                                 // Mp % 128 == 0: every wave gets whole K = 4 steps
+  for (int m0 = wv * mq; m0 < (wv + 1) * mq; m0 += 4) {
+    const double av = wrow[m0 + kq];
+    const double* tr = tab + (size_t)(m0 + kq) * KMp;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tr[coff[c]], acc[c], 0, 0, 0);
+  }
+  __shared__ double red[4][NC][4][64];
+#pragma unroll
+  for (int c = 0; c < NC; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wv][c][r][lane] = acc[c][r];
+  __syncthreads();
+  // accumulator layout: lane (l15 = table column, kq), register r  <->  batch row kq + 4 r
+  for (int idx = threadIdx.x; idx < NC * 4 * 64; idx += 256) {
+    const int ln = idx & 63, r = (idx >> 6) & 3, c = idx >> 8;
+    const int t = cg * NC + c;
+    const int b = bt * 16 + (ln >> 4) + 4 * r;
+    if (t < nct && b < B) {
+      const double v = (red[0][c][r][ln] + red[1][c][r][ln]) + (red[2][c][r][ln] + red[3][c][r][ln]);
+      mom[(((size_t)b * Po + po) * 2 + side) * KMp + t * 16 + (ln & 15)] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_s12: the part of an off-diagonal sum that the weight moments give exactly (f64),
+//   s12 = sum_ij what_i what'_j (1 + b_ij + b_ij^2 / 2),   b_ij = A_i . zc_j,  A_i = G^T (zc_i - dmu),
+//       = n0 q0 + P1 . q1 + 1/2 <P2, q2>,   P1 = G^T M1,  P2 = G^T M2 G,
+//   M1 = n1 - n0 dmu,  M2 = n2 - n1 dmu^T - dmu n1^T + n0 dmu dmu^T,   dmu = mu_b - zbar_a
+// (n: row-side moments against latent a's table, q: column side against latent a').  The tile kernel
+// adds the remainder sum_ij what_i what'_j (expm1(b_ij) - b_ij - b_ij^2 / 2).  One wave per (b, pair).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mm_sym_index(int k, int l, int d) {      // packed upper triangle behind (1, zc)
+  const int lo = k < l ? k : l, hi = k < l ? l : k;
+  return 1 + d + lo * d - lo * (lo - 1) / 2 + (hi - lo);
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_s12(const double* __restrict__ mom, int KMp, const double* __restrict__ pairmat,
+                                            const double* __restrict__ zbar, const T* __restrict__ mu,
+                                            int L, int d, int P, double* __restrict__ s12) {
+  extern __shared__ double sm[];
+  double* M2 = sm;                 // [d][d]
+  double* T1 = M2 + d * d;         // [d][d]  G^T M2
+  double* Gs = T1 + d * d;         // [d][d]
+  double* dmu = Gs + d * d;        // [d]
+  double* M1 = dmu + d;            // [d]
+  const int po = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int Po = P - L, p = L + po;
+  int a, a2;
+  mm_decode_pair(p, L, a, a2);
+  const double* n = mom + (((size_t)b * Po + po) * 2 + 0) * KMp;
+  const double* q = mom + (((size_t)b * Po + po) * 2 + 1) * KMp;
+  const double* pm = pairmat + ((size_t)b * P + p) * (3 * d * d + 1);
+  const double n0 = n[0];
+  for (int k = lane; k < d; k += 64) {
+    const double dm = (double)mu[(size_t)b * d + k] - zbar[a * d + k];
+    dmu[k] = dm;
+    M1[k] = n[1 + k] - n0 * dm;
+  }
+  for (int idx = lane; idx < d * d; idx += 64) Gs[idx] = pm[idx];
+  __syncthreads();
+  for (int idx = lane; idx < d * d; idx += 64) {
+    const int k = idx / d, l = idx - k * d;
+    M2[idx] = n[mm_sym_index(k, l, d)] - n[1 + k] * dmu[l] - dmu[k] * n[1 + l] + n0 * dmu[k] * dmu[l];
+  }
+  __syncthreads();
+  for (int idx = lane; idx < d * d; idx += 64) {             // T1 = G^T M2:  T1[i][l] = sum_k G[k][i] M2[k][l]
+    const int i = idx / d, l = idx - i * d;
+    double t = 0.0;
+    for (int k = 0; k < d; ++k) t = fma(Gs[k * d + i], M2[k * d + l], t);
+    T1[idx] = t;
+  }
+  __syncthreads();
+  double acc = 0.0;
+  for (int idx = lane; idx < d * d; idx += 64) {             // 1/2 <G^T M2 G, q2>
+    const int i = idx / d, j = idx - i * d;
+    double t = 0.0;
+    for (int l = 0; l < d; ++l) t = fma(T1[i * d + l], Gs[l * d + j], t);
+    acc = fma(0.5 * t, q[mm_sym_index(i, j, d)], acc);
+  }
+  for (int i = lane; i < d; i += 64) {                        // (G^T M1) . q1
+    double t = 0.0;
+    for (int k = 0; k < d; ++k) t = fma(Gs[k * d + i], M1[k], t);
+    acc = fma(t, q[1 + i], acc);
+  }
+  acc = mm_wave_sum(acc);
+  if (lane == 0) s12[(size_t)b * Po + po] = acc + n0 * q[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -555,7 +692,10 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
 #pragma unroll
     for (int k = 0; k < DK; ++k)
       if (k < d) delta += (ROWVEC ? ra[(size_t)k * Mp + i] : zrow[(size_t)i * Kz + k]) * g[k];
-    const T e = mm_expm1(delta);
+    // ROWVEC (f32 off-diagonal pairs): only the remainder expm1(b) - b - b^2/2 is reduced here, the
+    // rest comes from the f64 weight moments (k_s12); evaluated in f64 (portable cross-check kernel)
+    const T e = ROWVEC ? (T)(expm1((double)delta) - (double)delta - 0.5 * (double)delta * (double)delta)
+                       : mm_expm1(delta);
     accB += (ROWVEC ? ra[(size_t)d * Mp + i] : wr[i]) * e;
     if (withC) {
       const double cij = Cm[((size_t)a * Mp + i) * Mp + jj];
@@ -584,7 +724,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
                                                   const double* __restrict__ var, int B, int L, int P, int NS,
                                                   int nsB_diag, int nsB_off, int nsC, int full, int with_unc,
                                                   double jitter, const double* __restrict__ f1raw,
-                                                  const double* __restrict__ wsum, int nblk,
+                                                  const double* __restrict__ s12,
                                                   T* __restrict__ Sff) {
   // one wave per (b, pair): lanes stride over the slab (coalesced), fixed butterfly => reproducible
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -600,19 +740,11 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
     const double* pc = partC + ((size_t)b * L + a) * NS;
     for (int k = lane; k < nsC; k += 64) s += pc[k];
   }
-  double sr = 0.0, sc = 0.0;
-  if (a != a2 && wsum) {       // f32 mode: factored weights (k_pairvec), O(M) correction term
-    const double* wr = wsum + ((size_t)b * (P - L) + (p - L)) * 2 * nblk;
-    for (int k = lane; k < nblk; k += 64) { sr += wr[k]; sc += wr[nblk + k]; }
-  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    s += __shfl_xor(s, off, 64);
-    sr += __shfl_xor(sr, off, 64);
-    sc += __shfl_xor(sc, off, 64);
-  }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (lane != 0) return;
-  if (a != a2 && wsum) s += sr * sc - f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a2];
+  // f32 mode: the tile kernel reduced only the remainder; the moments supply 1 + b + b^2/2 (k_s12)
+  if (a != a2 && s12) s += s12[(size_t)b * (P - L) + (p - L)] - f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a2];
   if (a == a2) {
     if (with_unc) s += var[a];                 // models.py:254-261
     s += jitter;                               // models.py:293-296
@@ -825,7 +957,24 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     hipLaunchKernelGGL((k_pairvec<T, DK>), dim3(nsplit, wl.P, B), dim3(256), 0, s,
                        Z64, (const double*)(packed + ml.zbar), L, M, wl.Mp, d, wl.P, mu, pairmat,
                        (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO),
-                       (const double*)(ws + wl.w64), (double*)(ws + wl.wsum), nblk);
+                       (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), nblk);
+  }
+  MM_CHECK_LAUNCH();
+  if (sizeof(T) == 4 && wl.Po > 0) {
+    // exact (f64) linear + quadratic part of the off-diagonal sums from the weight moments
+    const int nct = ml.KMp / 16;
+    const int nc = nct < 4 ? nct : 4, ncg = (nct + nc - 1) / nc;
+    const dim3 grid((unsigned)(((B + 15) / 16) * ncg), (unsigned)wl.Po, 2);
+    const double* Zm = (const double*)(packed + ml.Zm);
+    double* mom = (double*)(ws + wl.mom);
+#define MM_WMOM(NC_) hipLaunchKernelGGL((k_wmoments<NC_>), grid, dim3(256), 0, s, (const double*)(ws + wl.whR),      \
+                                        (const double*)(ws + wl.whC), Zm, ml.KMp, ncg, L, wl.Mp, B, wl.Po, mom)
+    if (nc == 1) MM_WMOM(1); else if (nc == 2) MM_WMOM(2); else if (nc == 3) MM_WMOM(3); else MM_WMOM(4);
+#undef MM_WMOM
+    MM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_s12<T>), dim3(wl.Po, B), dim3(64), (size_t)(3 * d * d + 2 * d) * sizeof(double), s,
+                       (const double*)mom, ml.KMp, (const double*)pairmat, (const double*)(packed + ml.zbar), mu,
+                       L, d, wl.P, (double*)(ws + wl.s12));
   }
   MM_CHECK_LAUNCH();
   return 0;
@@ -892,7 +1041,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
     hipLaunchKernelGGL((k_finalize<T>), dim3((n + 3) / 4), dim3(256), 0, s,
                        partB, partC, (const double*)(packed + ml.var), B, L, wl.P, wl.NS,
                        nsB_diag, nsB_off, nsC, full, with_unc, jitter, (const double*)(ws + wl.f1raw),
-                       sizeof(T) == 4 ? (const double*)(ws + wl.wsum) : (const double*)nullptr, (wl.Mp + 255) / 256, Sff);
+                       sizeof(T) == 4 ? (const double*)(ws + wl.s12) : (const double*)nullptr, Sff);
     MM_CHECK_LAUNCH();
   }
   return 0;

@@ -1,15 +1,13 @@
 // f32 MFMA fused reduce of the off-diagonal kernel pairs (a < a') on gfx950.
 //
-// For every (b, pair) the kernel evaluates, without ever storing the M x M block Q_aa'
-// (the reference's eKuffu slice, utils/kernel_expectation.py:72-187, then
-// models.py:219-248),
-//     S = sum_ij w_i * expm1(delta_ij) * w'_j ,   delta_ij = rho_i + gamma'_j + zc_i . g_j
-//     S = sum_ij w_i expm1(delta_ij) w'_j,  delta_ij = rho'_i + gamma_j + b_ij,  b_ij = A_i . zc_j
-//       = sum_ij what_i expm1(b_ij) what'_j + (sum what)(sum what') - (sum w)(sum w'),
-//         what_i = w_i e^{rho'_i}, what'_j = w'_j e^{gamma_j}   (O(M) terms: k_pairvec / k_finalize)
+// For every (b, pair) the reference's eKuffu slice Q_aa' (utils/kernel_expectation.py:72-187, then
+// models.py:219-248) is never stored; with b_ij = A_i . zc_j, what_i = w_i e^{rho'_i}, what'_j = w'_j e^{gamma_j}
+//     S = sum_ij w_i expm1(delta_ij) w'_j,   delta_ij = rho'_i + gamma_j + b_ij
+//       = sum_ij what_i what'_j (1 + b_ij + b_ij^2/2)  - (sum w)(sum w')        exact, f64 moments (O(M d^2))
+//       + sum_ij what_i what'_j r(b_ij),   r(x) = expm1(x) - x - x^2/2            THIS kernel, f32, O(M^2)
 // The bilinear part runs on the bf16 matrix pipe as a 3-way split product with f32 accuracy
-// (v_mfma_f32_32x32x16_bf16), the expm1 polynomial + weighted reduction on the VALU in packed
-// f32 (v_pk_fma_f32), which overlaps with the matrix pipe.
+// (v_mfma_f32_32x32x16_bf16), the remainder polynomial + weighted reduction on the VALU in packed
+// f32 (v_pk_fma_f32); MFMA and f32 FMA-class VALU time add on a gfx950 SIMD (tools/ubench_overlap.hip).
 //
 // Work decomposition: workgroup = 4 waves = 256 rows of one (b, pair); a wave owns 64 rows
 // (two 32x32 MFMA row tiles; split A operands, rho' (the MFMA C operand) and the 32 row weights
@@ -36,37 +34,6 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
   a = i; a2 = i + 1 + r;
 }
 
-// expm1 on [-1, 1]: Taylor to degree 10 (truncation 1/11! relative, below f32 rounding).
-// Returns x * P(x); relative error ~1e-7 of expm1(x) itself (not of 1 + expm1(x)), which is
-// what the centred reduce needs (DESIGN.md "fp32 error budget").
-__device__ __forceinline__ f32x2 mm_expm1_small2(f32x2 x) {
-  f32x2 p = MM_PK(2.7557319e-7f);
-  p = mm_pkfma(p, x, MM_PK(2.7557319e-6f));
-  p = mm_pkfma(p, x, MM_PK(2.4801587e-5f));
-  p = mm_pkfma(p, x, MM_PK(1.9841270e-4f));
-  p = mm_pkfma(p, x, MM_PK(1.3888889e-3f));
-  p = mm_pkfma(p, x, MM_PK(8.3333333e-3f));
-  p = mm_pkfma(p, x, MM_PK(4.1666667e-2f));
-  p = mm_pkfma(p, x, MM_PK(1.6666667e-1f));
-  p = mm_pkfma(p, x, MM_PK(0.5f));
-  p = mm_pkfma(p, x, MM_PK(1.0f));
-  return p * x;
-}
-
-__device__ __forceinline__ float mm_expm1_small(float x) {
-  float p = 2.7557319e-7f;             // 1/10!
-  p = fmaf(p, x, 2.7557319e-6f);       // 1/9!
-  p = fmaf(p, x, 2.4801587e-5f);       // 1/8!
-  p = fmaf(p, x, 1.9841270e-4f);       // 1/7!
-  p = fmaf(p, x, 1.3888889e-3f);       // 1/6!
-  p = fmaf(p, x, 8.3333333e-3f);       // 1/5!
-  p = fmaf(p, x, 4.1666667e-2f);       // 1/4!
-  p = fmaf(p, x, 1.6666667e-1f);       // 1/3!
-  p = fmaf(p, x, 0.5f);
-  p = fmaf(p, x, 1.0f);
-  return p * x;
-}
-
 #ifndef MM_F32_WAVES
 #define MM_F32_WAVES 2
 #endif
@@ -88,63 +55,57 @@ __device__ __forceinline__ void mm_split3(float x, unsigned int& h, unsigned int
   l = mm_f2bf(r);
 }
 
-// expm1(x) / x on [-1, 1], degree 7 (near-minimax, relative error of x * P(x) ~2e-7 in f32)
-#define MM_P7_C7 2.480045805e-05f
-#define MM_P7_C6 2.039110987e-04f
-#define MM_P7_C5 1.389508019e-03f
-#define MM_P7_C4 8.329954930e-03f
-#define MM_P7_C3 4.166625813e-02f
-#define MM_P7_C2 1.666673273e-01f
-#define MM_P7_C1 5.000000596e-01f
-#define MM_P7_C0 1.0f
-
-// Near-minimax coefficients of expm1(x)/x by range tier (relative error of x*P(x) <= 2.3e-7 in f32):
-//   |x| <= 1/64: degree 2,  |x| <= 1/16: degree 3,  |x| <= 0.25: degree 4,  |x| <= 0.5: degree 5,
-//   |x| <= 1: degree 7   (tools/minimax_expm1.py).  Along the C3 rollout 90-100 % of the 64 x 32 wave
-//   tiles fall into the first two tiers (tools/tier_stats.py).
-template <int DEG> struct MMPoly;
-template <> struct MMPoly<2> {
-  static constexpr float c[3] = {1.000000000e+00f, 5.000076294e-01f, 1.666666716e-01f};
+// The tile kernel reduces only the REMAINDER r(x) = expm1(x) - x - x^2/2 of every entry: the constant,
+// linear and quadratic parts of sum_ij what_i what'_j (1 + expm1(b_ij)) are taken exactly from f64 moments
+// of the weights (k_wmoments / k_s12 in mm_kernels.hip).  In f32 the sum is ill-conditioned
+// (sum |what_i E_ij what'_j| >> |S|: weights of +-17 at M = 2000), and it is the rounding of the linear
+// term that costs the digits; r(x) = O(x^3) carries the same relative rounding but is 1e-3..1e-5 of it
+// (tools/error_budget.py: 2.5e-3 -> 1e-8 of max|Sff| at C3).
+//
+// Near-minimax R(x) ~ r(x) / x^3 by range tier, |x^3 R(x) - r(x)| <= 5e-8 |x| with fused f32 Horner
+// steps (tools/minimax_remainder.py):  |x| <= 1/16: degree 1,  <= 1/4: 3,  <= 1/2: 4,  <= 1: 5.
+// Along the C3 rollout 90-100 % of the 64 x 32 wave tiles are in the first tier (tools/tier_stats.py).
+template <int DEG> struct MMRem;
+template <> struct MMRem<1> {
+  static constexpr float c[2] = {1.666936278e-01f, 4.167173430e-02f};
 };
-template <> struct MMPoly<3> {
-  static constexpr float c[4] = {1.000000000e+00f, 5.000000000e-01f, 1.666992158e-01f, 4.166666791e-02f};
+template <> struct MMRem<3> {
+  static constexpr float c[4] = {1.666663289e-01f, 4.166659713e-02f, 8.350561373e-03f, 1.391559141e-03f};
 };
-template <> struct MMPoly<4> {
-  static constexpr float c[5] = {1.000000000e+00f, 4.999983013e-01f, 1.666673869e-01f, 4.177515209e-02f, 8.333330043e-03f};
+template <> struct MMRem<4> {
+  static constexpr float c[5] = {1.666666716e-01f, 4.166586325e-02f, 8.333111182e-03f, 1.398149878e-03f, 1.998390071e-04f};
 };
-template <> struct MMPoly<5> {
-  static constexpr float c[6] = {1.000000119e+00f, 4.999998212e-01f, 1.666597426e-01f, 4.166870192e-02f,
-                                 8.407683112e-03f, 1.388882170e-03f};
-};
-template <> struct MMPoly<7> {
-  static constexpr float c[8] = {MM_P7_C0, MM_P7_C1, MM_P7_C2, MM_P7_C3, MM_P7_C4, MM_P7_C5, MM_P7_C6, MM_P7_C7};
+template <> struct MMRem<5> {
+  static constexpr float c[6] = {1.666671634e-01f, 4.166677967e-02f, 8.330268785e-03f, 1.388406614e-03f,
+                                 2.037364029e-04f, 2.544890958e-05f};
 };
 
-// sum_r w_r * x_r * P_DEG(x_r) over the 16 register pairs of a wave tile.  The Horner steps run
+// sum_r w_r * x_r^3 * R_DEG(x_r) over the 16 register pairs of a wave tile.  The Horner steps run
 // "vertically" over the pairs so that consecutive v_pk_fma_f32 are independent.
 template <int DEG>
-__device__ __forceinline__ f32x2 mm_weighted_expm1(const f32x2 (&xx)[16], const f32x2 (&wrow)[2][8]) {
+__device__ __forceinline__ f32x2 mm_weighted_rem(const f32x2 (&xx)[16], const f32x2 (&wrow)[2][8]) {
   f32x2 pp[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(MM_PK(MMPoly<DEG>::c[DEG]), xx[r], MM_PK(MMPoly<DEG>::c[DEG - 1]));
+  for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(MM_PK(MMRem<DEG>::c[DEG]), xx[r], MM_PK(MMRem<DEG>::c[DEG - 1]));
 #pragma unroll
   for (int k = DEG - 2; k >= 0; --k)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(pp[r], xx[r], MM_PK(MMPoly<DEG>::c[k]));
+    for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(pp[r], xx[r], MM_PK(MMRem<DEG>::c[k]));
   f32x2 parts[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const f32x2 wx = wrow[r >> 3][r & 7] * xx[r];          // w_i * x
-    parts[r & 3] = mm_pkfma(wx, pp[r], parts[r & 3]);       // += w_i * x * P(x)
+    const f32x2 tv = (xx[r] * xx[r]) * pp[r];              // x^2 * R(x)
+    parts[r & 3] = mm_pkfma(tv, wx, parts[r & 3]);          // += w_i * x^3 * R(x)
   }
   return (parts[0] + parts[1]) + (parts[2] + parts[3]);
 }
 
-__device__ __forceinline__ float mm_expm1_p7(float x) {
-  float p = fmaf(MM_P7_C7, x, MM_P7_C6);
-  p = fmaf(p, x, MM_P7_C5); p = fmaf(p, x, MM_P7_C4); p = fmaf(p, x, MM_P7_C3);
-  p = fmaf(p, x, MM_P7_C2); p = fmaf(p, x, MM_P7_C1); p = fmaf(p, x, MM_P7_C0);
-  return p * x;
+__device__ __forceinline__ float mm_rem_p5(float x) {       // r(x) on [-1, 1]
+  float p = fmaf(MMRem<5>::c[5], x, MMRem<5>::c[4]);
+  p = fmaf(p, x, MMRem<5>::c[3]); p = fmaf(p, x, MMRem<5>::c[2]);
+  p = fmaf(p, x, MMRem<5>::c[1]); p = fmaf(p, x, MMRem<5>::c[0]);
+  return (x * x) * p * x;
 }
 
 // ND8: number of 8-wide blocks of input dimensions (d <= 8 * ND8).
@@ -269,27 +230,25 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
       for (int r = 0; r < 16; ++r) xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
       f32x2 part2;
       // wave-uniform tier choice (ballots, no cross-lane reduction)
-      if (!__any(mx > 0.015625f)) {
-        part2 = mm_weighted_expm1<2>(xx, wrow);
-      } else if (!__any(mx > 0.0625f)) {
-        part2 = mm_weighted_expm1<3>(xx, wrow);
+      if (!__any(mx > 0.0625f)) {
+        part2 = mm_weighted_rem<1>(xx, wrow);
       } else if (!__any(mx > 0.25f)) {
-        part2 = mm_weighted_expm1<4>(xx, wrow);
+        part2 = mm_weighted_rem<3>(xx, wrow);
       } else if (!__any(mx > 0.5f)) {
-        part2 = mm_weighted_expm1<5>(xx, wrow);
+        part2 = mm_weighted_rem<4>(xx, wrow);
       } else if (!__any(mx > 1.0f)) {
-        part2 = mm_weighted_expm1<7>(xx, wrow);
+        part2 = mm_weighted_rem<5>(xx, wrow);
       } else {
         part2 = (f32x2){0.0f, 0.0f};
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
           for (int e2 = 0; e2 < 2; ++e2) {
-            // |delta| > 1: exp2 on the transcendental unit (relative error ~ |x| * 6e-8)
+            // |b| > 1: exp2 on the transcendental unit, then the three leading terms subtracted
             const float x = xx[r][e2];
             const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
-            const float big = __builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f;
-            const float e = (fabsf(x) <= 1.0f) ? mm_expm1_p7(xs) : big;
+            const float big = (__builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f) - fmaf(0.5f * x, x, x);
+            const float e = (fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big;
             part2[e2] = fmaf(wrow[r >> 3][r & 7][e2], e, part2[e2]);
           }
       }

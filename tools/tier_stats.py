@@ -17,7 +17,7 @@ out = ops.rollout_closed(pm, mu0, S0, H, keep_trajectory=True)
 tmu, tS = out[-2], out[-1]
 Z = torch.tensor(syn.Z, dtype=torch.float64, device=dev); ls = torch.tensor(syn.lengthscales, dtype=torch.float64, device=dev)
 if Z.ndim == 2: Z = Z.expand(L, M, d)
-edges = [0.015625, 0.0625, 0.25, 0.5, 1.0]
+edges = [1 / 512, 1 / 256, 1 / 128, 0.015625, 1 / 32, 0.0625, 0.25, 0.5, 1.0]
 for h in (0, 5, 10, 20, 39):
   hist = np.zeros(len(edges) + 1); n = 0; trS = []
   for b in (0, 17, 101, 255):
@@ -32,4 +32,5 @@ for h in (0, 5, 10, 20, 39):
       zc = Z[a2] - Z[a2].mean(0)
       bij = (A @ zc.T).abs()[:1984, :1984].reshape(31, 64, 62, 32).amax(dim=(1, 3)).flatten().cpu().numpy()
       hist += np.histogram(bij, bins=[0] + edges + [1e30])[0]; n += bij.size
-  print(f"step {h:2d} mean diag(S) {np.mean(trS):.4f}  tile max|b| <=1/64 {hist[0]/n:.2f} <=1/16 {hist[1]/n:.2f} <=.25 {hist[2]/n:.2f} <=.5 {hist[3]/n:.2f} <=1 {hist[4]/n:.2f} >1 {hist[5]/n:.2f}")
+  names = ["<=1/512", "<=1/256", "<=1/128", "<=1/64", "<=1/32", "<=1/16", "<=1/4", "<=1/2", "<=1", ">1"]
+  print(f"step {h:2d} mean diag(S) {np.mean(trS):.4f}  tile max|b|: " + " ".join(f"{nm} {v / n:.2f}" for nm, v in zip(names, hist)))
