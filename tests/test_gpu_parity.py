@@ -4,9 +4,10 @@ Tolerances (max abs error / max abs value of the tensor):
   float64: 1e-9 on f1 / cross, 1e-6 on Sff -- the oracle itself carries cond(Kuu) * eps from
            its O(M^3) triangular solves (Kuu + 1e-6 I has condition numbers ~1e7 here; the two
            algebraically identical routes differ by ~1e-8 on the worst case), measured <= 1.3e-8.
-  float32: 1e-5 on f1 / cross, 2e-3 on Sff -- the state, outputs and the off-diagonal M x M
-           reduce are f32 (diagonal pairs stay f64, DESIGN.md "fp32 error budget");
-           measured <= 2.6e-4.
+  float32: 2e-6 on f1 / cross, 2e-5 on Sff -- the state and the outputs are f32; the diagonal pairs are
+           reduced in f64 and the off-diagonal pairs take their constant + linear + quadratic part
+           from f64 weight moments, only the O(b^3) remainder is reduced in f32 (DESIGN.md "fp32 error
+           budget"); measured <= 1.4e-6 (it was 2.6e-4 while the whole expm1 was summed in f32).
 """
 import numpy as np
 import pytest
@@ -21,7 +22,7 @@ from tests.helpers import (gp_model_from_oracle, oracle_params, random_svgp_para
 pytestmark = pytest.mark.gpu
 
 TOL = {torch.float64: dict(f1=1e-9, Sff=1e-6, cross=1e-9),
-       torch.float32: dict(f1=1e-5, Sff=2e-3, cross=1e-5)}
+       torch.float32: dict(f1=2e-6, Sff=2e-5, cross=2e-6)}
 
 CASES = [
     # name,        L, M,   d, B, scale
@@ -143,7 +144,7 @@ def test_euler_and_rollout(dtype, device):
   pm = model.packed(dtype, True, device)
   mu_t, S_t = to_dev(mu, device, dtype), to_dev(Sigma, device, dtype)
   m1, S1, tmu, tS = ops.rollout_closed(pm, mu_t, S_t, 5, dt=1.0, keep_trajectory=True)
-  tol = 1e-6 if dtype == torch.float64 else 2e-3
+  tol = 1e-6 if dtype == torch.float64 else 2e-5
   for h in range(5):
     assert scale_err(tmu[h], traj[h][0]) < tol
     assert scale_err(tS[h], traj[h][1]) < tol
@@ -228,7 +229,7 @@ def test_mfma_kernels_match_generic(shape, dtype, device):
   _, Sff_gen, _ = ops.moment_match(pm, mu_t, S_t, force_generic=True)
   scale = np.abs(Sffo).max()
   # the two f64 kernels sum the ill-conditioned C term (|C| up to 1/jitter) in different orders
-  tol = 1e-6 if dtype == torch.float64 else 1e-3
+  tol = 1e-6 if dtype == torch.float64 else 1e-5
   assert float((Sff_fast - Sff_gen).abs().max()) / scale < tol
   assert scale_err(Sff_fast, Sffo) < TOL[dtype]["Sff"]
   # diagonal-only and mean-only variants go through the same kernels
