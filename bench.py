@@ -190,9 +190,10 @@ def main():
     roofline["executed_mfma_bf16"] = {"achieved": round(mfma_flops / (k_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
                                       "unit": "TFLOP/s", "frac": round(mfma_flops / (k_ms * 1e-3) / 2.5e15, 4)}
     roofline["note"] = ("achieved = algorithmic f32 flops, E*(2d+12); the 2d part executes on the bf16 matrix pipe "
-                        "(3 MFMAs per 8 dims, f32-equivalent accuracy) and the expm1 degree adapts to the tile range "
-                        "(2..7 instead of a fixed 12-flop budget), so the fraction of the f32 peak can exceed 1; "
-                        "MFMA and f32 FMA VALU time add on a SIMD (tools/ubench_overlap.hip)")
+                        "(3 MFMAs per 8 dims, f32-equivalent accuracy); the tile kernel reduces the remainder "
+                        "expm1(b)-b-b^2/2 with a range-adaptive polynomial (5..9 VALU ops per entry) while the constant, "
+                        "linear and quadratic parts come from f64 weight moments at O(M d^2), so the fraction of the "
+                        "f32 peak can exceed 1; MFMA and f32 FMA VALU time add on a SIMD (tools/ubench_overlap.hip)")
   # second kernel of the step: the diagonal pairs, always f64 (upper-triangular tiles)
   ed = float(B) * L * M * (M + 1) / 2
   roofline_diag = {"bound": "mfma", "kernel": "k_qred_generic" if args.force_generic else "k_qred_f64_mfma",
