@@ -168,9 +168,10 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
           pm[j] = mm[2 * j] | (mm[2 * j + 1] << 16);
           pl[j] = ll[2 * j] | (ll[2 * j + 1] << 16);
         }
-        // MFMA1: (m,m) | (l,h)   MFMA2: (h,l) | (m,h)   MFMA3: (h,m) | (h,h)   [lane half 0 | 1]
-        a1[rt][nb] = __builtin_bit_cast(bf16x8, h ? pl : pm);
-        a2v[rt][nb] = __builtin_bit_cast(bf16x8, h ? pm : ph);
+        // MFMA1: (m,m) | (m,h)   MFMA3: (h,m) | (h,h)   MFMA2: (h,l) | (l,h)     [lane half 0 | 1]
+        // MFMA1 + MFMA3 alone are the 2-way (16-bit) product; MFMA2 adds the 2^-16 terms
+        a1[rt][nb] = __builtin_bit_cast(bf16x8, pm);
+        a2v[rt][nb] = __builtin_bit_cast(bf16x8, h ? pl : ph);
         a3[rt][nb] = __builtin_bit_cast(bf16x8, ph);
       }
 #pragma unroll
@@ -200,18 +201,29 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
       wc = wcf[ct * 32 + l31];
     };
 
-    auto mfma_tile = [&](const u32x4 (&zA)[ND8], const u32x4 (&zB)[ND8], f32x16 (&acc)[2]) {
+    // b_ij in two stages.  Stage 1: the 2-way split product (h + m parts, 2^-17 relative): enough when the
+    // whole tile has |b| <= 1/64 -- the kernel only reduces r(b) = O(b^3), whose sensitivity to an error
+    // in b is b^2/2.  Stage 2 (wave-uniform, only for larger tiles): the (h,l) and (l,h) terms.
+    auto mfma_tile_hm = [&](const u32x4 (&zA)[ND8], f32x16 (&acc)[2]) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int nb = 0; nb < ND8; ++nb) {
           const bf16x8 bA = __builtin_bit_cast(bf16x8, zA[nb]);
-          const bf16x8 bB = __builtin_bit_cast(bf16x8, zB[nb]);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[rt][nb], bA, c, 0, 0, 0);   // smallest terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v[rt][nb], bB, c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[rt][nb], bA, c, 0, 0, 0);   // smaller terms first
           c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[rt][nb], bA, c, 0, 0, 0);
         }
+        acc[rt] = c;
+      }
+    };
+    auto mfma_tile_l = [&](const u32x4 (&zB)[ND8], f32x16 (&acc)[2]) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        f32x16 c = acc[rt];
+#pragma unroll
+        for (int nb = 0; nb < ND8; ++nb)
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2v[rt][nb], __builtin_bit_cast(bf16x8, zB[nb]), c, 0, 0, 0);
         acc[rt] = c;
       }
     };
@@ -264,11 +276,15 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
     load_tile(0, zA0, zB0, w0);
     for (int ct = 0; ct < nct; ct += 2) {
       load_tile(ct + 1, zA1, zB1, w1);
-      mfma_tile(zA0, zB0, acc);
-      reduce_tile(acc, tile_max(acc), w0);
+      mfma_tile_hm(zA0, acc);
+      float mx = tile_max(acc);
+      if (__any(mx > 0.015625f)) mfma_tile_l(zB0, acc);
+      reduce_tile(acc, mx, w0);
       load_tile(ct + 2 < nct ? ct + 2 : ct, zA0, zB0, w0);      // clamped: the last pass re-reads its own tile
-      mfma_tile(zA1, zB1, acc);
-      reduce_tile(acc, tile_max(acc), w1);
+      mfma_tile_hm(zA1, acc);
+      mx = tile_max(acc);
+      if (__any(mx > 0.015625f)) mfma_tile_l(zB1, acc);
+      reduce_tile(acc, mx, w1);
     }
   }
   // workgroup reduction -> slab
