@@ -183,14 +183,16 @@ def main():
               "kernel_ms": round(k_ms, 4),
               "flops_per_launch": flops, "entries_per_launch": entries}
   if f32_mfma:
-    # executed work (DESIGN.md "f32 reduce roofline"): the bilinear form runs as a 3-way bf16 split
-    # product, 6 v_mfma_f32_32x32x16_bf16 per 64 x 32 wave tile and 8 input dims
+    # executed work (DESIGN.md "f32 reduce roofline"): the bilinear form runs as a bf16 split product,
+    # 4 v_mfma_f32_32x32x16_bf16 per 64 x 32 wave tile and 8 input dims, 6 for tiles with max|b| > 1/64:
+    # the figure below is the 6-MFMA upper bound
     nd8 = (d + 7) // 8
     mfma_flops = entries / 2048.0 * 6 * nd8 * 32768.0
     roofline["executed_mfma_bf16"] = {"achieved": round(mfma_flops / (k_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
-                                      "unit": "TFLOP/s", "frac": round(mfma_flops / (k_ms * 1e-3) / 2.5e15, 4)}
+                                      "unit": "TFLOP/s", "frac": round(mfma_flops / (k_ms * 1e-3) / 2.5e15, 4),
+                                      "bound": "upper (6 MFMAs per wave tile; 4 on tiles with max|b| <= 1/64)"}
     roofline["note"] = ("achieved = algorithmic f32 flops, E*(2d+12); the 2d part executes on the bf16 matrix pipe "
-                        "(3 MFMAs per 8 dims, f32-equivalent accuracy); the tile kernel reduces the remainder "
+                        "(2-3 MFMAs per 8 dims); the tile kernel reduces the remainder "
                         "expm1(b)-b-b^2/2 with a range-adaptive polynomial (5..9 VALU ops per entry) while the constant, "
                         "linear and quadratic parts come from f64 weight moments at O(M d^2), so the fraction of the "
                         "f32 peak can exceed 1; MFMA and f32 FMA VALU time add on a SIMD (tools/ubench_overlap.hip)")
