@@ -63,6 +63,8 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   return o;
 }
 
+// k_wmoments: workgroups per (batch tile, pair, side), each summing its slice of the m range
+#define MM_MOM_SPLIT 4
 // Rows per workgroup of the generic reduce kernel / columns per workgroup.
 #define MM_GEN_ROWS 64
 #define MM_GEN_COLS 256
@@ -87,7 +89,8 @@ struct MMWorkspaceLayout {
   size_t f1raw;    // [B][L] f64      sum_i w_i (f1 without the mean)
   size_t whR;      // [B][Po][Mp] f64  what_i  = w_i e^{rho'_i}   (f32 mode: row weights, unrounded)
   size_t whC;      // [B][Po][Mp] f64  what'_j = w'_j e^{gamma_j}
-  size_t mom;      // [B][Po][2][KMp] f64  sum_m what_m (1, zc_m, zc_m zc_m^T): row side, column side
+  size_t mom;      // [B][Po][2][MM_MOM_SPLIT][KMp] f64  partial sums over m of what_m (1, zc_m, zc_m zc_m^T):
+                   //                  row side, column side; MM_MOM_SPLIT slices of the m range
   size_t s12;      // [B][Po] f64  linear + quadratic part of the off-diagonal sums (+ the O(M) correction)
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
   size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i expm1(delta_ij) q_j  (+ q^T C q)
@@ -127,7 +130,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   const size_t nwh = dtype == MM_F64 ? 0 : (size_t)B * o.Po * o.Mp;
   o.whR = off;     off = mm_align_up(off + nwh * 8, A);
   o.whC = off;     off = mm_align_up(off + nwh * 8, A);
-  o.mom = off;     off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * 2 * mm_moment_cols(d) * 8), A);
+  o.mom = off;     off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * 2 * MM_MOM_SPLIT * mm_moment_cols(d) * 8), A);
   o.s12 = off;     off = mm_align_up(off + (size_t)B * o.Po * 8, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
   o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);

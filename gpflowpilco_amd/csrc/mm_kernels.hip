@@ -532,15 +532,13 @@ template <int NC>
 __global__ __launch_bounds__(256) void k_wmoments(const double* __restrict__ whR, const double* __restrict__ whC,
                                                   const double* __restrict__ Zm, int KMp, int ncg,
                                                   int L, int Mp, int B, int Po, double* __restrict__ mom) {
-  const int side = blockIdx.z, po = blockIdx.y;
+  const int side = blockIdx.z / MM_MOM_SPLIT, ms = blockIdx.z % MM_MOM_SPLIT, po = blockIdx.y;
   const int bt = blockIdx.x / ncg, cg = blockIdx.x - bt * ncg;
   int a, a2;
   mm_decode_pair(L + po, L, a, a2);
   const double* W = side ? whC : whR;
   const double* tab = Zm + (size_t)(side ? a2 : a) * Mp * KMp;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
-  const int brow = bt * 16 + l15;
-  const double* wrow = W + ((size_t)(brow < B ? brow : B - 1) * Po + po) * Mp;
   const int nct = KMp / 16;
   int coff[NC];
 #pragma unroll
@@ -551,12 +549,39 @@ __global__ __launch_bounds__(256) void k_wmoments(const double* __restrict__ whR
   f64x4k acc[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) acc[c] = (f64x4k){0.0, 0.0, 0.0, 0.0};
-  const int mq = Mp / 4;                                 // Mp % 128 == 0: every wave gets whole K = 4 steps
-  for (int m0 = wv * mq; m0 < (wv + 1) * mq; m0 += 4) {
-    const double av = wrow[m0 + kq];
-    const double* tr = tab + (size_t)(m0 + kq) * KMp;
+  // The A operand wants, per lane, 4 consecutive m of ONE batch row (16 rows 458 KB apart): read
+  // straight from memory that is 16 32-byte segments per load.  Instead each wave stages a
+  // [16 batch rows][64 m] block through LDS: 16 fully coalesced 512-byte row reads (the next block's
+  // are in flight while this one is consumed), then the operands come from LDS.
+  __shared__ double wst[4][16][66];                      // +2: rows 528 B apart spread the LDS banks
+  const double* wbase = W + ((size_t)(bt * 16) * Po + po) * Mp + lane;
+  const size_t rstride = (size_t)Po * Mp;
+  auto load_block = [&](int m0, double (&v)[16]) {
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tr[coff[c]], acc[c], 0, 0, 0);
+    for (int r = 0; r < 16; ++r) {
+      const int br = bt * 16 + r;
+      v[r] = wbase[(size_t)(br < B ? r : (B - 1 - bt * 16)) * rstride + m0];
+    }
+  };
+  // 64-row blocks: wave wv of slice ms takes blocks (ms * 4 + wv), + 4 MM_MOM_SPLIT, ... of the Mp / 64
+  double cur[16], nxt[16];
+  const int mend = Mp, mstep = 256 * MM_MOM_SPLIT, mfirst = (ms * 4 + wv) * 64;
+  load_block(mfirst < mend ? mfirst : 0, cur);
+  for (int mb = mfirst; mb < mend; mb += mstep) {
+    load_block(mb + mstep < mend ? mb + mstep : mb, nxt);    // unconditional (clamped): see the pathwise kernel
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wst[wv][r][lane] = cur[r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+    for (int s4 = 0; s4 < 16; ++s4) {
+      const double av = wst[wv][l15][4 * s4 + kq];
+      const double* tr = tab + (size_t)(mb + 4 * s4 + kq) * KMp;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tr[coff[c]], acc[c], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cur[r] = nxt[r];
   }
   __shared__ double red[4][NC][4][64];
 #pragma unroll
@@ -571,7 +596,7 @@ __global__ __launch_bounds__(256) void k_wmoments(const double* __restrict__ whR
     const int b = bt * 16 + (ln >> 4) + 4 * r;
     if (t < nct && b < B) {
       const double v = (red[0][c][r][ln] + red[1][c][r][ln]) + (red[2][c][r][ln] + red[3][c][r][ln]);
-      mom[(((size_t)b * Po + po) * 2 + side) * KMp + t * 16 + (ln & 15)] = v;
+      mom[((((size_t)b * Po + po) * 2 + side) * MM_MOM_SPLIT + ms) * KMp + t * 16 + (ln & 15)] = v;
     }
   }
 }
@@ -603,8 +628,20 @@ __global__ __launch_bounds__(64) void k_s12(const double* __restrict__ mom, int 
   const int Po = P - L, p = L + po;
   int a, a2;
   mm_decode_pair(p, L, a, a2);
-  const double* n = mom + (((size_t)b * Po + po) * 2 + 0) * KMp;
-  const double* q = mom + (((size_t)b * Po + po) * 2 + 1) * KMp;
+  // the MM_MOM_SPLIT partial moment vectors are summed into LDS first (fixed order)
+  double* n = sm + 3 * d * d + 2 * d;          // [KMp]
+  double* q = n + KMp;                         // [KMp]
+  {
+    const double* nm = mom + (((size_t)b * Po + po) * 2 + 0) * MM_MOM_SPLIT * KMp;
+    const double* qm = mom + (((size_t)b * Po + po) * 2 + 1) * MM_MOM_SPLIT * KMp;
+    for (int k = lane; k < KMp; k += 64) {
+      double sn = 0.0, sq = 0.0;
+#pragma unroll
+      for (int t = 0; t < MM_MOM_SPLIT; ++t) { sn += nm[t * KMp + k]; sq += qm[t * KMp + k]; }
+      n[k] = sn; q[k] = sq;
+    }
+    __syncthreads();
+  }
   const double* pm = pairmat + ((size_t)b * P + p) * (3 * d * d + 1);
   const double n0 = n[0];
   for (int k = lane; k < d; k += 64) {
@@ -964,7 +1001,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     // exact (f64) linear + quadratic part of the off-diagonal sums from the weight moments
     const int nct = ml.KMp / 16;
     const int nc = nct < 4 ? nct : 4, ncg = (nct + nc - 1) / nc;
-    const dim3 grid((unsigned)(((B + 15) / 16) * ncg), (unsigned)wl.Po, 2);
+    const dim3 grid((unsigned)(((B + 15) / 16) * ncg), (unsigned)wl.Po, 2 * MM_MOM_SPLIT);
     const double* Zm = (const double*)(packed + ml.Zm);
     double* mom = (double*)(ws + wl.mom);
 #define MM_WMOM(NC_) hipLaunchKernelGGL((k_wmoments<NC_>), grid, dim3(256), 0, s, (const double*)(ws + wl.whR),      \
@@ -972,7 +1009,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     if (nc == 1) MM_WMOM(1); else if (nc == 2) MM_WMOM(2); else if (nc == 3) MM_WMOM(3); else MM_WMOM(4);
 #undef MM_WMOM
     MM_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_s12<T>), dim3(wl.Po, B), dim3(64), (size_t)(3 * d * d + 2 * d) * sizeof(double), s,
+    hipLaunchKernelGGL((k_s12<T>), dim3(wl.Po, B), dim3(64), (size_t)(3 * d * d + 2 * d + 2 * ml.KMp) * sizeof(double), s,
                        (const double*)mom, ml.KMp, (const double*)pairmat, (const double*)(packed + ml.zbar), mu,
                        L, d, wl.P, (double*)(ws + wl.s12));
   }
