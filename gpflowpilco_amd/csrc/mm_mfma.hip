@@ -135,7 +135,7 @@ __device__ __forceinline__ float mm_rem_p5(float x) {       // r(x) on [-1, 1]
 //   their factored weights what_i; streaming operand: the model's pre-split centred inducing inputs
 //   of latent a' (b-independent, L2-resident) and what'_j per column.
 template <int ND8>
-__global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsigned short* __restrict__ Zs3,
+__global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32_mfma(const unsigned short* __restrict__ Zs3,
                                                           int L, int Mp, int d, int P, int Po, int NS,
                                                           int npanel, int nwork,
                                                           const float* __restrict__ rowO,
@@ -197,10 +197,12 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
         const float4 v = *reinterpret_cast<const float4*>(ra + (size_t)d * Mp + rr);   // factored row weights
         wrow[rt][2 * g + 0] = (f32x2){v.x, v.y};
         wrow[rt][2 * g + 1] = (f32x2){v.z, v.w};
+        if constexpr (ND8 == 1) {
 #pragma unroll
-        for (int q2 = 0; q2 < 2; ++q2) {
-          wc0[rt][2 * g + q2] = wrow[rt][2 * g + q2] * MM_PK(MMRem<1>::c[0]);
-          wc1[rt][2 * g + q2] = wrow[rt][2 * g + q2] * MM_PK(MMRem<1>::c[1]);
+          for (int q2 = 0; q2 < 2; ++q2) {
+            wc0[rt][2 * g + q2] = wrow[rt][2 * g + q2] * MM_PK(MMRem<1>::c[0]);
+            wc1[rt][2 * g + q2] = wrow[rt][2 * g + q2] * MM_PK(MMRem<1>::c[1]);
+          }
         }
       }
     }
@@ -265,7 +267,9 @@ __global__ __launch_bounds__(256, MM_F32_WAVES) void k_qred_f32_mfma(const unsig
       f32x2 part2;
       // wave-uniform tier choice (ballots, no cross-lane reduction)
       if (!__any(mx > 0.0625f)) {
-        part2 = mm_weighted_rem1(xx, wc0, wc1);
+        // (the folded coefficients cost 64 more VGPRs: only where the operand registers leave room, d <= 8)
+        if constexpr (ND8 == 1) part2 = mm_weighted_rem1(xx, wc0, wc1);
+        else part2 = mm_weighted_rem<1>(xx, wrow);
       } else if (!__any(mx > 0.25f)) {
         part2 = mm_weighted_rem<3>(xx, wrow);
       } else if (!__any(mx > 0.5f)) {
