@@ -156,7 +156,7 @@ __device__ __forceinline__ double mmb_expm1_any(double x) {
 // grid (Mp / 64, npairs, B).  SWAP == false: pairs [0, P), out_col [B][P][3 + d][Mp].
 //                             SWAP == true : pairs L + blockIdx.y, out_row [B][Po][2][Mp].
 template <int KS4, int NU, bool SWAP>
-__global__ __launch_bounds__(256, 2) void k_bwd_mfma(const double* __restrict__ Zc, int Kz,
+__global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const double* __restrict__ Zc, int Kz,
                                                      const double* __restrict__ zbar, const double* __restrict__ Cm,
                                                      const double* __restrict__ mu, int L, int Mp, int d, int P,
                                                      const double* __restrict__ w, const double* __restrict__ q,

@@ -98,7 +98,7 @@ struct MMF64Operands {
 // once per workgroup from the C tile.  delta_ij = rho_i + gamma'_j + zc_i . g_j: the two O(1) terms
 // initialise the MFMA accumulator (one add per entry; an extra K step would cost a whole MFMA).
 template <int KS4, bool DIAG, bool WITHC, bool LOWP>
-__global__ __launch_bounds__(256, 2) void k_qred_f64_mfma(const double* __restrict__ Zc, int Kz,
+__global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const double* __restrict__ Zc, int Kz,
                                                           const double* __restrict__ Cm,
                                                           const double* __restrict__ beta, int M,
                                                           int L, int Mp, int d, int P, int NS, int p0,

@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
       const double t = pw_wave_sum63(ps * (double)accp[s] + vr * (double)accu[s]);
       if (lane == 63 && s0 + s < S) {
         double f = t + mc;
-        if (euler) f = (double)xr[s][a < DK ? a : 0] + dt * f;
+        if (euler) f = (double)x[(size_t)(s0 + s) * d + a] + dt * f;     // re-read: no dynamic register indexing
         out[(size_t)(s0 + s) * L + a] = (T)f;
         if (traj) traj[(size_t)(s0 + s) * L + a] = (T)f;
       }
@@ -342,7 +342,9 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
         const double t = pw_wave_sum63(ps * (double)accp[s] + vr * (double)accu[s]);
         if (lane == 63 && s0 + s < S) {
           double f = t + mc;
-          if (euler) f = (double)xr[s][a < DK ? a : 0] + dt * f;
+          // x_a re-read (d == L here): indexing the register array with the runtime latent index would
+          // put it in scratch memory
+          if (euler) f = (double)x[(size_t)(s0 + s) * d + a] + dt * f;
           out[(size_t)(s0 + s) * L + a] = (T)f;
           if (traj) traj[(size_t)(s0 + s) * L + a] = (T)f;
         }
