@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
     for (int k = 0; k < 16; ++k) acc += stage[bl][j * 16 + ((k + j) & 15)];
     part16[bl][j] = acc;
     __syncthreads();
-    if (threadIdx.x < nb) {
+    if ((int)threadIdx.x < nb) {
       double tot = 0.0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) tot += part16[threadIdx.x][k];
