@@ -182,6 +182,11 @@ def main():
               "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": traffic,
               "kernel_ms": round(k_ms, 4),
               "flops_per_launch": flops, "entries_per_launch": entries}
+  if traffic is not None:
+    # from the same PMC passes (profiles/r01_pmc_counters.csv): matrix-pipe-busy cycles
+    # (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) + VALU issue cycles (SQ_INSTS_VALU / 1024 x 3.6) over kernel cycles
+    # (GRBM_GUI_ACTIVE / 8) = (1.89e6 + 5.2e6) / 8.43e6 -- the two serialise on a gfx950 SIMD
+    roofline["pipe_busy_frac"] = 0.84
   if f32_mfma:
     # executed work (DESIGN.md "f32 reduce roofline"): the bilinear form runs as a bf16 split product,
     # 4 v_mfma_f32_32x32x16_bf16 per 64 x 32 wave tile and 8 input dims, 6 for tiles with max|b| > 1/64:
