@@ -78,7 +78,7 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 struct MMWorkspaceLayout {
   int Mp, P, Po, NS;
   size_t pairmat;  // [B][P][3 d^2 + 1] f64: G, Drow, Dcol, const
-  size_t latmat;   // [B][L][d^2 + 1]   f64: (Sigma + Lambda_a)^-1, log-normaliser
+  size_t latmat;   // [B][L][d^2 + 2]   f64: (Sigma + Lambda_a)^-1, log-normaliser, log det(Sigma + Lambda_a)
   size_t w64;      // [B][L][Mp] f64  beta_i q_i
   size_t q64;      // [B][L][Mp] f64  q_i = <k_a(x, z_i)>
   size_t w;        // [B][L][Mp] T    (aliases w64 when T is f64)
@@ -116,7 +116,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.NS = ns;
   size_t off = 0;
   o.pairmat = off; off = mm_align_up(off + (size_t)B * o.P * (3 * d * d + 1) * 8, A);
-  o.latmat = off;  off = mm_align_up(off + (size_t)B * L * (d * d + 1) * 8, A);
+  o.latmat = off;  off = mm_align_up(off + (size_t)B * L * (d * d + 2) * 8, A);
   o.w64 = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.q64 = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.w = o.w64;

@@ -208,7 +208,10 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
                                              int L, int d, int P,
                                              const T* __restrict__ mu, const T* __restrict__ Sigma,
                                              double* __restrict__ pairmat, double* __restrict__ latmat,
-                                             int32_t* status) {
+                                             int32_t* status, int pairs_pass) {
+  // two launches: pairs_pass == 0: the L latent items (blockIdx.x = a); pairs_pass == 1: the P pair items,
+  // which take (Sigma + Lambda_a)^-1 and its log-determinant from the latent pass instead of
+  // refactorising them (one Cholesky-inverse per pair instead of three)
   extern __shared__ double smem[];
   const int dp = d + 1, msz = d * dp;
   double* Sg = smem;            // Sigma_b (symmetrised from the lower triangle)
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
   double* A2 = A1 + msz;        // (Sigma + Lambda_a')^-1
   double* Tm = A2 + msz;        // T
   double* Y = Tm + msz;         // scratch
-  const int lane = threadIdx.x, item = blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x, item = pairs_pass ? blockIdx.x : P + blockIdx.x, b = blockIdx.y;
   bool ok = true;
   const T* Sb = Sigma + (size_t)b * d * d;
   for (int idx = lane; idx < d * d; idx += 64) {
@@ -234,12 +237,13 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
       A1[i * dp + j] = Sg[i * dp + j] + (i == j ? la[i] : 0.0);
     }
     const double ld = mm_spd_inverse(A1, Y, d, dp, &ok);
-    double* out = latmat + ((size_t)b * L + a) * (d * d + 1);
+    double* out = latmat + ((size_t)b * L + a) * (d * d + 2);
     for (int idx = lane; idx < d * d; idx += 64) { const int i = idx / d, j = idx - i * d; out[idx] = A1[i * dp + j]; }
     if (lane == 0) {
       double sl = 0.0;
       for (int k = 0; k < d; ++k) sl += log(la[k]);
       out[d * d] = log(var[a]) + 0.5 * sl - 0.5 * ld;
+      out[d * d + 1] = ld;
     }
   } else {
     int a, a2;
@@ -251,12 +255,12 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
       const double s = Sg[i * dp + j];
       const double v = la[i] * lb[i] / (la[i] + lb[i]);   // kernel_expectation.py:119
       A0[i * dp + j] = s + (i == j ? v : 0.0);
-      A1[i * dp + j] = s + (i == j ? la[i] : 0.0);
-      A2[i * dp + j] = s + (i == j ? lb[i] : 0.0);
+      A1[i * dp + j] = latmat[((size_t)b * L + a) * (d * d + 2) + idx];       // (Sigma + Lambda_a)^-1
+      A2[i * dp + j] = latmat[((size_t)b * L + a2) * (d * d + 2) + idx];      // (Sigma + Lambda_a')^-1
     }
     const double ldS = mm_spd_inverse(A0, Y, d, dp, &ok);
-    const double ldA = mm_spd_inverse(A1, Y, d, dp, &ok);
-    const double ldB = mm_spd_inverse(A2, Y, d, dp, &ok);
+    const double ldA = latmat[((size_t)b * L + a) * (d * d + 2) + d * d + 1];
+    const double ldB = latmat[((size_t)b * L + a2) * (d * d + 2) + d * d + 1];
     // T = V S^-1 Sigma (product form: no cancellation), symmetrised below
     for (int idx = lane; idx < d * d; idx += 64) {
       const int i = idx / d, j = idx - i * d;
@@ -322,7 +326,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
   __shared__ double mub[MM_DMAX];
   __shared__ double red[4];
   __shared__ double sv[MM_DMAX + 1];
-  const double* lm = latmat + ((size_t)b * L + a) * (d * d + 1);
+  const double* lm = latmat + ((size_t)b * L + a) * (d * d + 2);
   for (int idx = tid; idx < d * d; idx += 256) Pa[idx] = lm[idx];
   if (tid < d) mub[tid] = (double)mu[(size_t)b * d + tid];
   __syncthreads();
@@ -977,8 +981,11 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   double* pairmat = (double*)(ws + wl.pairmat);
   double* latmat = (double*)(ws + wl.latmat);
   const size_t shm = (size_t)6 * d * (d + 1) * sizeof(double);
-  hipLaunchKernelGGL((k_prep<T>), dim3(wl.P + L, B), dim3(64), shm, s,
-                     ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status);
+  hipLaunchKernelGGL((k_prep<T>), dim3(L, B), dim3(64), shm, s,
+                     ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 0);
+  MM_CHECK_LAUNCH();
+  hipLaunchKernelGGL((k_prep<T>), dim3(wl.P, B), dim3(64), shm, s,
+                     ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 1);
   MM_CHECK_LAUNCH();
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
                      Z64, (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
