@@ -209,9 +209,10 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
                                              const T* __restrict__ mu, const T* __restrict__ Sigma,
                                              double* __restrict__ pairmat, double* __restrict__ latmat,
                                              int32_t* status, int pairs_pass) {
-  // two launches: pairs_pass == 0: the L latent items (blockIdx.x = a); pairs_pass == 1: the P pair items,
-  // which take (Sigma + Lambda_a)^-1 and its log-determinant from the latent pass instead of
-  // refactorising them (one Cholesky-inverse per pair instead of three)
+  // pairs_pass == 0: the L latent items (blockIdx.x = a); pairs_pass == 1: the P pair items, which take
+  // (Sigma + Lambda_a)^-1 and its log-determinant from the latent pass instead of refactorising them (one
+  // Cholesky-inverse per pair instead of three); pairs_pass == 2: all P + L items in ONE launch, pairs
+  // self-contained -- for small problems, where a launch boundary costs more than the factorisations
   extern __shared__ double smem[];
   const int dp = d + 1, msz = d * dp;
   double* Sg = smem;            // Sigma_b (symmetrised from the lower triangle)
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
   double* A2 = A1 + msz;        // (Sigma + Lambda_a')^-1
   double* Tm = A2 + msz;        // T
   double* Y = Tm + msz;         // scratch
-  const int lane = threadIdx.x, item = pairs_pass ? blockIdx.x : P + blockIdx.x, b = blockIdx.y;
+  const int lane = threadIdx.x, item = pairs_pass == 0 ? P + blockIdx.x : blockIdx.x, b = blockIdx.y;
   bool ok = true;
   const T* Sb = Sigma + (size_t)b * d * d;
   for (int idx = lane; idx < d * d; idx += 64) {
@@ -255,12 +256,23 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
       const double s = Sg[i * dp + j];
       const double v = la[i] * lb[i] / (la[i] + lb[i]);   // kernel_expectation.py:119
       A0[i * dp + j] = s + (i == j ? v : 0.0);
-      A1[i * dp + j] = latmat[((size_t)b * L + a) * (d * d + 2) + idx];       // (Sigma + Lambda_a)^-1
-      A2[i * dp + j] = latmat[((size_t)b * L + a2) * (d * d + 2) + idx];      // (Sigma + Lambda_a')^-1
+      if (pairs_pass == 1) {
+        A1[i * dp + j] = latmat[((size_t)b * L + a) * (d * d + 2) + idx];       // (Sigma + Lambda_a)^-1
+        A2[i * dp + j] = latmat[((size_t)b * L + a2) * (d * d + 2) + idx];      // (Sigma + Lambda_a')^-1
+      } else {
+        A1[i * dp + j] = s + (i == j ? la[i] : 0.0);
+        A2[i * dp + j] = s + (i == j ? lb[i] : 0.0);
+      }
     }
     const double ldS = mm_spd_inverse(A0, Y, d, dp, &ok);
-    const double ldA = latmat[((size_t)b * L + a) * (d * d + 2) + d * d + 1];
-    const double ldB = latmat[((size_t)b * L + a2) * (d * d + 2) + d * d + 1];
+    double ldA, ldB;
+    if (pairs_pass == 1) {
+      ldA = latmat[((size_t)b * L + a) * (d * d + 2) + d * d + 1];
+      ldB = latmat[((size_t)b * L + a2) * (d * d + 2) + d * d + 1];
+    } else {                       // single-launch mode (small problems): self-contained, three factorisations
+      ldA = mm_spd_inverse(A1, Y, d, dp, &ok);
+      ldB = mm_spd_inverse(A2, Y, d, dp, &ok);
+    }
     // T = V S^-1 Sigma (product form: no cancellation), symmetrised below
     for (int idx = lane; idx < d * d; idx += 64) {
       const int i = idx / d, j = idx - i * d;
@@ -981,12 +993,18 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   double* pairmat = (double*)(ws + wl.pairmat);
   double* latmat = (double*)(ws + wl.latmat);
   const size_t shm = (size_t)6 * d * (d + 1) * sizeof(double);
-  hipLaunchKernelGGL((k_prep<T>), dim3(L, B), dim3(64), shm, s,
-                     ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 0);
-  MM_CHECK_LAUNCH();
-  hipLaunchKernelGGL((k_prep<T>), dim3(wl.P, B), dim3(64), shm, s,
-                     ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 1);
-  MM_CHECK_LAUNCH();
+  if ((long long)(wl.P + L) * B <= 4096) {
+    hipLaunchKernelGGL((k_prep<T>), dim3(wl.P + L, B), dim3(64), shm, s,
+                       ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 2);
+    MM_CHECK_LAUNCH();
+  } else {
+    hipLaunchKernelGGL((k_prep<T>), dim3(L, B), dim3(64), shm, s,
+                       ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 0);
+    MM_CHECK_LAUNCH();
+    hipLaunchKernelGGL((k_prep<T>), dim3(wl.P, B), dim3(64), shm, s,
+                       ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 1);
+    MM_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
                      Z64, (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
                      L, M, wl.Mp, d, mu, latmat, (double*)(ws + wl.w64), (double*)(ws + wl.q64), (T*)(ws + wl.w),
