@@ -34,6 +34,11 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
   a = i; a2 = i + 1 + r;
 }
 
+// largest tile range max|b| for which the 2-way (h + m) product is used without the (h,l)/(l,h) terms
+// (measured at C3: 1/64, 1/32 and 1/16 all leave the Sff error at 3.5e-6; 1/32 keeps a factor 4 in hand)
+#ifndef MM_TWO_WAY_MAX
+#define MM_TWO_WAY_MAX 0.03125f
+#endif
 #ifndef MM_F32_WAVES
 #define MM_F32_WAVES 2
 #endif
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     };
 
     // b_ij in two stages.  Stage 1: the 2-way split product (h + m parts, 2^-17 relative): enough when the
-    // whole tile has |b| <= 1/64 -- the kernel only reduces r(b) = O(b^3), whose sensitivity to an error
+    // whole tile has |b| <= MM_TWO_WAY_MAX (1/32) -- the kernel only reduces r(b) = O(b^3), whose sensitivity to an error
     // in b is b^2/2.  Stage 2 (wave-uniform, only for larger tiles): the (h,l) and (l,h) terms.
     auto mfma_tile_hm = [&](const u32x4 (&zA)[ND8], f32x16 (&acc)[2]) {
 #pragma unroll
@@ -304,12 +309,12 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
       load_tile(ct + 1, zA1, zB1, w1);
       mfma_tile_hm(zA0, acc);
       float mx = tile_max(acc);
-      if (__any(mx > 0.015625f)) mfma_tile_l(zB0, acc);
+      if (__any(mx > MM_TWO_WAY_MAX)) mfma_tile_l(zB0, acc);
       reduce_tile(acc, mx, w0);
       load_tile(ct + 2 < nct ? ct + 2 : ct, zA0, zB0, w0);      // clamped: the last pass re-reads its own tile
       mfma_tile_hm(zA1, acc);
       mx = tile_max(acc);
-      if (__any(mx > 0.015625f)) mfma_tile_l(zB1, acc);
+      if (__any(mx > MM_TWO_WAY_MAX)) mfma_tile_l(zB1, acc);
       reduce_tile(acc, mx, w1);
     }
   }
