@@ -21,6 +21,8 @@ static inline int mm_moment_cols(int d) { return mm_round_up_int(1 + d + d * (d 
 struct MMModelLayout {
   int Mp, Kz, nd8, KMp;
   size_t Z64;     // [L][M][d]  f64 raw inducing inputs (prep stages run in f64)
+  size_t Zt64;    // [L][d][Mp] f64 the same, dimension-major and zero padded: a wave reading one
+                  //            dimension of 64 consecutive points is one 512-byte segment (k_qvec, k_pairvec)
   size_t zbar;    // [L][d]     f64 per-latent centroid of Z (centres the MFMA A operand)
   size_t ls2;     // [L][d]     f64 squared lengthscales (Lambda)
   size_t var;     // [L]        f64 kernel variances
@@ -45,6 +47,7 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   o.KMp = mm_moment_cols(d);
   size_t off = 0;
   o.Z64 = off;    off = mm_align_up(off + (size_t)L * M * d * 8, A);
+  o.Zt64 = off;   off = mm_align_up(off + (size_t)L * d * o.Mp * 8, A);
   o.zbar = off;   off = mm_align_up(off + (size_t)L * d * 8, A);
   o.ls2 = off;    off = mm_align_up(off + (size_t)L * d * 8, A);
   o.var = off;    off = mm_align_up(off + (size_t)L * 8, A);
@@ -77,8 +80,10 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 // term, whose conditioning rules out f32); off-diagonal pairs (p >= L) in T.
 struct MMWorkspaceLayout {
   int Mp, P, Po, NS;
-  size_t pairmat;  // [B][P][3 d^2 + 1] f64: G, Drow, Dcol, const
-  size_t latmat;   // [B][L][d^2 + 2]   f64: (Sigma + Lambda_a)^-1, log-normaliser, log det(Sigma + Lambda_a)
+  size_t pairmat;  // [B][P][d^2 + 1] f64: G, const
+  size_t latmat;   // [B][L][2 d^2 + 2] f64: P_a = (Sigma + Lambda_a)^-1, log-normaliser, log det(Sigma + Lambda_a),
+                   //                   E_a = sym(Lambda_a^-1 Sigma P_a)
+  size_t rho1;     // [B][L][Mp] f64  zeta_i^T E_a zeta_i (the pair-independent part of rho_i / gamma_j)
   size_t w64;      // [B][L][Mp] f64  beta_i q_i
   size_t q64;      // [B][L][Mp] f64  q_i = <k_a(x, z_i)>
   size_t w;        // [B][L][Mp] T    (aliases w64 when T is f64)
@@ -115,8 +120,9 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   if (dtype == MM_F64 && o.Po > 0 && nt * nt > ns) ns = nt * nt;  // f64 MFMA kernel, off-diagonal
   o.NS = ns;
   size_t off = 0;
-  o.pairmat = off; off = mm_align_up(off + (size_t)B * o.P * (3 * d * d + 1) * 8, A);
-  o.latmat = off;  off = mm_align_up(off + (size_t)B * L * (d * d + 2) * 8, A);
+  o.pairmat = off; off = mm_align_up(off + (size_t)B * o.P * (d * d + 1) * 8, A);
+  o.latmat = off;  off = mm_align_up(off + (size_t)B * L * (2 * d * d + 2) * 8, A);
+  o.rho1 = off;    off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.w64 = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.q64 = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.w = o.w64;

@@ -140,6 +140,13 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
     ((double*)(packed + lay.meanc))[a] = mean_c ? mean_c[a] : 0.0;
   }
   for (int idx = tid; idx < M * d; idx += 256) Z64[idx] = Z[(size_t)a * M * d + idx];
+  {
+    double* Zt = (double*)(packed + lay.Zt64) + (size_t)a * d * lay.Mp;
+    for (int idx = tid; idx < d * lay.Mp; idx += 256) {
+      const int k = idx / lay.Mp, m = idx - k * lay.Mp;
+      Zt[idx] = m < M ? Z[((size_t)a * M + m) * d + k] : 0.0;
+    }
+  }
   for (int m = tid; m < M; m += 256) b64[m] = beta[(size_t)a * M + m];
   for (int idx = tid; idx < lay.Mp * lay.Kz; idx += 256) {
     const int m = idx / lay.Kz, k = idx - m * lay.Kz;
@@ -238,13 +245,23 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
       A1[i * dp + j] = Sg[i * dp + j] + (i == j ? la[i] : 0.0);
     }
     const double ld = mm_spd_inverse(A1, Y, d, dp, &ok);
-    double* out = latmat + ((size_t)b * L + a) * (d * d + 2);
+    double* out = latmat + ((size_t)b * L + a) * (2 * d * d + 2);
     for (int idx = lane; idx < d * d; idx += 64) { const int i = idx / d, j = idx - i * d; out[idx] = A1[i * dp + j]; }
     if (lane == 0) {
       double sl = 0.0;
       for (int k = 0; k < d; ++k) sl += log(la[k]);
       out[d * d] = log(var[a]) + 0.5 * sl - 0.5 * ld;
       out[d * d + 1] = ld;
+    }
+    // E_a = sym(Lambda_a^-1 Sigma P_a) (= Lambda_a^-1 - P_a, in product form: no cancellation for small Sigma)
+    for (int idx = lane; idx < d * d; idx += 64) {
+      const int i = idx / d, j = idx - i * d;
+      double s1 = 0.0, t1 = 0.0;
+      for (int k = 0; k < d; ++k) {
+        s1 += Sg[i * dp + k] * A1[k * dp + j];
+        t1 += Sg[j * dp + k] * A1[k * dp + i];
+      }
+      out[d * d + 2 + idx] = 0.5 * (s1 / la[i] + t1 / la[j]);
     }
   } else {
     int a, a2;
@@ -256,10 +273,7 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
       const double s = Sg[i * dp + j];
       const double v = la[i] * lb[i] / (la[i] + lb[i]);   // kernel_expectation.py:119
       A0[i * dp + j] = s + (i == j ? v : 0.0);
-      if (pairs_pass == 1) {
-        A1[i * dp + j] = latmat[((size_t)b * L + a) * (d * d + 2) + idx];       // (Sigma + Lambda_a)^-1
-        A2[i * dp + j] = latmat[((size_t)b * L + a2) * (d * d + 2) + idx];      // (Sigma + Lambda_a')^-1
-      } else {
+      if (pairs_pass != 1) {      // single-launch mode: the two log-determinants are factorised here
         A1[i * dp + j] = s + (i == j ? la[i] : 0.0);
         A2[i * dp + j] = s + (i == j ? lb[i] : 0.0);
       }
@@ -267,8 +281,8 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
     const double ldS = mm_spd_inverse(A0, Y, d, dp, &ok);
     double ldA, ldB;
     if (pairs_pass == 1) {
-      ldA = latmat[((size_t)b * L + a) * (d * d + 2) + d * d + 1];
-      ldB = latmat[((size_t)b * L + a2) * (d * d + 2) + d * d + 1];
+      ldA = latmat[((size_t)b * L + a) * (2 * d * d + 2) + d * d + 1];
+      ldB = latmat[((size_t)b * L + a2) * (2 * d * d + 2) + d * d + 1];
     } else {                       // single-launch mode (small problems): self-contained, three factorisations
       ldA = mm_spd_inverse(A1, Y, d, dp, &ok);
       ldB = mm_spd_inverse(A2, Y, d, dp, &ok);
@@ -286,25 +300,11 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
       Tm[i * dp + j] = 0.5 * (Y[i * dp + j] + Y[j * dp + i]);
     }
     __syncthreads();
-    double* out = pairmat + ((size_t)b * P + item) * (3 * d * d + 1);
-    // G = Lambda_a^-1 T Lambda_a'^-1
+    double* out = pairmat + ((size_t)b * P + item) * (d * d + 1);
+    // G = Lambda_a^-1 T Lambda_a'^-1   (rho_i, gamma_j follow from G and the per-latent E_a: k_pairvec)
     for (int idx = lane; idx < d * d; idx += 64) {
       const int i = idx / d, j = idx - i * d;
       out[idx] = Tm[i * dp + j] / (la[i] * lb[j]);
-    }
-    // Drow = Lambda_a^-1 Sigma P_a - Lambda_a^-1 T Lambda_a^-1 ; Dcol likewise with a'
-    for (int idx = lane; idx < d * d; idx += 64) {
-      const int i = idx / d, j = idx - i * d;
-      double s1 = 0.0, s2 = 0.0, t1 = 0.0, t2 = 0.0;
-      for (int k = 0; k < d; ++k) {
-        s1 += Sg[i * dp + k] * A1[k * dp + j];
-        t1 += Sg[j * dp + k] * A1[k * dp + i];
-        s2 += Sg[i * dp + k] * A2[k * dp + j];
-        t2 += Sg[j * dp + k] * A2[k * dp + i];
-      }
-      const double tij = Tm[i * dp + j];
-      out[d * d + idx] = 0.5 * (s1 / la[i] + t1 / la[j]) - tij / (la[i] * la[j]);
-      out[2 * d * d + idx] = 0.5 * (s2 / lb[i] + t2 / lb[j]) - tij / (lb[i] * lb[j]);
     }
     if (lane == 0) {
       double lv = 0.0, sla = 0.0, slb = 0.0;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
         sla += log(la[k]); slb += log(lb[k]);
       }
       // log kappa_ab - lognorm_a - lognorm_a'  (the variances cancel)
-      out[3 * d * d] = -0.5 * ldS + 0.5 * lv - 0.5 * sla - 0.5 * slb + 0.5 * ldA + 0.5 * ldB;
+      out[d * d] = -0.5 * ldS + 0.5 * lv - 0.5 * sla - 0.5 * slb + 0.5 * ldA + 0.5 * ldB;
     }
   }
   if (!ok && lane == 0 && status) {
@@ -331,15 +331,15 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
                                               int L, int M, int Mp, int d,
                                               const T* __restrict__ mu, const double* __restrict__ latmat,
                                               double* __restrict__ w64, double* __restrict__ q64, T* __restrict__ w,
-                                              double* __restrict__ f1raw,
+                                              double* __restrict__ f1raw, double* __restrict__ rho1,
                                               T* __restrict__ f1, T* __restrict__ cross, T* __restrict__ q_out) {
   const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  __shared__ double Pa[MM_DMAX * MM_DMAX];
+  __shared__ double Pa[MM_DMAX * MM_DMAX], Ea[MM_DMAX * MM_DMAX];
   __shared__ double mub[MM_DMAX];
   __shared__ double red[4];
   __shared__ double sv[MM_DMAX + 1];
-  const double* lm = latmat + ((size_t)b * L + a) * (d * d + 2);
-  for (int idx = tid; idx < d * d; idx += 256) Pa[idx] = lm[idx];
+  const double* lm = latmat + ((size_t)b * L + a) * (2 * d * d + 2);
+  for (int idx = tid; idx < d * d; idx += 256) { Pa[idx] = lm[idx]; Ea[idx] = lm[d * d + 2 + idx]; }
   if (tid < d) mub[tid] = (double)mu[(size_t)b * d + tid];
   __syncthreads();
   const double lognorm = lm[d * d];
@@ -350,8 +350,9 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
   double* wb64 = w64 + ((size_t)b * L + a) * Mp;
   double* qb64 = q64 + ((size_t)b * L + a) * Mp;
   T* wb = w + ((size_t)b * L + a) * Mp;
+  double* r1 = rho1 + ((size_t)b * L + a) * Mp;
   for (int m = tid; m < Mp; m += 256) {
-    double wv = 0.0, qv = 0.0;
+    double wv = 0.0, qv = 0.0, rv = 0.0;
     if (m < M) {
       double z[DK];
 #pragma unroll
@@ -360,10 +361,11 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
 #pragma unroll
       for (int i = 0; i < DK; ++i) {
         if (i < d) {
-          double t = 0.0;
+          double t = 0.0, te = 0.0;
 #pragma unroll
-          for (int k = 0; k < DK; ++k) if (k < d) t += Pa[i * d + k] * z[k];
+          for (int k = 0; k < DK; ++k) if (k < d) { t += Pa[i * d + k] * z[k]; te += Ea[i * d + k] * z[k]; }
           maha += z[i] * t;
+          rv += z[i] * te;                                   // zeta^T E_a zeta
         }
       }
       qv = exp(lognorm - 0.5 * maha);
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
     }
     wb64[m] = wv;
     qb64[m] = qv;
+    r1[m] = rv;
     if (sizeof(T) != 8) wb[m] = (T)wv;
   }
   const double f = mm_block_sum256(acc_f, red);
@@ -400,139 +403,150 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
 // k_pairvec: streamed operands of the reduce.  grid (Mp/256, P, B)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int DK>
-__global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Z64, const double* __restrict__ zbar,
-                                                 int L, int M, int Mp, int d, int P,
+__global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64, const double* __restrict__ zbar,
+                                                 const double* __restrict__ ls2, int L, int M, int Mp, int d, int P,
                                                  const T* __restrict__ mu, const double* __restrict__ pairmat,
+                                                 const double* __restrict__ rho1,
                                                  double* __restrict__ rowD, double* __restrict__ colD,
                                                  T* __restrict__ rowO, T* __restrict__ colO,
                                                  const double* __restrict__ w64, double* __restrict__ whR,
                                                  double* __restrict__ whC, int nblk) {
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
-  // pair's matrices are fetched and staged once per workgroup, not once per chunk (at one chunk per
-  // workgroup the kernel was bound by that fetch -> barrier -> fetch Z latency chain)
+  // pair's matrix is fetched once per workgroup, not once per chunk
   const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   int a, a2;
   mm_decode_pair(p, L, a, a2);
-  // the per-(b, pair) matrices zero-padded to DK x DK (row stride DK) and the vectors to DK: every k loop
-  // below is unconditional straight-line code (with `if (k < d)` inside, the loops stay rolled and
-  // each LDS read is followed by its own s_waitcnt)
-  __shared__ double G[DK * DK], Dr[DK * DK], Dc[DK * DK];
-  __shared__ double mub[DK], dmu[DK], dmu2[DK];
-  const double* pm = pairmat + ((size_t)b * P + p) * (3 * d * d + 1);
-  for (int idx = tid; idx < DK * DK; idx += 256) {
-    const int i = idx / DK, k = idx - i * DK;
-    const bool in = i < d && k < d;
-    const int src = in ? i * d + k : 0;
-    const double g = pm[src], dr = pm[d * d + src], dc = pm[2 * d * d + src];
-    G[idx] = in ? g : 0.0; Dr[idx] = in ? dr : 0.0; Dc[idx] = in ? dc : 0.0;
+  // With zeta = z - mu, A_i = G^T zeta_i (row side, latent a), g_j = G zeta'_j (column side, latent a'):
+  //   zeta_i^T D_row zeta_i   = rho1_a[i]  - sum_k zeta_ik  A_ik Lam_a',k / Lam_a,k
+  //   zeta'_j^T D_col zeta'_j = rho1_a'[j] - sum_k zeta'_jk g_jk Lam_a,k  / Lam_a',k
+  // (D_row = E_a - Lam_a^-1 T Lam_a^-1, T Lam_a^-1 zeta = Lam_a' A; rho1 = zeta^T E zeta comes from k_qvec),
+  // so only G is needed per pair.  For d <= 8 every thread keeps G in registers (128 VGPRs): the two
+  // mat-vecs per row are then pure register FMAs (staged in LDS, each FMA needed a broadcast ds_read and
+  // the loop was LDS-issue bound); for larger d, G is read from LDS row by row.
+  constexpr bool GREG = DK <= 8;
+  __shared__ double Gs[GREG ? 1 : DK * DK];
+  __shared__ double vecs[5][DK];                             // mu, mu - zbar_a, mu - zbar_a', Lam_a'/Lam_a, Lam_a/Lam_a'
+  const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
+  double Gr[GREG ? DK * DK : 1];
+  if (GREG) {
+#pragma unroll
+    for (int idx = 0; idx < DK * DK; ++idx) {
+      const int i = idx / DK, k = idx - i * DK;
+      const bool in = i < d && k < d;
+      const double g = pm[in ? i * d + k : 0];               // uniform address: scalar load
+      Gr[idx] = in ? g : 0.0;
+    }
+  } else {
+    for (int idx = tid; idx < DK * DK; idx += 256) {
+      const int i = idx / DK, k = idx - i * DK;
+      const bool in = i < d && k < d;
+      const double g = pm[in ? i * d + k : 0];
+      Gs[idx] = in ? g : 0.0;
+    }
   }
   if (tid < DK) {
     const int k = tid < d ? tid : 0;
     const double mv = (double)mu[(size_t)b * d + k];
-    mub[tid] = tid < d ? mv : 0.0;
-    dmu[tid] = tid < d ? mv - zbar[a * d + k] : 0.0;     // the A operand is centred at zbar_a, not at mu_b
-    dmu2[tid] = tid < d ? mv - zbar[a2 * d + k] : 0.0;
+    const double la = ls2[a * d + k], lb = ls2[a2 * d + k];
+    vecs[0][tid] = tid < d ? mv : 0.0;
+    vecs[1][tid] = tid < d ? mv - zbar[a * d + k] : 0.0;    // the A operand is centred at zbar_a, not at mu_b
+    vecs[2][tid] = tid < d ? mv - zbar[a2 * d + k] : 0.0;
+    vecs[3][tid] = tid < d ? lb / la : 0.0;                  // Lam_a',k / Lam_a,k
+    vecs[4][tid] = tid < d ? la / lb : 0.0;
   }
   __syncthreads();
-  const double cst = pm[3 * d * d];
+  const double cst = pm[d * d];
   const bool diag = p < L;
   const int Po = P - L;
-  if (!diag && sizeof(T) == 4) {
-    // f32 off-diagonal format (mm_mfma.hip).  With A_i = G^T zeta_i and b_ij = A_i . zc^{a'}_j,
-    //   delta_ij = rho'_i + gamma_j + b_ij,  rho'_i = rho_i + const - A_i . (mu - zbar_a'),
-    // exp(delta) - 1 = e^{rho'_i} e^{gamma_j} (expm1(b_ij) + 1) - 1, hence
-    //   S = sum_ij what_i what'_j expm1(b_ij) + (sum_i what_i)(sum_j what'_j) - (sum_i w_i)(sum_j w'_j)
-    // with what_i = w_i e^{rho'_i}, what'_j = w'_j e^{gamma_j}: the M x M tile is a pure bilinear form.
-    // The f64 weights are kept as well: their moments against (1, zc, zc zc^T) give the O(M) correction
-    // and the linear + quadratic part of the sum exactly (k_wmoments / k_s12); the tile kernel only
-    // reduces the remainder expm1(b) - b - b^2/2 in f32.
-    T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
-    T* cO = colO + ((size_t)b * Po + (p - L)) * Mp;
-    double* hR = whR + ((size_t)b * Po + (p - L)) * Mp;
-    double* hC = whC + ((size_t)b * Po + (p - L)) * Mp;
-    for (int mblk = blockIdx.x; mblk < nblk; mblk += gridDim.x) {
-      const int m = mblk * 256 + tid;
-      if (m >= Mp) continue;
-      // centred inducing inputs of row / column index m (clamped loads, zero beyond d or M)
-      const int mm = m < M ? m : M - 1;
-      double zr[DK], zc[DK];
-#pragma unroll
-      for (int k = 0; k < DK; ++k) {
-        const int kk = k < d ? k : 0;
-        const double vr = Z64[((size_t)a * M + mm) * d + kk] - mub[k];
-        const double vc = Z64[((size_t)a2 * M + mm) * d + kk] - mub[k];
-        zr[k] = (k < d && m < M) ? vr : 0.0;
-        zc[k] = (k < d && m < M) ? vc : 0.0;
-      }
-      double rho = 0.0, gam = 0.0, corr = 0.0;
-#pragma unroll 2      // not fully: the compiler would hoist all 3 DK^2 LDS reads (> 256 VGPRs at DK = 8)
-      for (int i = 0; i < DK; ++i) {
-        double tr = 0.0, tc = 0.0, av = 0.0;
-#pragma unroll
-        for (int k = 0; k < DK; ++k) {
-          tr = fma(Dr[i * DK + k], zr[k], tr);
-          tc = fma(Dc[i * DK + k], zc[k], tc);
-          av = fma(G[k * DK + i], zr[k], av);
-        }
-        rho = fma(zr[i], tr, rho);
-        gam = fma(zc[i], tc, gam);
-        corr = fma(dmu2[i], av, corr);
-        if (i < d) rO[(size_t)i * Mp + m] = (T)av;          // zero for the padding rows m >= M
-      }
-      double whr = 0.0, whc = 0.0;
-      if (m < M) {
-        whr = w64[((size_t)b * L + a) * Mp + m] * exp(-0.5 * rho + cst - corr);
-        whc = w64[((size_t)b * L + a2) * Mp + m] * exp(-0.5 * gam);
-      }
-      rO[(size_t)d * Mp + m] = (T)whr;
-      cO[m] = (T)whc;
-      hR[m] = whr;
-      hC[m] = whc;
-    }
-    return;
-  }
+  const double* r1a = rho1 + ((size_t)b * L + a) * Mp;
+  const double* r1b = rho1 + ((size_t)b * L + a2) * Mp;
+  // f32 off-diagonal format (mm_mfma.hip).  With b_ij = A_i . zc^{a'}_j,
+  //   delta_ij = rho'_i + gamma_j + b_ij,  rho'_i = rho_i + const - A_i . (mu - zbar_a'),
+  // exp(delta) - 1 = e^{rho'_i} e^{gamma_j} (expm1(b_ij) + 1) - 1, hence
+  //   S = sum_ij what_i what'_j expm1(b_ij) + (sum_i what_i)(sum_j what'_j) - (sum_i w_i)(sum_j w'_j)
+  // with what_i = w_i e^{rho'_i}, what'_j = w'_j e^{gamma_j}: the M x M tile is a pure bilinear form.
+  // The f64 weights are kept as well: their moments against (1, zc, zc zc^T) give the O(M) correction
+  // and the linear + quadratic part of the sum exactly (k_wmoments / k_s12); the tile kernel only
+  // reduces the remainder expm1(b) - b - b^2/2 in f32.
+  const bool f32off = !diag && sizeof(T) == 4;
+  T* rO = rowO + ((size_t)b * Po + (f32off ? p - L : 0)) * (size_t)(d + 1) * Mp;
+  T* cO = colO + ((size_t)b * Po + (f32off ? p - L : 0)) * Mp;
+  double* hR = whR + ((size_t)b * Po + (f32off ? p - L : 0)) * Mp;
+  double* hC = whC + ((size_t)b * Po + (f32off ? p - L : 0)) * Mp;
   // diagonal pairs (p < L) stream f64 operands, off-diagonal pairs of the f64 mode likewise
   double* raD = rowD + ((size_t)b * L + (diag ? p : 0)) * Mp;
   double* cbD = colD + ((size_t)b * L + (diag ? p : 0)) * (size_t)(d + 1) * Mp;
   T* raO = rowO + ((size_t)b * Po + (diag ? 0 : p - L)) * Mp;
   T* cbO = colO + ((size_t)b * Po + (diag ? 0 : p - L)) * (size_t)(d + 1) * Mp;
-#define MM_PV_STORE_ROW(v_) do { if (diag) raD[m] = (v_); else raO[m] = (T)(v_); } while (0)
-#define MM_PV_STORE_COL(k_, v_) do { if (diag) cbD[(size_t)(k_) * Mp + m] = (v_); else cbO[(size_t)(k_) * Mp + m] = (T)(v_); } while (0)
   for (int mblk = blockIdx.x; mblk < nblk; mblk += gridDim.x) {
     const int m = mblk * 256 + tid;
     if (m >= Mp) continue;
     // centred inducing inputs of row / column index m (clamped loads, zero beyond d or M)
-    const int mm = m < M ? m : M - 1;
     double zr[DK], zc[DK];
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
       const int kk = k < d ? k : 0;
-      const double vr = Z64[((size_t)a * M + mm) * d + kk] - mub[k];
-      const double vc = Z64[((size_t)a2 * M + mm) * d + kk] - mub[k];
+      const double vr = Zt64[((size_t)a * d + kk) * Mp + m] - vecs[0][k];      // dimension-major: coalesced over m
+      const double vc = Zt64[((size_t)a2 * d + kk) * Mp + m] - vecs[0][k];
       zr[k] = (k < d && m < M) ? vr : 0.0;
       zc[k] = (k < d && m < M) ? vc : 0.0;
     }
-    double rho = 0.0, gam = 0.0, corr = 0.0;
-#pragma unroll 2
-    for (int i = 0; i < DK; ++i) {
-      double tr = 0.0, tc = 0.0, g = 0.0;
-#pragma unroll
-      for (int k = 0; k < DK; ++k) {
-        tr = fma(Dr[i * DK + k], zr[k], tr);
-        tc = fma(Dc[i * DK + k], zc[k], tc);
-        g = fma(G[i * DK + k], zc[k], g);
+    // A = G^T zr, g = G zc (for a diagonal pair G is symmetric and zr == zc: A == g)
+    double tA = 0.0, tg = 0.0, corrA = 0.0, corrg = 0.0;
+    auto row = [&](int i, double av, double gv) {
+      tA = fma(zr[i] * vecs[3][i], av, tA);
+      tg = fma(zc[i] * vecs[4][i], gv, tg);
+      corrA = fma(vecs[2][i], av, corrA);
+      corrg = fma(vecs[1][i], gv, corrg);
+      if (i < d) {
+        if (f32off) rO[(size_t)i * Mp + m] = (T)av;           // zero for the padding rows m >= M
+        else if (diag) cbD[(size_t)i * Mp + m] = gv;
+        else cbO[(size_t)i * Mp + m] = (T)gv;
       }
-      rho = fma(zr[i], tr, rho);
-      gam = fma(zc[i], tc, gam);
-      corr = fma(dmu[i], g, corr);
-      if (i < d) MM_PV_STORE_COL(i, g);                       // zero for the padding rows m >= M
+    };
+    if (GREG) {
+#pragma unroll
+      for (int i = 0; i < DK; ++i) {
+        double av = 0.0, gv = 0.0;
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+          gv = fma(Gr[(GREG ? i * DK + k : 0)], zc[k], gv);
+          av = fma(Gr[(GREG ? k * DK + i : 0)], zr[k], av);
+        }
+        row(i, av, gv);
+      }
+    } else {
+#pragma unroll 2      // not fully: the compiler would hoist all the LDS reads (> 256 VGPRs)
+      for (int i = 0; i < DK; ++i) {
+        double av = 0.0, gv = 0.0;
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+          gv = fma(Gs[(GREG ? 0 : i * DK + k)], zc[k], gv);
+          av = fma(Gs[(GREG ? 0 : k * DK + i)], zr[k], av);
+        }
+        row(i, av, gv);
+      }
     }
-    MM_PV_STORE_ROW(m < M ? -0.5 * rho : 0.0);
-    // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j
-    MM_PV_STORE_COL(d, m < M ? -0.5 * gam + cst - corr : 0.0);
+    const double rho_q = (m < M) ? r1a[m] - tA : 0.0;           // zeta_i^T D_row zeta_i
+    const double gam_q = (m < M) ? r1b[m] - tg : 0.0;           // zeta'_j^T D_col zeta'_j
+    if (f32off) {
+      double whr = 0.0, whc = 0.0;
+      if (m < M) {
+        whr = w64[((size_t)b * L + a) * Mp + m] * exp(-0.5 * rho_q + cst - corrA);
+        whc = w64[((size_t)b * L + a2) * Mp + m] * exp(-0.5 * gam_q);
+      }
+      rO[(size_t)d * Mp + m] = (T)whr;
+      cO[m] = (T)whc;
+      hR[m] = whr;
+      hC[m] = whc;
+    } else {
+      // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j
+      const double rowv = -0.5 * rho_q;
+      const double colv = (m < M) ? -0.5 * gam_q + cst - corrg : 0.0;
+      if (diag) { raD[m] = rowv; cbD[(size_t)d * Mp + m] = colv; }
+      else { raO[m] = (T)rowv; cbO[(size_t)d * Mp + m] = (T)colv; }
+    }
   }
-#undef MM_PV_STORE_ROW
-#undef MM_PV_STORE_COL
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -658,7 +672,7 @@ __global__ __launch_bounds__(64) void k_s12(const double* __restrict__ mom, int 
     }
     __syncthreads();
   }
-  const double* pm = pairmat + ((size_t)b * P + p) * (3 * d * d + 1);
+  const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
   const double n0 = n[0];
   for (int k = lane; k < d; k += 64) {
     const double dm = (double)mu[(size_t)b * d + k] - zbar[a * d + k];
@@ -1008,7 +1022,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
                      Z64, (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
                      L, M, wl.Mp, d, mu, latmat, (double*)(ws + wl.w64), (double*)(ws + wl.q64), (T*)(ws + wl.w),
-                     (double*)(ws + wl.f1raw), f1, cross, q_out);
+                     (double*)(ws + wl.f1raw), (double*)(ws + wl.rho1), f1, cross, q_out);
   MM_CHECK_LAUNCH();
   {
     const int nblk = (wl.Mp + 255) / 256;                  // 256-row chunks = wsum slots per (b, pair)
@@ -1017,7 +1031,8 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     if (nsplit > nblk) nsplit = nblk;
     if (nsplit < 1) nsplit = 1;
     hipLaunchKernelGGL((k_pairvec<T, DK>), dim3(nsplit, wl.P, B), dim3(256), 0, s,
-                       Z64, (const double*)(packed + ml.zbar), L, M, wl.Mp, d, wl.P, mu, pairmat,
+                       (const double*)(packed + ml.Zt64), (const double*)(packed + ml.zbar), ls2, L, M, wl.Mp, d, wl.P, mu, pairmat,
+                       (const double*)(ws + wl.rho1),
                        (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO),
                        (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), nblk);
   }
