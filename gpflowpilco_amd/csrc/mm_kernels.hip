@@ -424,6 +424,29 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   // mat-vecs per row are then pure register FMAs (staged in LDS, each FMA needed a broadcast ds_read and
   // the loop was LDS-issue bound); for larger d, G is read from LDS row by row.
   constexpr bool GREG = DK <= 8;
+  // the chunk loop is a load -> compute -> store chain per wave.  For d <= 8 the next chunk's operands are
+  // loaded (unconditionally, index-clamped) before the current chunk is processed, and the first chunk's
+  // before the workgroup's prologue (G fetch, LDS vectors, barrier); for larger d the extra live registers
+  // would halve the occupancy, so chunks are loaded in place.
+  constexpr bool PF = GREG;
+  const double* r1a = rho1 + ((size_t)b * L + a) * Mp;
+  const double* r1b = rho1 + ((size_t)b * L + a2) * Mp;
+  struct Ops { double zr[DK], zc[DK], r1r, r1c, wr, wc; };
+  auto load_ops = [&](int mblk, Ops& o) {
+    int m = mblk * 256 + tid;
+    m = m < Mp ? m : Mp - 1;
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+      const int kk = k < d ? k : 0;
+      o.zr[k] = Zt64[((size_t)a * d + kk) * Mp + m];        // dimension-major: coalesced over m
+      o.zc[k] = Zt64[((size_t)a2 * d + kk) * Mp + m];
+    }
+    o.r1r = r1a[m]; o.r1c = r1b[m];
+    o.wr = w64[((size_t)b * L + a) * Mp + m];
+    o.wc = w64[((size_t)b * L + a2) * Mp + m];
+  };
+  Ops cur, nxt;
+  if (PF) load_ops(blockIdx.x, cur);
   __shared__ double Gs[GREG ? 1 : DK * DK];
   __shared__ double vecs[5][DK];                             // mu, mu - zbar_a, mu - zbar_a', Lam_a'/Lam_a, Lam_a/Lam_a'
   const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
@@ -458,8 +481,6 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   const double cst = pm[d * d];
   const bool diag = p < L;
   const int Po = P - L;
-  const double* r1a = rho1 + ((size_t)b * L + a) * Mp;
-  const double* r1b = rho1 + ((size_t)b * L + a2) * Mp;
   // f32 off-diagonal format (mm_mfma.hip).  With b_ij = A_i . zc^{a'}_j,
   //   delta_ij = rho'_i + gamma_j + b_ij,  rho'_i = rho_i + const - A_i . (mu - zbar_a'),
   // exp(delta) - 1 = e^{rho'_i} e^{gamma_j} (expm1(b_ij) + 1) - 1, hence
@@ -479,18 +500,19 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   T* raO = rowO + ((size_t)b * Po + (diag ? 0 : p - L)) * Mp;
   T* cbO = colO + ((size_t)b * Po + (diag ? 0 : p - L)) * (size_t)(d + 1) * Mp;
   for (int mblk = blockIdx.x; mblk < nblk; mblk += gridDim.x) {
+    if (PF) load_ops(mblk + (int)gridDim.x < nblk ? mblk + (int)gridDim.x : mblk, nxt);
+    else load_ops(mblk, cur);
     const int m = mblk * 256 + tid;
-    if (m >= Mp) continue;
-    // centred inducing inputs of row / column index m (clamped loads, zero beyond d or M)
+    // centred inducing inputs of row / column index m (zero beyond d or M)
     double zr[DK], zc[DK];
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
-      const int kk = k < d ? k : 0;
-      const double vr = Zt64[((size_t)a * d + kk) * Mp + m] - vecs[0][k];      // dimension-major: coalesced over m
-      const double vc = Zt64[((size_t)a2 * d + kk) * Mp + m] - vecs[0][k];
-      zr[k] = (k < d && m < M) ? vr : 0.0;
-      zc[k] = (k < d && m < M) ? vc : 0.0;
+      zr[k] = (k < d && m < M) ? cur.zr[k] - vecs[0][k] : 0.0;
+      zc[k] = (k < d && m < M) ? cur.zc[k] - vecs[0][k] : 0.0;
     }
+    const double r1r = cur.r1r, r1c = cur.r1c, wrv = cur.wr, wcv = cur.wc;
+    if (PF) cur = nxt;
+    if (m >= Mp) continue;
     // A = G^T zr, g = G zc (for a diagonal pair G is symmetric and zr == zc: A == g)
     double tA = 0.0, tg = 0.0, corrA = 0.0, corrg = 0.0;
     auto row = [&](int i, double av, double gv) {
@@ -527,13 +549,13 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
         row(i, av, gv);
       }
     }
-    const double rho_q = (m < M) ? r1a[m] - tA : 0.0;           // zeta_i^T D_row zeta_i
-    const double gam_q = (m < M) ? r1b[m] - tg : 0.0;           // zeta'_j^T D_col zeta'_j
+    const double rho_q = (m < M) ? r1r - tA : 0.0;              // zeta_i^T D_row zeta_i
+    const double gam_q = (m < M) ? r1c - tg : 0.0;              // zeta'_j^T D_col zeta'_j
     if (f32off) {
       double whr = 0.0, whc = 0.0;
       if (m < M) {
-        whr = w64[((size_t)b * L + a) * Mp + m] * exp(-0.5 * rho_q + cst - corrA);
-        whc = w64[((size_t)b * L + a2) * Mp + m] * exp(-0.5 * gam_q);
+        whr = wrv * exp(-0.5 * rho_q + cst - corrA);
+        whc = wcv * exp(-0.5 * gam_q);
       }
       rO[(size_t)d * Mp + m] = (T)whr;
       cO[m] = (T)whc;
