@@ -195,7 +195,7 @@ def main():
     mfma_flops = entries / 2048.0 * 6 * nd8 * 32768.0
     roofline["executed_mfma_bf16"] = {"achieved": round(mfma_flops / (k_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
                                       "unit": "TFLOP/s", "frac": round(mfma_flops / (k_ms * 1e-3) / 2.5e15, 4),
-                                      "bound": "upper (6 MFMAs per wave tile; 4 on tiles with max|b| <= 1/64)"}
+                                      "bound": "upper (6 MFMAs per wave tile; 4 on tiles with max|b| <= 1/32)"}
     roofline["note"] = ("achieved = algorithmic f32 flops, E*(2d+12); the 2d part executes on the bf16 matrix pipe "
                         "(2-3 MFMAs per 8 dims); the tile kernel reduces the remainder "
                         "expm1(b)-b-b^2/2 with a range-adaptive polynomial (5..9 VALU ops per entry) while the constant, "
