@@ -147,6 +147,9 @@ def main():
   for _ in range(args.warmup):
     one_step(False)
   state["h"] = 0
+  if world > 1 and not args.rehearse_gloo:
+    # the warm-up steps do not reach the end of a rollout: bring up the collective's channels untimed
+    dist.all_gather(gathered, torch.zeros(B, H, dtype=dtype, device=dev))
   fence()
   t0 = time.perf_counter()
   for _ in range(args.steps):
@@ -308,7 +311,9 @@ def pathwise_bench(args, rank, world, dev, dist):
       dist.barrier()
     torch.cuda.synchronize()
 
-  rollout_steps(max(1, args.warmup))
+  warm = rollout_steps(max(1, args.warmup))
+  if world > 1:
+    dist.all_gather([torch.empty_like(warm) for _ in range(world)], warm)   # untimed channel bring-up
   fence()
   e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
   t0 = time.perf_counter()
