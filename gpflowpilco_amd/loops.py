@@ -53,7 +53,7 @@ class GraphedPolicyLoss:
   The reference traces the closure once under ``tf.function`` (pilco.py:219-220); here the equivalent
   is a graph capture: at cartpole sizes one composed rollout step is several hundred small kernels
   and the eager path is bound by the host launching them (measured: 10.7 ms/step forward+backward
-  eager, 2.4 ms/step replayed; 1.36 -> 0.39 ms/step forward only).
+  eager, 2.4 ms/step replayed; 1.5 -> 0.77 ms/step forward only).
 
   Everything the closure reads must live in fixed tensors: the state initializer has to return the SAME
   tensors on every call (``get_state_initializer`` does; write a new initial state into them with
