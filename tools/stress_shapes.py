@@ -1,5 +1,7 @@
 """Randomised shape sweep on the GPU: f32 mode vs f64 mode vs the portable kernels of the same library,
-over odd sizes (M not a multiple of anything, B = 1.., L = 1.., d = 1..12).  Prints the worst case."""
+over odd sizes (M not a multiple of anything, B = 1.., L = 1.., d = 1..12, or up to argv[3]).  Prints the worst case.
+
+  python tools/stress_shapes.py [seed] [cases] [max_d]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,9 +11,10 @@ from gpflowpilco_amd.synthetic import make_inputs, make_svgp
 dev = torch.device("cuda", 0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+dmax = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 worst = {"f32_vs_f64": (0.0, None), "f64_vs_generic": (0.0, None), "f32_vs_generic": (0.0, None)}
 for it in range(n):
-  L = int(rng.integers(1, 6)); M = int(rng.integers(1, 400)); d = int(rng.integers(1, 13)); B = int(rng.integers(1, 24))
+  L = int(rng.integers(1, 6)); M = int(rng.integers(1, 400)); d = int(rng.integers(1, dmax + 1)); B = int(rng.integers(1, 24))
   scale = float(rng.choice([0.02, 0.1, 0.3, 0.8]))
   syn = make_svgp(L, M, d, seed=int(rng.integers(1 << 30)), device=str(dev), ls_bounds=(0.5 + 0.1 * d, 1.5 + 0.3 * d))
   model = syn.to_model(dev)
