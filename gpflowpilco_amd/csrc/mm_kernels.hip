@@ -452,13 +452,16 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
   double Gr[GREG ? DK * DK : 1];
   if (GREG) {
+    // lane l of every wave loads padded entry l (one coalesced load), then the DK * DK <= 64 values are
+    // broadcast with v_readlane.  (Uniform-address loads pm[in ? i * d + k : 0] compiled to 64 serialised
+    // s_load + s_waitcnt pairs behind ~1200 SGPR spill moves: microseconds of prologue per workgroup.)
+    const int ln = tid & 63, li = ln / DK, lk = ln - li * DK;
+    const bool lin = li < d && lk < d && ln < DK * DK;
+    const double mine = lin ? pm[li * d + lk] : 0.0;
+    const int mlo = __double2loint(mine), mhi = __double2hiint(mine);
 #pragma unroll
-    for (int idx = 0; idx < DK * DK; ++idx) {
-      const int i = idx / DK, k = idx - i * DK;
-      const bool in = i < d && k < d;
-      const double g = pm[in ? i * d + k : 0];               // uniform address: scalar load
-      Gr[idx] = in ? g : 0.0;
-    }
+    for (int idx = 0; idx < DK * DK; ++idx)
+      Gr[idx] = __hiloint2double(__builtin_amdgcn_readlane(mhi, idx), __builtin_amdgcn_readlane(mlo, idx));
   } else {
     for (int idx = tid; idx < DK * DK; idx += 256) {
       const int i = idx / DK, k = idx - i * DK;
