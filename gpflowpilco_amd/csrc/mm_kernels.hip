@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
 // k_qvec: q_i, w_i = beta_i q_i, f1, Sigma^-1 Cov(x, f).  One workgroup per (latent, b).
 // ---------------------------------------------------------------------------------------------
 template <typename T, int DK>
-__global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, const double* __restrict__ beta64,
+__global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, const double* __restrict__ beta64,
                                               const double* __restrict__ meanc,
                                               int L, int M, int Mp, int d,
                                               const T* __restrict__ mu, const double* __restrict__ latmat,
@@ -334,13 +334,20 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
                                               double* __restrict__ f1raw, double* __restrict__ rho1,
                                               T* __restrict__ f1, T* __restrict__ cross, T* __restrict__ q_out) {
   const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-  __shared__ double Pa[MM_DMAX * MM_DMAX], Ea[MM_DMAX * MM_DMAX];
-  __shared__ double mub[MM_DMAX];
+  // P_a = (Sigma + Lambda_a)^-1 and E_a, zero padded to DK x DK: compile-time LDS offsets (wide broadcast reads)
+  __shared__ double Pa[DK * DK], Ea[DK * DK];
+  __shared__ double mub[DK];
   __shared__ double red[4];
-  __shared__ double sv[MM_DMAX + 1];
+  __shared__ double sv[DK + 1];
   const double* lm = latmat + ((size_t)b * L + a) * (2 * d * d + 2);
-  for (int idx = tid; idx < d * d; idx += 256) { Pa[idx] = lm[idx]; Ea[idx] = lm[d * d + 2 + idx]; }
-  if (tid < d) mub[tid] = (double)mu[(size_t)b * d + tid];
+  for (int idx = tid; idx < DK * DK; idx += 256) {
+    const int i = idx / DK, k = idx - i * DK;
+    const bool in = i < d && k < d;
+    const int src = in ? i * d + k : 0;
+    const double pv = lm[src], ev = lm[d * d + 2 + src];
+    Pa[idx] = in ? pv : 0.0; Ea[idx] = in ? ev : 0.0;
+  }
+  if (tid < DK) mub[tid] = tid < d ? (double)mu[(size_t)b * d + tid] : 0.0;
   __syncthreads();
   const double lognorm = lm[d * d];
   double acc_f = 0.0;
@@ -356,17 +363,33 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
     if (m < M) {
       double z[DK];
 #pragma unroll
-      for (int k = 0; k < DK; ++k) z[k] = (k < d) ? Z64[((size_t)a * M + m) * d + k] - mub[k] : 0.0;
+      for (int k = 0; k < DK; ++k)                           // dimension-major table: coalesced over m
+        z[k] = Zt64[((size_t)a * d + (k < d ? k : 0)) * Mp + m];
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        // index-clamped loads, made opaque: sunk under `k < d` each becomes a branch + s_waitcnt vmcnt(0)
+        asm volatile("" : "+v"(z[k]));
+        z[k] = (k < d) ? z[k] - mub[k] : 0.0;
+      }
       double maha = 0.0;
+      // opaque copies of the LDS pointers: hoisted out of the row loop, the two matrices would take
+      // 4 DK^2 registers (346 VGPRs at d = 8, scratch beyond)
+      typedef const __attribute__((address_space(3))) double* lds_cptr;     // stays a ds_read (not flat) access
+      lds_cptr Pl = (lds_cptr)Pa; lds_cptr El = (lds_cptr)Ea;
+      asm volatile("" : "+v"(Pl), "+v"(El));
+      auto row = [&](int i) {
+        double t = 0.0, te = 0.0;
 #pragma unroll
-      for (int i = 0; i < DK; ++i) {
-        if (i < d) {
-          double t = 0.0, te = 0.0;
+        for (int k = 0; k < DK; ++k) { t = fma(Pl[i * DK + k], z[k], t); te = fma(El[i * DK + k], z[k], te); }
+        maha = fma(z[i], t, maha);
+        rv = fma(z[i], te, rv);                              // zeta^T E_a zeta
+      };
+      if constexpr (DK <= 8) {
 #pragma unroll
-          for (int k = 0; k < DK; ++k) if (k < d) { t += Pa[i * d + k] * z[k]; te += Ea[i * d + k] * z[k]; }
-          maha += z[i] * t;
-          rv += z[i] * te;                                   // zeta^T E_a zeta
-        }
+        for (int i = 0; i < DK; ++i) row(i);
+      } else {
+#pragma unroll 2
+        for (int i = 0; i < DK; ++i) row(i);
       }
       qv = exp(lognorm - 0.5 * maha);
       wv = beta64[(size_t)a * M + m] * qv;
@@ -394,7 +417,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Z64, co
   if (tid < d) {
     // Sigma^-1 Cov(x, f_a) = P_a sum_i w_i (z_i - mu)      (models.py:263-277)
     double s = 0.0;
-    for (int k = 0; k < d; ++k) s += Pa[tid * d + k] * sv[k];
+    for (int k = 0; k < d; ++k) s += Pa[tid * DK + k] * sv[k];
     cross[((size_t)b * d + tid) * L + a] = (T)s;
   }
 }
@@ -1045,7 +1068,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     MM_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
-                     Z64, (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
+                     (const double*)(packed + ml.Zt64), (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
                      L, M, wl.Mp, d, mu, latmat, (double*)(ws + wl.w64), (double*)(ws + wl.q64), (T*)(ws + wl.w),
                      (double*)(ws + wl.f1raw), (double*)(ws + wl.rho1), f1, cross, q_out);
   MM_CHECK_LAUNCH();
