@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const unsigned int ah = (unsigned int)(__builtin_bit_cast(unsigned long long, acc[rt][ct][r]) >> 32) & 0x7fffffffu;
+          const double av = acc[rt][ct][r];                  // (see mm_f64.hip: bit_cast on a vector element miscompiles)
+          const unsigned int ah = (unsigned int)__double2hiint(av) & 0x7fffffffu;
           mxh = ah > mxh ? ah : mxh;
         }
 #define MMB_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))

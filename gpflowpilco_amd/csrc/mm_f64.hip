@@ -259,7 +259,10 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
       for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const unsigned int hi = (unsigned int)(__builtin_bit_cast(unsigned long long, cacc[rt][ct][r]) >> 32);
+          // (__double2hiint, not bit_cast<u64>(vec[r]) >> 32: on a vector element the latter compiles to a test of
+          // element 0 only with this toolchain -- tools/bitcast_repro.hip)
+          const double cv = cacc[rt][ct][r];
+          const unsigned int hi = (unsigned int)__double2hiint(cv);
           const unsigned int ah = hi & 0x7fffffffu;
           mxh = ah > mxh ? ah : mxh;
         }
