@@ -83,6 +83,37 @@ def test_mfma_backward_sums_match_portable_kernel(shape, unc, device):
       assert float((a_ - b_).abs().amax()) < 1e-10 * max(scale, 1.0), (float((a_ - b_).abs().amax()), scale)
 
 
+def test_mfma_backward_tier_selection_sees_every_row(device):
+  """Same construction as test_gpu_parity.py::test_f64_tier_selection_sees_every_row for k_bwd_mfma:
+  far-away inducing points at rows 5, 22, 47, 62 (large |delta| among them) inside a tight cluster."""
+  from gpflowpilco_amd import _lib, ops
+  rng = np.random.default_rng(12)
+  L, M, d, B = 2, 64, 2, 2
+  Z = 0.5 + 0.01 * rng.standard_normal((L, M, d))
+  beta = rng.standard_normal((L, M))
+  for row in (5, 22, 47, 62):
+    Z[:, row] = 0.5 + np.array([1.0, -0.8]) + 0.02 * rng.standard_normal((L, d))
+    beta[:, row] = 3.0
+  Cm = rng.standard_normal((L, M, M)); Cm = 0.05 * (Cm + Cm.transpose(0, 2, 1))
+  t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=device)
+  pm = ops.pack_model(t64(Z), t64(np.full((L, d), 0.8)), t64(np.ones(L)), t64(beta), t64(Cm), None, dtype=torch.float64)
+  mu_t = to_dev(0.5 + 0.01 * rng.standard_normal((B, d)), device, torch.float64)
+  S_t = to_dev(np.broadcast_to(0.16 * np.eye(d), (B, d, d)).copy(), device, torch.float64)
+  flags = ops.make_flags(True, True)
+  ops.q_forward(pm, mu_t, S_t, flags)
+  ws = pm.workspace(B, flags)
+  n = _lib.lib().mm_backward_bytes(B, L, M, d, flags)
+  outs = []
+  for fl in (flags, flags | _lib.MM_FORCE_GENERIC):
+    out = torch.zeros(n // 8, dtype=torch.float64, device=device)
+    rc = _lib.lib().mm_backward_sums(pm.buf.data_ptr(), pm.nbytes, L, M, d, _lib.MM_F64, B, mu_t.data_ptr(), fl,
+                                     ws.data_ptr(), ws.numel(), out.data_ptr(), n, ops._stream(device))
+    _lib.check(rc, "mm_backward_sums")
+    outs.append(out)
+  scale = float(outs[1].abs().amax())
+  assert float((outs[0] - outs[1]).abs().amax()) < 1e-12 * scale, (float((outs[0] - outs[1]).abs().amax()), scale)
+
+
 @pytest.mark.parametrize("full", [True, False], ids=["full", "diagcov"])
 @pytest.mark.parametrize("unc", [True, False], ids=["unc", "nounc"])
 def test_moment_form_backward_equals_reference_surrogate(full, unc, device):

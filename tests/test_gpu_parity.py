@@ -265,3 +265,29 @@ def test_expected_cost_kernel(dtype, device):
   got = ops.expected_cost(to_dev(mean, device, dtype), to_dev(cov, device, dtype),
                           to_dev(target, device, dtype), to_dev(W, device, dtype))
   assert scale_err(got, want) < (1e-12 if dtype == torch.float64 else 1e-5)
+
+
+def test_f64_tier_selection_sees_every_row(device):
+  """The f64 reduce picks its expm1 Taylor degree from the tile's max |delta|.  A tight cluster of
+  inducing points (|delta| ~ 1e-4) plus four far-away points at rows that are NOT among the first four
+  of their 16-row tile (|delta| ~ 0.4 between them): a range test that samples only some accumulator
+  entries picks the lowest degree and is off by 1e-9 (this happened: tools/bitcast_repro.hip); the
+  portable kernel evaluates expm1 per entry.  (The f32 mode's diagonal pairs run the same code.)"""
+  rng = np.random.default_rng(11)
+  L, M, d, B = 1, 64, 2, 2
+  dtype = torch.float64
+  Z = 0.5 + 0.01 * rng.standard_normal((L, M, d))
+  beta = rng.standard_normal((L, M))
+  for row in (5, 22, 47, 62):
+    Z[0, row] = 0.5 + np.array([1.0, -0.8]) + 0.02 * rng.standard_normal(d)
+    beta[0, row] = 3.0
+  ls = np.full((L, d), 0.8); var = np.ones(L)
+  Cm = rng.standard_normal((L, M, M)); Cm = 0.05 * (Cm + Cm.transpose(0, 2, 1))
+  t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=device)
+  pm = ops.pack_model(t64(Z), t64(ls), t64(var), t64(beta), t64(Cm), None, dtype=dtype)
+  mu = to_dev(0.5 + 0.01 * rng.standard_normal((B, d)), device, dtype)
+  Sigma = to_dev(np.broadcast_to(0.16 * np.eye(d), (B, d, d)).copy(), device, dtype)
+  _, Sff_fast, _ = ops.moment_match(pm, mu, Sigma)
+  _, Sff_gen, _ = ops.moment_match(pm, mu, Sigma, force_generic=True)
+  rel = float((Sff_fast - Sff_gen).abs().max() / Sff_gen.abs().max())
+  assert rel < 1e-12, rel
