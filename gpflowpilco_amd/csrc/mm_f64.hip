@@ -13,8 +13,8 @@
 //               workgroup loops over its chunk of the batch -- C traffic is M^2*8 B per chunk
 //               instead of per batch element; with model uncertainty ONE fused sum
 //               sum_ij q_i q_j (D_ij expm1(delta_ij) + C_ij), D = C + beta beta^T;
-//   expm1     : wave-uniform Taylor tiers by the tile's range (degree 6/8/10/15 for an f32 model,
-//               7/9/12/15 for an f64 model), Horner steps vertical over 8 entries; beyond the last
+//   expm1     : wave-uniform Taylor tiers by the tile's range (degree 6/7/8/9/10/15 for an f32 model,
+//               7/8/9/10/12/15 for an f64 model), Horner steps vertical over 8 entries; beyond the last
 //               tier k ln2 + r reduction + v_ldexp_f64 (relative error ~2e-16 for every argument);
 //   pipeline  : operands of batch element b + 1 prefetched into a second register set; per-thread
 //               partials of 16 batch elements staged in LDS and reduced together;
@@ -25,7 +25,7 @@
 #include "mm_common.h"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-// Taylor degrees of the f32-mode (LOWP) tiers |x| <= 1/64, 1/16, 1/4
+// Taylor degrees of the f32-mode (LOWP) tiers |x| <= 1/64, 1/16, 1/4 (the half steps 1/32, 1/8 take D0 + 1, D1 + 1)
 #ifndef MM_LOWP_D0
 #define MM_LOWP_D0 6
 #define MM_LOWP_D1 8
