@@ -192,7 +192,7 @@ def main():
     roofline["pipe_busy_frac"] = 0.84
   if f32_mfma:
     # executed work (DESIGN.md "f32 reduce roofline"): the bilinear form runs as a bf16 split product,
-    # 4 v_mfma_f32_32x32x16_bf16 per 64 x 32 wave tile and 8 input dims, 6 for tiles with max|b| > 1/64:
+    # 4 v_mfma_f32_32x32x16_bf16 per 64 x 32 wave tile and 8 input dims, 6 for tiles with max|b| > 1/32:
     # the figure below is the 6-MFMA upper bound
     nd8 = (d + 7) // 8
     mfma_flops = entries / 2048.0 * 6 * nd8 * 32768.0
