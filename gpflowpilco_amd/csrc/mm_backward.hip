@@ -209,22 +209,46 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
     for (int u = 0; u < NU; ++u) Uacc[ct][u] = (f64x4b){0.0, 0.0, 0.0, 0.0};
   double pc[2] = {0.0, 0.0}, pC[2] = {0.0, 0.0}, pK[2] = {0.0, 0.0};
 
-  for (int it = 0; it < nt; ++it) {
-    const int rbase = it * 64 + rh * 32;
-    // ---- this iteration's 32 "rows" -------------------------------------------------------------
-    double arow[2][KS4], rinit[2][4], rwt[2][4], rq[2][4];
+  // The A operand and the accumulator init of iteration it + 1 are fetched while iteration it evaluates its
+  // polynomials (they are the first thing an iteration needs; with two waves per SIMD their latency was a
+  // stall at the top of every iteration).  Unconditional, index-clamped loads.
+  auto load_first = [&](int it, double (&ar)[2][KS4], double (&ri)[2][4]) {
+    const int rb = it * 64 + rh * 32;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
 #pragma unroll
       for (int s = 0; s < KS4; ++s) {
-        const int k = 4 * s + kq, row = rbase + rt * 16 + l15;
-        const double v = SWAP ? gcol[(size_t)(k < d ? k : d) * Mp + row] : zc_a[(size_t)row * Kz + (k < Kz ? k : Kz - 1)];
-        arow[rt][s] = (SWAP ? k < d : k < Kz) ? v : 0.0;
+        const int k = 4 * s + kq, row = rb + rt * 16 + l15;
+        ar[rt][s] = SWAP ? gcol[(size_t)(k < d ? k : d) * Mp + row] : zc_a[(size_t)row * Kz + (k < Kz ? k : Kz - 1)];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rb + rt * 16 + kq + 4 * r;
+        ri[rt][r] = SWAP ? gcol[(size_t)d * Mp + row] : rho[row];
+      }
+    }
+  };
+  // (24 more live registers: kept where they fit -- KS4 <= 2 at two waves per SIMD, every NU >= 2 variant)
+  constexpr bool PFB = KS4 <= 2 || NU >= 2;
+  double arow_n[2][KS4], rinit_n[2][4];
+  if (PFB) load_first(0, arow_n, rinit_n);
+
+  for (int it = 0; it < nt; ++it) {
+    const int rbase = it * 64 + rh * 32;
+    // ---- this iteration's 32 "rows" -------------------------------------------------------------
+    double arow[2][KS4], rinit[2][4], rwt[2][4], rq[2][4];
+    if (!PFB) load_first(it, arow_n, rinit_n);
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+      for (int s = 0; s < KS4; ++s) {
+        const int k = 4 * s + kq;
+        arow[rt][s] = (SWAP ? k < d : k < Kz) ? arow_n[rt][s] : 0.0;
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + rt * 16 + kq + 4 * r;
-        rinit[rt][r] = SWAP ? gcol[(size_t)d * Mp + row] : rho[row];
+        rinit[rt][r] = rinit_n[rt][r];
         rwt[rt][r] = SWAP ? w_a2[row] : w_a[row];
         rq[rt][r] = withC ? q_a[row] : 0.0;
       }
@@ -267,6 +291,7 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
         for (int s = 0; s < KS4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[rt][s], bfix[ct][s], c, 0, 0, 0);
         acc[rt][ct] = c;
       }
+    if (PFB) load_first(it + 1 < nt ? it + 1 : it, arow_n, rinit_n);
     unsigned int mxh = 0u;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
