@@ -183,6 +183,7 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
   const double* w_a = w + ((size_t)b * L + a) * Mp;
   const double* w_a2 = w + ((size_t)b * L + a2) * Mp;
   const double* q_a = q + ((size_t)b * L + a) * Mp;
+  const double* Ca = Cm ? Cm + (size_t)a * Mp * Mp : nullptr;      // this latent's C (32-bit indices below: Mp^2 < 2^32)
 
   // ---- the workgroup's fixed side: its 32 "columns" per wave ---------------------------------
   // !SWAP: columns = j (latent a'):  B operand g_j, init gamma'_j, weights w'_j, q_j
@@ -208,6 +209,13 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
 #pragma unroll
     for (int u = 0; u < NU; ++u) Uacc[ct][u] = (f64x4b){0.0, 0.0, 0.0, 0.0};
   double pc[2] = {0.0, 0.0}, pC[2] = {0.0, 0.0}, pK[2] = {0.0, 0.0};
+  double zmul[NU], zadd[NU];                              // column k = 16 u + l15 of (zc | 1 | 0 ...)
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int k = 16 * u + l15;
+    zmul[u] = (k < d && k < Kz) ? 1.0 : 0.0;
+    zadd[u] = (k == d) ? 1.0 : 0.0;
+  }
 
   // The A operand and the accumulator init of iteration it + 1 are fetched while iteration it evaluates its
   // polynomials (they are the first thing an iteration needs; with two waves per SIMD their latency was a
@@ -219,12 +227,14 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
 #pragma unroll
       for (int s = 0; s < KS4; ++s) {
         const int k = 4 * s + kq, row = rb + rt * 16 + l15;
-        ar[rt][s] = SWAP ? gcol[(size_t)(k < d ? k : d) * Mp + row] : zc_a[(size_t)row * Kz + (k < Kz ? k : Kz - 1)];
+        // 24-bit multiplies (full rate; row, Mp, Kz < 2^24): the 64-bit index products were ~40 quarter-rate
+        // integer multiplies per iteration
+        ar[rt][s] = SWAP ? gcol[__umul24(k < d ? k : d, Mp) + row] : zc_a[__umul24(row, Kz) + (k < Kz ? k : Kz - 1)];
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rb + rt * 16 + kq + 4 * r;
-        ri[rt][r] = SWAP ? gcol[(size_t)d * Mp + row] : rho[row];
+        ri[rt][r] = SWAP ? gcol[__umul24(d, Mp) + row] : rho[row];
       }
     }
   };
@@ -263,7 +273,7 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
         for (int r = 0; r < 4; ++r) {
           const int row = rbase + rt * 16 + kq + 4 * r;
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) creg[rt][ct][r] = Cm[((size_t)a * Mp + row) * Mp + cbase + ct * 16 + l15];
+          for (int ct = 0; ct < 2; ++ct) creg[rt][ct][r] = Ca[__umul24(row, Mp) + cbase + ct * 16 + l15];
         }
     }
     if (!SWAP) {
@@ -273,8 +283,8 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const int row = rbase + (i >> 2) * 16 + 4 * (i & 3) + kq;
-          const double zv = zc_a[(size_t)row * Kz + (k < Kz ? k : Kz - 1)];
-          zB[u][i] = (k < d) ? (k < Kz ? zv : 0.0) : (k == d ? 1.0 : 0.0);
+          const double zv = zc_a[__umul24(row, Kz) + (k < Kz ? k : Kz - 1)];
+          zB[u][i] = fma(zv, zmul[u], zadd[u]);              // (zc | 1 | 0): lane-constant select as one FMA
         }
       }
     }
