@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void k_wmoments(const double* __restrict__ whR
 #pragma unroll 4
     for (int s4 = 0; s4 < 16; ++s4) {
       const double av = wst[wv][l15][4 * s4 + kq];
-      const double* tr = tab + (size_t)(mb + 4 * s4 + kq) * KMp;
+      const double* tr = tab + __umul24(mb + 4 * s4 + kq, KMp);   // 24-bit multiply (full rate): Mp * KMp < 2^32
 #pragma unroll
       for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tr[coff[c]], acc[c], 0, 0, 0);
     }
