@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
         const int row = rbase + rt * 16 + kq + 4 * r;
         rinit[rt][r] = rinit_n[rt][r];
         rwt[rt][r] = SWAP ? w_a2[row] : w_a[row];
-        rq[rt][r] = withC ? q_a[row] : 0.0;
+        rq[rt][r] = q_a[row];                                // only read under withC: loaded unconditionally (no branch)
       }
     }
     // C tile and the B operand of the U product: issued here, consumed after the polynomial (their
