@@ -291,3 +291,46 @@ def test_f64_tier_selection_sees_every_row(device):
   _, Sff_gen, _ = ops.moment_match(pm, mu, Sigma, force_generic=True)
   rel = float((Sff_fast - Sff_gen).abs().max() / Sff_gen.abs().max())
   assert rel < 1e-12, rel
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_c_abi_from_a_compiled_host(dtype, device, tmp_path):
+  """examples/abi_host.cpp: a C++ program on include/gpflowpilco_mm.h and the HIP runtime alone (no torch,
+  no Python) packs a model and runs one moment match.  Its outputs must equal the Python binding's bit for
+  bit (same kernels, same launch parameters) and agree with the oracle."""
+  import os, shutil, struct, subprocess
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+  if not os.path.exists(hipcc):
+    pytest.skip("hipcc not available")
+  exe = str(tmp_path / "abi_host")
+  libdir = os.path.join(root, "gpflowpilco_amd")
+  subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", "-I" + os.path.join(root, "include"),
+                  os.path.join(root, "examples", "abi_host.cpp"), "-L" + libdir, "-lgpflowpilco_mm",
+                  "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True, timeout=300)
+  L, M, d, B = 3, 150, 5, 4
+  syn = make_svgp(L, M, d, seed=91)
+  model = syn.to_model(device)
+  Z, ls, var, beta, C, mean_c = model.precompute(device)
+  mu, Sigma = make_inputs(B, d, seed=4, scale=0.2)
+  code = 1 if dtype == torch.float64 else 0
+  flags = ops.make_flags(True, True, False)
+  mc = np.zeros(L) if mean_c is None else mean_c.cpu().numpy()
+  with open(tmp_path / "in.bin", "wb") as f:
+    f.write(struct.pack("6i", L, M, d, B, code, flags))
+    for a in (Z.cpu().numpy(), ls.cpu().numpy(), var.cpu().numpy(), beta.cpu().numpy(), C.cpu().numpy(), mc, mu, Sigma):
+      f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+  r = subprocess.run([exe, str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, timeout=120)
+  assert r.returncode == 0, r.stderr
+  raw = open(tmp_path / "out.bin", "rb").read()
+  n1, n2, n3 = B * L, B * L * L, B * d * L
+  vals = np.frombuffer(raw[: 8 * (n1 + n2 + n3)], dtype=np.float64)
+  status = struct.unpack("i", raw[8 * (n1 + n2 + n3):])[0]
+  assert status == 0
+  f1c, Sffc, crc = vals[:n1].reshape(B, L), vals[n1:n1 + n2].reshape(B, L, L), vals[n1 + n2:].reshape(B, d, L)
+  pm = ops.pack_model(Z, ls, var, beta, C, None if mean_c is None else mean_c, dtype=dtype)
+  f1, Sff, cr = ops.moment_match(pm, to_dev(mu, device, dtype), to_dev(Sigma, device, dtype))
+  for got, want in ((f1c, f1), (Sffc, Sff), (crc, cr)):
+    assert np.array_equal(got, want.double().cpu().numpy())
+  _, Sffo, _ = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
+  assert scale_err(torch.tensor(Sffc), Sffo) < TOL[dtype]["Sff"]
