@@ -334,3 +334,23 @@ def test_c_abi_from_a_compiled_host(dtype, device, tmp_path):
     assert np.array_equal(got, want.double().cpu().numpy())
   _, Sffo, _ = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
   assert scale_err(torch.tensor(Sffc), Sffo) < TOL[dtype]["Sff"]
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_deterministic_input_is_the_limit_of_small_covariance(dtype, device):
+  """Sigma = 0 exactly (a point input): the centred reduce has no 0/0 -- Sff is the predictive covariance at mu
+  (diagonal for independent latents), finite, and continuous with Sigma = 1e-10 I, where the oracle is defined."""
+  L, M, d, B = 3, 200, 4, 3
+  syn = make_svgp(L, M, d, seed=5)
+  mu, _ = make_inputs(B, d, seed=1, scale=0.1)
+  pm = syn.to_model(device).packed(dtype, True, device)
+  S0 = np.zeros((B, d, d)); S1 = np.broadcast_to(1e-10 * np.eye(d), (B, d, d)).copy()
+  f0, Sff0, cr0 = ops.moment_match(pm, to_dev(mu, device, dtype), to_dev(S0, device, dtype))
+  pm.check_status(B)
+  assert bool(torch.isfinite(Sff0).all() and torch.isfinite(cr0).all())
+  off = Sff0 - torch.diag_embed(torch.diagonal(Sff0, dim1=-2, dim2=-1))
+  assert float(off.abs().max()) < 1e-12 and float(torch.diagonal(Sff0, dim1=-2, dim2=-1).min()) > 0
+  f1o, Sffo, cro = mo.mm_gauss_svgp_mo(mu, S1, oracle_params(syn))
+  # (the two inputs differ by O(1e-10) themselves)
+  assert scale_err(f0, f1o) < max(TOL[dtype]["f1"], 1e-7) and scale_err(Sff0, Sffo) < TOL[dtype]["Sff"]
+  assert scale_err(cr0, cro) < max(TOL[dtype]["cross"], 1e-7)
