@@ -136,10 +136,14 @@ def moment_match(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor,
   """(mu [B,d], Sigma [B,d,d]) -> f1 [B,L], Sff [B,L,L] | [B,L], Sigma^-1 Cov(x,f) [B,d,L]."""
   B, mu, Sigma = _prep_state(pm, mu, Sigma)
   flags = make_flags(full_output_cov, model_uncertainty, force_generic)
-  ws = pm.workspace(B, flags)
   f1 = torch.empty(B, pm.L, dtype=pm.dtype, device=pm.device)
   Sff = torch.empty((B, pm.L, pm.L) if full_output_cov else (B, pm.L), dtype=pm.dtype, device=pm.device)
   cross = torch.empty(B, pm.d, pm.L, dtype=pm.dtype, device=pm.device)
+  if B == 0:                       # an empty batch gives empty outputs (as the reference's tensor ops do); no launch
+    if model_uncertainty and not pm.with_C:
+      check(-5, "mm_moment_match")                    # MM_E_NO_C, as the C ABI reports it
+    return f1, Sff, cross
+  ws = pm.workspace(B, flags)
   rc = lib().mm_moment_match(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B,
                              mu.data_ptr(), Sigma.data_ptr(), flags, float(jitter),
                              f1.data_ptr(), Sff.data_ptr(), cross.data_ptr(),

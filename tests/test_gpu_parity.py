@@ -354,3 +354,19 @@ def test_deterministic_input_is_the_limit_of_small_covariance(dtype, device):
   # (the two inputs differ by O(1e-10) themselves)
   assert scale_err(f0, f1o) < max(TOL[dtype]["f1"], 1e-7) and scale_err(Sff0, Sffo) < TOL[dtype]["Sff"]
   assert scale_err(cr0, cro) < max(TOL[dtype]["cross"], 1e-7)
+
+
+def test_empty_batch_returns_empty_outputs(device):
+  """B = 0: shapes follow the reference's tensor ops (empty outputs), no kernel launch, argument checks still apply."""
+  syn = make_svgp(2, 40, 3, seed=2)
+  model = syn.to_model(device)
+  pm = model.packed(torch.float64, True, device)
+  mu = torch.empty(0, 3, dtype=torch.float64, device=device); S = torch.empty(0, 3, 3, dtype=torch.float64, device=device)
+  f1, Sff, cr = ops.moment_match(pm, mu, S)
+  assert f1.shape == (0, 2) and Sff.shape == (0, 2, 2) and cr.shape == (0, 3, 2)
+  _, Sd, _ = ops.moment_match(pm, mu, S, full_output_cov=False)
+  assert Sd.shape == (0, 2)
+  with pytest.raises(ValueError, match="MM_E_NO_C"):
+    ops.moment_match(model.packed(torch.float64, False, device), mu, S, model_uncertainty=True)
+  with pytest.raises(ValueError):
+    ops.moment_match(pm, torch.empty(0, 4, dtype=torch.float64, device=device), torch.empty(0, 4, 4, dtype=torch.float64, device=device))
