@@ -314,8 +314,11 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
           mxh = ah > mxh ? ah : mxh;
         }
 #define MMB_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))
-    const int tier = !__any(mxh >= MMB_HI32(0.015625)) ? 0 : !__any(mxh >= MMB_HI32(0.0625)) ? 1
-                   : !__any(mxh >= MMB_HI32(0.25)) ? 2 : !__any(mxh >= MMB_HI32(0.5)) ? 3 : 4;
+    // Taylor degree by range (absolute truncation |x|^(D+1)/(D+1)! <= 2e-18): 1/64 -> 7, 1/32 -> 8, 1/16 -> 9,
+    // 1/8 -> 10, 1/4 -> 12, 1/2 -> 15; the half steps as in mm_f64.hip (most tiles of a rollout sit in them)
+    const int tier = !__any(mxh >= MMB_HI32(0.015625)) ? 0 : !__any(mxh >= MMB_HI32(0.03125)) ? 1
+                   : !__any(mxh >= MMB_HI32(0.0625)) ? 2 : !__any(mxh >= MMB_HI32(0.125)) ? 3
+                   : !__any(mxh >= MMB_HI32(0.25)) ? 4 : !__any(mxh >= MMB_HI32(0.5)) ? 5 : 6;
 #undef MMB_HI32
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
@@ -323,9 +326,11 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
 #pragma unroll
       for (int i = 0; i < 8; ++i) x[i] = acc[i >> 2][ct][i & 3];
       if (tier == 0) mmb_expm1_poly8<7>(x, E);
-      else if (tier == 1) mmb_expm1_poly8<9>(x, E);
-      else if (tier == 2) mmb_expm1_poly8<12>(x, E);
-      else if (tier == 3) mmb_expm1_poly8<15>(x, E);
+      else if (tier == 1) mmb_expm1_poly8<8>(x, E);
+      else if (tier == 2) mmb_expm1_poly8<9>(x, E);
+      else if (tier == 3) mmb_expm1_poly8<10>(x, E);
+      else if (tier == 4) mmb_expm1_poly8<12>(x, E);
+      else if (tier == 5) mmb_expm1_poly8<15>(x, E);
       else {
 #pragma unroll
         for (int i = 0; i < 8; ++i) E[i] = mmb_expm1_any(x[i]);
