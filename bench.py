@@ -1,50 +1,79 @@
 #!/usr/bin/env python
 """Benchmark of the moment-matched GP rollout (BASELINE.json metric) on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W [--config c3|c2|c1]
+  python bench.py --gpus N --steps K --warmup W [--config c1|c2|c3|c4|c5] [--scaling weak|strong]
+                  [--recipe pilco|baseline|worst]
 
-One "step" = one rollout time-step of the whole local batch: q stage + fused Q reduce +
-Euler moment update for B input distributions (state resets to (mu0, Sigma0) every H steps,
-per-step expected costs are all-gathered after each H-step rollout).  value = B_total * K /
-wall time ("rollout step-elements per second", B x H per rollout time).  Weak scaling: every
-rank owns B_local = B input distributions; no data-path collective inside a rollout.
+One "step" = one pass of the hot path over the local batch: q stage + fused Q reduce (+ Euler moment update
+where the state is closed, d == L).  Per-step expected costs are evaluated and all-gathered once per H-step
+rollout, so K is rounded UP to a whole number of rollouts: the cost kernel and the collective are
+always inside the timed region.  value = B_total * K / wall time ("rollout step-elements per second").
 
-The JSON line also carries
-  roofline     -- the dominant kernel (f32 MFMA off-diagonal reduce), HIP-event timed in the
-                  timed region on the launch stream; algorithmic flops per SURVEY.md section 8d;
-  cpu_baseline -- the literal fp64 CPU oracle (reference algorithm: materialised eKuffu +
-                  triangular solves) timed on this host on a bounded sample (rank 0, N=1);
+Configurations (BASELINE.json configs; `config.workload` names what ran):
+  c1  configs[0] shaped: N=100, d=D=6, H=30, B=1, fp64, closed rollout        (weak)
+  c2  configs[1] shaped: N=1000, d=D=5, H=40, B=64, fp64, closed rollout      (weak)
+  c3  configs[2]: N=2000, d=D=8, H=40, B=256 per GPU, fp32, closed rollout    (weak; THE metric's config)
+  c4  configs[3]: N=4000, d=16, D=32, H=50, B=256 sharded over the ranks, fp32; d != D, so the step kernel runs on
+      H independent (mu, Sigma) draws per rollout                 (strong)
+  c5  configs[4]: pathwise sample rollout, S=65536 sharded over the ranks, N=2000, K=1024, H=50, fp32 (strong)
+Recipes (the reduce kernels choose range tiers per tile, so their time depends on the data):
+  pilco     lengthscales log-uniform [0.7, 3], contracting targets: the state stays inside the data's support for
+            the whole closed rollout -- default for c1..c3;
+  baseline  BASELINE.md's own recipe: lengthscales log-uniform [0.3, 3], GP-prior targets; a closed dt = 1 rollout
+            leaves the support within a few steps there, so every step takes a fresh (mu, Sigma) draw
+            (mu ~ U[0,1]^d, Sigma std 0.1) -- default for c4;
+  worst     the pilco data with MM_FORCE_WORST_TIER: every tile takes its most expensive tier.
+
+The JSON line carries
+  roofline     -- the kernel with the largest measured share of the step, HIP-event timed inside the timed region on
+                  the launch stream.  `frac` = executed-work ceiling / measured time: the ceiling is the kernel's OWN
+                  executed instruction mix (hardware counters of the same workload, profiles/r02_pmc_<config>.json,
+                  collected by tools/collect_pmc.sh and accepted only if they were taken on the kernel sources
+                  now in the tree) priced with the issue costs measured by tools/ubench_gap.hip at the peak clock;
+                  the SURVEY 8d algorithmic figure is reported beside it as `algorithmic_*` and never as `frac`;
+  cpu_baseline -- the literal fp64 CPU oracle (reference algorithm: materialised eKuffu + triangular solves) timed on
+                  this host on a bounded sample (rank 0, N=1);
   parity       -- max abs error of one GPU step against that oracle on the same inputs.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from gpflowpilco_amd import _lib, ops  # noqa: E402
-from gpflowpilco_amd.cost import expected_gaussian_cost  # noqa: E402
-from gpflowpilco_amd.synthetic import make_inputs, make_svgp  # noqa: E402
-
 CONFIGS = {
-    # name: (L, M, d, H, B_local, dtype, seed)   -- BASELINE.json configs[0..2]
-    "c1": dict(L=6, M=100, d=6, H=30, B=1, dtype=torch.float64, seed=1000,
-               label="C1-shaped closed rollout: N=100 d=6 D=6 H=30 B=1 fp64"),
-    "c2": dict(L=5, M=1000, d=5, H=40, B=64, dtype=torch.float64, seed=1001,
-               label="C2-shaped closed rollout: N=1000 d=5 D=5 H=40 B=64 fp64"),
-    "c3": dict(L=8, M=2000, d=8, H=40, B=256, dtype=torch.float32, seed=1002,
-               label="C3: N=2000 d=8 D=8 H=40 B per GPU fp32 closed drift rollout"),
+    "c1": dict(L=6, M=100, d=6, H=30, B=1, dtype="f64", seed=1000, scaling="weak", recipe="pilco", closed=True,
+               label="C1-shaped (BASELINE configs[0]): N=100 d=6 D=6 H=30 B=1 fp64 closed drift rollout"),
+    "c2": dict(L=5, M=1000, d=5, H=40, B=64, dtype="f64", seed=1001, scaling="weak", recipe="pilco", closed=True,
+               label="C2-shaped (BASELINE configs[1]): N=1000 d=5 D=5 H=40 B=64 fp64 closed drift rollout"),
+    "c3": dict(L=8, M=2000, d=8, H=40, B=256, dtype="f32", seed=1002, scaling="weak", recipe="pilco", closed=True,
+               label="C3 (BASELINE configs[2]): N=2000 d=8 D=8 H=40 fp32 closed drift rollout"),
+    "c4": dict(L=32, M=4000, d=16, H=50, B=256, dtype="f32", seed=1003, scaling="strong", recipe="baseline", closed=False,
+               label="C4 (BASELINE configs[3]): N=4000 d=16 D=32 H=50 B=256 total fp32, step kernel on H independent draws"),
 }
-# BASELINE.json configs[4] per GPU: S = 65536 / 8 sample paths, N = 2000, K = 1024 bases, H = 50
-PATHWISE = dict(L=8, M=2000, d=8, K=1024, H=50, S=8192, dtype=torch.float32, seed=1004,
-                label="C5 per-GPU shard: pathwise sample rollout S=8192 (65536/8) N=2000 K=1024 d=D=8 H=50 fp32")
-PEAK_TFLOPS = {torch.float32: 157.3, torch.float64: 78.6}   # MI355X_MICROARCH.md dense MFMA peaks
+# BASELINE.json configs[4]: S = 65536 sample paths in total, N = 2000, K = 1024 bases, H = 50
+PATHWISE = dict(L=8, M=2000, d=8, K=1024, H=50, S=65536, dtype="f32", seed=1004, scaling="strong",
+                label="C5 (BASELINE configs[4]): pathwise sample rollout S=65536 total N=2000 K=1024 d=D=8 H=50 fp32")
+RECIPES = {
+    "pilco": dict(ls_bounds=(0.7, 3.0), stable=True, independent=False, worst=False,
+                  text="lengthscales log-U[0.7,3], targets -0.5(z_a-0.5)+0.25*prior draw (state stays in the data's support)"),
+    "baseline": dict(ls_bounds=(0.3, 3.0), stable=False, independent=True, worst=False,
+                     text="BASELINE.md recipe: lengthscales log-U[0.3,3], GP-prior targets, fresh mu~U[0,1]^d / Sigma std 0.1 draw per step"),
+    "worst": dict(ls_bounds=(0.7, 3.0), stable=True, independent=False, worst=True,
+                  text="pilco data with MM_FORCE_WORST_TIER: every tile of both reduce kernels takes its most expensive tier"),
+}
+# MI355X_MICROARCH.md: dense peaks and the peak clock; per-SIMD issue costs measured by tools/ubench_gap.hip /
+# tools/ubench_rates.hip on MI355X (profiles/r02_ubench_gap.txt): cycles per wave-instruction on one SIMD
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+PEAK_HBM_GBS = 8000.0
+PEAK_CLOCK_HZ = 2.4e9
+N_SIMD = 1024
+ISSUE = {"mfma_bf16_32x32x16": 32.0, "mfma_f64_16x16x4": 64.0, "valu_f32": 4.0, "valu_f64": 5.0, "valu_other": 4.0,
+         "valu_trans": 8.0}
 
 
 def parse():
@@ -53,19 +82,104 @@ def parse():
   ap.add_argument("--steps", type=int, default=80)
   ap.add_argument("--warmup", type=int, default=8)
   ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c5"])
-  ap.add_argument("--batch", type=int, default=None, help="override B per GPU")
+  ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                  help="weak: the config's B (or S) per GPU; strong: the config's B (or S) sharded over the ranks "
+                       "(default: weak for c1..c3, strong for c4/c5 -- BASELINE.json shards those)")
+  ap.add_argument("--recipe", default=None, choices=sorted(RECIPES))
+  ap.add_argument("--batch", type=int, default=None, help="override B (or S): per GPU if weak, total if strong")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--force-generic", action="store_true")
+  ap.add_argument("--pmc-run", action="store_true", help="set by tools/collect_pmc.sh: exact --steps, no rounding to rollouts")
   ap.add_argument("--rehearse-gloo", action="store_true",
                   help="multi-process rehearsal on ONE GPU: gloo backend, every rank on cuda:0, costs gathered via host")
   return ap.parse_args()
 
 
+def spawn_ranks(args):
+  """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process
+  (this process has not touched the GPU and only relays the child's output and exit code)."""
+  port = 29500 + (os.getpid() % 2000)
+  cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+         "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+  env = dict(os.environ)
+  env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+  return subprocess.run(cmd, env=env).returncode
+
+
+def src_hash():
+  from tools.pmc_summary import src_hash as h
+  return h(ROOT)
+
+
+def load_pmc(tag):
+  """profiles/r02_pmc_<tag>.json if it was collected on the kernel sources now in the tree, else (None, reason)."""
+  path = os.path.join(ROOT, "profiles", f"r02_pmc_{tag}.json")
+  if not os.path.exists(path):
+    return None, f"profiles/r02_pmc_{tag}.json not collected"
+  with open(path) as fh:
+    pmc = json.load(fh)
+  cur = src_hash()
+  if pmc.get("src_hash") != cur:
+    return None, f"profiles/r02_pmc_{tag}.json is stale (collected on kernel sources {pmc.get('src_hash')}, tree has {cur})"
+  return pmc, os.path.relpath(path, ROOT)
+
+
+def pmc_kernel(pmc, prefix):
+  """Counters of the kernel whose short name starts with ``prefix`` (the instantiation with the most time)."""
+  if pmc is None:
+    return None
+  best = None
+  for name, ent in pmc["kernels"].items():
+    if name.startswith(prefix):
+      w = ent.get("dur_us_under_pmc", 0.0) * ent.get("dispatches", 1)
+      if best is None or w > best[0]:
+        best = (w, name, ent)
+  return None if best is None else (best[1], best[2])
+
+
+def executed_ceiling(ent, mfma_cost):
+  """Executed-work ceiling of one dispatch from its hardware counters: cycles per SIMD =
+  (MFMA instructions x pipe cycles + VALU instructions x measured issue cost by class) / 1024 SIMDs, priced at the
+  2.4 GHz peak clock.  tools/ubench_gap.hip (profiles/r02_ubench_gap.txt): on a gfx950 SIMD the f32 FMA-class VALU
+  serialises with the bf16 MFMA, and the f64 FMA with the f64 MFMA, beyond the first ~3 instructions per MFMA, so
+  the two add; only that small free quota is credited back."""
+  c = ent["counters"]
+  n_mfma = c.get("SQ_INSTS_MFMA", 0.0)
+  n_valu = max(0.0, c.get("SQ_INSTS_VALU", 0.0) - n_mfma)
+  f32 = c.get("SQ_INSTS_VALU_FMA_F32", 0.0) + c.get("SQ_INSTS_VALU_MUL_F32", 0.0) + c.get("SQ_INSTS_VALU_ADD_F32", 0.0)
+  f64 = c.get("SQ_INSTS_VALU_FMA_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0)
+  trans = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+  have_classes = "SQ_INSTS_VALU_FMA_F32" in c
+  if not have_classes:
+    f32, f64, trans = n_valu, 0.0, 0.0
+  other = max(0.0, n_valu - f32 - f64 - trans)
+  free = min(n_valu, 3.0 * n_mfma)                        # instructions hidden in the MFMA issue gaps
+  valu_cyc = f32 * ISSUE["valu_f32"] + f64 * ISSUE["valu_f64"] + trans * ISSUE["valu_trans"] + other * ISSUE["valu_other"]
+  valu_cyc *= (1.0 - free / n_valu) if n_valu else 1.0
+  mfma_cyc = c.get("SQ_VALU_MFMA_BUSY_CYCLES", n_mfma * mfma_cost)
+  cyc_per_simd = (mfma_cyc + valu_cyc) / N_SIMD
+  return {"ceiling_ms": cyc_per_simd / PEAK_CLOCK_HZ * 1e3,
+          "mix": {"mfma": n_mfma, "valu_f32": f32, "valu_f64": f64, "valu_trans": trans, "valu_other": other,
+                  "mfma_pipe_cycles_per_simd": mfma_cyc / N_SIMD, "valu_issue_cycles_per_simd": valu_cyc / N_SIMD}}
+
+
 def main():
   args = parse()
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    raise SystemExit(spawn_ranks(args))
+  import numpy as np
+  import torch
+  from gpflowpilco_amd import _lib, ops
+  from gpflowpilco_amd.cost import expected_gaussian_cost
+  from gpflowpilco_amd.distributed import shard_range
+  from gpflowpilco_amd.synthetic import make_inputs, make_svgp
+
   rank = int(os.environ.get("RANK", "0"))
   world = int(os.environ.get("WORLD_SIZE", "1"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus and not args.rehearse_gloo:
+    raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                     "(or run `python bench.py --gpus N` alone, which starts the ranks itself)")
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs a GPU (no CPU fallback)")
   if args.rehearse_gloo:
@@ -83,60 +197,100 @@ def main():
   if args.config == "c5":
     return pathwise_bench(args, rank, world, dev, dist)
   cfg = dict(CONFIGS[args.config])
-  if args.batch:
-    cfg["B"] = args.batch
-  L, M, d, H, B, dtype = cfg["L"], cfg["M"], cfg["d"], cfg["H"], cfg["B"], cfg["dtype"]
-  # lengthscales log-uniform in [0.7, 3] (not BASELINE.md's [0.3, 3]): with 0.3 the M points cannot
-  # cover the d-dimensional cube, the predictive variance stays at the prior and the closed rollout's
-  # covariance random-walks out of the data's support within ~5 steps (DESIGN.md "Synthetic workload")
-  syn = make_svgp(L, M, d, seed=cfg["seed"], device=str(dev), ls_bounds=(0.7, 3.0))
+  scaling = args.scaling or cfg["scaling"]
+  recipe_name = args.recipe or cfg["recipe"]
+  rec = RECIPES[recipe_name]
+  if not cfg["closed"] and not rec["independent"]:
+    raise SystemExit(f"{args.config} has d != D: it cannot run as a closed rollout (use --recipe baseline)")
+  L, M, d, H = cfg["L"], cfg["M"], cfg["d"], cfg["H"]
+  dtype = torch.float32 if cfg["dtype"] == "f32" else torch.float64
+  Bcfg = args.batch or cfg["B"]
+  if scaling == "strong":
+    B_total = Bcfg
+    lo, hi = shard_range(B_total, rank, world)           # contiguous, balanced slice of the batch axis
+    B = hi - lo
+  else:
+    B, B_total, lo = Bcfg, Bcfg * world, rank * Bcfg
+  if B <= 0:
+    raise SystemExit(f"rank {rank} got an empty shard of B={B_total}")
+  steps = args.steps if args.pmc_run else max(H, -(-args.steps // H) * H)     # whole rollouts (see module docstring)
+
+  syn = make_svgp(L, M, d, seed=cfg["seed"], device=str(dev), ls_bounds=rec["ls_bounds"], stable=rec["stable"])
   model = syn.to_model(dev)
   pm = model.packed(dtype, True, dev)
-  mu0_np, S0_np = make_inputs(B, d, seed=2000 + rank, scale=0.1, lo=0.3, hi=0.7)
+  if rec["independent"]:
+    # the step kernel on H independent draws of the whole batch; rank-independent global draw so that
+    # a strong-scaling run processes the same B_total inputs at every N
+    mu_np, S_np = make_inputs(B_total * H, d, seed=2000 + cfg["seed"], scale=0.1, lo=0.0, hi=1.0)
+    mu_np = mu_np.reshape(H, B_total, d)[:, lo:lo + B]
+    S_np = S_np.reshape(H, B_total, d, d)[:, lo:lo + B]
+    draws_mu = torch.tensor(np.ascontiguousarray(mu_np), dtype=dtype, device=dev)
+    draws_S = torch.tensor(np.ascontiguousarray(S_np), dtype=dtype, device=dev)
+    mu0_np, S0_np = mu_np[0], S_np[0]
+  else:
+    mu_all, S_all = make_inputs(B_total, d, seed=2000 + cfg["seed"], scale=0.1, lo=0.3, hi=0.7)
+    mu0_np, S0_np = mu_all[lo:lo + B], S_all[lo:lo + B]
   mu0 = torch.tensor(mu0_np, dtype=dtype, device=dev)
   S0 = torch.tensor(S0_np, dtype=dtype, device=dev)
-  target = torch.full((d,), 0.5, dtype=dtype, device=dev)
-  precis = torch.eye(d, dtype=dtype, device=dev) * 4.0
+  dc = d if cfg["closed"] else L                           # dimension of the per-step cost statistic's argument
+  target = torch.full((dc,), 0.5 if cfg["closed"] else 0.0, dtype=dtype, device=dev)
+  precis = torch.eye(dc, dtype=dtype, device=dev) * 4.0
 
-  base = ops.make_flags(True, True, args.force_generic)
   F = _lib
-  traj_mu = torch.empty(H, B, d, dtype=dtype, device=dev)
-  traj_S = torch.empty(H, B, d, d, dtype=dtype, device=dev)
-  gathered = [torch.empty(B, H, dtype=dtype, device=dev) for _ in range(world)] if world > 1 else None
-  ev, evd = [], []
-  state = {"mu": mu0.clone(), "S": S0.clone(), "h": 0, "cost": None}
+  base = ops.make_flags(True, True, args.force_generic) | (F.MM_FORCE_WORST_TIER if rec["worst"] else 0)
+  traj_mu = torch.empty(H, B, dc, dtype=dtype, device=dev)
+  traj_S = torch.empty(H, B, dc, dc, dtype=dtype, device=dev)
+  Bmax = -(-B_total // world)
+  gathered = [torch.empty(Bmax, H, dtype=dtype, device=dev) for _ in range(world)] if world > 1 else None
+  pad_cost = torch.zeros(Bmax, H, dtype=dtype, device=dev)
+  ev = []
+  state = {"mu": mu0.clone(), "S": S0.clone(), "h": 0, "cost": None, "rollouts": 0}
+  Ev = lambda: torch.cuda.Event(enable_timing=True)
 
   def one_step(timed):
-    if state["h"] == 0:
+    h = state["h"]
+    if rec["independent"]:
+      state["mu"], state["S"] = draws_mu[h], draws_S[h]
+    elif h == 0:
       state["mu"], state["S"] = mu0.clone(), S0.clone()
+    e = [Ev() for _ in range(5)] if timed else None
+    if timed: e[0].record()
     f1, cross, _ = ops.q_forward(pm, state["mu"], state["S"], base)
-    if timed:
-      d0 = torch.cuda.Event(enable_timing=True); d1 = torch.cuda.Event(enable_timing=True)
-      e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-      d0.record()
+    if timed: e[1].record()
     ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_DIAG)
-    if timed:
-      d1.record(); e0.record()
+    if timed: e[2].record()
     ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_OFFDIAG)
-    if timed:
-      e1.record(); ev.append((e0, e1)); evd.append((d0, d1))
+    if timed: e[3].record()
     Sff = ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_FINALIZE)
-    state["mu"], state["S"] = ops.euler_update(state["mu"], state["S"], f1, Sff, cross, 1.0)
-    traj_mu[state["h"]].copy_(state["mu"]); traj_S[state["h"]].copy_(state["S"])
-    state["h"] += 1
+    if cfg["closed"]:
+      state["mu"], state["S"] = ops.euler_update(state["mu"], state["S"], f1, Sff, cross, 1.0)
+      traj_mu[h].copy_(state["mu"]); traj_S[h].copy_(state["S"])
+    else:
+      traj_mu[h].copy_(f1); traj_S[h].copy_(Sff)            # the predicted increment's moments carry the cost statistic
+    if timed:
+      e[4].record(); ev.append(e)
+    state["h"] = h + 1
     if state["h"] == H:
-      # per-step cost statistic of the finished rollout, [B_local, H] -> all ranks
+      # per-step cost statistic of the finished rollout, [B_local, H] -> all ranks: ONE collective
       cost = expected_gaussian_cost(traj_mu, traj_S, target, precis).T.contiguous()
-      if world > 1 and args.rehearse_gloo:
-        host = [torch.empty(B, H, dtype=dtype) for _ in range(world)]
-        dist.all_gather(host, cost.cpu())
-        state["cost"] = torch.cat(host, 0).to(dev)
-      elif world > 1:
-        dist.all_gather(gathered, cost)
-        state["cost"] = torch.cat(gathered, 0)
+      if world > 1:
+        pad_cost[:B].copy_(cost)
+        if args.rehearse_gloo:
+          host = [torch.empty(Bmax, H, dtype=dtype) for _ in range(world)]
+          dist.all_gather(host, pad_cost.cpu())
+          full = [t.to(dev) for t in host]
+        else:
+          dist.all_gather(gathered, pad_cost)
+          full = gathered
+        if scaling == "strong":
+          sizes = [shard_range(B_total, r, world) for r in range(world)]
+          state["cost"] = torch.cat([t[:b - a] for t, (a, b) in zip(full, sizes)], 0)
+        else:
+          state["cost"] = torch.cat([t[:B] for t in full], 0)
       else:
         state["cost"] = cost
       state["h"] = 0
+      state["rollouts"] += 1
 
   def fence():
     torch.cuda.synchronize()
@@ -147,12 +301,13 @@ def main():
   for _ in range(args.warmup):
     one_step(False)
   state["h"] = 0
+  state["rollouts"] = 0
   if world > 1 and not args.rehearse_gloo:
-    # the warm-up steps do not reach the end of a rollout: bring up the collective's channels untimed
-    dist.all_gather(gathered, torch.zeros(B, H, dtype=dtype, device=dev))
+    # the warm-up steps need not reach the end of a rollout: bring up the collective's channels untimed
+    dist.all_gather(gathered, pad_cost)
   fence()
   t0 = time.perf_counter()
-  for _ in range(args.steps):
+  for _ in range(steps):
     one_step(True)
   fence()
   elapsed = time.perf_counter() - t0
@@ -161,78 +316,108 @@ def main():
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
   pm.check_status(B)
-  if not torch.isfinite(state["S"]).all():
+  if cfg["closed"] and not torch.isfinite(state["S"]).all():
     raise SystemExit("non-finite state in the timed rollout")
-  if state["cost"] is not None and tuple(state["cost"].shape) != (B * world, H):
-    raise SystemExit(f"gathered cost matrix has shape {tuple(state['cost'].shape)}, expected {(B * world, H)}")
+  if not args.pmc_run:
+    if state["cost"] is None or tuple(state["cost"].shape) != (B_total, H):
+      raise SystemExit(f"gathered cost matrix has shape {None if state['cost'] is None else tuple(state['cost'].shape)}, "
+                       f"expected {(B_total, H)}")
+    if not torch.isfinite(state["cost"]).all():
+      raise SystemExit("non-finite per-step costs")
 
-  # ---- roofline of the dominant kernel (the off-diagonal reduce) ----------------------------
-  k_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else float("nan")
-  kd_ms = float(np.mean([a.elapsed_time(b) for a, b in evd])) if evd else float("nan")
+  # ---- per-segment device time (HIP events on the launch stream, inside the timed region) -------------------
+  seg = {k: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i, k in enumerate(("q_stage", "diag", "offdiag", "tail"))}
   Po = L * (L - 1) // 2
-  entries = float(B) * Po * M * M
-  flops = entries * (2 * d + 12)                           # E * (2d + 12), E = B*Po*M^2
-  achieved = flops / (k_ms * 1e-3) / 1e12 if Po else 0.0
-  f32_mfma = dtype == torch.float32 and not args.force_generic
-  kname = "k_qred_generic" if args.force_generic else ("k_qred_f32_mfma" if f32_mfma else "k_qred_f64_mfma")
-  # HBM bytes per launch of the dominant kernel from the PMC passes kept in
-  # profiles/r01_pmc_counters.csv (FETCH_SIZE x 2 per MI355X_MICROARCH.md "HBM" + WRITE_SIZE, KB):
-  # 2 * 289494 KB + 448 KB = 0.59 GB against 0.59 GB of streamed operands (rowO + colO).
-  # Only valid for the default C3 / B = 256 launch; other shapes report null.
-  traffic = 2 * 289494 * 1024 + 448 * 1024 if (args.config == "c3" and B == 256 and f32_mfma) else None
-  roofline = {"bound": "mfma", "kernel": kname,
-              "achieved": round(achieved, 3), "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s",
-              "frac": round(achieved / PEAK_TFLOPS[dtype], 4), "traffic": traffic,
-              "kernel_ms": round(k_ms, 4),
-              "flops_per_launch": flops, "entries_per_launch": entries}
-  if traffic is not None:
-    # from the same PMC passes (profiles/r01_pmc_counters.csv): matrix-pipe-busy cycles
-    # (SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs) + VALU issue cycles (SQ_INSTS_VALU / 1024 x 3.6) over kernel cycles
-    # (GRBM_GUI_ACTIVE / 8) = (1.89e6 + 5.2e6) / 8.43e6 -- the two serialise on a gfx950 SIMD
-    roofline["pipe_busy_frac"] = 0.84
-  if f32_mfma:
-    # executed work (DESIGN.md "f32 reduce roofline"): the bilinear form runs as a bf16 split product,
-    # 4 v_mfma_f32_32x32x16_bf16 per 64 x 32 wave tile and 8 input dims, 6 for tiles with max|b| > 1/32:
-    # the figure below is the 6-MFMA upper bound
-    nd8 = (d + 7) // 8
-    mfma_flops = entries / 2048.0 * 6 * nd8 * 32768.0
-    roofline["executed_mfma_bf16"] = {"achieved": round(mfma_flops / (k_ms * 1e-3) / 1e12, 1), "peak": 2500.0,
-                                      "unit": "TFLOP/s", "frac": round(mfma_flops / (k_ms * 1e-3) / 2.5e15, 4),
-                                      "bound": "upper (6 MFMAs per wave tile; 4 on tiles with max|b| <= 1/32)"}
-    roofline["note"] = ("achieved = algorithmic f32 flops, E*(2d+12); the 2d part executes on the bf16 matrix pipe "
-                        "(2-3 MFMAs per 8 dims); the tile kernel reduces the remainder "
-                        "expm1(b)-b-b^2/2 with a range-adaptive polynomial (5..9 VALU ops per entry) while the constant, "
-                        "linear and quadratic parts come from f64 weight moments at O(M d^2), so the fraction of the "
-                        "f32 peak can exceed 1; MFMA and f32 FMA VALU time add on a SIMD (tools/ubench_overlap.hip)")
-  # second kernel of the step: the diagonal pairs, always f64 (upper-triangular tiles)
-  ed = float(B) * L * M * (M + 1) / 2
-  roofline_diag = {"bound": "mfma", "kernel": "k_qred_generic" if args.force_generic else "k_qred_f64_mfma",
-                   "achieved": round(ed * (2 * d + 12) / (kd_ms * 1e-3) / 1e12, 3), "peak": PEAK_TFLOPS[torch.float64],
-                   "unit": "TFLOP/s", "frac": round(ed * (2 * d + 12) / (kd_ms * 1e-3) / 1e12 / PEAK_TFLOPS[torch.float64], 4),
-                   "kernel_ms": round(kd_ms, 4), "entries_per_launch": ed}
+  f32_mode = dtype == torch.float32
+  pmc, pmc_src = load_pmc(args.config if recipe_name == cfg["recipe"] else f"{args.config}_{recipe_name}")
+  e_off = float(B) * Po * M * M
+  e_diag = float(B) * L * M * (M + 1) / 2
+
+  def reduce_roofline(which):
+    entries = e_off if which == "offdiag" else e_diag
+    k_ms = seg[which]
+    f32k = which == "offdiag" and f32_mode and not args.force_generic
+    prefix = "k_qred_generic" if args.force_generic else ("k_qred_f32_mfma" if f32k else "k_qred_f64_mfma")
+    if which == "diag" and not args.force_generic:
+      prefix = "k_qred_f64_mfma<" + str((d + 3) // 4 if (d + 3) // 4 <= 4 else (6 if (d + 3) // 4 <= 6 else 8)) + ", true"
+    elif which == "offdiag" and not f32k and not args.force_generic:
+      prefix = "k_qred_f64_mfma<" + str((d + 3) // 4 if (d + 3) // 4 <= 4 else (6 if (d + 3) // 4 <= 6 else 8)) + ", false"
+    flops = entries * (2 * d + 12)                      # E * (2d + 12)
+    peak = PEAK_TFLOPS["f32" if f32k else "f64"]
+    r = {"bound": "mfma", "kernel": prefix, "kernel_ms": round(k_ms, 4), "entries_per_launch": entries,
+         "algorithmic_flops_per_launch": flops,
+         "algorithmic_tflops": round(flops / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else None,
+         "algorithmic_note": "SURVEY 8d E*(2d+12) flops / kernel time: NOT a utilisation -- the kernel executes a different, "
+                             "cheaper instruction mix (bf16 split-product MFMAs, range-tiered polynomials, low orders from f64 moments)",
+         "unit": "TFLOP/s", "peak": peak, "traffic": None}
+    got = pmc_kernel(pmc, prefix)
+    if got is None:
+      r.update({"achieved": None, "frac": None, "pmc": pmc_src})
+      return r
+    name, ent = got
+    ce = executed_ceiling(ent, ISSUE["mfma_bf16_32x32x16" if f32k else "mfma_f64_16x16x4"])
+    # counters are per dispatch of the profiled run; scale to this run's launch by entries (same config => factor 1)
+    scale = entries / ent["entries"] if ent.get("entries") else 1.0
+    ceiling_ms = ce["ceiling_ms"] * scale
+    frac = ceiling_ms / k_ms if k_ms > 0 else None
+    r.update({"kernel": name, "frac": round(frac, 4), "achieved": round(peak * frac, 2),
+              "ceiling_ms": round(ceiling_ms, 4),
+              "frac_definition": "executed-work ceiling / measured kernel time; ceiling = (MFMA pipe cycles + VALU issue cycles "
+                                 "by class, first 3 VALU per MFMA gap free) / 1024 SIMDs / 2.4 GHz from the kernel's own hardware "
+                                 "counters; `achieved` = peak x frac",
+              "instruction_mix_per_launch": {k: round(v, 1) for k, v in ce["mix"].items()},
+              "traffic": ent["counters"].get("hbm_bytes"), "pmc": pmc_src})
+    c = ent["counters"]
+    if "SQ_BUSY_CYCLES" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+      r["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / (c["GRBM_GUI_ACTIVE"] / 8.0), 4) if c.get("GRBM_GUI_ACTIVE") else None
+    return r
+
+  roofs = {"offdiag": reduce_roofline("offdiag") if Po else None, "diag": reduce_roofline("diag")}
+  dominant = "offdiag" if (Po and seg["offdiag"] >= seg["diag"]) else "diag"
+  # q stage: HBM-bound operand producers (k_qvec, k_pairvec, k_wmoments): bytes from the counters
+  qroof = {"bound": "hbm", "kernels": "k_prep + k_qvec + k_pairvec (+ k_wmoments + k_s12)", "segment_ms": round(seg["q_stage"], 4),
+           "peak": PEAK_HBM_GBS, "unit": "GB/s", "per_kernel": {}}
+  if pmc is not None:
+    for pre in ("k_qvec", "k_pairvec", "k_wmoments"):
+      got = pmc_kernel(pmc, pre)
+      if got and "hbm_bytes" in got[1]["counters"]:
+        qroof["per_kernel"][got[0]] = {"hbm_bytes": got[1]["counters"]["hbm_bytes"]}
 
   out = {
       "metric": "moment_matched_rollout_step_elements_per_sec",
-      "value": round(B * world * args.steps / elapsed, 2),
+      "value": round(B_total * steps / elapsed, 2),
       "unit": "rollout step-elements/s (B*H per rollout second)",
-      "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-      "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-      "dtype": "f32" if dtype == torch.float32 else "f64", "data": "synthetic",
-      "config": {"workload": cfg["label"].replace("B per GPU", f"B={B} per GPU"), "N": M, "d": d, "D": L, "H": H,
-                 "B_per_gpu": B, "B_total": B * world, "parallelism": f"dp{world} over B",
-                 "diag_pairs": "f64", "offdiag_pairs": "f32" if dtype == torch.float32 else "f64"},
-      "roofline": roofline,
-      "roofline_diag": roofline_diag,
+      "n_gpus": world, "steps": steps, "warmup": args.warmup,
+      "ms_per_step": round(1e3 * elapsed / steps, 4),
+      "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+      "dtype": cfg["dtype"], "data": "synthetic",
+      "config": {"workload": f"{cfg['label']}; recipe={recipe_name}: {rec['text']}",
+                 "N": M, "d": d, "D": L, "H": H, "B_per_gpu": B if scaling == "weak" else None, "B_total": B_total,
+                 "B_this_rank": B, "parallelism": f"dp{world} over B ({scaling})", "recipe": recipe_name,
+                 "rollouts_timed": state["rollouts"], "collectives_timed": state["rollouts"] if world > 1 else 0,
+                 "steps_requested": args.steps,
+                 "diag_pairs": "f64", "offdiag_pairs": cfg["dtype"]},
+      "segments_ms": {k: round(v, 4) for k, v in seg.items()},
+      "roofline": roofs[dominant],
+      "roofline_other": roofs["diag" if dominant == "offdiag" else "offdiag"],
+      "roofline_q_stage": qroof,
   }
 
   # ---- CPU baseline + parity (rank 0, N == 1 only) -----------------------------------------
-  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+  if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pmc_run:
     from oracle import mm_oracle as mo
+    small = M <= 256
     Bc = 1 if M >= 1000 else min(B, 4)
-    po = mo.SVGPParams(Z=np.broadcast_to(syn.Z, (L, M, d)).copy(), lengthscales=syn.lengthscales,
-                       variance=syn.variance, q_mu=syn.q_mu, q_sqrt=syn.q_sqrt, whiten=True)
+    # the literal algorithm materialises eKuffu [B,L,M,L,M] (8 B L^2 M^2 bytes) and needs 2 L^2 M^3 flops per element:
+    # where that does not fit a bounded sample (C4: 131 GB), the sample is the sub-problem of the first Lc latents
+    # (latents are independent: f1, Sff[:Lc,:Lc], cross[:,:Lc] of the full model ARE the sub-model's outputs)
+    Lc = L
+    while Lc > 1 and (8.0 * Bc * Lc * Lc * M * M > 2.2e9 or 2.0 * Lc * Lc * float(M) ** 3 > 1.2e12):
+      Lc -= 1
+    po = mo.SVGPParams(Z=np.broadcast_to(syn.Z, (L, M, d))[:Lc].copy(), lengthscales=syn.lengthscales[:Lc],
+                       variance=syn.variance[:Lc], q_mu=syn.q_mu[:, :Lc], q_sqrt=syn.q_sqrt[:Lc], whiten=True)
     mu_c, S_c = mu0_np[:Bc].copy(), S0_np[:Bc].copy()
+    budget = 20.0
     t0 = time.perf_counter()
     nst = 0
     while True:
@@ -240,44 +425,56 @@ def main():
       nst += 1
       if nst == 1:
         first = (f1o, Sffo, cro)
-      Sxf = mo.cross_covariance(S_c, cro, True)
-      mu_c, S_c = mo.euler_moment_update(mu_c, S_c, f1o, Sffo, Sxf, 1.0)
-      if time.perf_counter() - t0 > 10.0 or nst >= H:
+      if cfg["closed"] and not rec["independent"] and Lc == L:
+        Sxf = mo.cross_covariance(S_c, cro, True)
+        mu_c, S_c = mo.euler_moment_update(mu_c, S_c, f1o, Sffo, Sxf, 1.0)
+      if time.perf_counter() - t0 > budget or nst >= (H if not small else 4 * H):
         break
     tc = time.perf_counter() - t0
-    out["cpu_baseline"] = {"value": round(Bc * nst / tc, 4), "unit": out["unit"],
+    sub = "" if Lc == L else f" of the sub-problem with the first {Lc} of {L} latents (the full eKuffu tensor would need {8.0 * L * L * M * M / 1e9:.0f} GB)"
+    out["cpu_baseline"] = {"value": round(Bc * nst / tc, 4), "unit": out["unit"] + ("" if Lc == L else f" [{Lc}-latent sub-problem]"),
                            "cores": os.cpu_count(), "kind": "port",
                            "sample": f"literal fp64 oracle (materialised eKuffu [B,L,M,L,M] + triangular solves, "
-                                     f"numpy/OpenBLAS threads), B={Bc}, {nst} step(s) of the same rollout, {tc:.1f}s"}
-    # second CPU figure: the algorithm-matched restatement -- beta / C hoisted out of the
-    # step, O(M^2) per kernel pair -- so the ratio to the GPU is not merely the O(M^3) -> O(M^2) change
-    from oracle import mm_fused_ref as fr
-    beta_c, C_c = fr.precompute(po)                        # not timed: once per model, like mm_pack_model
-    t0 = time.perf_counter()
-    fm = fr.moment_match(mu0_np[:Bc], S0_np[:Bc], po, beta_c, C_c)
-    tm = time.perf_counter() - t0
-    out["cpu_baseline_matched"] = {"value": round(Bc / tm, 4), "unit": out["unit"], "cores": os.cpu_count(), "kind": "port",
-                                   "sample": f"algorithm-matched fp64 restatement (oracle/mm_fused_ref.py: numpy, O(M^2) per pair, "
-                                             f"precompute excluded), B={Bc}, 1 step without the Euler update, {tm:.1f}s",
-                                   "max_abs_diff_vs_literal": {"f1": float(np.abs(fm[0] - first[0]).max()),
-                                                               "Sff": float(np.abs(fm[1] - first[1]).max())}}
+                                     f"numpy/OpenBLAS threads), B={Bc}, {nst} step(s) of the same workload{sub}, {tc:.1f}s"}
+    if M >= 1000 and Lc == L:
+      # second CPU figure: the algorithm-matched restatement -- beta / C hoisted out of the
+      # step, O(M^2) per kernel pair -- so the ratio to the GPU is not merely the O(M^3) -> O(M^2) change
+      from oracle import mm_fused_ref as fr
+      beta_c, C_c = fr.precompute(po)                        # not timed: once per model, like mm_pack_model
+      t0 = time.perf_counter()
+      fm = fr.moment_match(mu0_np[:Bc], S0_np[:Bc], po, beta_c, C_c)
+      tm = time.perf_counter() - t0
+      out["cpu_baseline_matched"] = {"value": round(Bc / tm, 4), "unit": out["unit"], "cores": os.cpu_count(), "kind": "port",
+                                     "sample": f"algorithm-matched fp64 restatement (oracle/mm_fused_ref.py: numpy, O(M^2) per pair, "
+                                               f"precompute excluded), B={Bc}, 1 step without the Euler update, {tm:.1f}s",
+                                     "max_abs_diff_vs_literal": {"f1": float(np.abs(fm[0] - first[0]).max()),
+                                                                 "Sff": float(np.abs(fm[1] - first[1]).max())}}
     f1, Sff, cross = ops.moment_match(pm, mu0[:Bc].contiguous(), S0[:Bc].contiguous())
+    f1, Sff, cross = f1[:, :Lc], Sff[:, :Lc, :Lc], cross[:, :, :Lc]
     err = lambda g, w: float(np.abs(g.double().cpu().numpy() - w).max())
-    out["parity"] = {"vs": "fp64 CPU oracle, first step, same inputs", "B": Bc,
+    out["parity"] = {"vs": "fp64 CPU oracle, first step, same inputs" + ("" if Lc == L else f" (first {Lc} latents)"), "B": Bc,
                      "max_abs_err": {"f1": err(f1, first[0]), "Sff": err(Sff, first[1]), "cross_pre": err(cross, first[2])},
                      "max_abs": {"f1": float(np.abs(first[0]).max()), "Sff": float(np.abs(first[1]).max()),
                                  "cross_pre": float(np.abs(first[2]).max())}}
-    # rollout-level agreement (final mu_H, Sigma_H): the same kernels in f64 mode on 8 elements
-    if dtype == torch.float32:
+    if f32_mode:
+      # f32 mode against the same kernels in f64 mode on a larger sample of THIS workload's inputs
       Br = min(B, 8)
       pm64 = model.packed(torch.float64, True, dev)
-      m32, S32 = ops.rollout_closed(pm, mu0[:Br].contiguous(), S0[:Br].contiguous(), H)
-      m64, S64 = ops.rollout_closed(pm64, mu0[:Br].double().contiguous(), S0[:Br].double().contiguous(), H)
-      pm64.check_status(Br)
-      out["parity"]["rollout_f32_vs_f64_mode"] = {
-          "B": Br, "H": H, "max_abs_diff": {"mu_H": float((m32.double() - m64).abs().max()),
-                                            "Sigma_H": float((S32.double() - S64).abs().max())},
-          "max_abs": {"mu_H": float(m64.abs().max()), "Sigma_H": float(S64.abs().max())}}
+      if cfg["closed"] and not rec["independent"]:
+        m32, S32 = ops.rollout_closed(pm, mu0[:Br].contiguous(), S0[:Br].contiguous(), H)
+        m64, S64 = ops.rollout_closed(pm64, mu0[:Br].double().contiguous(), S0[:Br].double().contiguous(), H)
+        pm64.check_status(Br)
+        out["parity"]["rollout_f32_vs_f64_mode"] = {
+            "B": Br, "H": H, "max_abs_diff": {"mu_H": float((m32.double() - m64).abs().max()),
+                                              "Sigma_H": float((S32.double() - S64).abs().max())},
+            "max_abs": {"mu_H": float(m64.abs().max()), "Sigma_H": float(S64.abs().max())}}
+      else:
+        g32 = ops.moment_match(pm, mu0[:Br].contiguous(), S0[:Br].contiguous(), force_generic=False)
+        g64 = ops.moment_match(pm64, mu0[:Br].double().contiguous(), S0[:Br].double().contiguous())
+        pm64.check_status(Br)
+        out["parity"]["step_f32_vs_f64_mode"] = {
+            "B": Br, "max_abs_diff": {k: float((a.double() - b).abs().max()) for k, a, b in zip(("f1", "Sff", "cross_pre"), g32, g64)},
+            "max_abs": {k: float(b.abs().max()) for k, b in zip(("f1", "Sff", "cross_pre"), g64)}}
   if rank == 0:
     print(json.dumps(out))
   if world > 1:
@@ -286,11 +483,21 @@ def main():
 
 def pathwise_bench(args, rank, world, dev, dist):
   """configs[4]: one step = one Euler step of all local sample paths (HBM-bound weight stream)."""
+  import torch
+  from gpflowpilco_amd.distributed import shard_range
   from gpflowpilco_amd.pathwise import PathwiseSVGP
+  from gpflowpilco_amd.synthetic import make_svgp
   c = dict(PATHWISE)
-  if args.batch:
-    c["S"] = args.batch
-  L, M, d, K, H, S, dtype = c["L"], c["M"], c["d"], c["K"], c["H"], c["S"], c["dtype"]
+  scaling = args.scaling or c["scaling"]
+  Scfg = args.batch or c["S"]
+  L, M, d, K, H, dtype = c["L"], c["M"], c["d"], c["K"], c["H"], torch.float32
+  if scaling == "strong":
+    S_total = Scfg
+    lo, hi = shard_range(S_total, rank, world)
+    S = hi - lo
+  else:
+    S, S_total = Scfg, Scfg * world
+  steps = max(H, -(-args.steps // H) * H)
   syn = make_svgp(L, M, d, seed=c["seed"], device=str(dev), ls_bounds=(0.7, 3.0))
   base = syn.to_model(dev)
   model = PathwiseSVGP(kernel=base.kernel, inducing_variable=base.inducing_variable, q_mu=base.q_mu,
@@ -299,6 +506,7 @@ def pathwise_bench(args, rank, world, dev, dist):
   paths = model.generate_paths(S, K, dtype=dtype, device=dev, generator=g)
   x0 = 0.3 + 0.4 * torch.rand(S, d, dtype=dtype, device=dev, generator=g)
   target = torch.full((d,), 0.5, dtype=dtype, device=dev)
+  Smax = -(-S_total // world)
 
   def rollout_steps(n):
     x, traj = paths.rollout(x0, n, dt=1.0, keep_trajectory=True)
@@ -311,21 +519,24 @@ def pathwise_bench(args, rank, world, dev, dist):
       dist.barrier()
     torch.cuda.synchronize()
 
-  warm = rollout_steps(max(1, args.warmup))
+  rollout_steps(max(1, min(args.warmup, H)))
+  pad = torch.zeros(Smax, H, dtype=dtype, device=dev)
+  outs = [torch.empty_like(pad) for _ in range(world)] if world > 1 else None
   if world > 1:
-    dist.all_gather([torch.empty_like(warm) for _ in range(world)], warm)   # untimed channel bring-up
+    dist.all_gather(outs, pad)                                            # untimed channel bring-up
   fence()
   e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
   t0 = time.perf_counter()
   done = 0
+  ncoll = 0
   e0.record()
-  while done < args.steps:
-    n = min(H, args.steps - done)
-    cost = rollout_steps(n)
-    if n == H and world > 1:
-      out = [torch.empty_like(cost) for _ in range(world)]
-      dist.all_gather(out, cost)
-    done += n
+  while done < steps:
+    cost = rollout_steps(H)
+    if world > 1:
+      pad[:S].copy_(cost)
+      dist.all_gather(outs, pad)                                          # [S_local, H] -> every rank, once per rollout
+      ncoll += 1
+    done += H
   e1.record()
   fence()
   elapsed = time.perf_counter() - t0
@@ -333,19 +544,26 @@ def pathwise_bench(args, rank, world, dev, dist):
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
-  k_ms = e0.elapsed_time(e1) / args.steps
+  if not torch.isfinite(cost).all():
+    raise SystemExit("non-finite sample costs")
+  k_ms = e0.elapsed_time(e1) / steps
   bytes_per_launch = float(S) * L * (K + M) * 4
   achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
-  out = {"metric": "pathwise_rollout_sample_steps_per_sec", "value": round(S * world * args.steps / elapsed, 1),
-         "unit": "sample step-elements/s (S*H per rollout second)", "n_gpus": world, "steps": args.steps,
-         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True,
-         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-         "config": {"workload": c["label"], "N": M, "d": d, "D": L, "K": K, "H": H, "S_per_gpu": S,
-                    "parallelism": f"dp{world} over S"},
-         "roofline": {"bound": "hbm", "kernel": "k_pathwise", "achieved": round(achieved, 1), "peak": 8000.0,
-                      "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": None,
+  pmc, pmc_src = load_pmc("c5")
+  got = pmc_kernel(pmc, "k_pathwise")
+  out = {"metric": "pathwise_rollout_sample_steps_per_sec", "value": round(S_total * steps / elapsed, 1),
+         "unit": "sample step-elements/s (S*H per rollout second)", "n_gpus": world, "steps": steps,
+         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True,
+         "scaling": scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+         "config": {"workload": c["label"], "N": M, "d": d, "D": L, "K": K, "H": H, "S_total": S_total, "S_this_rank": S,
+                    "parallelism": f"dp{world} over S ({scaling})", "rollouts_timed": steps // H, "collectives_timed": ncoll,
+                    "steps_requested": args.steps},
+         "roofline": {"bound": "hbm", "kernel": "k_pathwise", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
+                      "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
+                      "traffic": got[1]["counters"].get("hbm_bytes") if got else None, "pmc": pmc_src,
                       "kernel_ms": round(k_ms, 4), "bytes_per_launch": bytes_per_launch,
-                      "note": "kernel_ms includes the (small) cost kernels between launches"}}
+                      "note": "achieved = algorithmic bytes S*L*(K+M)*4 per step / step time (the step time includes the small cost kernels "
+                              "between launches)"}}
   if rank == 0:
     print(json.dumps(out))
   if world > 1:

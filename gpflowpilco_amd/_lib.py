@@ -21,6 +21,7 @@ MM_FORCE_GENERIC = 4
 MM_STAGE_DIAG = 8
 MM_STAGE_OFFDIAG = 16
 MM_STAGE_FINALIZE = 32
+MM_FORCE_WORST_TIER = 64
 
 ERRORS = {
     -1: "MM_E_ARG: NULL pointer or non-positive size",

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
                                                           const double* __restrict__ beta, int M,
                                                           int L, int Mp, int d, int P, int NS, int p0,
                                                           int B, int bchunk, int np, int nslots, int nchunk, int nwork,
+                                                          int force_worst,
                                                           const double* __restrict__ w,
                                                           const double* __restrict__ q,
                                                           const double* __restrict__ rowA,
@@ -267,6 +268,7 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
           mxh = ah > mxh ? ah : mxh;
         }
 #define MM_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))
+    if (force_worst) mxh = 0x7ff00000u;                          // MM_FORCE_WORST_TIER: wave-uniform override
     double sv = 0.0;
 #define MM_F64_ACCUM(EXPM1_)                                                              \
     _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                    \
@@ -358,7 +360,7 @@ int mm_f64_num_slots(int Mp, int diag) {
 // Launch over `npairs` pairs starting at global pair index p0.  diag != 0: pairs are (a, a).
 // lowp != 0: the model is f32 (diagonal pairs only need ~1e-14 relative accuracy of expm1).
 int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double* beta, int M, int L, int Mp, int d,
-                       int P, int NS, int p0, int npairs, int B, int diag, int lowp,
+                       int P, int NS, int p0, int npairs, int B, int diag, int lowp, int force_worst,
                        const double* w, const double* q, const double* rowA, const double* colB,
                        double* partB, double* partC, hipStream_t stream) {
   if (npairs <= 0) return 0;
@@ -384,7 +386,7 @@ int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double*
   const int ks4 = (d + 3) / 4;
 #define MM_LAUNCH_F64_(KS_, DG_, WC_, LP_)                                                                  \
   hipLaunchKernelGGL((k_qred_f64_mfma<KS_, DG_, WC_, LP_>), grid, dim3(256), 0, stream, Zc, Kz, Cm, beta, M, \
-                     L, Mp, d, P, NS, p0, B, bchunk, npairs, nslots, nchunk, nwork, w, q, rowA, colB, partB, partC)
+                     L, Mp, d, P, NS, p0, B, bchunk, npairs, nslots, nchunk, nwork, force_worst, w, q, rowA, colB, partB, partC)
 #define MM_LAUNCH_F64(KS_, DG_)                                                  \
   do {                                                                           \
     const bool wc = DG_ && Cm != nullptr;                                        \

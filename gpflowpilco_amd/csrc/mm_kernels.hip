@@ -989,11 +989,11 @@ int mm_mfma_num_slots(int Mp);
 // f64 MFMA reduce (mm_f64.hip): diagonal pairs of both modes, off-diagonal pairs of the f64 mode
 int mm_f64_num_slots(int Mp, int diag);
 int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double* beta, int M, int L, int Mp, int d,
-                       int P, int NS, int p0, int npairs, int B, int diag, int lowp,
+                       int P, int NS, int p0, int npairs, int B, int diag, int lowp, int force_worst,
                        const double* w, const double* q, const double* rowA, const double* colB,
                        double* partB, double* partC, hipStream_t stream);
 int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
-                        int B, int L, int d, hipStream_t stream);
+                        int B, int L, int d, int flags, hipStream_t stream);
 
 #define MM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -1134,7 +1134,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
     } else {
       const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, Cm,
                                         (const double*)(packed + ml.beta64), M, L, wl.Mp, d, wl.P, wl.NS,
-                                        0, L, B, 1, sizeof(T) == 4 ? 1 : 0,
+                                        0, L, B, 1, sizeof(T) == 4 ? 1 : 0, (flags & MM_FORCE_WORST_TIER) ? 1 : 0,
                                         (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
                                         (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD),
                                         partB, partC, s);
@@ -1144,12 +1144,12 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
   // (2) off-diagonal pairs in T
   if (wl.Po > 0 && (stages & MM_STAGE_OFFDIAG)) {
     if (use_mfma32) {
-      const int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, s);
+      const int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, flags, s);
       if (rc) return rc;
     } else if (sizeof(T) == 8 && !generic) {
       const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, nullptr,
                                         (const double*)(packed + ml.beta64), M, L, wl.Mp, d, wl.P, wl.NS,
-                                        L, wl.Po, B, 0, 0, (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+                                        L, wl.Po, B, 0, 0, (flags & MM_FORCE_WORST_TIER) ? 1 : 0, (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
                                         (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO),
                                         partB, partC, s);
       if (rc) return rc;

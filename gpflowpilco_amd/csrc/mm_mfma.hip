@@ -142,7 +142,7 @@ __device__ __forceinline__ float mm_rem_p5(float x) {       // r(x) on [-1, 1]
 template <int ND8>
 __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32_mfma(const unsigned short* __restrict__ Zs3,
                                                           int L, int Mp, int d, int P, int Po, int NS,
-                                                          int npanel, int nwork,
+                                                          int npanel, int nwork, int force_worst,
                                                           const float* __restrict__ rowO,
                                                           const float* __restrict__ colO,
                                                           double* __restrict__ partB) {
@@ -308,12 +308,12 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     for (int ct = 0; ct < nct; ct += 2) {
       load_tile(ct + 1, zA1, zB1, w1);
       mfma_tile_hm(zA0, acc);
-      float mx = tile_max(acc);
+      float mx = force_worst ? 2.0f : tile_max(acc);            // MM_FORCE_WORST_TIER: wave-uniform override
       if (__any(mx > MM_TWO_WAY_MAX)) mfma_tile_l(zB0, acc);
       reduce_tile(acc, mx, w0);
       load_tile(ct + 2 < nct ? ct + 2 : ct, zA0, zB0, w0);      // clamped: the last pass re-reads its own tile
       mfma_tile_hm(zA1, acc);
-      mx = tile_max(acc);
+      mx = force_worst ? 2.0f : tile_max(acc);
       if (__any(mx > MM_TWO_WAY_MAX)) mfma_tile_l(zB1, acc);
       reduce_tile(acc, mx, w1);
     }
@@ -332,8 +332,9 @@ extern "C" int mm_mfma_supported(int d) { return d >= 1 && d <= 32; }
 int mm_mfma_num_slots(int Mp) { return (Mp + MM_PANEL_ROWS - 1) / MM_PANEL_ROWS; }
 
 int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
-                        int B, int L, int d, hipStream_t stream) {
+                        int B, int L, int d, int flags, hipStream_t stream) {
   const int npanel = mm_mfma_num_slots(wl.Mp);
+  const int force_worst = (flags & MM_FORCE_WORST_TIER) ? 1 : 0;
   const long long nwork_ll = (long long)npanel * wl.Po * B;
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const int nwork = (int)nwork_ll;
@@ -343,7 +344,7 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
   double* partB = (double*)(ws + wl.partB);
 #define MM_LAUNCH_ND(ND_)                                                                         \
   hipLaunchKernelGGL((k_qred_f32_mfma<ND_>), dim3(nwork), dim3(256), 0, stream, Zs3, L, wl.Mp, d, \
-                     wl.P, wl.Po, wl.NS, npanel, nwork, rowO, colO, partB)
+                     wl.P, wl.Po, wl.NS, npanel, nwork, force_worst, rowO, colO, partB)
   switch (ml.nd8) {
     case 1: MM_LAUNCH_ND(1); break;
     case 2: MM_LAUNCH_ND(2); break;

@@ -63,7 +63,9 @@ class GraphedPolicyLoss:
   ``loss()`` / ``loss_and_grad()`` return static tensors that the next replay
   overwrites; gradients are also left in ``p.grad`` (overwritten, not accumulated).  No host-side
   checks run inside a replay: a non-PD state shows up as nan in the loss and in the packed models'
-  status words (``PackedModel.check_status``).
+  status words (``PackedModel.check_status``); a failed Kuu factorisation of the trainable policy poisons its
+  factor with NaN inside the graph and is recorded in ``linalg.capture_status`` -- ``check()`` (synchronising)
+  raises for either.
   """
 
   def __init__(self, closure: Callable, parameters: Sequence[torch.Tensor], warmup: int = 2):
@@ -95,6 +97,12 @@ class GraphedPolicyLoss:
       self._loss_bwd.sum().backward()
     self._grads = [p.grad for p in self.parameters]
     self._loss_bwd = self._loss_bwd.detach()
+    self._device = dev
+
+  def check(self):
+    """Synchronising check of what the replays could not raise: in-graph factorisation failures."""
+    from .linalg import check_capture_status
+    check_capture_status(self._device)
 
   def loss(self) -> torch.Tensor:
     """Forward only: the per-batch-element loss [B]."""

@@ -21,7 +21,7 @@ from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 
-from .linalg import cholesky as robust_cholesky
+from .linalg import cholesky
 
 DEFAULT_JITTER = 1e-6  # gpflow.config.default_jitter()
 DEFAULT_FLOAT = torch.float64  # gpflow.config.default_float()
@@ -264,7 +264,7 @@ class SVGP:
     d2 = (A * A).sum(-1)[:, :, None] + (A * A).sum(-1)[:, None, :] - 2.0 * A @ A.transpose(1, 2)
     Kuu = var[:, None, None] * torch.exp(-0.5 * d2.clamp_min(0.0))
     Kuu = Kuu + DEFAULT_JITTER * torch.eye(M, dtype=DEFAULT_FLOAT, device=device)  # models.py:216
-    Luu = robust_cholesky(Kuu)                                                # :217
+    Luu = cholesky(Kuu)                                                # :217
     v = self.q_mu.to(device=device, dtype=DEFAULT_FLOAT).T.unsqueeze(-1)            # [L,M,1]  :228
     S = torch.tril(self.q_sqrt.to(device=device, dtype=DEFAULT_FLOAT))              # :229
     if not self.whiten:                                                             # :230-232
@@ -330,7 +330,7 @@ class GPR:
     Z, ls, var = _stack_kernel_params([self.kernel], [X], device)
     N = X.shape[0]
     Kyy = self.kernel.K(X) + self.likelihood.variance.to(X) * torch.eye(N, dtype=DEFAULT_FLOAT, device=device)
-    Lyy = robust_cholesky(Kyy)                                                # :66-68
+    Lyy = cholesky(Kyy)                                                # :66-68
     beta = torch.cholesky_solve(Y, Lyy).T.contiguous()                              # [1,N]   :75
     C = -torch.cholesky_inverse(Lyy).unsqueeze(0)                                   # -(K + s2 I)^-1  (:86-88)
     return Z, ls, var, beta, C, c

@@ -18,7 +18,7 @@ from typing import Optional
 
 import torch
 
-from .linalg import cholesky as robust_cholesky
+from .linalg import cholesky
 
 from . import _lib
 from .models import DEFAULT_FLOAT, DEFAULT_JITTER, SVGP, Constant, Zero, _stack_kernel_params, unpack_multioutput
@@ -129,7 +129,7 @@ def generate_paths(model: SVGP, num_samples: int, num_bases: int = 1024, dtype=t
   A = Z / ls[:, None, :]
   d2 = (A * A).sum(-1)[:, :, None] + (A * A).sum(-1)[:, None, :] - 2.0 * A @ A.transpose(1, 2)
   Kuu = var[:, None, None] * torch.exp(-0.5 * d2.clamp_min(0.0)) + DEFAULT_JITTER * torch.eye(M, dtype=DEFAULT_FLOAT, device=device)
-  Luu = robust_cholesky(Kuu)
+  Luu = cholesky(Kuu)
   q_mu = model.q_mu.to(device=device, dtype=DEFAULT_FLOAT).T                       # [L, M]
   q_sqrt = torch.tril(model.q_sqrt.to(device=device, dtype=DEFAULT_FLOAT))          # [L, M, M]
   eps = rn(S, L, M)

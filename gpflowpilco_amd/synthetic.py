@@ -6,6 +6,9 @@ drawn from the GP prior (+ noise), q_mu / q_sqrt = the exact posterior at Z (whi
 mu0 ~ U[0,1]^d, Sigma0 = random correlation scaled to std 0.1 (the reference tests'
 ``generate_covariance``, ``tests/utils.py:99-121``).
 
+q_mu / q_sqrt are formed in whitened coordinates from (I + L^T L / s2)^-1, positive definite by
+construction (no eigendecomposition or eigenvalue clipping in the set-up path).
+
 One deviation, stated in DESIGN.md: with ``stable=True`` the targets are
 ``-0.5 (z_a - 0.5) + 0.25 * prior draw`` so that a closed d == L rollout stays inside the
 data's support; with pure prior draws the state leaves [0,1]^d within a few steps, every q
@@ -19,7 +22,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .linalg import cholesky as robust_cholesky
+from .linalg import cholesky
 
 from . import models as gp
 
@@ -74,7 +77,7 @@ def make_svgp(L: int, M: int, d: int, seed: int, stable: bool = True,
     A = Zt / torch.tensor(ls[a], dtype=F64, device=device)
     d2 = (A * A).sum(-1)[:, None] + (A * A).sum(-1)[None, :] - 2.0 * A @ A.T
     K = var[a] * torch.exp(-0.5 * d2.clamp_min(0.0))
-    Lk = robust_cholesky(K + gp.DEFAULT_JITTER * eye)
+    Lk = cholesky(K + gp.DEFAULT_JITTER * eye)                       # the model's own prior factor (Kuu + jitter)
     draw = Lk @ torch.tensor(eps_f[a], dtype=F64, device=device)
     if stable:
       col = Zt[:, a % d]
@@ -82,18 +85,19 @@ def make_svgp(L: int, M: int, d: int, seed: int, stable: bool = True,
     else:
       y = draw
     y = y + np.sqrt(noise[a]) * torch.tensor(eps_n[a], dtype=F64, device=device)
-    Ly = robust_cholesky(K + noise[a] * eye)
-    m = K @ torch.cholesky_solve(y[:, None], Ly)                      # posterior mean of u
-    S = K - K @ torch.cholesky_solve(K, Ly)                          # posterior cov of u
-    v = torch.linalg.solve_triangular(Lk, m, upper=False)            # whitened mean
-    T1 = torch.linalg.solve_triangular(Lk, S, upper=False)
-    Sw = torch.linalg.solve_triangular(Lk, T1.T, upper=False)
-    Sw = 0.5 * (Sw + Sw.T)
-    ew, ev = torch.linalg.eigh(Sw)                                   # clip rounding-negative modes
-    Sw = (ev * ew.clamp_min(1e-8)) @ ev.T
-    Sw = 0.5 * (Sw + Sw.T) + 1e-10 * eye
+    # Exact posterior of u ~ N(0, Lk Lk^T) given y = u + eps, in whitened coordinates u = Lk v:
+    #   cov(v | y) = (I + Lk^T Lk / s2)^-1 =: A^-1,   E[v | y] = A^-1 Lk^T y / s2.
+    # A is positive definite with eigenvalues >= 1 BY CONSTRUCTION (no K - K (K + s2 I)^-1 K cancellation, hence no
+    # eigenvalue clipping and no eigh in the set-up path).  q_sqrt must be LOWER triangular with
+    # q_sqrt q_sqrt^T = A^-1: factor A = U U^T with U UPPER triangular (Cholesky of the index-reversed matrix),
+    # then A^-1 = U^-T U^-1 and q_sqrt = U^-T.
+    Am = eye + (Lk.T @ Lk) / noise[a]
+    Am = 0.5 * (Am + Am.T)
+    v = torch.cholesky_solve((Lk.T @ y / noise[a])[:, None], cholesky(Am))
+    Rrev = cholesky(torch.flip(Am, (0, 1)))
+    U = torch.flip(Rrev, (0, 1))                                     # upper triangular, U U^T = A
+    q_sqrt[a] = torch.linalg.solve_triangular(U.T, eye, upper=False).cpu().numpy()
     q_mu[:, a] = v[:, 0].cpu().numpy()
-    q_sqrt[a] = robust_cholesky(Sw).cpu().numpy()
   mc = rng.standard_normal(L) * 0.1 if mean_c else None
   return SyntheticSVGP(Z=Z, lengthscales=ls, variance=var, noise=noise, q_mu=q_mu, q_sqrt=q_sqrt, mean_c=mc)
 

@@ -50,6 +50,10 @@ extern "C" {
 #define MM_STAGE_DIAG        8   /* f64 reduce of the diagonal pairs a == a' (incl. the C-weighted term) */
 #define MM_STAGE_OFFDIAG    16   /* T reduce of the off-diagonal pairs a < a'                          */
 #define MM_STAGE_FINALIZE   32   /* partial slabs -> Sff                                               */
+/* measurement aid: every tile of the reduce kernels takes its most expensive range tier (f32 reduce: all three
+ * split-product stages + the exp2 branch; f64 reduce: the k ln2 + r form) whatever the data.  The tiers are all
+ * valid on the whole range, so results are unchanged up to rounding; bench.py --recipe worst times it. */
+#define MM_FORCE_WORST_TIER 64
 
 /* error codes */
 #define MM_E_ARG      (-1)  /* NULL pointer / non-positive size                  */

@@ -6,6 +6,10 @@ The reference (TensorFlow/GPflow) cannot run here and holds no golden vectors of
 to the reference's own test designs by ``tests/test_oracle_pin.py`` -- with seeded numpy inputs
 (SURVEY.md section 8c "Golden vectors the build must create itself").
 
+The fixtures are only (re)written after the oracle passes its digit-level pin: the tensor Gauss-Hermite
+quadrature of oracle/quadrature_pin.py (<= 1e-9 on mean, full covariance and cross-covariance for whiten=True,
+SeparateIndependent, model_uncertainty=False, GPR and the Euler update).
+
   python tests/golden/make_golden.py        # rewrites tests/golden/*.npz
 """
 import os
@@ -18,7 +22,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from gpflowpilco_amd.synthetic import generate_covariance, make_inputs, make_svgp  # noqa: E402
 from oracle import mm_oracle as mo  # noqa: E402
+from oracle import quadrature_pin as qp  # noqa: E402
 from tests.helpers import oracle_params, random_svgp_params  # noqa: E402
+
+if qp.main() != 0:
+  raise SystemExit("oracle/quadrature_pin.py failed: the golden fixtures are NOT regenerated from an unpinned oracle")
 
 
 def svgp_fixture(name, p: mo.SVGPParams, mu, Sigma, rollout_steps=0):

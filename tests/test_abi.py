@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
 def test_header_constants_match_python():
   text = open(HEADER).read()
   for name in ("MM_F32", "MM_F64", "MM_DMAX", "MM_M_ALIGN", "MM_FULL_OUTPUT_COV", "MM_MODEL_UNCERTAINTY",
-               "MM_FORCE_GENERIC", "MM_STAGE_DIAG", "MM_STAGE_OFFDIAG", "MM_STAGE_FINALIZE"):
+               "MM_FORCE_GENERIC", "MM_STAGE_DIAG", "MM_STAGE_OFFDIAG", "MM_STAGE_FINALIZE",
+               "MM_FORCE_WORST_TIER"):
     m = re.search(rf"#define\s+{name}\s+(\d+)", text)
     assert m and int(m.group(1)) == getattr(_lib, name), name
 

@@ -72,3 +72,87 @@ def test_c3_rollout_stays_in_regime_and_matches_f64_mode(device):
   assert (out[torch.float32][1] - out[torch.float64][1]).abs().max() < 2e-6
   std = torch.diagonal(out[torch.float64][1], dim1=-2, dim2=-1).sqrt()
   assert 0.02 < std.mean() < 0.5            # the state stays inside the data's support
+
+
+def test_c4_shard_shape_L32_d16(device):
+  """BASELINE configs[3] per-GPU shard: N=4000, d=16, D=32 (496 off-diagonal pairs), B=32, fp32, BASELINE.md's own
+  recipe (lengthscales log-U[0.3,3], GP-prior targets, mu ~ U[0,1]^d, Sigma std 0.1).  Checker: the fused fp64
+  restatement on a sub-model of 3 latents (latents are independent: the (a, a') blocks of the full result ARE the
+  sub-model's result) for two batch elements; plus shard invariance, symmetry, positive definiteness."""
+  L, M, d, B = 32, 4000, 16, 32
+  syn = make_svgp(L, M, d, seed=1003, device=str(device), ls_bounds=(0.3, 3.0), stable=False)
+  mu, Sigma = make_inputs(B, d, seed=3003, scale=0.1, lo=0.0, hi=1.0)
+  pm = syn.to_model(device).packed(torch.float32, True, device)
+  mu_t, S_t = to_dev(mu, device, torch.float32), to_dev(Sigma, device, torch.float32)
+  f1, Sff, cross = ops.moment_match(pm, mu_t, S_t)
+  pm.check_status(B)
+  assert torch.isfinite(f1).all() and torch.isfinite(Sff).all() and torch.isfinite(cross).all()
+  sel = [0, 13, 31]
+  from oracle import mm_oracle as mo
+  po = mo.SVGPParams(Z=np.broadcast_to(syn.Z, (L, M, d))[sel].copy(), lengthscales=syn.lengthscales[sel],
+                     variance=syn.variance[sel], q_mu=syn.q_mu[:, sel], q_sqrt=syn.q_sqrt[sel], whiten=True)
+  beta, C = fr.precompute(po)
+  f1o, Sffo, cro = fr.moment_match(mu[:2], Sigma[:2], po, beta, C)
+  idx = torch.tensor(sel, device=device)
+  assert scale_err(f1[:2][:, idx], f1o) < 2e-6 and scale_err(cross[:2][:, :, idx], cro) < 2e-6
+  assert scale_err(Sff[:2][:, idx][:, :, idx], Sffo) < 5e-5
+  f1s, Sffs, crs = ops.moment_match(pm, mu_t[9:12].contiguous(), S_t[9:12].contiguous())
+  assert torch.equal(f1s, f1[9:12]) and torch.equal(Sffs, Sff[9:12]) and torch.equal(crs, cross[9:12])
+  assert torch.equal(Sff, Sff.transpose(1, 2))
+  assert torch.linalg.eigvalsh(Sff.double()).min() > 0
+
+
+def test_c3_baseline_recipe_f32_error_bound(device):
+  """f32 mode on BASELINE.md's own synthetic recipe (lengthscales log-U[0.3,3], GP-prior targets, mu ~ U[0,1]^d,
+  Sigma std 0.1) -- the regime with short lengthscales, larger |b| and the higher range tiers -- against the fused
+  fp64 restatement, and against the same kernels in f64 mode on a larger batch."""
+  L = d = 8
+  M = 2000
+  syn = make_svgp(L, M, d, seed=1002, device=str(device), ls_bounds=(0.3, 3.0), stable=False)
+  mu, Sigma = make_inputs(32, d, seed=3002, scale=0.1, lo=0.0, hi=1.0)
+  model = syn.to_model(device)
+  pm32, pm64 = model.packed(torch.float32, True, device), model.packed(torch.float64, True, device)
+  g32 = ops.moment_match(pm32, to_dev(mu, device, torch.float32), to_dev(Sigma, device, torch.float32))
+  g64 = ops.moment_match(pm64, to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64))
+  pm32.check_status(32); pm64.check_status(32)
+  po = oracle_params(syn)
+  beta, C = fr.precompute(po)
+  f1o, Sffo, cro = fr.moment_match(mu[:2], Sigma[:2], po, beta, C)
+  assert scale_err(g64[0][:2], f1o) < 1e-8 and scale_err(g64[2][:2], cro) < 1e-8 and scale_err(g64[1][:2], Sffo) < 5e-5
+  # f32 mode vs f64 mode, all 32 elements: the stated f32 tolerance of the BASELINE recipe
+  for a, b, tol in zip(g32, g64, (2e-6, 5e-5, 2e-6)):
+    assert float((a.double() - b).abs().max() / b.abs().max()) < tol
+
+
+def test_forced_worst_tier_gives_the_same_result(device):
+  """MM_FORCE_WORST_TIER (bench.py --recipe worst) only changes which range tier evaluates a tile."""
+  from gpflowpilco_amd import _lib
+  L = d = 4
+  syn = make_svgp(L, 300, d, seed=77, ls_bounds=(0.7, 3.0))
+  mu, Sigma = make_inputs(6, d, seed=5, scale=0.1, lo=0.3, hi=0.7)
+  model = syn.to_model(device)
+  for dtype, tol in ((torch.float64, 1e-12), (torch.float32, 2e-6)):
+    pm = model.packed(dtype, True, device)
+    mu_t, S_t = to_dev(mu, device, dtype), to_dev(Sigma, device, dtype)
+    _, Sff, _ = ops.moment_match(pm, mu_t, S_t)
+    flags = ops.make_flags(True, True) | _lib.MM_FORCE_WORST_TIER
+    ops.q_forward(pm, mu_t, S_t, flags)
+    Sw = ops.Q_reduce_forward(pm, 6, flags)
+    assert float((Sw - Sff).abs().max() / Sff.abs().max()) < tol
+
+
+def test_wide_sigma_short_lengthscales_f32_is_finite_and_bounded(device):
+  """|b| >> 1: input std 1.0 against lengthscales down to 0.3 -- the exp2 branch with factored weights
+  what_i = w_i e^{rho'_i}.  Outputs must be finite (no overflow of the factored weights) and the f32 mode must
+  stay within 2e-3 of the fp64 oracle relative to max |Sff| (test_large_delta_slow_path_f32's bound)."""
+  from oracle import mm_oracle as mo
+  syn = make_svgp(3, 160, 4, seed=21, ls_bounds=(0.3, 1.0), stable=False)
+  mu, Sigma = make_inputs(5, 4, seed=8, scale=1.0, lo=0.0, hi=1.0)
+  f1o, Sffo, cro = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
+  model = syn.to_model(device)
+  for dtype, tol in ((torch.float64, 1e-6), (torch.float32, 2e-3)):
+    pm = model.packed(dtype, True, device)
+    f1, Sff, cross = ops.moment_match(pm, to_dev(mu, device, dtype), to_dev(Sigma, device, dtype))
+    pm.check_status(5)
+    assert torch.isfinite(f1).all() and torch.isfinite(Sff).all() and torch.isfinite(cross).all()
+    assert scale_err(Sff, Sffo) < tol and scale_err(f1, f1o) < tol

@@ -172,12 +172,41 @@ def test_moment_matching_euler_python_path():
   assert len(hist) == 2
 
 
-def test_robust_cholesky_matches_torch_and_raises_on_non_pd():
+def test_cholesky_matches_torch_and_raises_with_evidence_on_non_pd(tmp_path, monkeypatch):
   import torch
-  from gpflowpilco_amd.linalg import cholesky
+  from gpflowpilco_amd.linalg import CholeskyError, cholesky
   g = torch.Generator().manual_seed(0)
   A = torch.randn(3, 6, 6, generator=g, dtype=torch.float64)
   A = A @ A.transpose(1, 2) + 1e-3 * torch.eye(6, dtype=torch.float64)
   assert torch.equal(cholesky(A), torch.linalg.cholesky(A))
-  with pytest.raises(torch.linalg.LinAlgError):
-    cholesky(-A)
+  bad = A.clone()
+  bad[1] = -bad[1]
+  monkeypatch.setenv("GPFLOWPILCO_DUMP_DIR", str(tmp_path))
+  with pytest.raises(torch.linalg.LinAlgError) as ei:           # no retry, no fallback: the failure is reported
+    cholesky(bad)
+  assert isinstance(ei.value, CholeskyError)
+  msg = str(ei.value)
+  assert "batch item 1 of 3" in msg and "info=1" in msg and "max|A-A^T|" in msg
+  dumps = list(tmp_path.glob("cholesky_fail_pid*.pt"))
+  assert len(dumps) == 1 and torch.equal(torch.load(dumps[0])["A"], bad)
+
+
+def test_synthetic_posterior_is_exact_and_pd_by_construction():
+  """make_svgp's (q_mu, q_sqrt) is the exact whitened posterior of u ~ N(0, Kuu + jitter) given the targets,
+  formed without an eigendecomposition: q_sqrt is lower triangular and reproduces (I + L^T L / s2)^-1."""
+  import numpy as np
+  from gpflowpilco_amd.synthetic import make_svgp
+  syn = make_svgp(2, 40, 3, seed=9)
+  for a in range(2):
+    A = syn.Z / syn.lengthscales[a]
+    d2 = ((A[:, None, :] - A[None, :, :]) ** 2).sum(-1)
+    K = syn.variance[a] * np.exp(-0.5 * d2) + 1e-6 * np.eye(40)
+    Lk = np.linalg.cholesky(K)
+    Am = np.eye(40) + Lk.T @ Lk / syn.noise[a]
+    qs = syn.q_sqrt[a]
+    assert np.allclose(qs, np.tril(qs))
+    assert np.abs(qs @ qs.T @ Am - np.eye(40)).max() < 1e-8
+    # unwhitened: cov(u | y) = K - K (K + s2 I)^-1 K
+    S = Lk @ qs @ qs.T @ Lk.T
+    ref = K - K @ np.linalg.solve(K + syn.noise[a] * np.eye(40), K)
+    assert np.abs(S - ref).max() < 1e-8

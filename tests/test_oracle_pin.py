@@ -1,10 +1,17 @@
 """Pins the CPU oracle the way the reference pins itself: its three Monte-Carlo test designs
 (tests/test_kernel_expectation.py:51-93, tests/test_moment_matching.py:88-264) re-run in numpy
 against oracle/mm_oracle.py, with the reference's acceptance |a-b| <= 10/sqrt(n) and the 1e-12
-diag-vs-full checks.  2e5 samples here (CI time); ``python -m oracle.pin_oracle`` runs 1e6."""
+diag-vs-full checks.  2e5 samples here (CI time); ``python -m oracle.pin_oracle`` runs 1e6.
+
+Monte Carlo pins the formulas, not the digits (1e-2 absolute).  The second half pins the digits: tensor
+Gauss-Hermite quadrature (oracle/quadrature_pin.py) of the DEFINITION the reference's estimator samples
+(tests/test_moment_matching.py:57-84) -- mean, full covariance incl. off-diagonal pairs of latents with
+different lengthscales, cross-covariance -- to <= 1e-9 for exactly the cases no reference test touches
+(SURVEY.md section 8c): whiten=True, SeparateIndependent, model_uncertainty=False, the Euler moment update."""
 import pytest
 
 from oracle import pin_oracle as po
+from oracle import quadrature_pin as qp
 
 N = int(2e5)
 
@@ -37,3 +44,32 @@ def test_larger_input_covariance_still_matches_mc():
   """The reference designs use input std 0.01 (a weak test of the Sigma dependence); std 0.3 here."""
   errs, exact, tol = po.check_svgp(401, N, multi_output=True, whiten=True, scale_x=0.3)
   assert all(v <= tol for v in errs.values()), errs
+
+
+# ---- digits: Gauss-Hermite quadrature of the full handler outputs (d = 2: 60^2 nodes, d = 3: 40^3 nodes) ------
+GH = {2: 60, 3: 40}
+
+
+@pytest.mark.parametrize("d", [2, 3])
+@pytest.mark.parametrize("kw", [dict(whiten=True), dict(whiten=True, model_uncertainty=False), dict(whiten=False),
+                                dict(whiten=False, lcm_outputs=4), dict(whiten=True, single_output=True)],
+                         ids=["sep_whiten", "sep_whiten_no_model_unc", "sep", "lcm", "single_output_whiten"])
+def test_svgp_handlers_match_quadrature(d, kw):
+  errs, scale = qp.check_svgp(7 + d, d, 3, GH[d], **kw)
+  assert all(v <= 1e-9 for v in errs.values()), (errs, scale)
+  if not kw.get("single_output"):
+    assert scale["cov"] > 1e-2                                 # the pinned off-diagonal entries are not vacuous
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_gpr_handler_matches_quadrature(d):
+  errs = qp.check_gpr(17 + d, d, GH[d])
+  assert all(v <= 1e-9 for v in errs.values()), errs
+
+
+@pytest.mark.parametrize("d", [2, 3])
+@pytest.mark.parametrize("model_uncertainty", [True, False])
+def test_euler_moment_update_matches_quadrature(d, model_uncertainty):
+  """MomentMatchingEuler.step (dynamics/solvers.py:110-135): moments of x + dt f(x), dt = 0.7."""
+  errs = qp.check_euler(27 + d, d, GH[d], model_uncertainty=model_uncertainty)
+  assert all(v <= 1e-9 for v in errs.values()), errs

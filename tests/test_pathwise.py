@@ -79,3 +79,30 @@ def test_generated_paths_statistics_and_model_surface(device):
   assert np.all(np.abs(fv - np.diagonal(cov[0])) < 0.1 * np.diagonal(cov[0]) + 2e-2)
   with pytest.raises(RuntimeError, match="no sample paths"):
     model(torch.zeros(S, 2, dtype=torch.float64, device=device))
+
+
+@pytest.mark.gpu
+def test_c5_shard_shape_against_oracle_on_a_slice_of_samples(device):
+  """BASELINE configs[4] per-GPU shard: S = 8192 (65536 / 8) sample paths, N = 2000, K = 1024 bases, d = D = 8,
+  fp32 -- the LDS-resident streaming kernel at the shape the bench runs.  The HIP evaluation and a 3-step rollout
+  of ALL paths run on the GPU; the numpy oracle re-evaluates a slice of 24 samples spread over the stream
+  (first / middle / last sample groups) on identical path tensors."""
+  from gpflowpilco_amd.pathwise import paths_from_arrays
+  L, M, d, S, K = 8, 2000, 8, 8192, 1024
+  syn = make_svgp(L, M, d, seed=1004, device=str(device), ls_bounds=(0.7, 3.0))
+  po = oracle_params(syn)
+  rng = np.random.default_rng(11)
+  paths = pw.draw_paths(rng, po, S, K)
+  x = rng.uniform(0.3, 0.7, size=(S, d))
+  gp_paths = paths_from_arrays(paths.omega, paths.phase, paths.w, paths.v, po.Z, po.lengthscales, po.variance,
+                               po.mean_c, dtype=torch.float32, device=device)
+  xt = torch.tensor(x, dtype=torch.float32, device=device)
+  fg = gp_paths(xt)
+  assert torch.isfinite(fg).all()
+  sel = np.r_[0:8, 4093:4101, 8184:8192]
+  sub = pw.Paths(omega=paths.omega, phase=paths.phase, w=paths.w[sel], v=paths.v[sel])
+  fo = pw.eval_paths(sub, po, x[sel])
+  assert scale_err(fg[torch.tensor(sel, device=device)], fo) < 2e-3
+  xo, traj = pw.rollout(sub, po, x[sel], 3, dt=0.5, keep=True)
+  xg, tg = gp_paths.rollout(xt, 3, dt=0.5, keep_trajectory=True)
+  assert scale_err(tg[:, torch.tensor(sel, device=device)], traj) < 5e-3
