@@ -10,7 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpflowpilco_mm.so")
+# GPFLOWPILCO_MM_LIB: an alternative build of the same library (A/B experiments of kernel variants: csrc/build.sh
+# with OUT=... and extra -D flags); the default is the in-tree build
+LIB_PATH = os.environ.get("GPFLOWPILCO_MM_LIB") or os.path.join(_HERE, "libgpflowpilco_mm.so")
 
 MM_F32, MM_F64 = 0, 1
 MM_DMAX = 32
@@ -52,6 +54,16 @@ SIGNATURES = {
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "mm_euler_update": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double] + [C.c_void_p] * 8),
     "mm_expected_cost": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
+    "mm_offdiag_stats": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "mm_compose_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "mm_rollout_composed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                      C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                      C.c_void_p, C.c_void_p]),
     "mm_backward_bytes": (C.c_size_t, [C.c_int] * 5),
     "mm_backward_sums": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -2,13 +2,13 @@
 # Build the gfx950 shared library in-tree (hipcc cross-compiles without a GPU).
 set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
-out="${here}/../libgpflowpilco_mm.so"
-obj="${here}/.obj"
+out="${OUT:-${here}/../libgpflowpilco_mm.so}"      # OUT=path: a variant build beside the default one
+obj="${OBJDIR:-${here}/.obj}"
 mkdir -p "${obj}"
 common=(-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-result)
 objs=()
 pids=()
-for src in mm_kernels mm_mfma mm_f64 mm_pathwise mm_backward; do
+for src in mm_kernels mm_mfma mm_f64 mm_moments mm_compose mm_pathwise mm_backward; do
   extra=()
   # mm_mfma.hip alone is built with -fno-honor-nans: its per-tile range check max(|x|) then folds
   # into one v_max3_f32 per two entries (no canonicalising v_max x, x); inputs are finite by the

@@ -14,8 +14,23 @@ static inline int mm_num_pairs(int L, int flags) {
   return (flags & MM_FULL_OUTPUT_COV) ? L * (L + 1) / 2 : L;
 }
 
-// Columns of the moment table: 1 + d + d (d + 1) / 2, rounded up to the 16-wide MFMA tile.
-static inline int mm_moment_cols(int d) { return mm_round_up_int(1 + d + d * (d + 1) / 2, 16); }
+// Moment table of the f32 mode: every monomial of the centred inducing inputs up to total degree
+// mm_moment_deg(d), graded (degree 0, 1, 2, ...), colex order of the sorted index tuple inside a degree
+// (rank of k1 <= ... <= kn is sum_t C(k_t + t - 1, t)).  Degree 4 for d <= 8: the off-diagonal sums are then
+// collapsed to moments up to the quartic term (mm_moments.hip); degree 2 beyond (the table would have
+// C(d + 4, 4) columns: 4845 at d = 16).
+static inline int mm_moment_deg(int d) { return d <= 8 ? 4 : 2; }
+static inline long long mm_binom(int n, int k) {
+  if (k < 0 || k > n) return 0;
+  long long r = 1;
+  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+  return r;
+}
+// number of monomials of degree exactly n in d variables, and of degree < n (offset of the degree-n block)
+static inline int mm_mono_count(int n, int d) { return (int)mm_binom(d + n - 1, n); }
+static inline int mm_mono_offset(int n, int d) { int o = 0; for (int m = 0; m < n; ++m) o += mm_mono_count(m, d); return o; }
+// columns of the table, rounded up to the 16-wide MFMA tile
+static inline int mm_moment_cols(int d) { return mm_round_up_int(mm_mono_offset(mm_moment_deg(d) + 1, d), 16); }
 
 // Packed model: byte offsets inside the caller-owned device buffer.
 struct MMModelLayout {
@@ -30,9 +45,10 @@ struct MMModelLayout {
   size_t beta64;  // [L][M]     f64 Kuu^-1 u
   size_t Zc64;    // [L][Mp][Kz] f64 centred inducing inputs, zero padded (rows >= M, cols >= d)
   size_t Zc;      // [L][Mp][Kz] T   same, element type T (aliases Zc64 when T is f64)
-  size_t Zs3;     // [L][Mp][3][8 nd8] bf16: Zc split into bf16 parts (h, m, l), f32 mode only
-  size_t Zm;      // [L][Mp][KMp] f64: (1, zc_k, zc_k zc_l (k <= l)) per inducing point, zero padded -- the
-                  // table the weight moments sum_m what_m (1, zc, zc zc^T) are taken against (f32 mode only)
+  size_t Zs3;     // [L][Mp/32][3][32][8 nd8] bf16: Zc split into bf16 parts (h, m, l), tile-and-part major, f32 mode only
+  size_t Zm;      // [L][Mp][KMp] f64: the monomials of zc up to degree mm_moment_deg(d) per inducing point (graded colex,
+                  // zero padded) -- the table the weight moments sum_m what_m zc_m^alpha are taken against (f32 mode only)
+  size_t zmax2;   // [L] f64 max_m |zc_m|^2 (Cauchy-Schwarz bound on |b_ij| that admits a (b, pair) to the collapse)
   size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
                   // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
@@ -60,14 +76,22 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   if (dtype != MM_F64) off = mm_align_up(off + (size_t)L * o.Mp * 24 * o.nd8 * 2, A);
   o.Zm = off;
   if (dtype != MM_F64) off = mm_align_up(off + (size_t)L * o.Mp * o.KMp * 8, A);
+  o.zmax2 = off;  off = mm_align_up(off + (size_t)L * 8, A);
   o.Cm = off;
   if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;
   return o;
 }
 
-// k_wmoments: workgroups per (batch tile, pair, side), each summing its slice of the m range
-#define MM_MOM_SPLIT 4
+// k_wmom_gemm: slices of the m range (split-K) per output tile; k_spoly adds the partial moment vectors
+#define MM_MOM_SPLIT 2
+// a (b, pair) is collapsed (cubic + quartic term of the remainder taken from moments, tiles with max|b| <= 1/16
+// skipped) when max_i |A_i|^2 * max_j |zc_j|^2 <= MM_COLLAPSE_BOUND2, i.e. every |b_ij| <= 1 by Cauchy-Schwarz
+#define MM_COLLAPSE_BOUND2 1.0f
+// first-tier near-minimax approximant of the remainder r(x) = expm1(x) - x - x^2/2 ~ x^3 (C0 + C1 x), |x| <= 1/16,
+// error <= 5e-8 |x| (tools/minimax_remainder.py): the polynomial the collapse takes from the moments
+#define MM_REM1_C0 1.666936278e-01f
+#define MM_REM1_C1 4.167173430e-02f
 // Rows per workgroup of the generic reduce kernel / columns per workgroup.
 #define MM_GEN_ROWS 64
 #define MM_GEN_COLS 256
@@ -89,14 +113,18 @@ struct MMWorkspaceLayout {
   size_t w;        // [B][L][Mp] T    (aliases w64 when T is f64)
   size_t rowD;     // [B][L][Mp] f64        rho_i          diagonal pairs
   size_t colD;     // [B][L][d+1][Mp] f64   g_j, gamma'_j  diagonal pairs
+  size_t qhR;      // [B][L][Mp] f64  diagonal pairs, factored weights of the f64 MFMA reduce: u_i e^{rho_i}, u = q with
+  size_t qhC;      // [B][L][Mp] f64  model uncertainty (w without): column side u_j e^{gamma'_j}; then delta = zc_i . g_j only
   size_t rowO;     // off-diagonal pairs.  f64: [B][Po][Mp] rho_i            f32: [B][Po][d+1][Mp] A_i, what_i
   size_t colO;     //                      f64: [B][Po][d+1][Mp] g_j, gamma'_j  f32: [B][Po][Mp] what'_j
   size_t f1raw;    // [B][L] f64      sum_i w_i (f1 without the mean)
   size_t whR;      // [B][Po][Mp] f64  what_i  = w_i e^{rho'_i}   (f32 mode: row weights, unrounded)
   size_t whC;      // [B][Po][Mp] f64  what'_j = w'_j e^{gamma_j}
-  size_t mom;      // [B][Po][2][MM_MOM_SPLIT][KMp] f64  partial sums over m of what_m (1, zc_m, zc_m zc_m^T):
-                   //                  row side, column side; MM_MOM_SPLIT slices of the m range
-  size_t s12;      // [B][Po] f64  linear + quadratic part of the off-diagonal sums (+ the O(M) correction)
+  size_t mom;      // [B][Po][2][MM_MOM_SPLIT][KMp] f64  partial sums over m of what_m zc_m^alpha (all monomials of the
+                   //                  table): row side, column side; MM_MOM_SPLIT slices of the m range
+  size_t amax;     // [B][Po] u32  bits of max_i |A_i|^2 (f32, >= 0: ordered like the integer), zeroed by k_prep
+  size_t s12;      // [B][Po] f64  the polynomial part of the off-diagonal sums from the moments:
+                   //              orders 0..2 always, orders 3 and 4 as well where the (b, pair) is collapsed
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
   size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i expm1(delta_ij) q_j  (+ q^T C q)
   size_t f1s;      // [B][L] T      rollout scratch outputs
@@ -129,6 +157,8 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   if (dtype != MM_F64) { o.w = off; off = mm_align_up(off + (size_t)B * L * o.Mp * es, A); }
   o.rowD = off;    off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.colD = off;    off = mm_align_up(off + (size_t)B * L * (d + 1) * o.Mp * 8, A);
+  o.qhR = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
+  o.qhC = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   const size_t nrow = dtype == MM_F64 ? 1 : (size_t)(d + 1), ncol = dtype == MM_F64 ? (size_t)(d + 1) : 1;
   o.rowO = off;    off = mm_align_up(off + (size_t)B * o.Po * nrow * o.Mp * es, A);
   o.colO = off;    off = mm_align_up(off + (size_t)B * o.Po * ncol * o.Mp * es, A);
@@ -137,6 +167,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.whR = off;     off = mm_align_up(off + nwh * 8, A);
   o.whC = off;     off = mm_align_up(off + nwh * 8, A);
   o.mom = off;     off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * 2 * MM_MOM_SPLIT * mm_moment_cols(d) * 8), A);
+  o.amax = off;    off = mm_align_up(off + (size_t)B * o.Po * 4, A);
   o.s12 = off;     off = mm_align_up(off + (size_t)B * o.Po * 8, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
   o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);

@@ -1,0 +1,334 @@
+// Rollout COMPOSITION around the two GP moment matches of a PILCO step, as device code (gfx950).
+//
+// One step of MomentMatchingPILCO's policy-loss rollout (gpflow_pilco/loops/pilco.py:192-220) with encoder and
+// policy present (gpflow_pilco/dynamics/forward_sde.py:95-137):
+//     x (nx)  --TrigonometricEncoder on `active` dims-->  e = [sin a, cos a, x_inactive]            (ne = 2 na + nb)
+//     e       --policy: SVGP mean (KernelRegressor) -> Chain[Scale, Shift, NormalCDF]-->  u         (nu = 1)
+//     d = joint(e, u) (nd = ne + 1)  --drift SVGP-->  f (nx);  Cov(x, f) ~ Cov(x, d) Cov(d, d)^-1 Cov(d, f)
+//     Euler moment update (dynamics/solvers.py:110-135), expected Gaussian cost of the encoded new state.
+// The GP matches are the library's own kernels (mm_moment_match); everything between them is <= 25 x 25 algebra
+// per batch element and runs here, one wave per element, f64 in LDS:
+//   k_compose_encode : moment_matching/components.py:19-57 + maths.py:143-176 (sincos moments, Cov(x, e))
+//   k_compose_policy : moment_matching/bijectors.py:39-69 (NormalCDF: Owen's T by 48-point Gauss-Legendre, the
+//                      quadrature gpflowpilco_amd/special.py uses), Shift, Scale, the chain rule
+//                      (gaussian.py:66-83) and GaussianMatch.joint (gaussian.py:53-63)
+//   k_compose_step   : forward_sde.py:105-131 bookkeeping + solvers.py:110-135
+// mm_rollout_composed enqueues the whole H-step rollout (4 small kernels + 2 GP matches + the cost per step).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "mm_common.h"
+
+#define MMC_NX 16          // largest state dimension
+#define MMC_NA 8           // largest number of encoded (angle) dimensions
+#define MMC_ND 32          // largest drift input dimension (= MM_DMAX)
+
+struct MMComposeDims {
+  int nx, na, nb, ne, nd;
+  int active[MMC_NA];
+  int inactive[MMC_NX];
+  int slot[MMC_NX];        // state dim r -> ia (< na) if active, else na + ib
+};
+
+static __device__ const double MM_GL48_X[48] = {-9.98771007252426068e-01, -9.93530172266350764e-01, -9.84124583722826851e-01, -9.70591592546247273e-01, -9.52987703160430910e-01, -9.31386690706554332e-01, -9.05879136715569633e-01, -8.76572020274247854e-01, -8.43588261624393487e-01, -8.07066204029442624e-01, -7.67159032515740358e-01, -7.24034130923814634e-01, -6.77872379632663891e-01, -6.28867396776513599e-01, -5.77224726083972683e-01, -5.23160974722232996e-01, -4.66902904750958414e-01, -4.08686481990716721e-01, -3.48755886292160755e-01, -2.87362487355455554e-01, -2.24763790394689050e-01, -1.61222356068891709e-01, -9.70046992094626970e-02, -3.23801709628693674e-02, 3.23801709628693674e-02, 9.70046992094626970e-02, 1.61222356068891709e-01, 2.24763790394689050e-01, 2.87362487355455554e-01, 3.48755886292160755e-01, 4.08686481990716721e-01, 4.66902904750958414e-01, 5.23160974722232996e-01, 5.77224726083972683e-01, 6.28867396776513599e-01, 6.77872379632663891e-01, 7.24034130923814634e-01, 7.67159032515740358e-01, 8.07066204029442624e-01, 8.43588261624393487e-01, 8.76572020274247854e-01, 9.05879136715569633e-01, 9.31386690706554332e-01, 9.52987703160430910e-01, 9.70591592546247273e-01, 9.84124583722826851e-01, 9.93530172266350764e-01, 9.98771007252426068e-01};
+static __device__ const double MM_GL48_W[48] = {3.15334605230917957e-03, 7.32755390127649234e-03, 1.14772345792349736e-02, 1.55793157229429276e-02, 1.96161604573552965e-02, 2.35707608393240925e-02, 2.74265097083568818e-02, 3.11672278327983394e-02, 3.47772225647706573e-02, 3.82413510658306741e-02, 4.15450829434645535e-02, 4.46745608566940997e-02, 4.76166584924902839e-02, 5.03590355538542783e-02, 5.28901894851934867e-02, 5.51995036999840538e-02, 5.72772921004029295e-02, 5.91148396983954827e-02, 6.07044391658935825e-02, 6.20394231598924636e-02, 6.31141922862537841e-02, 6.39242385846479494e-02, 6.44661644359498381e-02, 6.47376968126836816e-02, 6.47376968126836816e-02, 6.44661644359498381e-02, 6.39242385846479494e-02, 6.31141922862537841e-02, 6.20394231598924636e-02, 6.07044391658935825e-02, 5.91148396983954827e-02, 5.72772921004029295e-02, 5.51995036999840538e-02, 5.28901894851934867e-02, 5.03590355538542783e-02, 4.76166584924902839e-02, 4.46745608566940997e-02, 4.15450829434645535e-02, 3.82413510658306741e-02, 3.47772225647706573e-02, 3.11672278327983394e-02, 2.74265097083568818e-02, 2.35707608393240925e-02, 1.96161604573552965e-02, 1.55793157229429276e-02, 1.14772345792349736e-02, 7.32755390127649234e-03, 3.15334605230917957e-03};
+
+// ---- workspace of the composition (caller-owned; sizes from mm_compose_workspace_bytes) ------------------------
+struct MMComposeLayout {
+  size_t me, See;            // [B][ne], [B][ne][ne] T   policy GP input
+  size_t pf1, pSff, pcross;  // [B][1], [B][1][1], [B][ne][1] T   policy GP output
+  size_t md, Sdd;            // [B][nd], [B][nd][nd] T   drift GP input
+  size_t df1, dSff, dcross;  // [B][nx], [B][nx][nx], [B][nd][nx] T   drift GP output
+  size_t Sxe, cpol;          // [B][nx][ne], [B][ne] f64   Cov(x, e);  Cov(e,e)^-1 Cov(e, u)
+  size_t total;
+};
+
+static inline MMComposeLayout mm_compose_layout(int B, int nx, int na, int dtype) {
+  MMComposeLayout o;
+  const size_t es = mm_elem_size(dtype), A = 256;
+  const int nb = nx - na, ne = 2 * na + nb, nd = ne + 1;
+  size_t off = 0;
+  o.me = off;     off = mm_align_up(off + (size_t)B * ne * es, A);
+  o.See = off;    off = mm_align_up(off + (size_t)B * ne * ne * es, A);
+  o.pf1 = off;    off = mm_align_up(off + (size_t)B * es, A);
+  o.pSff = off;   off = mm_align_up(off + (size_t)B * es, A);
+  o.pcross = off; off = mm_align_up(off + (size_t)B * ne * es, A);
+  o.md = off;     off = mm_align_up(off + (size_t)B * nd * es, A);
+  o.Sdd = off;    off = mm_align_up(off + (size_t)B * nd * nd * es, A);
+  o.df1 = off;    off = mm_align_up(off + (size_t)B * nx * es, A);
+  o.dSff = off;   off = mm_align_up(off + (size_t)B * nx * nx * es, A);
+  o.dcross = off; off = mm_align_up(off + (size_t)B * nd * nx * es, A);
+  o.Sxe = off;    off = mm_align_up(off + (size_t)B * nx * ne * 8, A);
+  o.cpol = off;   off = mm_align_up(off + (size_t)B * ne * 8, A);
+  o.total = off;
+  return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_compose_encode: (mx, Sxx) -> moments of e = [sin a, cos a, x_inactive] and Cov(x, e)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_compose_encode(MMComposeDims D, const T* __restrict__ mx, const T* __restrict__ Sxx,
+                                                       T* __restrict__ me, T* __restrict__ See, double* __restrict__ Sxe) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nx = D.nx, na = D.na, nb = D.nb, ne = D.ne, n2 = 2 * na;
+  __shared__ double m[MMC_NX], S[MMC_NX * MMC_NX];
+  __shared__ double s1[MMC_NA], c1[MMC_NA];
+  __shared__ double Syy[4 * MMC_NA * MMC_NA];      // centred covariance of [sin a, cos a]
+  __shared__ double Sxy[MMC_NX * 2 * MMC_NA];      // Cov(x, [sin a, cos a])
+  for (int i = lane; i < nx; i += 64) m[i] = (double)mx[(size_t)b * nx + i];
+  for (int i = lane; i < nx * nx; i += 64) S[i] = (double)Sxx[(size_t)b * nx * nx + i];
+  __syncthreads();
+  if (lane < na) {                                 // maths.py:143-176: first moments
+    const int r = D.active[lane];
+    const double a = m[r], ev = exp(-0.5 * S[r * nx + r]);
+    s1[lane] = ev * sin(a); c1[lane] = ev * cos(a);
+  }
+  __syncthreads();
+  for (int idx = lane; idx < na * na; idx += 64) { // second moments (uncentred), then centred
+    const int i = idx / na, j = idx - i * na;
+    const int ri = D.active[i], rj = D.active[j];
+    const double ai = m[ri], aj = m[rj], vi = S[ri * nx + ri], vj = S[rj * nx + rj];
+    const double sij = 0.5 * (S[ri * nx + rj] + S[rj * nx + ri]);       // (Sxx + Sxx^T) / 2
+    const double A = exp(-0.5 * (vi + vj) - sij), Bm = exp(-0.5 * (vi + vj) + sij);
+    const double Acos = A * cos(ai + aj), Bcos = Bm * cos(ai - aj);
+    const double s2 = 0.5 * (Bcos - Acos), c2 = 0.5 * (Bcos + Acos);
+    const double sc = 0.5 * (sin(ai) * cos(aj) * (Bm + A) - sin(aj) * cos(ai) * (Bm - A));   // E[sin a_i cos a_j]
+    Syy[i * n2 + j] = s2 - s1[i] * s1[j];
+    Syy[(na + i) * n2 + na + j] = c2 - c1[i] * c1[j];
+    Syy[i * n2 + na + j] = sc - s1[i] * c1[j];
+    Syy[(na + j) * n2 + i] = sc - s1[i] * c1[j];
+  }
+  // Cov(x, y) = Sxa [diag(c1), diag(-s1)]   (pre-inverted cross of sincos, components.py:35-37)
+  for (int idx = lane; idx < nx * na; idx += 64) {
+    const int r = idx / na, j = idx - r * na;
+    const double sra = S[r * nx + D.active[j]];
+    Sxy[r * n2 + j] = sra * c1[j];
+    Sxy[r * n2 + na + j] = -sra * s1[j];
+  }
+  __syncthreads();
+  T* meb = me + (size_t)b * ne;
+  T* Seb = See + (size_t)b * ne * ne;
+  double* Sxeb = Sxe + (size_t)b * nx * ne;
+  for (int k = lane; k < ne; k += 64)
+    meb[k] = (T)(k < na ? s1[k] : k < n2 ? c1[k - na] : m[D.inactive[k - n2]]);
+  for (int idx = lane; idx < ne * ne; idx += 64) {           // components.py:41-53
+    const int i = idx / ne, j = idx - i * ne;
+    double v;
+    if (i < n2 && j < n2) v = Syy[i * n2 + j];
+    else if (i >= n2 && j >= n2) v = S[D.inactive[i - n2] * nx + D.inactive[j - n2]];
+    else if (i >= n2) v = Sxy[D.inactive[i - n2] * n2 + j];  // Sby
+    else v = Sxy[D.inactive[j - n2] * n2 + i];               // Sby^T
+    Seb[idx] = (T)v;
+  }
+  for (int idx = lane; idx < nx * ne; idx += 64) {
+    const int r = idx / ne, k = idx - r * ne;
+    Sxeb[idx] = k < n2 ? Sxy[r * n2 + k] : S[r * nx + D.inactive[k - n2]];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_compose_policy: policy GP output (mean-only) -> u = scale (Phi(f) + shift); joint moments of d = (e, u)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_compose_policy(MMComposeDims D, double scale, double shift,
+                                                       const T* __restrict__ me, const T* __restrict__ See,
+                                                       const T* __restrict__ pf1, const T* __restrict__ pSff,
+                                                       const T* __restrict__ pcross,
+                                                       T* __restrict__ md, T* __restrict__ Sdd, double* __restrict__ cpol) {
+  const int b = blockIdx.x, lane = threadIdx.x, ne = D.ne, nd = D.nd;
+  __shared__ double cp[MMC_ND], Seu[MMC_ND];
+  __shared__ double hv[4];                     // mu_u, Suu, head_pre
+  const double mf = (double)pf1[b];
+  double vx = (double)pSff[b];
+  vx = vx > 0.0 ? vx : 0.0;                    // variance of the regressor's mean under x ~ N: >= 0 up to rounding
+  // bijectors.py:39-69, 1-D branch
+  const double isq = rsqrt(vx + 1.0), z = isq * mf;
+  const double y1 = 0.5 * erfc(-z * 0.70710678118654752440);
+  // Owen's T(z, a), a = rsqrt(1 + 2 vx) in (0, 1]: 48-point Gauss-Legendre on [0, a] (gpflowpilco_amd/special.py)
+  const double aa = rsqrt(1.0 + 2.0 * vx);
+  double part = 0.0;
+  if (lane < 48) {
+    const double t = 0.5 * aa * (MM_GL48_X[lane] + 1.0);
+    part = MM_GL48_W[lane] * exp(-0.5 * z * z * (1.0 + t * t)) / (1.0 + t * t);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+  const double owen = 0.5 * aa * part * 0.15915494309189533577;        // / (2 pi)
+  const double y2 = y1 - 2.0 * owen;                                   // E[Phi^2]
+  const double head_pre = isq * 0.39894228040143267794 * exp(-0.5 * z * z) * scale;   // Var(f)^-1 Cov(f, u)
+  if (lane == 0) { hv[0] = scale * (y1 + shift); hv[1] = scale * scale * (y2 - y1 * y1); }
+  // chain rule (gaussian.py:66-83): Cov(e,e)^-1 Cov(e, u) = cross_pre(GP) * head_pre
+  for (int k = lane; k < ne; k += 64) cp[k] = (double)pcross[(size_t)b * ne + k] * head_pre;
+  __syncthreads();
+  for (int k = lane; k < ne; k += 64) {
+    double s = 0.0;
+    for (int l = 0; l < ne; ++l) s = fma((double)See[((size_t)b * ne + k) * ne + l], cp[l], s);
+    Seu[k] = s;
+    cpol[(size_t)b * ne + k] = cp[k];
+  }
+  __syncthreads();
+  T* mdb = md + (size_t)b * nd;
+  T* Sdb = Sdd + (size_t)b * nd * nd;
+  for (int k = lane; k < nd; k += 64) mdb[k] = k < ne ? me[(size_t)b * ne + k] : (T)hv[0];
+  for (int idx = lane; idx < nd * nd; idx += 64) {           // gaussian.py:53-63
+    const int i = idx / nd, j = idx - i * nd;
+    double v;
+    if (i < ne && j < ne) v = (double)See[((size_t)b * ne + i) * ne + j];
+    else if (i < ne) v = Seu[i];
+    else if (j < ne) v = Seu[j];
+    else v = hv[1];
+    Sdb[idx] = (T)v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_compose_step: Cov(x, f) bookkeeping of forward_sde.py:105-131 and the Euler moment update
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_compose_step(MMComposeDims D, double dt, const double* __restrict__ Sxe,
+                                                     const double* __restrict__ cpol, const T* __restrict__ Sdd,
+                                                     const T* __restrict__ df1, const T* __restrict__ dSff,
+                                                     const T* __restrict__ dcross, T* mx, T* Sxx,
+                                                     T* traj_mu, T* traj_S) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nx = D.nx, na = D.na, ne = D.ne, nd = D.nd, n2 = 2 * na;
+  __shared__ double Sxd[MMC_NX * MMC_ND], Sxf[MMC_NX * MMC_NX];
+  const double* Sxeb = Sxe + (size_t)b * nx * ne;
+  const double* cp = cpol + (size_t)b * ne;
+  const T* Sdb = Sdd + (size_t)b * nd * nd;
+  // Cov(x, d): rows of the encoded dims = [Sae, Sae cpol] (Cov(a, e) and its image under the policy), rows of the
+  // other dims = the corresponding rows of Cov(d, d)
+  for (int idx = lane; idx < nx * nd; idx += 64) {
+    const int r = idx / nd, k = idx - r * nd;
+    const int sl = D.slot[r];
+    double v;
+    if (sl < na) {
+      if (k < ne) v = Sxeb[r * ne + k];
+      else {
+        double s = 0.0;
+        for (int l = 0; l < ne; ++l) s = fma(Sxeb[r * ne + l], cp[l], s);
+        v = s;
+      }
+    } else {
+      v = (double)Sdb[(n2 + (sl - na)) * nd + k];
+    }
+    Sxd[idx] = v;
+  }
+  __syncthreads();
+  const T* dc = dcross + (size_t)b * nd * nx;
+  for (int idx = lane; idx < nx * nx; idx += 64) {           // Cov(x, f) = Cov(x, d) Cov(d,d)^-1 Cov(d, f)
+    const int r = idx / nx, c = idx - r * nx;
+    double s = 0.0;
+    for (int k = 0; k < nd; ++k) s = fma(Sxd[r * nd + k], (double)dc[k * nx + c], s);
+    Sxf[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = lane; idx < nx * nx; idx += 64) {           // solvers.py:110-135
+    const int r = idx / nx, c = idx - r * nx;
+    const double v = (double)Sxx[(size_t)b * nx * nx + idx] + dt * (Sxf[r * nx + c] + Sxf[c * nx + r])
+                   + dt * dt * (double)dSff[(size_t)b * nx * nx + idx];
+    Sxx[(size_t)b * nx * nx + idx] = (T)v;
+    if (traj_S) traj_S[(size_t)b * nx * nx + idx] = (T)v;
+  }
+  if (lane < nx) {
+    const double v = (double)mx[(size_t)b * nx + lane] + dt * (double)df1[(size_t)b * nx + lane];
+    mx[(size_t)b * nx + lane] = (T)v;
+    if (traj_mu) traj_mu[(size_t)b * nx + lane] = (T)v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int mm_compose_dims(int nx, int na, const int32_t* active_dims, MMComposeDims& D) {
+  if (nx <= 0 || nx > MMC_NX || na <= 0 || na > MMC_NA || na > nx || !active_dims) return MM_E_DIM;
+  D.nx = nx; D.na = na; D.nb = nx - na; D.ne = 2 * na + D.nb; D.nd = D.ne + 1;
+  if (D.nd > MMC_ND) return MM_E_DIM;
+  bool used[MMC_NX] = {false};
+  for (int i = 0; i < na; ++i) {
+    const int r = active_dims[i];
+    if (r < 0 || r >= nx || used[r]) return MM_E_ARG;
+    used[r] = true; D.active[i] = r; D.slot[r] = i;
+  }
+  int ib = 0;
+  for (int r = 0; r < nx; ++r) if (!used[r]) { D.inactive[ib] = r; D.slot[r] = na + ib; ++ib; }   // sorted (components.py:66)
+  return 0;
+}
+
+extern "C" size_t mm_compose_workspace_bytes(int B, int nx, int na, int dtype) {
+  if (B <= 0 || nx <= 0 || nx > MMC_NX || na <= 0 || na > MMC_NA || na > nx) return 0;
+  if (2 * na + (nx - na) + 1 > MMC_ND) return 0;
+  return mm_compose_layout(B, nx, na, dtype).total;
+}
+
+template <typename T>
+static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, const void* policy, size_t policy_bytes, int Mpol,
+                                 int dtype, int B, int H, double dt, const MMComposeDims& D, double scale, double shift,
+                                 const T* target, const T* precis, T* mx, T* Sxx, T* cost, T* traj_mu, T* traj_S,
+                                 void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
+                                 char* wsc, const MMComposeLayout& cl, int32_t* status, hipStream_t s) {
+  const int nx = D.nx, ne = D.ne, nd = D.nd;
+  T* me = (T*)(wsc + cl.me); T* See = (T*)(wsc + cl.See);
+  T* pf1 = (T*)(wsc + cl.pf1); T* pSff = (T*)(wsc + cl.pSff); T* pcross = (T*)(wsc + cl.pcross);
+  T* md = (T*)(wsc + cl.md); T* Sdd = (T*)(wsc + cl.Sdd);
+  T* df1 = (T*)(wsc + cl.df1); T* dSff = (T*)(wsc + cl.dSff); T* dcross = (T*)(wsc + cl.dcross);
+  double* Sxe = (double*)(wsc + cl.Sxe); double* cpol = (double*)(wsc + cl.cpol);
+#define MMC_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+  hipLaunchKernelGGL((k_compose_encode<T>), dim3(B), dim3(64), 0, s, D, (const T*)mx, (const T*)Sxx, me, See, Sxe);
+  MMC_CHECK();
+  for (int h = 0; h < H; ++h) {
+    // policy: mean-only regressor (models.py:34-41: model_uncertainty = False), one latent
+    int rc = mm_moment_match(policy, policy_bytes, 1, Mpol, ne, dtype, B, me, See, MM_FULL_OUTPUT_COV, 0.0,
+                             pf1, pSff, pcross, ws_policy, ws_policy_bytes, status, (void*)s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_compose_policy<T>), dim3(B), dim3(64), 0, s, D, scale, shift, (const T*)me, (const T*)See,
+                       (const T*)pf1, (const T*)pSff, (const T*)pcross, md, Sdd, cpol);
+    MMC_CHECK();
+    rc = mm_moment_match(drift, drift_bytes, nx, Md, nd, dtype, B, md, Sdd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY, 0.0,
+                         df1, dSff, dcross, ws_drift, ws_drift_bytes, status, (void*)s);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_compose_step<T>), dim3(B), dim3(64), 0, s, D, dt, (const double*)Sxe, (const double*)cpol,
+                       (const T*)Sdd, (const T*)df1, (const T*)dSff, (const T*)dcross, mx, Sxx,
+                       traj_mu ? traj_mu + (size_t)h * B * nx : (T*)nullptr,
+                       traj_S ? traj_S + (size_t)h * B * nx * nx : (T*)nullptr);
+    MMC_CHECK();
+    // the new state's encoding: the cost statistic of this step (pilco.py:199-205) and the next step's policy input
+    hipLaunchKernelGGL((k_compose_encode<T>), dim3(B), dim3(64), 0, s, D, (const T*)mx, (const T*)Sxx, me, See, Sxe);
+    MMC_CHECK();
+    if (cost) {
+      rc = mm_expected_cost(B, ne, dtype, me, See, target, precis, cost + (size_t)h * B, (void*)s);
+      if (rc) return rc;
+    }
+  }
+#undef MMC_CHECK
+  return 0;
+}
+
+extern "C" int mm_rollout_composed(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
+                                   const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
+                                   int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
+                                   double head_scale, double head_shift, const void* target, const void* precis,
+                                   void* mx, void* Sxx, void* cost, void* traj_mu, void* traj_Sigma,
+                                   void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
+                                   void* ws_compose, size_t ws_compose_bytes, int32_t* status, void* stream) {
+  if (!drift_packed || !policy_packed || !mx || !Sxx || !ws_drift || !ws_policy || !ws_compose) return MM_E_ARG;
+  if (B <= 0 || H <= 0 || drift_M <= 0 || policy_M <= 0) return MM_E_ARG;
+  if (dtype != MM_F32 && dtype != MM_F64) return MM_E_DTYPE;
+  if (cost && (!target || !precis)) return MM_E_ARG;
+  MMComposeDims D;
+  int rc = mm_compose_dims(nx, na, active_dims, D);
+  if (rc) return rc;
+  if (drift_L != nx || drift_d != D.nd || policy_d != D.ne) return MM_E_STATE;
+  const MMComposeLayout cl = mm_compose_layout(B, nx, na, dtype);
+  if (ws_compose_bytes < cl.total) return MM_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MM_F64)
+    return mm_rollout_composed_t<double>(drift_packed, drift_bytes, drift_M, policy_packed, policy_bytes, policy_M, dtype, B, H, dt,
+                                         D, head_scale, head_shift, (const double*)target, (const double*)precis, (double*)mx,
+                                         (double*)Sxx, (double*)cost, (double*)traj_mu, (double*)traj_Sigma, ws_drift, ws_drift_bytes,
+                                         ws_policy, ws_policy_bytes, (char*)ws_compose, cl, status, s);
+  return mm_rollout_composed_t<float>(drift_packed, drift_bytes, drift_M, policy_packed, policy_bytes, policy_M, dtype, B, H, dt,
+                                      D, head_scale, head_shift, (const float*)target, (const float*)precis, (float*)mx,
+                                      (float*)Sxx, (float*)cost, (float*)traj_mu, (float*)traj_Sigma, ws_drift, ws_drift_bytes,
+                                      ws_policy, ws_policy_bytes, (char*)ws_compose, cl, status, s);
+}

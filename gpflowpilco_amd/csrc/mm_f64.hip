@@ -12,7 +12,11 @@
 //               upper tiles count twice); the C tile is loaded ONCE into registers and the
 //               workgroup loops over its chunk of the batch -- C traffic is M^2*8 B per chunk
 //               instead of per batch element; with model uncertainty ONE fused sum
-//               sum_ij q_i q_j (D_ij expm1(delta_ij) + C_ij), D = C + beta beta^T;
+//               sum_ij q_i q_j (D_ij expm1(delta_ij) + C_ij) = sum_ij qh_i qh'_j D_ij e^{b_ij} - (sum_i w_i)^2,
+//               D = C + beta beta^T, with the rank-one parts of delta_ij = rho_i + gamma'_j + b_ij FACTORED into the
+//               weights (qh_i = q_i e^{rho_i}, qh'_j = q_j e^{gamma'_j}: k_pairvec): no accumulator initialisation,
+//               |b| < |delta| (lower Taylor tiers), 10 fewer operand loads per lane and batch element, and only
+//               the D tile in registers;
 //   expm1     : wave-uniform Taylor tiers by the tile's range (degree 6/7/8/9/10/15 for an f32 model,
 //               7/8/9/10/12/15 for an f64 model), Horner steps vertical over 8 entries; beyond the last
 //               tier k ln2 + r reduction + v_ldexp_f64 (relative error ~2e-16 for every argument);
@@ -32,6 +36,11 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define MM_LOWP_D2 10
 #endif
 #define MM_F64_NB 16      // batch elements whose partial sums are staged in LDS between workgroup reductions
+// diagonal pairs with the rank-one terms factored into the weights need ~100 fewer VGPRs: three waves per SIMD
+// up to this many K = 4 steps (d <= 4 MM_F64_3WAVE_KS4)
+#ifndef MM_F64_3WAVE_KS4
+#define MM_F64_3WAVE_KS4 2
+#endif
 
 __device__ __forceinline__ void mm_decode_pair_f(int p, int L, int& a, int& a2) {
   if (p < L) { a = p; a2 = p; return; }
@@ -78,13 +87,13 @@ __device__ __forceinline__ double mm_expm1_f64_poly(double x) {
 }
 
 // Per-b operands of one wave's 32 x 32 sub-tile (prefetched one batch element ahead).
-template <int KS4>
+template <int KS4, bool DIAG>
 struct MMF64Operands {
-  double rho[2][4];      // rho_i of the rows (rt, kq + 4 r)
-  double rw[2][4];       // row weight: q_i (C-weighted diagonal) or w_i
+  double rho[DIAG ? 1 : 2][DIAG ? 1 : 4];      // rho_i of the rows (rt, kq + 4 r)      (off-diagonal pairs only)
+  double rw[2][4];       // row weight: factored q_i e^{rho_i} / w_i e^{rho_i} (diagonal pairs) or w_i
   double breg[2][KS4];   // MFMA B operand: g_j components of column (ct, l15)
-  double gam[2];         // gamma'_j
-  double cw[2];          // column weight: q_j or w'_j
+  double gam[DIAG ? 1 : 2];                    // gamma'_j                                (off-diagonal pairs only)
+  double cw[2];          // column weight: factored (diagonal pairs) or w'_j
 };
 
 // KS4: number of K=4 MFMA steps covering the d input dimensions.  LOWP: f32 mode (the diagonal pairs
@@ -98,7 +107,7 @@ struct MMF64Operands {
 // once per workgroup from the C tile.  delta_ij = rho_i + gamma'_j + zc_i . g_j: the two O(1) terms
 // initialise the MFMA accumulator (one add per entry; an extra K step would cost a whole MFMA).
 template <int KS4, bool DIAG, bool WITHC, bool LOWP>
-__global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const double* __restrict__ Zc, int Kz,
+__global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : (DIAG && KS4 <= MM_F64_3WAVE_KS4 ? 3 : 2))) void k_qred_f64_mfma(const double* __restrict__ Zc, int Kz,
                                                           const double* __restrict__ Cm,
                                                           const double* __restrict__ beta, int M,
                                                           int L, int Mp, int d, int P, int NS, int p0,
@@ -150,8 +159,8 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
       const double v = zr[(size_t)(rbase + rt * 16 + l15) * Kz + (k < Kz ? k : Kz - 1)];
       areg[rt][s] = (k < Kz) ? v : 0.0;
     }
-  // C and D = C + beta beta^T tiles -> registers (element (row(rt, r), col(ct)) in the MFMA accumulator layout)
-  double creg[2][2][4], dreg[2][2][4];
+  // D = C + beta beta^T tile -> registers (element (row(rt, r), col(ct)) in the MFMA accumulator layout)
+  double dreg[2][2][4];
   if (withC) {
     double bcol[2];
 #pragma unroll
@@ -170,7 +179,6 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           const double cv = Cm[((size_t)a * Mp + row) * Mp + cbase + ct * 16 + l15];
-          creg[rt][ct][r] = cv;
           dreg[rt][ct][r] = fma(brow, bcol[ct], cv);
         }
       }
@@ -190,17 +198,18 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
   // per-b operand pointers advance by constant strides (no 64-bit multiplies in the loop)
   const double* ra = rowA + ((size_t)b0 * np + lp) * Mp;
   const double* cb = colB + ((size_t)b0 * np + lp) * (size_t)(d + 1) * Mp;
-  const double* rwp = (withC ? q : w) + ((size_t)b0 * L + a) * Mp;
-  const double* cwp = (withC ? q : w) + ((size_t)b0 * L + a2) * Mp;
+  // diagonal pairs: `w` / `q` are the factored row / column weights (workspace qhR / qhC), indexed by latent
+  const double* rwp = w + ((size_t)b0 * L + a) * Mp;
+  const double* cwp = (DIAG ? q : w) + ((size_t)b0 * L + a2) * Mp;
   const size_t st_ra = (size_t)np * Mp, st_cb = (size_t)np * (d + 1) * Mp, st_w = (size_t)L * Mp;
 
-  auto load_ops = [&](MMF64Operands<KS4>& o) {
+  auto load_ops = [&](MMF64Operands<KS4, DIAG>& o) {
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = rbase + rt * 16 + kq + 4 * r;
-        o.rho[rt][r] = ra[row];
+        if constexpr (!DIAG) o.rho[rt][r] = ra[row];
         o.rw[rt][r] = rwp[row];
       }
 #pragma unroll
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
       for (int s = 0; s < KS4; ++s) {
         o.breg[ct][s] = cb[boff[s] + col];     // k >= d reads the (finite) gamma row against a zero A operand
       }
-      o.gam[ct] = cb[goff + col];
+      if constexpr (!DIAG) o.gam[ct] = cb[goff + col];
       o.cw[ct] = cwp[col];
     }
   };
@@ -236,7 +245,7 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
     }
   };
 
-  auto reduce_b = [&](int b, const MMF64Operands<KS4>& o) {
+  auto reduce_b = [&](int b, const MMF64Operands<KS4, DIAG>& o) {
     f64x4 cacc[2][2];
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -244,7 +253,7 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
       for (int rt = 0; rt < 2; ++rt) {
         f64x4 c;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[r] = o.rho[rt][r] + o.gam[ct];
+        for (int r = 0; r < 4; ++r) c[r] = DIAG ? 0.0 : o.rho[rt][r] + o.gam[ct];
 #pragma unroll
         for (int s = 0; s < KS4; ++s)
           c = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[rt][s], o.breg[ct][s], c, 0, 0, 0);
@@ -270,13 +279,16 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
 #define MM_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))
     if (force_worst) mxh = 0x7ff00000u;                          // MM_FORCE_WORST_TIER: wave-uniform override
     double sv = 0.0;
+    // DIAG (factored weights): the entry contributes [D_ij] e^{b_ij} (the caller subtracts (sum w)^2 once);
+    // off-diagonal pairs of the f64 mode: expm1(delta_ij)
 #define MM_F64_ACCUM(EXPM1_)                                                              \
     _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                    \
       double pv = 0.0;                                                                    \
       _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                    \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                   \
-          const double e = EXPM1_(cacc[rt][ct][r]);                                       \
-          if (withC) pv = fma(fma(dreg[rt][ct][r], e, creg[rt][ct][r]), o.rw[rt][r], pv); \
+          double e = EXPM1_(cacc[rt][ct][r]);                                             \
+          if (DIAG) e += 1.0;                                                             \
+          if (withC) pv = fma(dreg[rt][ct][r] * e, o.rw[rt][r], pv);                      \
           else pv = fma(o.rw[rt][r], e, pv);                                              \
         }                                                                                 \
       sv = fma(pv, o.cw[ct], sv);                                                         \
@@ -293,10 +305,10 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
       }                                                                                   \
       _Pragma("unroll") for (int k = DEG_ - 2; k >= 1; --k)                               \
         _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] = fma(pp[i], xv[i], mm_inv_fact(k)); \
-      _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] *= xv[i];                       \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] = DIAG ? fma(pp[i], xv[i], 1.0) : pp[i] * xv[i]; \
       double pa = 0.0, pb = 0.0;                                                          \
       if (withC) {                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] = fma(dreg[i >> 2][ct][i & 3], pp[i], creg[i >> 2][ct][i & 3]); \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] *= dreg[i >> 2][ct][i & 3];   \
       }                                                                                   \
       _Pragma("unroll") for (int i = 0; i < 8; i += 2) {                                  \
         pa = fma(pp[i], o.rw[i >> 2][i & 3], pa);                                         \
@@ -336,7 +348,7 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_mfma(const
   // two operand sets in registers: batch element b + 1 is in flight while b is reduced
   // (the prefetch is unconditional -- past the end it re-reads the last element -- so that the
   // compiler's s_waitcnt for the current set does not have to cover a maybe-not-issued prefetch)
-  MMF64Operands<KS4> o0, o1;
+  MMF64Operands<KS4, DIAG> o0, o1;
   auto advance = [&](bool more) {
     const size_t m = more ? 1 : 0;
     ra += m * st_ra; cb += m * st_cb; rwp += m * st_w; cwp += m * st_w;

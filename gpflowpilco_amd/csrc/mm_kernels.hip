@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
+#include "mm_mono.h"
 
 #define MM_ABI_VERSION 1
 
@@ -156,28 +157,43 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
     if (sizeof(T) != 8) Zc[idx] = (T)v;
   }
   if (sizeof(T) != 8) {
-    // moment table (1, zc_k, zc_k zc_l for k <= l), zero beyond M and beyond the last column
+    // moment table: every monomial of zc of total degree <= mm_moment_deg(d), graded colex order (mm_mono.h);
+    // zero beyond M and beyond the last column
     double* Zm = (double*)(packed + lay.Zm) + (size_t)a * lay.Mp * lay.KMp;
+    const int deg = d <= 8 ? 4 : 2;                       // mm_moment_deg(d) (host function)
+    const int ncol = mm_mono_off(deg + 1, d);
     for (int idx = tid; idx < lay.Mp * lay.KMp; idx += 256) {
       const int m = idx / lay.KMp, c = idx - m * lay.KMp;
       double v = 0.0;
-      if (m < M) {
-        if (c == 0) v = 1.0;
-        else if (c <= d) v = Z[((size_t)a * M + m) * d + (c - 1)] - zb[c - 1];
-        else {
-          int r = c - 1 - d, k = 0;                      // packed upper triangle, row k: entries (k, k..d-1)
-          while (k < d && r >= d - k) { r -= d - k; ++k; }
-          if (k < d) {
-            const int l = k + r;
-            v = (Z[((size_t)a * M + m) * d + k] - zb[k]) * (Z[((size_t)a * M + m) * d + l] - zb[l]);
-          }
-        }
+      if (m < M && c < ncol) {
+        int n = 0;
+        while (mm_mono_off(n + 1, d) <= c) ++n;                // degree of column c
+        int k[4] = {0, 0, 0, 0};
+        mm_mono_unrank(c - mm_mono_off(n, d), n, k);
+        v = 1.0;
+        for (int t = 0; t < n; ++t) v *= Z[((size_t)a * M + m) * d + k[t]] - zb[k[t]];
       }
       Zm[idx] = v;
     }
+    // max_m |zc_m|^2 (the column side of the Cauchy-Schwarz bound on |b_ij|)
+    double zm2 = 0.0;
+    for (int m = tid; m < M; m += 256) {
+      double s2 = 0.0;
+      for (int k = 0; k < d; ++k) { const double v = Z[((size_t)a * M + m) * d + k] - zb[k]; s2 += v * v; }
+      zm2 = s2 > zm2 ? s2 : zm2;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_down(zm2, off, 64); zm2 = o > zm2 ? o : zm2; }
+    __syncthreads();
+    if ((tid & 63) == 0) red[tid >> 6] = zm2;
+    __syncthreads();
+    if (tid == 0) ((double*)(packed + lay.zmax2))[a] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    __syncthreads();
   }
   if (sizeof(T) != 8) {
-    // bf16 3-way split of the centred inputs for the f32 MFMA kernel: [Mp][3 (h,m,l)][8 nd8]
+    // bf16 3-way split of the centred inputs for the f32 MFMA kernel, tile-and-part major:
+    // [Mp / 32 column tiles][3 (h,m,l)][32 columns][8 nd8] -- one part of one 32-column tile is ONE contiguous
+    // 512 nd8-byte block, so each half-wave of a tile load reads a fully coalesced segment
     unsigned short* Zs3 = (unsigned short*)(packed + lay.Zs3) + (size_t)a * lay.Mp * 24 * lay.nd8;
     const int kw = 8 * lay.nd8;
     for (int idx = tid; idx < lay.Mp * kw; idx += 256) {
@@ -189,10 +205,10 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
       const __bf16 mm = (__bf16)r;
       r -= (float)mm;
       const __bf16 l = (__bf16)r;
-      unsigned short* o = Zs3 + (size_t)m * 3 * kw + k;
+      unsigned short* o = Zs3 + ((size_t)(m >> 5) * 3 * 32 + (m & 31)) * kw + k;
       o[0] = __builtin_bit_cast(unsigned short, h);
-      o[kw] = __builtin_bit_cast(unsigned short, mm);
-      o[2 * kw] = __builtin_bit_cast(unsigned short, l);
+      o[32 * kw] = __builtin_bit_cast(unsigned short, mm);
+      o[64 * kw] = __builtin_bit_cast(unsigned short, l);
     }
   }
 }
@@ -215,7 +231,7 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
                                              int L, int d, int P,
                                              const T* __restrict__ mu, const T* __restrict__ Sigma,
                                              double* __restrict__ pairmat, double* __restrict__ latmat,
-                                             int32_t* status, int pairs_pass) {
+                                             unsigned int* __restrict__ amax, int32_t* status, int pairs_pass) {
   // pairs_pass == 0: the L latent items (blockIdx.x = a); pairs_pass == 1: the P pair items, which take
   // (Sigma + Lambda_a)^-1 and its log-determinant from the latent pass instead of refactorising them (one
   // Cholesky-inverse per pair instead of three); pairs_pass == 2: all P + L items in ONE launch, pairs
@@ -266,6 +282,7 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
   } else {
     int a, a2;
     mm_decode_pair(item, L, a, a2);
+    if (amax && item >= L && lane == 0) amax[(size_t)b * (P - L) + (item - L)] = 0u;   // k_pairvec max-es |A_i|^2 into it
     const double* la = ls2 + a * d;
     const double* lb = ls2 + a2 * d;
     for (int idx = lane; idx < d * d; idx += 64) {
@@ -433,7 +450,9 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
                                                  double* __restrict__ rowD, double* __restrict__ colD,
                                                  T* __restrict__ rowO, T* __restrict__ colO,
                                                  const double* __restrict__ w64, double* __restrict__ whR,
-                                                 double* __restrict__ whC, int nblk) {
+                                                 double* __restrict__ whC, unsigned int* __restrict__ amax,
+                                                 const double* __restrict__ q64, double* __restrict__ qhR,
+                                                 double* __restrict__ qhC, int with_unc, int nblk) {
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
   // pair's matrix is fetched once per workgroup, not once per chunk
   const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
@@ -525,6 +544,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   double* cbD = colD + ((size_t)b * L + (diag ? p : 0)) * (size_t)(d + 1) * Mp;
   T* raO = rowO + ((size_t)b * Po + (diag ? 0 : p - L)) * Mp;
   T* cbO = colO + ((size_t)b * Po + (diag ? 0 : p - L)) * (size_t)(d + 1) * Mp;
+  float a2max = 0.0f;                                         // max_i |A_i|^2 over this thread's rows (f32 off-diagonal pairs)
   for (int mblk = blockIdx.x; mblk < nblk; mblk += gridDim.x) {
     if (PF) load_ops(mblk + (int)gridDim.x < nblk ? mblk + (int)gridDim.x : mblk, nxt);
     else load_ops(mblk, cur);
@@ -541,7 +561,9 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
     if (m >= Mp) continue;
     // A = G^T zr, g = G zc (for a diagonal pair G is symmetric and zr == zc: A == g)
     double tA = 0.0, tg = 0.0, corrA = 0.0, corrg = 0.0;
+    double asq = 0.0;
     auto row = [&](int i, double av, double gv) {
+      asq = fma(av, av, asq);
       tA = fma(zr[i] * vecs[3][i], av, tA);
       tg = fma(zc[i] * vecs[4][i], gv, tg);
       corrA = fma(vecs[2][i], av, corrA);
@@ -578,6 +600,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
     const double rho_q = (m < M) ? r1r - tA : 0.0;              // zeta_i^T D_row zeta_i
     const double gam_q = (m < M) ? r1c - tg : 0.0;              // zeta'_j^T D_col zeta'_j
     if (f32off) {
+      a2max = fmaxf(a2max, (float)asq * 1.000001f);           // rounded up: the bound must not be under-estimated
       double whr = 0.0, whc = 0.0;
       if (m < M) {
         whr = wrv * exp(-0.5 * rho_q + cst - corrA);
@@ -591,170 +614,23 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
       // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j
       const double rowv = -0.5 * rho_q;
       const double colv = (m < M) ? -0.5 * gam_q + cst - corrg : 0.0;
-      if (diag) { raD[m] = rowv; cbD[(size_t)d * Mp + m] = colv; }
-      else { raO[m] = (T)rowv; cbO[(size_t)d * Mp + m] = (T)colv; }
+      if (diag) {
+        raD[m] = rowv; cbD[(size_t)d * Mp + m] = colv;
+        // factored weights of the f64 MFMA reduce (mm_f64.hip): e^{delta_ij} = e^{rho_i} e^{gamma'_j} e^{zc_i . g_j};
+        // u = q with model uncertainty (the fused sum runs over q_i q_j D_ij e^{delta}), w without
+        const size_t qi = ((size_t)b * L + p) * Mp + m;
+        const double u = (m < M) ? (with_unc ? q64[qi] : wrv) : 0.0;
+        qhR[qi] = u * exp(rowv);
+        qhC[qi] = u * exp(colv);
+      } else { raO[m] = (T)rowv; cbO[(size_t)d * Mp + m] = (T)colv; }
     }
   }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_wmoments: raw moments of the factored f64 weights of every off-diagonal pair (f32 mode),
-//     mom[b][po][side][:] = sum_m what_side[b][po][m] * Zm[latent(side)][m][:],   Zm = (1, zc, zc zc^T),
-// a skinny GEMM over M on the f64 matrix pipe (v_mfma_f64_16x16x4_f64: 16 batch elements x 16 table
-// columns per tile).  grid (ceil(B/16) * ncg, Po, 2); a workgroup = 4 waves splitting the m range, NC
-// (<= 4) column tiles each; the waves' partial tiles are combined through LDS in a fixed order.
-// ---------------------------------------------------------------------------------------------
-typedef double f64x4k __attribute__((ext_vector_type(4)));
-
-template <int NC>
-__global__ __launch_bounds__(256) void k_wmoments(const double* __restrict__ whR, const double* __restrict__ whC,
-                                                  const double* __restrict__ Zm, int KMp, int ncg,
-                                                  int L, int Mp, int B, int Po, double* __restrict__ mom) {
-  const int side = blockIdx.z / MM_MOM_SPLIT, ms = blockIdx.z % MM_MOM_SPLIT, po = blockIdx.y;
-  const int bt = blockIdx.x / ncg, cg = blockIdx.x - bt * ncg;
-  int a, a2;
-  mm_decode_pair(L + po, L, a, a2);
-  const double* W = side ? whC : whR;
-  const double* tab = Zm + (size_t)(side ? a2 : a) * Mp * KMp;
-  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
-  const int nct = KMp / 16;
-  int coff[NC];
+  if (f32off && amax) {
+    // one atomicMax per wave: non-negative floats are ordered like their bit patterns (max is order independent)
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int t = cg * NC + c;
-    coff[c] = (t < nct ? t : nct - 1) * 16 + l15;       // tiles past the end recompute the last one (not stored)
+    for (int off = 32; off > 0; off >>= 1) a2max = fmaxf(a2max, __shfl_down(a2max, off, 64));
+    if ((tid & 63) == 0) atomicMax(amax + (size_t)b * Po + (p - L), __float_as_uint(a2max));
   }
-  f64x4k acc[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) acc[c] = (f64x4k){0.0, 0.0, 0.0, 0.0};
-  // The A operand wants, per lane, 4 consecutive m of ONE batch row (16 rows 458 KB apart): read
-  // straight from memory that is 16 32-byte segments per load.  Instead each wave stages a
-  // [16 batch rows][64 m] block through LDS: 16 fully coalesced 512-byte row reads (the next block's
-  // are in flight while this one is consumed), then the operands come from LDS.
-  __shared__ double wst[4][16][66];                      // +2: rows 528 B apart spread the LDS banks
-  const double* wbase = W + ((size_t)(bt * 16) * Po + po) * Mp + lane;
-  const size_t rstride = (size_t)Po * Mp;
-  auto load_block = [&](int m0, double (&v)[16]) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int br = bt * 16 + r;
-      v[r] = wbase[(size_t)(br < B ? r : (B - 1 - bt * 16)) * rstride + m0];
-    }
-  };
-  // 64-row blocks: wave wv of slice ms takes blocks (ms * 4 + wv), + 4 MM_MOM_SPLIT, ... of the Mp / 64
-  double cur[16], nxt[16];
-  const int mend = Mp, mstep = 256 * MM_MOM_SPLIT, mfirst = (ms * 4 + wv) * 64;
-  load_block(mfirst < mend ? mfirst : 0, cur);
-  for (int mb = mfirst; mb < mend; mb += mstep) {
-    load_block(mb + mstep < mend ? mb + mstep : mb, nxt);    // unconditional (clamped): see the pathwise kernel
-#pragma unroll
-    for (int r = 0; r < 16; ++r) wst[wv][r][lane] = cur[r];
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-    for (int s4 = 0; s4 < 16; ++s4) {
-      const double av = wst[wv][l15][4 * s4 + kq];
-      const double* tr = tab + __umul24(mb + 4 * s4 + kq, KMp);   // 24-bit multiply (full rate): Mp * KMp < 2^32
-#pragma unroll
-      for (int c = 0; c < NC; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tr[coff[c]], acc[c], 0, 0, 0);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) cur[r] = nxt[r];
-  }
-  __shared__ double red[4][NC][4][64];
-#pragma unroll
-  for (int c = 0; c < NC; ++c)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) red[wv][c][r][lane] = acc[c][r];
-  __syncthreads();
-  // accumulator layout: lane (l15 = table column, kq), register r  <->  batch row kq + 4 r
-  for (int idx = threadIdx.x; idx < NC * 4 * 64; idx += 256) {
-    const int ln = idx & 63, r = (idx >> 6) & 3, c = idx >> 8;
-    const int t = cg * NC + c;
-    const int b = bt * 16 + (ln >> 4) + 4 * r;
-    if (t < nct && b < B) {
-      const double v = (red[0][c][r][ln] + red[1][c][r][ln]) + (red[2][c][r][ln] + red[3][c][r][ln]);
-      mom[((((size_t)b * Po + po) * 2 + side) * MM_MOM_SPLIT + ms) * KMp + t * 16 + (ln & 15)] = v;
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_s12: the part of an off-diagonal sum that the weight moments give exactly (f64),
-//   s12 = sum_ij what_i what'_j (1 + b_ij + b_ij^2 / 2),   b_ij = A_i . zc_j,  A_i = G^T (zc_i - dmu),
-//       = n0 q0 + P1 . q1 + 1/2 <P2, q2>,   P1 = G^T M1,  P2 = G^T M2 G,
-//   M1 = n1 - n0 dmu,  M2 = n2 - n1 dmu^T - dmu n1^T + n0 dmu dmu^T,   dmu = mu_b - zbar_a
-// (n: row-side moments against latent a's table, q: column side against latent a').  The tile kernel
-// adds the remainder sum_ij what_i what'_j (expm1(b_ij) - b_ij - b_ij^2 / 2).  One wave per (b, pair).
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int mm_sym_index(int k, int l, int d) {      // packed upper triangle behind (1, zc)
-  const int lo = k < l ? k : l, hi = k < l ? l : k;
-  return 1 + d + lo * d - lo * (lo - 1) / 2 + (hi - lo);
-}
-
-template <typename T>
-__global__ __launch_bounds__(64) void k_s12(const double* __restrict__ mom, int KMp, const double* __restrict__ pairmat,
-                                            const double* __restrict__ zbar, const T* __restrict__ mu,
-                                            int L, int d, int P, double* __restrict__ s12) {
-  extern __shared__ double sm[];
-  double* M2 = sm;                 // [d][d]
-  double* T1 = M2 + d * d;         // [d][d]  G^T M2
-  double* Gs = T1 + d * d;         // [d][d]
-  double* dmu = Gs + d * d;        // [d]
-  double* M1 = dmu + d;            // [d]
-  const int po = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  const int Po = P - L, p = L + po;
-  int a, a2;
-  mm_decode_pair(p, L, a, a2);
-  // the MM_MOM_SPLIT partial moment vectors are summed into LDS first (fixed order)
-  double* n = sm + 3 * d * d + 2 * d;          // [KMp]
-  double* q = n + KMp;                         // [KMp]
-  {
-    const double* nm = mom + (((size_t)b * Po + po) * 2 + 0) * MM_MOM_SPLIT * KMp;
-    const double* qm = mom + (((size_t)b * Po + po) * 2 + 1) * MM_MOM_SPLIT * KMp;
-    for (int k = lane; k < KMp; k += 64) {
-      double sn = 0.0, sq = 0.0;
-#pragma unroll
-      for (int t = 0; t < MM_MOM_SPLIT; ++t) { sn += nm[t * KMp + k]; sq += qm[t * KMp + k]; }
-      n[k] = sn; q[k] = sq;
-    }
-    __syncthreads();
-  }
-  const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
-  const double n0 = n[0];
-  for (int k = lane; k < d; k += 64) {
-    const double dm = (double)mu[(size_t)b * d + k] - zbar[a * d + k];
-    dmu[k] = dm;
-    M1[k] = n[1 + k] - n0 * dm;
-  }
-  for (int idx = lane; idx < d * d; idx += 64) Gs[idx] = pm[idx];
-  __syncthreads();
-  for (int idx = lane; idx < d * d; idx += 64) {
-    const int k = idx / d, l = idx - k * d;
-    M2[idx] = n[mm_sym_index(k, l, d)] - n[1 + k] * dmu[l] - dmu[k] * n[1 + l] + n0 * dmu[k] * dmu[l];
-  }
-  __syncthreads();
-  for (int idx = lane; idx < d * d; idx += 64) {             // T1 = G^T M2:  T1[i][l] = sum_k G[k][i] M2[k][l]
-    const int i = idx / d, l = idx - i * d;
-    double t = 0.0;
-    for (int k = 0; k < d; ++k) t = fma(Gs[k * d + i], M2[k * d + l], t);
-    T1[idx] = t;
-  }
-  __syncthreads();
-  double acc = 0.0;
-  for (int idx = lane; idx < d * d; idx += 64) {             // 1/2 <G^T M2 G, q2>
-    const int i = idx / d, j = idx - i * d;
-    double t = 0.0;
-    for (int l = 0; l < d; ++l) t = fma(T1[i * d + l], Gs[l * d + j], t);
-    acc = fma(0.5 * t, q[mm_sym_index(i, j, d)], acc);
-  }
-  for (int i = lane; i < d; i += 64) {                        // (G^T M1) . q1
-    double t = 0.0;
-    for (int k = 0; k < d; ++k) t = fma(Gs[k * d + i], M1[k], t);
-    acc = fma(t, q[1 + i], acc);
-  }
-  acc = mm_wave_sum(acc);
-  if (lane == 0) s12[(size_t)b * Po + po] = acc + n0 * q[0];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -770,7 +646,8 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
                                                       int L, int Mp, int d, int P, int NS, int ncb, int p0,
                                                       const T* __restrict__ w, const T* __restrict__ q,
                                                       const T* __restrict__ rowA, const T* __restrict__ colB,
-                                                      double* __restrict__ partB, double* __restrict__ partC) {
+                                                      double* __restrict__ partB, double* __restrict__ partC,
+                                                      const unsigned int* __restrict__ amax, const double* __restrict__ zmax2) {
   const int cbk = blockIdx.x % ncb, rbk = blockIdx.x / ncb;
   const int lp = blockIdx.y, np = gridDim.y, p = p0 + lp, b = blockIdx.z, tid = threadIdx.x;
   int a, a2;
@@ -802,6 +679,10 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
   const int i1 = (i0 + MM_GEN_ROWS < Mp) ? i0 + MM_GEN_ROWS : Mp;
   T accB = (T)0;
   double sumB = 0.0, sumC = 0.0;
+  // ROWVEC: a collapsed (b, pair) has the cubic and quartic term of the remainder in the moments (mm_moments.hip)
+  const bool coll = ROWVEC && amax != nullptr && zmax2 != nullptr &&
+                    mm_collapse_bound2(amax[(size_t)b * np + lp], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
+  const double sub0 = coll ? (double)MM_REM1_C0 : 0.0, sub1 = coll ? (double)MM_REM1_C1 : 0.0;
   for (int i = i0; i < i1; ++i) {
     T delta = ROWVEC ? (T)0 : ra[i] + gam;
 #pragma unroll
@@ -809,7 +690,8 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
       if (k < d) delta += (ROWVEC ? ra[(size_t)k * Mp + i] : zrow[(size_t)i * Kz + k]) * g[k];
     // ROWVEC (f32 off-diagonal pairs): only the remainder expm1(b) - b - b^2/2 is reduced here, the
     // rest comes from the f64 weight moments (k_s12); evaluated in f64 (portable cross-check kernel)
-    const T e = ROWVEC ? (T)(expm1((double)delta) - (double)delta - 0.5 * (double)delta * (double)delta)
+    const double dd = (double)delta;
+    const T e = ROWVEC ? (T)(expm1(dd) - dd - 0.5 * dd * dd - dd * dd * dd * fma(sub1, dd, sub0))
                        : mm_expm1(delta);
     accB += (ROWVEC ? ra[(size_t)d * Mp + i] : wr[i]) * e;
     if (withC) {
@@ -839,7 +721,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
                                                   const double* __restrict__ var, int B, int L, int P, int NS,
                                                   int nsB_diag, int nsB_off, int nsC, int full, int with_unc,
                                                   double jitter, const double* __restrict__ f1raw,
-                                                  const double* __restrict__ s12,
+                                                  const double* __restrict__ s12, int diag_factored,
                                                   T* __restrict__ Sff) {
   // one wave per (b, pair): lanes stride over the slab (coalesced), fixed butterfly => reproducible
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -861,6 +743,8 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
   // f32 mode: the tile kernel reduced only the remainder; the moments supply 1 + b + b^2/2 (k_s12)
   if (a != a2 && s12) s += s12[(size_t)b * (P - L) + (p - L)] - f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a2];
   if (a == a2) {
+    // factored f64 reduce: the slabs hold sum_ij u_i u_j [D_ij] e^{delta_ij}; minus (sum_i w_i)^2 gives the centred sum
+    if (diag_factored) s -= f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a];
     if (with_unc) s += var[a];                 // models.py:254-261
     s += jitter;                               // models.py:293-296
     if (full) Sff[((size_t)b * L + a) * L + a] = (T)s;
@@ -994,6 +878,9 @@ int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double*
                        double* partB, double* partC, hipStream_t stream);
 int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
                         int B, int L, int d, int flags, hipStream_t stream);
+// f32 mode: weight moments against the monomial tables + their per-(b, pair) contraction (mm_moments.hip): fills s12
+int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
+                      int B, int L, int d, const void* mu_f32, int flags, hipStream_t stream);
 
 #define MM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -1047,7 +934,7 @@ extern "C" int mm_pack_model(void* packed, size_t packed_bytes, int L, int M, in
 
 template <typename T, int DK>
 static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
-                          int L, int M, int d, int B, const T* mu, const T* Sigma,
+                          int L, int M, int d, int B, const T* mu, const T* Sigma, int flags,
                           T* f1, T* cross, T* q_out, int32_t* status, hipStream_t s) {
   const double* ls2 = (const double*)(packed + ml.ls2);
   const double* var = (const double*)(packed + ml.var);
@@ -1055,16 +942,17 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   double* pairmat = (double*)(ws + wl.pairmat);
   double* latmat = (double*)(ws + wl.latmat);
   const size_t shm = (size_t)6 * d * (d + 1) * sizeof(double);
+  unsigned int* amax = (sizeof(T) == 4 && wl.Po > 0) ? (unsigned int*)(ws + wl.amax) : nullptr;
   if ((long long)(wl.P + L) * B <= 4096) {
     hipLaunchKernelGGL((k_prep<T>), dim3(wl.P + L, B), dim3(64), shm, s,
-                       ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 2);
+                       ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, amax, status, 2);
     MM_CHECK_LAUNCH();
   } else {
     hipLaunchKernelGGL((k_prep<T>), dim3(L, B), dim3(64), shm, s,
-                       ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 0);
+                       ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, amax, status, 0);
     MM_CHECK_LAUNCH();
     hipLaunchKernelGGL((k_prep<T>), dim3(wl.P, B), dim3(64), shm, s,
-                       ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, status, 1);
+                       ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, amax, status, 1);
     MM_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
@@ -1082,24 +970,15 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
                        (const double*)(packed + ml.Zt64), (const double*)(packed + ml.zbar), ls2, L, M, wl.Mp, d, wl.P, mu, pairmat,
                        (const double*)(ws + wl.rho1),
                        (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO),
-                       (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), nblk);
+                       (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), amax,
+                       (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC),
+                       (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk);
   }
   MM_CHECK_LAUNCH();
   if (sizeof(T) == 4 && wl.Po > 0) {
-    // exact (f64) linear + quadratic part of the off-diagonal sums from the weight moments
-    const int nct = ml.KMp / 16;
-    const int nc = nct < 4 ? nct : 4, ncg = (nct + nc - 1) / nc;
-    const dim3 grid((unsigned)(((B + 15) / 16) * ncg), (unsigned)wl.Po, 2 * MM_MOM_SPLIT);
-    const double* Zm = (const double*)(packed + ml.Zm);
-    double* mom = (double*)(ws + wl.mom);
-#define MM_WMOM(NC_) hipLaunchKernelGGL((k_wmoments<NC_>), grid, dim3(256), 0, s, (const double*)(ws + wl.whR),      \
-                                        (const double*)(ws + wl.whC), Zm, ml.KMp, ncg, L, wl.Mp, B, wl.Po, mom)
-    if (nc == 1) MM_WMOM(1); else if (nc == 2) MM_WMOM(2); else if (nc == 3) MM_WMOM(3); else MM_WMOM(4);
-#undef MM_WMOM
-    MM_CHECK_LAUNCH();
-    hipLaunchKernelGGL((k_s12<T>), dim3(wl.Po, B), dim3(64), (size_t)(3 * d * d + 2 * d + 2 * ml.KMp) * sizeof(double), s,
-                       (const double*)mom, ml.KMp, (const double*)pairmat, (const double*)(packed + ml.zbar), mu,
-                       L, d, wl.P, (double*)(ws + wl.s12));
+    // exact (f64) polynomial part of the off-diagonal sums from the weight moments (mm_moments.hip)
+    const int rc = mm_launch_moments(packed, ml, ws, wl, B, L, d, (const void*)mu, flags, s);
+    if (rc) return rc;
   }
   MM_CHECK_LAUNCH();
   return 0;
@@ -1129,13 +1008,14 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
       hipLaunchKernelGGL((k_qred_generic<double, DK, false>), dim3(nrb * ncb, L, B), dim3(256), 0, s,
                          (const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS, ncb, 0,
                          (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
-                         (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD), partB, partC);
+                         (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD), partB, partC,
+                         (const unsigned int*)nullptr, (const double*)nullptr);
       MM_CHECK_LAUNCH();
     } else {
       const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, Cm,
                                         (const double*)(packed + ml.beta64), M, L, wl.Mp, d, wl.P, wl.NS,
                                         0, L, B, 1, sizeof(T) == 4 ? 1 : 0, (flags & MM_FORCE_WORST_TIER) ? 1 : 0,
-                                        (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+                                        (const double*)(ws + wl.qhR), (const double*)(ws + wl.qhC),   // factored weights
                                         (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD),
                                         partB, partC, s);
       if (rc) return rc;
@@ -1157,7 +1037,9 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
       hipLaunchKernelGGL((k_qred_generic<T, DK, sizeof(T) == 4>), dim3(nrb * ncb, wl.Po, B), dim3(256), 0, s,
                          (const T*)(packed + ml.Zc), ml.Kz, (const double*)nullptr, L, wl.Mp, d, wl.P, wl.NS, ncb, L,
                          (const T*)(ws + wl.w), (const T*)nullptr, (const T*)(ws + wl.rowO),
-                         (const T*)(ws + wl.colO), partB, partC);
+                         (const T*)(ws + wl.colO), partB, partC,
+                         (sizeof(T) == 4 && !(flags & MM_FORCE_WORST_TIER)) ? (const unsigned int*)(ws + wl.amax) : (const unsigned int*)nullptr,
+                         (sizeof(T) == 4 && mm_moment_deg(d) >= 4) ? (const double*)(packed + ml.zmax2) : (const double*)nullptr);
       MM_CHECK_LAUNCH();
     }
   }
@@ -1166,7 +1048,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
     hipLaunchKernelGGL((k_finalize<T>), dim3((n + 3) / 4), dim3(256), 0, s,
                        partB, partC, (const double*)(packed + ml.var), B, L, wl.P, wl.NS,
                        nsB_diag, nsB_off, nsC, full, with_unc, jitter, (const double*)(ws + wl.f1raw),
-                       sizeof(T) == 4 ? (const double*)(ws + wl.s12) : (const double*)nullptr, Sff);
+                       sizeof(T) == 4 ? (const double*)(ws + wl.s12) : (const double*)nullptr, generic ? 0 : 1, Sff);
     MM_CHECK_LAUNCH();
   }
   return 0;
@@ -1187,7 +1069,7 @@ static int mm_moment_match_t(const char* packed, size_t packed_bytes, int L, int
   if (ws_bytes < wl.total) return MM_E_WORKSPACE;
   int rc = 0;
   if (do_q) {
-    rc = mm_q_forward_t<T, DK>(packed, ml, ws, wl, L, M, d, B, mu, Sigma, f1, cross, q_out, status, s);
+    rc = mm_q_forward_t<T, DK>(packed, ml, ws, wl, L, M, d, B, mu, Sigma, flags, f1, cross, q_out, status, s);
     if (rc) return rc;
   }
   if (do_Q) rc = mm_Q_reduce_t<T, DK>(packed, ml, has_C, ws, wl, L, M, d, B, flags, jitter, Sff, s);

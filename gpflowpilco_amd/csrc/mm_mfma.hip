@@ -5,6 +5,12 @@
 //     S = sum_ij w_i expm1(delta_ij) w'_j,   delta_ij = rho'_i + gamma_j + b_ij
 //       = sum_ij what_i what'_j (1 + b_ij + b_ij^2/2)  - (sum w)(sum w')        exact, f64 moments (O(M d^2))
 //       + sum_ij what_i what'_j r(b_ij),   r(x) = expm1(x) - x - x^2/2            THIS kernel, f32, O(M^2)
+// Where the model's input dimension allows a degree-4 moment table (d <= 8) and a (b, pair)'s Cauchy-Schwarz bound
+// guarantees |b_ij| <= 1, the (b, pair) is COLLAPSED (mm_moments.hip): the cubic and quartic terms of r -- this
+// kernel's own first-tier approximant c0 x^3 + c1 x^4, exact to 5e-8 |x| on |x| <= 1/16 -- are taken from f64
+// moments as well, every wave tile whose max|b| is <= 1/16 (known after ONE screening MFMA per 32 x 32 block,
+// the (h, h + m) part of the split product) contributes nothing and is skipped, and the other tiles reduce the
+// correction r(x) - c0 x^3 - c1 x^4 with the same range tiers.
 // The bilinear part runs on the bf16 matrix pipe as a 3-way split product with f32 accuracy
 // (v_mfma_f32_32x32x16_bf16), the remainder polynomial + weighted reduction on the VALU in packed
 // f32 (v_pk_fma_f32); MFMA and f32 FMA-class VALU time add on a gfx950 SIMD (tools/ubench_overlap.hip).
@@ -19,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
+#include "mm_mono.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -72,7 +79,7 @@ __device__ __forceinline__ void mm_split3(float x, unsigned int& h, unsigned int
 // Along the C3 rollout 90-100 % of the 64 x 32 wave tiles are in the first tier (tools/tier_stats.py).
 template <int DEG> struct MMRem;
 template <> struct MMRem<1> {
-  static constexpr float c[2] = {1.666936278e-01f, 4.167173430e-02f};
+  static constexpr float c[2] = {MM_REM1_C0, MM_REM1_C1};      // mm_common.h: shared with the moment collapse
 };
 template <> struct MMRem<3> {
   static constexpr float c[4] = {1.666663289e-01f, 4.166659713e-02f, 8.350561373e-03f, 1.391559141e-03f};
@@ -87,21 +94,31 @@ template <> struct MMRem<5> {
 
 // sum_r w_r * x_r^3 * R_DEG(x_r) over the 16 register pairs of a wave tile.  The Horner steps run
 // "vertically" over the pairs so that consecutive v_pk_fma_f32 are independent.
+// sub0, sub1: what a collapsed (b, pair) already has from the moments (c0, c1 of the first tier; 0, 0 otherwise) --
+// wave-uniform, subtracted from the two leading coefficients (both differences are exact in f32: Sterbenz).
 template <int DEG>
-__device__ __forceinline__ f32x2 mm_weighted_rem(const f32x2 (&xx)[16], const f32x2 (&wrow)[2][8]) {
-  f32x2 pp[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(MM_PK(MMRem<DEG>::c[DEG]), xx[r], MM_PK(MMRem<DEG>::c[DEG - 1]));
-#pragma unroll
-  for (int k = DEG - 2; k >= 0; --k)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pp[r] = mm_pkfma(pp[r], xx[r], MM_PK(MMRem<DEG>::c[k]));
+__device__ __forceinline__ f32x2 mm_weighted_rem(const f32x2 (&xx)[16], const f32x2 (&wrow)[2][8], float sub0, float sub1) {
+  const float cc0 = MMRem<DEG>::c[0] - sub0, cc1 = MMRem<DEG>::c[1] - sub1;
   f32x2 parts[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  // two halves of 8 register pairs (one 32-row MFMA tile each): 8 independent chains cover the packed-FMA latency,
+  // and the temporaries of one half are dead before the other starts (register pressure)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const f32x2 wx = wrow[r >> 3][r & 7] * xx[r];          // w_i * x
-    const f32x2 tv = (xx[r] * xx[r]) * pp[r];              // x^2 * R(x)
-    parts[r & 3] = mm_pkfma(tv, wx, parts[r & 3]);          // += w_i * x^3 * R(x)
+  for (int hh = 0; hh < 2; ++hh) {
+    f32x2 pp[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      pp[r] = mm_pkfma(MM_PK(MMRem<DEG>::c[DEG]), xx[8 * hh + r], MM_PK(DEG - 1 == 1 ? cc1 : MMRem<DEG>::c[DEG - 1]));
+#pragma unroll
+    for (int k = DEG - 2; k >= 0; --k)
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        pp[r] = mm_pkfma(pp[r], xx[8 * hh + r], MM_PK(k == 0 ? cc0 : (k == 1 ? cc1 : MMRem<DEG>::c[k])));
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const f32x2 wx = wrow[hh][r] * xx[8 * hh + r];                   // w_i * x
+      const f32x2 tv = (xx[8 * hh + r] * xx[8 * hh + r]) * pp[r];      // x^2 * R(x)
+      parts[r & 3] = mm_pkfma(tv, wx, parts[r & 3]);                   // += w_i * x^3 * R(x)
+    }
   }
   return (parts[0] + parts[1]) + (parts[2] + parts[3]);
 }
@@ -110,16 +127,19 @@ __device__ __forceinline__ f32x2 mm_weighted_rem(const f32x2 (&xx)[16], const f3
 //   w x^3 (c0 + c1 x) = (x^2 x) * fma(w c1, x, w c0):  four packed ops per entry pair instead of five.
 __device__ __forceinline__ f32x2 mm_weighted_rem1(const f32x2 (&xx)[16], const f32x2 (&wc0)[2][8],
                                                   const f32x2 (&wc1)[2][8]) {
-  f32x2 t3[16], rw[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) t3[r] = xx[r] * xx[r];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) rw[r] = mm_pkfma(wc1[r >> 3][r & 7], xx[r], wc0[r >> 3][r & 7]);
-#pragma unroll
-  for (int r = 0; r < 16; ++r) t3[r] = t3[r] * xx[r];
   f32x2 parts[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
-  for (int r = 0; r < 16; ++r) parts[r & 3] = mm_pkfma(t3[r], rw[r], parts[r & 3]);
+  for (int hh = 0; hh < 2; ++hh) {
+    f32x2 t3[8], rw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t3[r] = xx[8 * hh + r] * xx[8 * hh + r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) rw[r] = mm_pkfma(wc1[hh][r], xx[8 * hh + r], wc0[hh][r]);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) t3[r] = t3[r] * xx[8 * hh + r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) parts[r & 3] = mm_pkfma(t3[r], rw[r], parts[r & 3]);
+  }
   return (parts[0] + parts[1]) + (parts[2] + parts[3]);
 }
 
@@ -143,6 +163,8 @@ template <int ND8>
 __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32_mfma(const unsigned short* __restrict__ Zs3,
                                                           int L, int Mp, int d, int P, int Po, int NS,
                                                           int npanel, int nwork, int force_worst,
+                                                          const unsigned int* __restrict__ amax,
+                                                          const double* __restrict__ zmax2,
                                                           const float* __restrict__ rowO,
                                                           const float* __restrict__ colO,
                                                           double* __restrict__ partB) {
@@ -165,8 +187,14 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
   if (row0 < Mp) {   // Mp % 128 == 0, so a wave's 64 rows are all inside or all outside
     const float* ra = rowO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;   // [d+1][Mp]: A_i, what_i
     const float* wcf = colO + ((size_t)b * Po + lp) * Mp;                    // what'_j
-    // pre-split centred inducing inputs of latent a': [Mp][3 (h,m,l)][8 ND8] bf16
+    // pre-split centred inducing inputs of latent a': [Mp/32][3 (h,m,l)][32][8 ND8] bf16
     const unsigned short* zs = Zs3 + (size_t)a2 * Mp * (24 * ND8);
+    // collapsed (b, pair)?  Cauchy-Schwarz: |b_ij| <= |A_i| |zc_j| <= sqrt(bound2); the same predicate as k_spoly
+    const float bound2 = zmax2 ? mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) : 3.0e38f;
+    const bool coll = (ND8 == 1) && !force_worst && bound2 <= MM_COLLAPSE_BOUND2;
+    const float sub0 = coll ? MM_REM1_C0 : 0.0f, sub1 = coll ? MM_REM1_C1 : 0.0f;
+    // a tile is skipped on the screening product alone: its error is <= 2^-9 sum_k |A_k||Z_k| <= 2^-9 sqrt(bound2)
+    const float thr_skip = 0.0625f - 0.00390625f * __builtin_sqrtf(bound2) - 1e-6f;
 
     // ---- stationary operands --------------------------------------------------------------
     bf16x8 a1[2][ND8], a2v[2][ND8], a3[2][ND8];
@@ -213,10 +241,11 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     }
 
     // ---- streaming operands: lane half 0 reads parts (m, l), half 1 reads (h, h) ------------
-    // lane byte offsets inside the latent's [Mp][3][8 ND8] bf16 block; the tile offset is wave-uniform
-    const unsigned int tile_bytes = 32u * 48u * ND8;
-    const unsigned int offA = (unsigned int)l31 * (48u * ND8) + (h ? 0u : 1u) * 16u * ND8;
-    const unsigned int offB = (unsigned int)l31 * (48u * ND8) + (h ? 0u : 2u) * 16u * ND8;
+    // lane byte offsets inside the latent's [Mp/32][3][32][8 ND8] bf16 block; the tile offset is wave-uniform and each
+    // half-wave reads one contiguous 512 ND8-byte part of the tile
+    const unsigned int tile_bytes = 32u * 48u * ND8, part_bytes = 32u * 16u * ND8;
+    const unsigned int offA = (h ? 0u : 1u) * part_bytes + (unsigned int)l31 * (16u * ND8);
+    const unsigned int offB = (h ? 0u : 2u) * part_bytes + (unsigned int)l31 * (16u * ND8);
     const char* zbase = reinterpret_cast<const char*>(zs);
     const int nct = Mp >> 5;                     // Mp % 128 == 0: nct is a multiple of 4
 
@@ -233,16 +262,25 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // b_ij in two stages.  Stage 1: the 2-way split product (h + m parts, 2^-17 relative): enough when the
     // whole tile has |b| <= MM_TWO_WAY_MAX (1/32) -- the kernel only reduces r(b) = O(b^3), whose sensitivity to an error
     // in b is b^2/2.  Stage 2 (wave-uniform, only for larger tiles): the (h,l) and (l,h) terms.
-    auto mfma_tile_hm = [&](const u32x4 (&zA)[ND8], f32x16 (&acc)[2]) {
+    // screening product = MFMA3 alone: (h, m) | (h, h) = A_h . (Z_h + Z_m), |error| <= 2^-9 sum_k |A_k||Z_k|
+    auto mfma_tile_screen = [&](const u32x4 (&zA)[ND8], f32x16 (&acc)[2]) {
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int nb = 0; nb < ND8; ++nb) {
-          const bf16x8 bA = __builtin_bit_cast(bf16x8, zA[nb]);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[rt][nb], bA, c, 0, 0, 0);   // smaller terms first
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[rt][nb], bA, c, 0, 0, 0);
-        }
+        for (int nb = 0; nb < ND8; ++nb)
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[rt][nb], __builtin_bit_cast(bf16x8, zA[nb]), c, 0, 0, 0);
+        acc[rt] = c;
+      }
+    };
+    // + MFMA1: (m, m) | (m, h): together with the screening product the 2-way (h + m) product
+    auto mfma_tile_m = [&](const u32x4 (&zA)[ND8], f32x16 (&acc)[2]) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        f32x16 c = acc[rt];
+#pragma unroll
+        for (int nb = 0; nb < ND8; ++nb)
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[rt][nb], __builtin_bit_cast(bf16x8, zA[nb]), c, 0, 0, 0);
         acc[rt] = c;
       }
     };
@@ -264,7 +302,8 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
         mx = fmaxf(fmaxf(mx, fabsf(acc[r >> 3][2 * (r & 7)])), fabsf(acc[r >> 3][2 * (r & 7) + 1]));
       return mx;
     };
-    // b_ij = acc: a pure bilinear form (rho'_i, gamma_j live in the weights); tile range -> tier
+    // b_ij = acc: a pure bilinear form (rho'_i, gamma_j live in the weights); tile range -> tier.
+    // (sub0, sub1) = (c0, c1) of the first tier for a collapsed (b, pair) -- already in the moments -- else (0, 0).
     auto reduce_tile = [&](const f32x16 (&acc)[2], float mx, float wc) {
       f32x2 xx[16];
 #pragma unroll
@@ -272,15 +311,16 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
       f32x2 part2;
       // wave-uniform tier choice (ballots, no cross-lane reduction)
       if (!__any(mx > 0.0625f)) {
+        // reached only by a (b, pair) that is not collapsed (a collapsed one has nothing left to add in this tier)
         // (the folded coefficients cost 64 more VGPRs: only where the operand registers leave room, d <= 8)
         if constexpr (ND8 == 1) part2 = mm_weighted_rem1(xx, wc0, wc1);
-        else part2 = mm_weighted_rem<1>(xx, wrow);
+        else part2 = mm_weighted_rem<1>(xx, wrow, 0.0f, 0.0f);
       } else if (!__any(mx > 0.25f)) {
-        part2 = mm_weighted_rem<3>(xx, wrow);
+        part2 = mm_weighted_rem<3>(xx, wrow, sub0, sub1);
       } else if (!__any(mx > 0.5f)) {
-        part2 = mm_weighted_rem<4>(xx, wrow);
+        part2 = mm_weighted_rem<4>(xx, wrow, sub0, sub1);
       } else if (!__any(mx > 1.0f)) {
-        part2 = mm_weighted_rem<5>(xx, wrow);
+        part2 = mm_weighted_rem<5>(xx, wrow, sub0, sub1);
       } else {
         part2 = (f32x2){0.0f, 0.0f};
 #pragma unroll
@@ -291,11 +331,27 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
             const float x = xx[r][e2];
             const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
             const float big = (__builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f) - fmaf(0.5f * x, x, x);
-            const float e = (fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big;
+            float e = (fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big;
+            if (coll) e -= (x * x) * x * fmaf(sub1, x, sub0);    // wave-uniform; a collapsed pair has |b| <= 1 + rounding
             part2[e2] = fmaf(wrow[r >> 3][r & 7][e2], e, part2[e2]);
           }
       }
       sum += (double)wc * (double)(part2[0] + part2[1]);
+    };
+    // one wave tile: screening product; a collapsed (b, pair) stops here when the whole tile is inside the collapsed
+    // range; else the rest of the split product, the range tier and the weighted reduction
+    auto process_tile = [&](const u32x4 (&zA)[ND8], const u32x4 (&zB)[ND8], float wc) {
+      f32x16 acc[2];
+      mfma_tile_screen(zA, acc);
+      if (coll) {
+        const float ms = tile_max(acc);
+        if (!__any(ms > thr_skip)) return;
+      }
+      mfma_tile_m(zA, acc);
+      const float mx = force_worst ? 2.0f : tile_max(acc);       // MM_FORCE_WORST_TIER: wave-uniform override
+      if (coll && !__any(mx > 0.0625f)) return;                  // first tier of a collapsed pair: all in the moments
+      if (__any(mx > MM_TWO_WAY_MAX)) mfma_tile_l(zB, acc);
+      reduce_tile(acc, mx, wc);
     };
 
     // two-stage register ping-pong: tile ct + 1 is in flight while tile ct is reduced.  (Issuing the MFMAs
@@ -303,19 +359,12 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // 182 VGPRs -- was measured: 4.27 ms against 4.25 ms; three waves per SIMD already overlap the two.)
     u32x4 zA0[ND8], zB0[ND8], zA1[ND8], zB1[ND8];
     float w0, w1;
-    f32x16 acc[2];
     load_tile(0, zA0, zB0, w0);
     for (int ct = 0; ct < nct; ct += 2) {
       load_tile(ct + 1, zA1, zB1, w1);
-      mfma_tile_hm(zA0, acc);
-      float mx = force_worst ? 2.0f : tile_max(acc);            // MM_FORCE_WORST_TIER: wave-uniform override
-      if (__any(mx > MM_TWO_WAY_MAX)) mfma_tile_l(zB0, acc);
-      reduce_tile(acc, mx, w0);
+      process_tile(zA0, zB0, w0);
       load_tile(ct + 2 < nct ? ct + 2 : ct, zA0, zB0, w0);      // clamped: the last pass re-reads its own tile
-      mfma_tile_hm(zA1, acc);
-      mx = force_worst ? 2.0f : tile_max(acc);
-      if (__any(mx > MM_TWO_WAY_MAX)) mfma_tile_l(zB1, acc);
-      reduce_tile(acc, mx, w1);
+      process_tile(zA1, zB1, w1);
     }
   }
   // workgroup reduction -> slab
@@ -335,6 +384,8 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
                         int B, int L, int d, int flags, hipStream_t stream) {
   const int npanel = mm_mfma_num_slots(wl.Mp);
   const int force_worst = (flags & MM_FORCE_WORST_TIER) ? 1 : 0;
+  const unsigned int* amax = (const unsigned int*)(ws + wl.amax);
+  const double* zmax2 = mm_moment_deg(d) >= 4 ? (const double*)(packed + ml.zmax2) : nullptr;
   const long long nwork_ll = (long long)npanel * wl.Po * B;
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const int nwork = (int)nwork_ll;
@@ -344,7 +395,7 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
   double* partB = (double*)(ws + wl.partB);
 #define MM_LAUNCH_ND(ND_)                                                                         \
   hipLaunchKernelGGL((k_qred_f32_mfma<ND_>), dim3(nwork), dim3(256), 0, stream, Zs3, L, wl.Mp, d, \
-                     wl.P, wl.Po, wl.NS, npanel, nwork, force_worst, rowO, colO, partB)
+                     wl.P, wl.Po, wl.NS, npanel, nwork, force_worst, amax, zmax2, rowO, colO, partB)
   switch (ml.nd8) {
     case 1: MM_LAUNCH_ND(1); break;
     case 2: MM_LAUNCH_ND(2); break;

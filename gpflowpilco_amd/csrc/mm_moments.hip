@@ -1,0 +1,339 @@
+// Weight moments of the f32 off-diagonal pairs and their per-(b, pair) contraction (gfx950).
+//
+// For an off-diagonal pair (a, a') of an f32 model the tile kernel (mm_mfma.hip) reduces
+//     S = sum_ij what_i what'_j E(b_ij),     b_ij = (zc_i - dmu)^T G zc'_j,   dmu = mu_b - zbar_a,
+// with zc, zc' the model's inducing inputs centred at their per-latent centroids.  Any POLYNOMIAL part
+// P(x) = sum_n a_n x^n of E collapses to moments of the two weight vectors against model-constant monomial
+// tables -- O(M C(d+n, n)) instead of O(M^2) per (b, pair), and exact in f64:
+//     sum_ij what_i what'_j b_ij^n = < M_n , G^{(x)n} Q_n >,
+//     Q_n = sum_j what'_j zc'_j^{(x)n},   M_n = sum_i what_i (zc_i - dmu)^{(x)n}.
+// Orders 0..2 (1 + b + b^2/2) are ALWAYS taken this way: in f32 it is the rounding of the linear term that
+// costs the digits of S (DESIGN.md "fp32 error budget").  For d <= 8 the tables go to degree 4, and a (b, pair)
+// whose Cauchy-Schwarz bound max_i |A_i| max_j |zc'_j| is <= 1 is COLLAPSED: the cubic and quartic terms
+// c0 x^3 + c1 x^4 -- the tile kernel's own first-tier approximant of the remainder, valid to 5e-8 |x| on
+// |x| <= 1/16 -- come from the moments too, the tile kernel skips every tile with max|b| <= 1/16 after a one-MFMA
+// screening product and reduces only the correction r(x) - c0 x^3 - c1 x^4 on the others.
+//
+//   k_wmom_gemm : mom[(b, pair, side)][:] = sum_m what_m Zm[latent(side)][m][:]   -- an f64 GEMM
+//                 [rows = B per (pair, side)] x [K = Mp] x [N = KMp columns] on v_mfma_f64_16x16x4_f64:
+//                 64 x 128 output tile per workgroup (4 waves x 64 x 32), K-blocks of 32 staged through LDS
+//                 (bank-conflict-free strides), next block's global loads in flight during the MFMAs,
+//                 split-K over MM_MOM_SPLIT slices, XCD-aware 1-D grid (tiles sharing a table slice share an L2);
+//   k_spoly     : per (b, pair) the d^n contractions above for n = 0..2 (or 0..4), one workgroup each.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "mm_common.h"
+#include "mm_mono.h"
+
+typedef double f64x4m __attribute__((ext_vector_type(4)));
+
+#define MM_GEMM_RB 64        // batch rows per workgroup
+#define MM_GEMM_NB 128       // table columns per workgroup (4 waves x 32)
+#define MM_GEMM_KB 32        // K block staged through LDS
+#define MM_GEMM_AS 34        // LDS row stride (doubles) of the A block: 16 rows x 2 k land on 32 distinct 8-byte banks
+#define MM_GEMM_BS 144       // LDS row stride of the B block: rows k and k + 1 are 16 banks apart
+
+__device__ __forceinline__ void mm_decode_pair_m(int p, int L, int& a, int& a2) {
+  int r = p - L, i = 0;
+  while (r >= L - 1 - i) { r -= L - 1 - i; ++i; }
+  a = i; a2 = i + 1 + r;
+}
+
+__global__ __launch_bounds__(256, 2) void k_wmom_gemm(const double* __restrict__ whR, const double* __restrict__ whC,
+                                                      const double* __restrict__ Zm, int KMp, int L, int Mp, int B, int Po,
+                                                      int nrb, int ncb, int nwork, int col_deg3,
+                                                      const unsigned int* __restrict__ amax, const double* __restrict__ zmax2,
+                                                      double* __restrict__ mom) {
+  // work item -> (pair, side, column block, k slice, row block); consecutive items (one XCD after the remap)
+  // share the table slice [k slice][column block] of one latent
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, slot = orig >> 3;
+  const int qn = nwork >> 3, rn = nwork & 7;
+  int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
+  const int rb = wi % nrb; wi /= nrb;
+  const int ks = wi % MM_MOM_SPLIT; wi /= MM_MOM_SPLIT;
+  const int cb = wi % ncb; wi /= ncb;
+  const int side = wi & 1, po = wi >> 1;
+  int a, a2;
+  mm_decode_pair_m(L + po, L, a, a2);
+  const double* W = side ? whC : whR;
+  const double* tab = Zm + (size_t)(side ? a2 : a) * Mp * KMp;
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
+  // a column block made of cubic / quartic monomials only is needed by collapsed (b, pair) items alone: the
+  // workgroup leaves when none of its 64 batch elements is collapsed (k_spoly then never reads those columns)
+  if (cb * MM_GEMM_NB >= col_deg3) {
+    const int bb = rb * MM_GEMM_RB + lane;
+    const bool c = amax != nullptr && bb < B && mm_collapse_bound2(amax[(size_t)bb * Po + po], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
+    if (!__any(c)) return;                                  // every wave evaluates the same 64 elements: uniform exit
+  }
+  const int kslice = Mp / MM_MOM_SPLIT;                     // Mp % 128 == 0: a multiple of MM_GEMM_KB
+  const int k_begin = ks * kslice, nkb = kslice / MM_GEMM_KB;
+
+  __shared__ double As[MM_GEMM_RB * MM_GEMM_AS];
+  __shared__ double Bs[MM_GEMM_KB * MM_GEMM_BS];
+
+  // global -> register staging: A: row ar, 8 consecutive k;  B: table row bk, 16 consecutive columns
+  const int ar = tid >> 2, ak = (tid & 3) * 8;
+  int brow = rb * MM_GEMM_RB + ar;
+  brow = brow < B ? brow : B - 1;                           // rows past the batch recompute the last one (not stored)
+  const double* aptr = W + ((size_t)brow * Po + po) * Mp + k_begin + ak;
+  const int bk = tid >> 3, bc = (tid & 7) * 16;
+  const int col0 = cb * MM_GEMM_NB + bc;
+  const bool bvalid = col0 < KMp;                           // KMp % 16 == 0: a 16-column chunk is all in or all out
+  const double* bptr = tab + (size_t)(k_begin + bk) * KMp + (bvalid ? col0 : 0);
+  double2 ra[4], rbv[8];
+  auto load_regs = [&](int kb) {
+    const double* ap = aptr + kb * MM_GEMM_KB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const double2*>(ap + 2 * i);
+    const double* bp = bptr + (size_t)kb * MM_GEMM_KB * KMp;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) rbv[i] = *reinterpret_cast<const double2*>(bp + 2 * i);
+  };
+  f64x4m acc[4][2];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) acc[rt][ct] = (f64x4m){0.0, 0.0, 0.0, 0.0};
+
+  load_regs(0);
+  for (int kb = 0; kb < nkb; ++kb) {
+    __syncthreads();                                        // the previous block's MFMA operands have been read
+    // 16-byte stores.  The 8 threads of a table row write chunks 128 bytes (= all 32 banks) apart: stored in place
+    // they would all hit the same banks.  Pair i of chunk c therefore goes to slot (i + c) & 7 of the chunk (a rotation
+    // inside the 16 doubles); the B-operand read below undoes it.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<double2*>(&As[ar * MM_GEMM_AS + ak + 2 * i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      *reinterpret_cast<double2*>(&Bs[bk * MM_GEMM_BS + bc + 2 * ((i + (tid & 7)) & 7)]) = bvalid ? rbv[i] : make_double2(0.0, 0.0);
+    __syncthreads();
+    load_regs(kb + 1 < nkb ? kb + 1 : kb);                  // unconditional (clamped): in flight during the MFMAs
+#pragma unroll
+    for (int s = 0; s < MM_GEMM_KB / 4; ++s) {
+      double av[4], bv[2];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) av[rt] = As[(rt * 16 + l15) * MM_GEMM_AS + 4 * s + kq];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)     // column wv*32 + ct*16 + l15: chunk c = 2 wv + ct, pair l15 >> 1 sits in slot (pair + c) & 7
+        bv[ct] = Bs[(4 * s + kq) * MM_GEMM_BS + wv * 32 + ct * 16 + 2 * (((l15 >> 1) + 2 * wv + ct) & 7) + (l15 & 1)];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          acc[rt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[rt], bv[ct], acc[rt][ct], 0, 0, 0);
+    }
+  }
+  // accumulator layout: lane (l15 = column, kq), register r  <->  row kq + 4 r of the 16 x 16 tile
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = rb * MM_GEMM_RB + rt * 16 + kq + 4 * r;
+      if (b >= B) continue;
+      double* o = mom + ((((size_t)b * Po + po) * 2 + side) * MM_MOM_SPLIT + ks) * KMp;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        const int col = cb * MM_GEMM_NB + wv * 32 + ct * 16 + l15;
+        if (col < KMp) o[col] = acc[rt][ct][r];
+      }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_spoly: s12[b][po] = sum_{n=0}^{N} a_n < M_n, G^{(x)n} Q_n >,  a = (1, 1, 1/2, c0, c1); N = 4 for a collapsed
+// (b, pair), else 2.  One 256-thread workgroup per (b, pair); tensors are held in full (d^n entries) in LDS:
+//   T <- Q_n expanded from the packed column-side moments; G applied along every index in place (each thread
+//   owns whole fibres); then, with < (zc - dmu)^{(x)n}, T > = sum_k C(n,k) (-1)^{n-k} < zc^{(x)k} (x) dmu^{(x)(n-k)}, T >
+//   (T symmetric), k runs from n down to 0: dot of the leading-k-index tensor with the packed row moments of
+//   degree k, then the last index is contracted with dmu.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mm_flat_rank(int flat, int n, int d) {
+  // rank (inside the degree-n block) of the index tuple encoded base d in `flat`
+  int k0 = flat % d; flat /= d;
+  int k1 = flat % d; flat /= d;
+  int k2 = flat % d; flat /= d;
+  int k3 = flat % d;
+  if (n < 4) k3 = 1 << 20;
+  if (n < 3) k2 = 1 << 20;
+  if (n < 2) k1 = 1 << 20;
+  // sorting network on (k0, k1, k2, k3); absent slots hold a large value and stay on top
+  int t;
+#define MM_CX(x_, y_) t = min(x_, y_); y_ = max(x_, y_); x_ = t
+  MM_CX(k0, k1); MM_CX(k2, k3); MM_CX(k0, k2); MM_CX(k1, k3); MM_CX(k1, k2);
+#undef MM_CX
+  int r = k0;                                              // C(k0, 1)
+  if (n >= 2) r += k1 * (k1 + 1) / 2;                      // C(k1 + 1, 2)
+  if (n >= 3) r += k2 * (k2 + 1) * (k2 + 2) / 6;           // C(k2 + 2, 3)
+  if (n >= 4) r += k3 * (k3 + 1) * (k3 + 2) * (k3 + 3) / 24;
+  return r;
+}
+
+__device__ __forceinline__ double mm_block_sum256m(double v, double* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+template <int DK>
+__global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, int KMp, const double* __restrict__ pairmat,
+                                               const double* __restrict__ zbar, const double* __restrict__ zmax2,
+                                               const unsigned int* __restrict__ amax, const float* __restrict__ mu,
+                                               int L, int d, int P, int deg, int allow_collapse,
+                                               double c0, double c1, double* __restrict__ s12) {
+  extern __shared__ double sm[];
+  const int po = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int Po = P - L, p = L + po;
+  int a, a2;
+  mm_decode_pair_m(p, L, a, a2);
+  int dn = 1;                                              // d^deg
+  for (int i = 0; i < deg; ++i) dn *= d;
+  double* T = sm;                      // [d^deg]
+  double* U = T + dn;                  // [d^(deg-1)]
+  double* nh = U + dn / d;             // [KMp] row-side moments
+  double* qh = nh + KMp;               // [KMp] column-side moments
+  double* Gs = qh + KMp;               // [d][d]
+  double* dmu = Gs + d * d;            // [d]
+  __shared__ double red[4];
+  {
+    const double* nm = mom + (((size_t)b * Po + po) * 2 + 0) * MM_MOM_SPLIT * KMp;
+    const double* qm = mom + (((size_t)b * Po + po) * 2 + 1) * MM_MOM_SPLIT * KMp;
+    for (int k = tid; k < KMp; k += 256) {                 // fixed summation order of the split-K partials
+      double sn = 0.0, sq = 0.0;
+#pragma unroll
+      for (int t = 0; t < MM_MOM_SPLIT; ++t) { sn += nm[t * KMp + k]; sq += qm[t * KMp + k]; }
+      nh[k] = sn; qh[k] = sq;
+    }
+    const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
+    for (int idx = tid; idx < d * d; idx += 256) Gs[idx] = pm[idx];
+    if (tid < d) dmu[tid] = (double)mu[(size_t)b * d + tid] - zbar[a * d + tid];
+  }
+  __syncthreads();
+  const bool coll = allow_collapse && deg >= 4 &&
+                    mm_collapse_bound2(amax[(size_t)b * Po + po], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
+  const int nmax = coll ? 4 : 2;
+  double total = 0.0;                                      // per-thread partial of the final sum
+  for (int n = nmax; n >= 1; --n) {
+    const double an = n == 1 ? 1.0 : n == 2 ? 0.5 : n == 3 ? c0 : c1;
+    int dsz = 1;
+    for (int i = 0; i < n; ++i) dsz *= d;
+    const int offn = mm_mono_off(n, d);
+    for (int idx = tid; idx < dsz; idx += 256) T[idx] = qh[offn + mm_flat_rank(idx, n, d)];
+    __syncthreads();
+    // T <- G applied along every index: axis t has stride d^t; a fibre = the d entries along that axis,
+    // owned by one thread (registers), so the transform is in place
+    int stride = 1;
+    for (int t = 0; t < n; ++t) {
+      const int nfib = dsz / d;
+      for (int f = tid; f < nfib; f += 256) {
+        const int lo = f % stride, hi = f / stride;
+        double* base = T + (size_t)hi * stride * d + lo;
+        double v[DK];
+#pragma unroll
+        for (int l = 0; l < DK; ++l) v[l] = l < d ? base[(size_t)l * stride] : 0.0;
+        for (int k = 0; k < d; ++k) {
+          double s = 0.0;
+#pragma unroll
+          for (int l = 0; l < DK; ++l) s = fma(l < d ? Gs[k * d + l] : 0.0, v[l], s);
+          base[(size_t)k * stride] = s;
+        }
+      }
+      __syncthreads();
+      stride *= d;
+    }
+    // k = n .. 0: dot with the row moments of degree k, then contract the last (highest-stride) index with dmu
+    double* cur = T;
+    double* oth = U;
+    int ksz = dsz;
+    double sign_binom = 1.0;                               // C(n, k) (-1)^(n-k), starting at k = n
+    for (int k = n; k >= 0; --k) {
+      const int offk = mm_mono_off(k, d);
+      double part = 0.0;
+      for (int idx = tid; idx < ksz; idx += 256) part = fma(cur[idx], nh[offk + (k ? mm_flat_rank(idx, k, d) : 0)], part);
+      total = fma(an * sign_binom, part, total);
+      if (k == 0) break;
+      const int nsz = ksz / d;                             // contract the highest index (stride nsz) with dmu
+      for (int idx = tid; idx < nsz; idx += 256) {
+        double s = 0.0;
+        for (int l = 0; l < d; ++l) s = fma(cur[(size_t)l * nsz + idx], dmu[l], s);
+        oth[idx] = s;
+      }
+      __syncthreads();
+      double* tsw = cur; cur = oth; oth = tsw;
+      ksz = nsz;
+      sign_binom = -sign_binom * (double)k / (double)(n - k + 1);
+    }
+    __syncthreads();
+  }
+  const double tot = mm_block_sum256m(total, red);
+  if (tid == 0) s12[(size_t)b * Po + po] = tot + nh[0] * qh[0];
+}
+
+int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
+                      int B, int L, int d, const void* mu_f32, int flags, hipStream_t stream) {
+  const double* Zm = (const double*)(packed + ml.Zm);
+  double* mom = (double*)(ws + wl.mom);
+  const int nrb = (B + MM_GEMM_RB - 1) / MM_GEMM_RB, ncb = (ml.KMp + MM_GEMM_NB - 1) / MM_GEMM_NB;
+  const long long nwork_ll = (long long)wl.Po * 2 * ncb * MM_MOM_SPLIT * nrb;
+  if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
+  const int nwork = (int)nwork_ll;
+  const int deg = mm_moment_deg(d);
+  // collapse: not with the forced worst tier (bench.py --recipe worst times the dense path)
+  const int allow = (flags & MM_FORCE_WORST_TIER) ? 0 : 1;
+  const int col_deg3 = mm_mono_offset(3, d);                // first column of a cubic monomial
+  hipLaunchKernelGGL(k_wmom_gemm, dim3(nwork), dim3(256), 0, stream, (const double*)(ws + wl.whR),
+                     (const double*)(ws + wl.whC), Zm, ml.KMp, L, wl.Mp, B, wl.Po, nrb, ncb, nwork, col_deg3,
+                     (allow && deg >= 4) ? (const unsigned int*)(ws + wl.amax) : (const unsigned int*)nullptr,
+                     (const double*)(packed + ml.zmax2), mom);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  int dn = 1;
+  for (int i = 0; i < deg; ++i) dn *= d;
+  const size_t shm = (size_t)(dn + dn / d + 2 * ml.KMp + d * d + d) * sizeof(double);
+#define MM_SPOLY(DK_) hipLaunchKernelGGL((k_spoly<DK_>), dim3(wl.Po, B), dim3(256), shm, stream, (const double*)mom, ml.KMp, \
+                     (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), (const double*)(packed + ml.zmax2),    \
+                     (const unsigned int*)(ws + wl.amax), (const float*)mu_f32, L, d, wl.P, deg, allow,                          \
+                     (double)MM_REM1_C0, (double)MM_REM1_C1, (double*)(ws + wl.s12))
+  if (d <= 8) MM_SPOLY(8); else MM_SPOLY(32);
+#undef MM_SPOLY
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+// ---------------------------------------------------------------------------------------------
+// mm_offdiag_stats: how many (b, off-diagonal pair) items of the last mm_q_forward are collapsed (bench.py reports
+// it with the timing: the reduce kernels' time depends on the regime).  out: device int32[2] = {collapsed, total}.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_offdiag_stats(const unsigned int* __restrict__ amax, const double* __restrict__ zmax2, int L, int Po, int n,
+                                int32_t* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  bool c = false;
+  if (idx < n) {
+    int a, a2;
+    mm_decode_pair_m(L + idx % Po, L, a, a2);
+    c = mm_collapse_bound2(amax[idx], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
+  }
+  const unsigned long long m = __ballot(c);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (int)__popcll(m));
+  if (idx == 0) out[1] = n;
+}
+
+extern "C" int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
+                                const void* workspace, size_t workspace_bytes, int32_t* out, void* stream) {
+  if (!packed || !workspace || !out || L <= 0 || M <= 0 || d <= 0 || d > MM_DMAX || B <= 0) return MM_E_ARG;
+  const MMModelLayout ml = mm_model_layout(L, M, d, dtype, 1);
+  const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
+  if (packed_bytes < ml.Cm || workspace_bytes < wl.total) return MM_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(int32_t), s);
+  if (e != hipSuccess) return (int)e;
+  if (dtype != MM_F32 || wl.Po == 0 || mm_moment_deg(d) < 4 || (flags & MM_FORCE_WORST_TIER)) return 0;   // nothing collapses
+  const int n = B * wl.Po;
+  hipLaunchKernelGGL(k_offdiag_stats, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned int*)((const char*)workspace + wl.amax),
+                     (const double*)((const char*)packed + ml.zmax2), L, wl.Po, n, out);
+  e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}

@@ -1,0 +1,52 @@
+// Monomial indexing of the moment tables (host + device): graded order, colex rank of the sorted index tuple
+// inside a degree.  See mm_common.h (mm_moment_deg / mm_mono_offset) and mm_moments.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+// C(n, k) for the small arguments used here (n <= 40, k <= 5)
+__host__ __device__ __forceinline__ int mm_binom_i(int n, int k) {
+  if (k < 0 || k > n) return 0;
+  int r = 1;
+  for (int i = 1; i <= k; ++i) r = r * (n - k + i) / i;
+  return r;
+}
+
+// offset of the degree-n block: number of monomials of degree < n in d variables
+__host__ __device__ __forceinline__ int mm_mono_off(int n, int d) {
+  int o = 0;
+  for (int m = 0; m < n; ++m) o += mm_binom_i(d + m - 1, m);
+  return o;
+}
+
+// rank of the multiset {k[0] <= k[1] <= ... <= k[n-1]} inside the degree-n block
+__host__ __device__ __forceinline__ int mm_mono_rank(const int* k, int n) {
+  int r = 0;
+  for (int t = 0; t < n; ++t) r += mm_binom_i(k[t] + t, t + 1);
+  return r;
+}
+
+// rank of an UNSORTED index tuple of length n <= 4 (sorted with a tiny network first)
+__host__ __device__ __forceinline__ int mm_mono_rank_unsorted(int k0, int k1, int k2, int k3, int n) {
+  // unused slots must be passed as values that keep the order (the caller passes n)
+  int k[4] = {k0, k1, k2, k3};
+  for (int i = 1; i < n; ++i)
+    for (int j = i; j > 0 && k[j - 1] > k[j]; --j) { const int t = k[j]; k[j] = k[j - 1]; k[j - 1] = t; }
+  return mm_mono_rank(k, n);
+}
+
+// inverse of mm_mono_rank: k[0..n-1] sorted ascending
+__host__ __device__ __forceinline__ void mm_mono_unrank(int r, int n, int* k) {
+  for (int t = n - 1; t >= 0; --t) {
+    int v = 0;
+    while (mm_binom_i(v + 1 + t, t + 1) <= r) ++v;
+    k[t] = v;
+    r -= mm_binom_i(v + t, t + 1);
+  }
+}
+
+// Cauchy-Schwarz bound (squared) on |b_ij| of one (b, off-diagonal pair): max_i |A_i|^2 (k_pairvec, f32 bits, rounded
+// up) times max_j |zc'_j|^2 (pack time).  ONE definition: k_spoly, the f32 tile kernel and the portable kernel must
+// agree on which (b, pair) is collapsed.
+__device__ __forceinline__ float mm_collapse_bound2(unsigned int amax_bits, double zmax2) {
+  return __uint_as_float(amax_bits) * ((float)zmax2 * 1.000001f);
+}

@@ -20,14 +20,74 @@ def get_state_initializer(mean: torch.Tensor, covariance: torch.Tensor) -> Calla
   return lambda: (mx, Sxx)
 
 
+def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: int, dt: float = 1.0):
+  """``f(mx, Sxx) -> loss [B]`` running the whole rollout in ``mm_rollout_composed`` (csrc/mm_compose.hip), or None
+  when the system is not the shape that entry point implements: TrigonometricEncoder, policy =
+  InverseLinkWrapper(KernelRegressor(SVGP with one latent), Chain[Scale, Shift, NormalCDF]) with scalar scale and
+  shift, SVGP drift, no diffusion, MomentMatchingEuler, GaussianObjective -- the cartpole wiring of
+  ``examples/cartpole_swingup/swingup_loops.py:41-91``.  Forward only: callers that differentiate (a trainable
+  policy under autograd) take the torch composition."""
+  from . import bijectors as tfb
+  from . import ops
+  from .components import TrigonometricEncoder
+  from .cost import GaussianObjective
+  from .models import SVGP, InverseLinkWrapper, KernelRegressor, LinearCoregionalization
+  enc, pol, drift = system.encoder, system.policy, system.drift
+  if system.diffusion is not None or not isinstance(system.solver, MomentMatchingEuler):
+    return None
+  if not isinstance(enc, TrigonometricEncoder) or not isinstance(objective, GaussianObjective):
+    return None
+  if not isinstance(pol, InverseLinkWrapper) or not isinstance(pol.model, KernelRegressor):
+    return None
+  pm_, head = pol.model.model, pol.invlink
+  if not isinstance(pm_, SVGP) or not isinstance(drift, SVGP) or pm_.num_latent_gps != 1:
+    return None
+  if isinstance(pm_.kernel, LinearCoregionalization) or isinstance(drift.kernel, LinearCoregionalization):
+    return None
+  if any(k.active_dims is not None for k in pm_.latent_kernels + drift.latent_kernels):
+    return None
+  bj = head.bijectors if isinstance(head, tfb.Chain) else None
+  if not (bj and len(bj) == 3 and isinstance(bj[0], tfb.Scale) and isinstance(bj[1], tfb.Shift) and isinstance(bj[2], tfb.NormalCDF)):
+    return None
+  try:
+    scale, shift = float(bj[0].scale), float(bj[1].shift)
+  except (TypeError, ValueError):
+    return None
+  cache = {}
+
+  def run(mx: torch.Tensor, Sxx: torch.Tensor):
+    key = (mx.dtype, str(mx.device))
+    roll = cache.get(key)
+    if roll is None:
+      nx = mx.shape[-1]
+      roll = ops.ComposedRollout(drift.packed(mx.dtype, True, mx.device), pm_.packed(mx.dtype, False, mx.device), nx=nx,
+                                 active_dims=enc.active_dims, head_scale=scale, head_shift=shift,
+                                 target=objective.target, precis=objective.precis)
+      cache[key] = roll
+    _, _, cost = roll(mx, Sxx, num_steps, dt=dt)
+    return cost.sum(1)
+  return run
+
+
 def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_initializer: Callable,
                         num_steps: int, initial_time: float = 0.0,
-                        solution_times: Optional[Sequence[float]] = None, **kwargs) -> Callable:
+                        solution_times: Optional[Sequence[float]] = None, native: Optional[bool] = None,
+                        **kwargs) -> Callable:
   """pilco.py:176-220.  Returns ``closure() -> loss [B]``; ``system.solver`` should be a
-  ``MomentMatchingEuler`` (pilco.py:141-144)."""
+  ``MomentMatchingEuler`` (pilco.py:141-144).
+
+  ``native``: None (default) runs the rollout in one ``mm_rollout_composed`` call whenever the system has the shape it
+  implements (``native_policy_loss``), the state is on the GPU and nothing requires a gradient; False always takes
+  the torch composition (``forward_sde`` over ``moment_matching``); True insists on the native path."""
+  uniform = solution_times is None
   if solution_times is None:
     solution_times = np.arange(1, 1 + num_steps, dtype=np.float64)     # pilco.py:186
   encoder = system.encoder
+  fast = None
+  if native is not False and uniform and float(initial_time) == 0.0 and not kwargs:
+    fast = native_policy_loss(system, objective, num_steps, dt=1.0)
+  if native is True and fast is None:
+    raise ValueError("native=True: the system is not the shape mm_rollout_composed implements")
 
   def _accumulate_loss(t, state, loss):                                # pilco.py:199-205
     x = GaussianMoments(moments=state, centered=True)
@@ -35,8 +95,21 @@ def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_init
       x = moment_matching(x, encoder).y
     return loss + objective(x=x, t=t)
 
+  def _use_native(mx, Sxx):
+    if fast is None or not mx.is_cuda or mx.ndim != 2:
+      return False
+    models = [system.drift, getattr(getattr(system.policy, "model", None), "model", None)]
+    trainable = any(t.requires_grad for m in models if m is not None for t in m._parameters())
+    if torch.is_grad_enabled() and (trainable or mx.requires_grad or Sxx.requires_grad):
+      return False                       # someone differentiates: the torch composition carries the autograd graph
+    if trainable and torch.cuda.is_current_stream_capturing():
+      return False                       # a captured graph must evaluate a trainable model FROM its parameters, not
+    return True                          # from a packed snapshot that goes stale at the next optimiser step
+
   def _closure():                                                      # pilco.py:207-217
     mx, Sxx = state_initializer()
+    if _use_native(mx, Sxx):
+      return fast(mx, Sxx)
     loss = torch.zeros(mx.shape[:-1], dtype=mx.dtype, device=mx.device)
     _, loss = system.solve_forward(iterator="foldl", initial_time=initial_time,
                                    initial_state=(mx, Sxx), solution_times=solution_times,

@@ -183,14 +183,56 @@ class _PackCache:
     return self._packed[slot]
 
 
+# lengthscale given to an input dimension a latent kernel does NOT act on (per-latent ``active_dims``): the SE kernel
+# with lengthscale l -> infinity on a dimension is the kernel that ignores it; 1e6 perturbs every expectation by
+# O(Sigma_kk / 1e12) relative
+INACTIVE_LENGTHSCALE = 1.0e6
+
+
+def kernel_input_dims(kernels, ndims: Optional[int] = None):
+  """Sorted union of the latent kernels' ``active_dims`` (None if every kernel acts on all inputs), and whether
+  the kernels differ in what they act on."""
+  if all(k.active_dims is None for k in kernels):
+    return None, False
+  if any(k.active_dims is None for k in kernels):
+    if ndims is None:
+      raise ValueError("mixing sliced and unsliced latent kernels needs the input dimension")
+    union = tuple(range(ndims))
+  else:
+    union = tuple(sorted(set(i for k in kernels for i in k.active_dims)))
+  differ = any((k.active_dims if k.active_dims is not None else union) != kernels[0].active_dims for k in kernels) \
+      or kernels[0].active_dims is None
+  return union, differ
+
+
 def _stack_kernel_params(kernels, Zs, device):
-  d = Zs[0].shape[-1] if kernels[0].active_dims is None else len(kernels[0].active_dims)
-  active = kernels[0].active_dims
-  for k in kernels:
-    if k.active_dims != active:
-      raise NotImplementedError("latent kernels with different active_dims are not supported")
-  Z = torch.stack([k.slice(z.to(device=device, dtype=DEFAULT_FLOAT)) for k, z in zip(kernels, Zs)])
-  ls = torch.stack([k.lengthscales_vector(d).to(device=device, dtype=DEFAULT_FLOAT) for k in kernels])
+  """-> Z [L,M,d], lengthscales [L,d], variance [L] on the kernels' common input dimensions.
+
+  Kernels with the same ``active_dims`` (the reference's assumption, utils/kernel_expectation.py:98-100): sliced
+  as the reference slices.  Kernels acting on DIFFERENT subsets (moment_matching/models.py:264-270 slices per
+  kernel): every latent is embedded into the sorted union of the active dimensions with the lengthscale
+  ``INACTIVE_LENGTHSCALE`` (and inducing coordinate 0) on the dimensions it ignores -- the kernels, their
+  expectations under any (dense or diagonal) Gaussian and all pair terms are then exact to ~1e-12, including the
+  product shortcut of disjoint kernels under a diagonal Gaussian (utils/kernel_expectation.py:85-89), which is the
+  special case G = 0 of the general pair term."""
+  union, differ = kernel_input_dims(kernels, Zs[0].shape[-1])
+  if not differ:
+    d = Zs[0].shape[-1] if kernels[0].active_dims is None else len(kernels[0].active_dims)
+    Z = torch.stack([k.slice(z.to(device=device, dtype=DEFAULT_FLOAT)) for k, z in zip(kernels, Zs)])
+    ls = torch.stack([k.lengthscales_vector(d).to(device=device, dtype=DEFAULT_FLOAT) for k in kernels])
+  else:
+    d = len(union)
+    pos = {u: i for i, u in enumerate(union)}
+    Zl, lsl = [], []
+    for k, z in zip(kernels, Zs):
+      act = union if k.active_dims is None else k.active_dims
+      zf = torch.zeros(z.shape[0], d, dtype=DEFAULT_FLOAT, device=device)
+      lf = torch.full((d,), INACTIVE_LENGTHSCALE, dtype=DEFAULT_FLOAT, device=device)
+      idx = torch.tensor([pos[u] for u in act], device=device)
+      zf[:, idx] = k.slice(z.to(device=device, dtype=DEFAULT_FLOAT))
+      lf[idx] = k.lengthscales_vector(len(act)).to(device=device, dtype=DEFAULT_FLOAT)
+      Zl.append(zf); lsl.append(lf)
+    Z, ls = torch.stack(Zl), torch.stack(lsl)
   var = torch.stack([k.variance.to(device=device, dtype=DEFAULT_FLOAT).reshape(()) for k in kernels])
   return Z, ls, var
 
@@ -220,7 +262,8 @@ class SVGP:
     Plain torch (policy evaluation on real states; not on the moment-matching hot path)."""
     Z, ls, var, beta, _, mean_c = self.precompute(x.device)
     kernels = self.latent_kernels
-    xs = kernels[0].slice(x).to(DEFAULT_FLOAT)
+    union, differ = kernel_input_dims(kernels, x.shape[-1])
+    xs = (x[..., list(union)] if differ else kernels[0].slice(x)).to(DEFAULT_FLOAT)
     lead = xs.shape[:-1]
     xs2 = xs.reshape(-1, xs.shape[-1])
     A = xs2[None] / ls[:, None, :]                              # [L, n, d]

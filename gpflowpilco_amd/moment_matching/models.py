@@ -39,16 +39,23 @@ def _mm_gauss_kr(x: GaussianMoments, regressor: KernelRegressor, /, **kwargs):
   return dispatcher(x, regressor.model, model_uncertainty=False, **kwargs)
 
 
-def _sliced_state(x: GaussianMoments, kernel):
-  mu = kernel.slice(x.mean())
-  Sxx = kernel.slice_cov(x.covariance(dense=True))
-  return mu.contiguous(), Sxx.contiguous()
+def _sliced_state(x: GaussianMoments, kernels):
+  """The state on the latent kernels' common input dimensions (models.py:264-270 slices per kernel; latents that act
+  on different subsets are embedded into the union of them, gpflowpilco_amd/models.py:_stack_kernel_params).
+  Returns (mu, Sxx, union | None)."""
+  from ..models import kernel_input_dims
+  mu, Sxx = x.mean(), x.covariance(dense=True)
+  union, differ = kernel_input_dims(kernels, mu.shape[-1])
+  if not differ:
+    return kernels[0].slice(mu).contiguous(), kernels[0].slice_cov(Sxx).contiguous(), None
+  idx = list(union)
+  return mu[..., idx].contiguous(), Sxx[..., idx, :][..., :, idx].contiguous(), union
 
 
 def _run_kernels(x: GaussianMoments, model, full_output_cov, model_uncertainty, jitter,
                  latent_full_cov=None):
-  kernel0 = model.latent_kernels[0]
-  mu, Sxx = _sliced_state(x, kernel0)
+  kernels = model.latent_kernels
+  mu, Sxx, union = _sliced_state(x, kernels)
   if not mu.is_cuda:
     raise RuntimeError("moment matching of GP models runs on the GPU only (no CPU fallback)")
   lead = mu.shape[:-1]
@@ -75,6 +82,16 @@ def _run_kernels(x: GaussianMoments, model, full_output_cov, model_uncertainty, 
     pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
     f1, Sff, cross = ops.moment_match(pm, mu2, S2, full_output_cov=full,
                                       model_uncertainty=model_uncertainty, jitter=0.0)
+  if union is not None:
+    # the reference stacks every latent's cross term in that latent's OWN sliced coordinates (models.py:264-277:
+    # x1, dX and Sxx are sliced per kernel and stacked, which needs equally many active dims per latent); the kernels
+    # return it on the union of the dims (zero, to ~1e-12, where a latent does not act): gather column a at a's dims
+    pos = {u: i for i, u in enumerate(union)}
+    acts = [union if k.active_dims is None else k.active_dims for k in kernels]
+    if len(set(len(a) for a in acts)) != 1:
+      raise NotImplementedError("latent kernels with different NUMBERS of active dims cannot be stacked (models.py:264-270)")
+    gather = torch.tensor([[pos[u] for u in a] for a in acts], device=cross.device)        # [L, D]
+    cross = torch.stack([cross[:, gather[a], a] for a in range(len(acts))], dim=-1)        # [B, D, L]
   f1 = f1.reshape(lead + f1.shape[1:])
   Sff = Sff.reshape(lead + Sff.shape[1:])
   cross = cross.reshape(lead + cross.shape[1:])

@@ -178,6 +178,18 @@ def Q_reduce_forward(pm: PackedModel, B: int, flags: int, jitter: float = 0.0):
   return Sff
 
 
+def offdiag_stats(pm: PackedModel, B: int, flags: int):
+  """(collapsed, total) (b, off-diagonal pair) items of the last ``q_forward`` / ``moment_match`` with this B and flags
+  (f32 models with d <= 8; (0, 0) otherwise).  Synchronises."""
+  ws = pm.workspace(B, flags)
+  out = torch.zeros(2, dtype=torch.int32, device=pm.device)
+  rc = lib().mm_offdiag_stats(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, flags,
+                              ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(pm.device))
+  check(rc, "mm_offdiag_stats")
+  c, n = out.tolist()
+  return c, n
+
+
 def euler_update(mu, Sigma, f1, Sff, cross_pre, dt: float = 1.0):
   """MomentMatchingEuler.step on the GPU (d == L)."""
   _require_device(mu, Sigma, f1, Sff, cross_pre)
@@ -266,6 +278,73 @@ class GraphedRollout:
     self.mu_in.copy_(mu); self.S_in.copy_(Sigma)
     self.graph.replay()
     return (self.mu, self.S, self.tmu, self.tS) if self.tmu is not None else (self.mu, self.S)
+
+
+class ComposedRollout:
+  """The whole moment-matched policy rollout of the cartpole-shaped system on the device (``mm_rollout_composed``):
+  TrigonometricEncoder -> policy (SVGP mean, Chain[Scale, Shift, NormalCDF]) -> drift SVGP with the
+  ``forward_sde`` cross-covariance bookkeeping -> Euler moment update -> per-step expected cost.
+
+  ``drift`` / ``policy``: PackedModel (drift with C; policy one latent).  ``__call__(mx, Sxx, H)`` returns
+  ``(mx_H, Sxx_H, cost [B, H])`` (and the trajectory if asked); the inputs are not modified.
+  """
+
+  def __init__(self, drift: PackedModel, policy: PackedModel, nx: int, active_dims, head_scale: float, head_shift: float,
+               target: torch.Tensor, precis: torch.Tensor):
+    self.drift, self.policy = drift, policy
+    self.nx, self.active = int(nx), tuple(int(i) for i in active_dims)
+    self.na = len(self.active)
+    self.ne = self.nx + self.na
+    self.nd = self.ne + 1
+    if drift.dtype != policy.dtype:
+      raise TypeError("drift and policy must be packed with the same dtype")
+    if drift.L != self.nx or drift.d != self.nd or policy.L != 1 or policy.d != self.ne:
+      raise ValueError(f"shapes do not compose: drift L={drift.L} d={drift.d} (want {self.nx}, {self.nd}), "
+                       f"policy L={policy.L} d={policy.d} (want 1, {self.ne})")
+    if not drift.with_C:
+      raise ValueError("the drift is evaluated with model uncertainty: pack it with C")
+    self.scale, self.shift = float(head_scale), float(head_shift)
+    self.target = target.to(dtype=drift.dtype, device=drift.device).contiguous()
+    self.precis = precis.to(dtype=drift.dtype, device=drift.device).contiguous()
+    self._act = (_lib.C.c_int32 * self.na)(*self.active)
+    self._wsc = {}
+
+  def _compose_ws(self, B):
+    ws = self._wsc.get(B)
+    if ws is None:
+      n = lib().mm_compose_workspace_bytes(B, self.nx, self.na, _dtype_code(self.drift.dtype))
+      if n == 0:
+        raise ValueError("mm_compose_workspace_bytes rejected the shape")
+      ws = torch.empty(n, dtype=torch.uint8, device=self.drift.device)
+      self._wsc[B] = ws
+    return ws
+
+  def __call__(self, mx: torch.Tensor, Sxx: torch.Tensor, num_steps: int, dt: float = 1.0, keep_trajectory: bool = False):
+    _require_device(mx, Sxx)
+    dt_ = self.drift.dtype
+    if mx.dtype != dt_ or Sxx.dtype != dt_:
+      raise TypeError(f"state dtype {mx.dtype} does not match the packed models ({dt_})")
+    B = mx.shape[0]
+    if mx.shape != (B, self.nx) or Sxx.shape != (B, self.nx, self.nx):
+      raise ValueError(f"expected mx [B,{self.nx}], Sxx [B,{self.nx},{self.nx}]")
+    mx, Sxx = mx.contiguous().clone(), Sxx.contiguous().clone()
+    H = int(num_steps)
+    cost = torch.empty(H, B, dtype=dt_, device=mx.device)
+    tmu = torch.empty(H, B, self.nx, dtype=dt_, device=mx.device) if keep_trajectory else None
+    tS = torch.empty(H, B, self.nx, self.nx, dtype=dt_, device=mx.device) if keep_trajectory else None
+    wd = self.drift.workspace(B, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY)
+    wp = self.policy.workspace(B, MM_FULL_OUTPUT_COV)
+    wc = self._compose_ws(B)
+    rc = lib().mm_rollout_composed(self.drift.buf.data_ptr(), self.drift.nbytes, self.drift.L, self.drift.M, self.drift.d,
+                                   self.policy.buf.data_ptr(), self.policy.nbytes, self.policy.M, self.policy.d,
+                                   _dtype_code(dt_), B, H, float(dt), self.nx, self.na, self._act,
+                                   self.scale, self.shift, self.target.data_ptr(), self.precis.data_ptr(),
+                                   mx.data_ptr(), Sxx.data_ptr(), cost.data_ptr(), _ptr(tmu), _ptr(tS),
+                                   wd.data_ptr(), wd.numel(), wp.data_ptr(), wp.numel(), wc.data_ptr(), wc.numel(),
+                                   self.drift.status().data_ptr(), _stream(mx.device))
+    check(rc, "mm_rollout_composed")
+    out = (mx, Sxx, cost.T.contiguous())
+    return out + (tmu, tS) if keep_trajectory else out
 
 
 def expected_cost(mean: torch.Tensor, cov: torch.Tensor, target: torch.Tensor, precis: torch.Tensor):

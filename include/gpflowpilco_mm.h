@@ -134,6 +134,37 @@ int mm_rollout_closed(const void* packed, size_t packed_bytes, int L, int M, int
 int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
                      const void* target, const void* precis, void* cost, void* stream);
 
+/* Diagnostic: after mm_q_forward (f32 model, d <= 8), how many (batch element, off-diagonal pair) items take the
+ * moment collapse of csrc/mm_moments.hip (cubic + quartic term of the remainder from f64 moments, tiles with
+ * max |b| <= 1/16 skipped).  out: device int32[2] = {collapsed, total}; {0, 0} where the collapse does not apply. */
+int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
+                     const void* workspace, size_t workspace_bytes, int32_t* out, void* stream);
+
+/* ---- composed policy rollout: SURVEY.md row f-2 -------------------------------------------------------
+ * The rollout harness of MomentMatchingPILCO (gpflow_pilco/loops/pilco.py:192-220) for the cartpole-shaped system
+ *   x (nx) -> TrigonometricEncoder on `active_dims` (components.py:73-75, moment_matching/components.py:19-57,
+ *             maths.py:143-176) -> e = [sin a, cos a, x_inactive]  (ne = nx + na)
+ *          -> policy = InverseLinkWrapper(KernelRegressor(SVGP, one latent), Chain[Scale, Shift, NormalCDF])
+ *             (models/core.py:60-71, moment_matching/models.py:27-41, bijectors.py:21-69): u = scale (Phi(f(e)) + shift)
+ *          -> drift SVGP on d = joint(e, u) (nd = ne + 1) with the cross-covariance bookkeeping of
+ *             dynamics/forward_sde.py:95-137 -> MomentMatchingEuler.step (solvers.py:110-135)
+ *          -> expected Gaussian cost of the encoded new state (components.py:26-37), per step.
+ * H steps are enqueued back to back: per step two mm_moment_match calls and four small kernels
+ * (csrc/mm_compose.hip).  drift: packed with C (model uncertainty on), drift_L == nx, drift_d == nd;
+ * policy: one latent, policy_d == ne, evaluated without model uncertainty (a KernelRegressor has none).
+ * mx [B,nx] / Sxx [B,nx,nx] are updated in place; cost [H,B] (optional, needs target [ne], precis [ne,ne]) receives
+ * the per-step statistic (the loss of pilco.py:199-205 is its sum over H); traj_* [H,B,..] optional.
+ * active_dims: HOST array of na distinct state indices.  Only the 1-D action (Owen's T branch, bijectors.py:57-58)
+ * is supported; the n-D branch needs the Genz BVN (utils/bvn.py), out of scope. */
+size_t mm_compose_workspace_bytes(int B, int nx, int na, int dtype);
+int mm_rollout_composed(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
+                        const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
+                        int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
+                        double head_scale, double head_shift, const void* target, const void* precis,
+                        void* mx, void* Sxx, void* cost, void* traj_mu, void* traj_Sigma,
+                        void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
+                        void* ws_compose, size_t ws_compose_bytes, int32_t* status, void* stream);
+
 /* ---- backward w.r.t. the input moments, stage A (f64 mode) ---------------------
  * The M x M part of d(f1, Sff, cross)/d(mu, Sigma) reduced to M-sized sums (see csrc/mm_backward.hip);
  * gpflowpilco_amd/autodiff.py finishes the chain rule.  Must follow mm_moment_match / mm_q_forward +

@@ -171,6 +171,20 @@ def eKuffu_se_pair(mu, Sigma, ls1, var1, Z1, ls2, var2, Z2,
   return determinant[:, None, None] * matrix_term[None] * exp_mahalanobis  # :187
 
 
+def eKuffu_se_pair_separate_dims(mu, var_diag, dims1, ls1, var1, Z1, dims2, ls2, var2, Z2):
+  """The shortcut of utils/kernel_expectation.py:85-89: two kernels on DISJOINT input dims under a DiagonalGaussian
+  (mean mu [B,D], variances var_diag [B,D]) need no joint expectation --
+  <k1(Z1,x) k2(x,Z2)> = <k1(x,Z1)> (x) <k2(x,Z2)>  ->  [B, M1, M2].
+  Z1 [M1, len(dims1)], Z2 [M2, len(dims2)] are already sliced to their kernels' active dims."""
+  assert not set(dims1) & set(dims2), "kern1.on_separate_dims(kern2)"
+  d1, d2 = list(dims1), list(dims2)
+  S1 = var_diag[:, d1, None] * np.eye(len(d1))[None]
+  S2 = var_diag[:, d2, None] * np.eye(len(d2))[None]
+  e1 = eKfu_se(mu[:, d1], S1, Z1, ls1, var1)                 # :86
+  e2 = eKfu_se(mu[:, d2], S2, Z2, ls2, var2)                 # :87
+  return e1[:, :, None] * e2[:, None, :]                     # :88
+
+
 def eKff_list(mu, variances):
   """_eKff fan-out -> [B, L]; utils/kernel_expectation.py:190-197."""
   return np.stack([eKff_se(mu, v) for v in variances], axis=-1)

@@ -175,5 +175,54 @@ def test_gpu_policy_rollout_matches_oracle(dtype, device):
   assert scale_err(loss, loss_o) < tol
   # the same through the MomentMatchingPILCO harness (loops/pilco.py:176-220)
   from gpflowpilco_amd.loops import get_state_initializer, policy_loss_closure
-  closure = policy_loss_closure(system, objective, get_state_initializer(x.mean(), x.covariance()), H)
+  closure = policy_loss_closure(system, objective, get_state_initializer(x.mean(), x.covariance()), H, native=False)
   assert torch.allclose(closure(), loss)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_native_composed_rollout_matches_oracle_and_torch_path(dtype, device):
+  """mm_rollout_composed (csrc/mm_compose.hip): the WHOLE policy rollout on the device -- encoder sincos moments,
+  policy GP + NormalCDF head (Owen's T), joint, drift GP, forward_sde's cross-covariance bookkeeping, Euler update,
+  per-step expected cost -- against the numpy oracle rollout and against the torch composition of the same kernels.
+  Config-1 sizes: drift M = 100, H = 30 (f64: 1e-7; f32: 2e-4 of the per-quantity scale)."""
+  from gpflowpilco_amd import ops
+  from gpflowpilco_amd.loops import get_state_initializer, native_policy_loss, policy_loss_closure
+  drift_syn = make_svgp(4, 100, 6, seed=10, ls_bounds=(0.8, 3.0))
+  drift_o = oracle_params(drift_syn)
+  drift_o.Z = drift_o.Z * np.array([1, 1, 1, 1, 1, 4.0]) - np.array([0, 0, 0, 0, 0, 2.0])
+  pol_o = random_svgp_params(seed=11, L=1, M=30, d=5, whiten=True, ls_bounds=(0.7, 2.0), mean=False)
+  pol_o.q_mu = 0.3 * pol_o.q_mu
+  rng = np.random.default_rng(12)
+  mu = np.array([[0.4, 0.2, 0.5, 0.3], [0.6, -0.1, 0.4, 0.5], [0.5, 0.0, 0.45, 0.4]])
+  S = generate_covariance(rng, 4, (3,), 0.05)
+  target = np.array([0.0, 1.0, 0, 0, 0])
+  precis = 16 * np.array([[0.25, 0, -0.5, 0, 0], [0, 0.25, 0, 0, 0], [-0.5, 0, 1, 0, 0], [0] * 5, [0] * 5], dtype=float)
+  scale, shift, active, H = 2.0, -0.5, (1,), 30
+  policy_fn = lambda s: co.mm_policy(s, pol_o, scale, shift)
+  loss_o, traj_o = co.policy_rollout_loss(mu, S, drift_o, policy_fn, active, target, precis, H, keep=True)
+
+  drift = gp_model_from_oracle(drift_o, device)
+  pol_model = gp_model_from_oracle(pol_o, device)
+  roll = ops.ComposedRollout(drift.packed(dtype, True, device), pol_model.packed(dtype, False, device), nx=4,
+                             active_dims=active, head_scale=scale, head_shift=shift,
+                             target=to_dev(target, device, dtype), precis=to_dev(precis, device, dtype))
+  m_H, S_H, cost, tmu, tS = roll(to_dev(mu, device, dtype), to_dev(S, device, dtype), H, keep_trajectory=True)
+  roll.drift.check_status(3)
+  tol = 1e-7 if dtype == torch.float64 else 2e-4
+  for h in (0, 1, H // 2, H - 1):
+    assert scale_err(tmu[h], traj_o[h][0]) < tol and scale_err(tS[h], traj_o[h][1]) < tol, h
+  assert scale_err(cost.sum(1), loss_o) < tol
+  assert torch.equal(m_H, tmu[-1]) and torch.equal(S_H, tS[-1])
+  # the torch composition of the same GP kernels (dynamics.forward_sde + moment_matching/{maths,components,bijectors}.py)
+  policy = gp.InverseLinkWrapper(gp.KernelRegressor(pol_model),
+                                 invlink=tfb.Chain([tfb.Scale(scale), tfb.Shift(shift), tfb.NormalCDF()]))
+  encoder = TrigonometricEncoder(active_dims=active)
+  objective = GaussianObjective(target=to_dev(target, device, dtype), precis=to_dev(precis, device, dtype))
+  system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=encoder, solver=dynamics.MomentMatchingEuler())
+  init = get_state_initializer(to_dev(mu, device, dtype), to_dev(S, device, dtype))
+  loss_t = policy_loss_closure(system, objective, init, H, native=False)()
+  loss_n = policy_loss_closure(system, objective, init, H)()            # picks the native rollout by itself
+  assert scale_err(loss_n, loss_t.double().cpu().numpy()) < (1e-9 if dtype == torch.float64 else 2e-4)
+  assert torch.allclose(loss_n, cost.sum(1))
+  assert native_policy_loss(system, objective, H) is not None

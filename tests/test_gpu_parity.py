@@ -370,3 +370,52 @@ def test_empty_batch_returns_empty_outputs(device):
     ops.moment_match(model.packed(torch.float64, False, device), mu, S, model_uncertainty=True)
   with pytest.raises(ValueError):
     ops.moment_match(pm, torch.empty(0, 4, dtype=torch.float64, device=device), torch.empty(0, 4, 4, dtype=torch.float64, device=device))
+
+
+def test_latents_with_different_active_dims_match_quadrature(device):
+  """Per-latent ``active_dims`` (moment_matching/models.py:264-270 slices per kernel): latents acting on different
+  -- overlapping and disjoint -- subsets of a 3-D input, dense input covariance.  Checker: the tensor Gauss-Hermite
+  quadrature of the definition (oracle/quadrature_pin.py) with a predict_f that slices per latent, so nothing of the
+  embedding the product path uses enters the check.  The cross term comes back per latent in that latent's own
+  sliced coordinates, as the reference stacks it."""
+  from gpflowpilco_amd import models as gp
+  from gpflowpilco_amd.moment_matching import GaussianMoments, moment_matching
+  from oracle import mm_oracle as mo
+  from oracle import pin_oracle as po
+  from oracle import quadrature_pin as qp
+  rng = np.random.default_rng(31)
+  D, M = 3, 10
+  acts = [(0, 1), (1, 2), (0, 2)]
+  L = len(acts)
+  Zs = [rng.uniform(size=(M, D)) for _ in range(L)]
+  lss = [np.exp(rng.uniform(np.log(0.5), np.log(2.0), size=2)) for _ in range(L)]
+  var = 0.89 ** 2 * (1 + 0.3 * rng.uniform(size=L))
+  q_mu = 0.89 * rng.standard_normal((M, L))
+  q_sqrt = np.linalg.cholesky(po.generate_covariance(rng, M, (L,), 0.5))
+  mu = rng.uniform(0.2, 0.8, size=(2, D)); Sigma = po.generate_covariance(rng, D, (2,), 0.25)
+  t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=device)
+  kernels = [gp.SquaredExponential(variance=t(var[a]), lengthscales=t(lss[a]), active_dims=acts[a]) for a in range(L)]
+  iv = gp.SeparateIndependentInducingVariables([gp.InducingPoints(t(Zs[a])) for a in range(L)])
+  model = gp.SVGP(kernel=gp.SeparateIndependent(kernels), inducing_variable=iv, q_mu=t(q_mu), q_sqrt=t(q_sqrt),
+                  whiten=True, num_latent_gps=L)
+  x = GaussianMoments((t(mu), t(Sigma)), centered=True)
+  m = moment_matching(x, model)
+  f1, Sff, cross = (v.cpu().numpy() for v in (m.y.mean(), m.y.covariance(), m.cross[0]))
+  assert cross.shape == (2, 2, L) and m.cross[1] is True
+
+  def predict(X):                                  # the definition: every latent sees its own slice of x
+    mean = np.empty((X.shape[0], L)); covd = np.empty((X.shape[0], L))
+    for a in range(L):
+      pa = mo.SVGPParams(Z=Zs[a][None][:, :, list(acts[a])], lengthscales=lss[a][None], variance=var[a:a + 1],
+                         q_mu=q_mu[:, a:a + 1], q_sqrt=q_sqrt[a:a + 1], whiten=True)
+      ma, ca = po.svgp_predict_f(X[:, list(acts[a])], pa)
+      mean[:, a], covd[:, a] = ma[:, 0], ca[:, 0, 0]
+    return mean, covd[:, :, None] * np.eye(L)[None]
+
+  for b in range(2):
+    qf, qS, qX = qp.quadrature_moments(predict, mu[b], Sigma[b], 40)
+    assert np.abs(f1[b] - qf).max() < 1e-9 and np.abs(Sff[b] - qS).max() < 1e-9
+    for a in range(L):                             # Sigma_act^-1 Cov(x_act, f_a) in latent a's coordinates
+      idx = list(acts[a])
+      pre = np.linalg.solve(Sigma[b][np.ix_(idx, idx)], qX[idx, a])
+      assert np.abs(cross[b, :, a] - pre).max() < 1e-8

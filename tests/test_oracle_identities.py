@@ -104,3 +104,34 @@ def test_euler_update_and_cross_covariance():
   assert np.allclose(S2, Sigma + 0.5 * (Sxf + np.swapaxes(Sxf, 1, 2)) + 0.25 * Sff)
   jm, jS = mo.joint(mu, Sigma, f1, Sff, Sxf)
   assert jm.shape == (2, 2 * d) and np.allclose(jS[:, :d, d:], Sxf) and np.allclose(jS, np.swapaxes(jS, 1, 2))
+
+
+def test_disjoint_dims_shortcut_is_the_large_lengthscale_limit_of_the_general_pair_term():
+  """utils/kernel_expectation.py:85-89 (kernels on disjoint dims under a DiagonalGaussian: product of the two
+  first-order expectations) equals the general pair term :98-187 on the UNION of the dims when each kernel gets a
+  huge lengthscale on the dims it ignores -- the embedding gpflowpilco_amd/models.py uses for latents with
+  different ``active_dims``.  Also with overlapping dims and a dense Gaussian, where only the embedding applies,
+  the embedded kernel must equal the sliced kernel pointwise."""
+  from oracle import mm_oracle as mo
+  rng = np.random.default_rng(5)
+  BIG = 1.0e6
+  B, D, M1, M2 = 3, 4, 7, 6
+  mu = rng.uniform(size=(B, D)); var = rng.uniform(0.01, 0.1, size=(B, D))
+  Sigma = var[:, :, None] * np.eye(D)[None]
+  d1, d2 = (0, 2), (1, 3)
+  ls1, ls2 = rng.uniform(0.5, 2.0, 2), rng.uniform(0.5, 2.0, 2)
+  Z1, Z2 = rng.uniform(size=(M1, 2)), rng.uniform(size=(M2, 2))
+  short = mo.eKuffu_se_pair_separate_dims(mu, var, d1, ls1, 0.8, Z1, d2, ls2, 1.3, Z2)
+  def embed(Z, ls, dims):
+    Zf = np.zeros((Z.shape[0], D)); lf = np.full(D, BIG)
+    Zf[:, list(dims)] = Z; lf[list(dims)] = ls
+    return Zf, lf
+  Z1f, l1f = embed(Z1, ls1, d1); Z2f, l2f = embed(Z2, ls2, d2)
+  full = mo.eKuffu_se_pair(mu, Sigma, l1f, 0.8, Z1f, l2f, 1.3, Z2f, False, False)
+  assert np.abs(full - short).max() < 1e-10 * np.abs(short).max()
+  # first-order terms and the kernel itself under the embedding
+  e_emb = mo.eKfu_se(mu, Sigma, Z1f, l1f, 0.8)
+  e_sl = mo.eKfu_se(mu[:, list(d1)], Sigma[:, list(d1)][:, :, list(d1)], Z1, ls1, 0.8)
+  assert np.abs(e_emb - e_sl).max() < 1e-10
+  X = rng.uniform(size=(5, D))
+  assert np.abs(mo.se_kernel(X, Z1f, l1f, 0.8) - mo.se_kernel(X[:, list(d1)], Z1, ls1, 0.8)).max() < 1e-10

