@@ -10,7 +10,9 @@ rollout, so K is rounded UP to a whole number of rollouts: the cost 
 always inside the timed region.  value = B_total * K / wall time ("rollout step-elements per second").
 
 Configurations (BASELINE.json configs; `config.workload` names what ran):
-  c1  configs[0] shaped: N=100, d=D=6, H=30, B=1, fp64, closed rollout        (weak)
+  c1  configs[0]: the cartpole wiring x(4) -> encoder -> policy SVGP(30) + NormalCDF head -> drift SVGP(N=100, d=6 -> D=4)
+      -> Euler -> cost, H=30, B=1, fp64: the whole rollout in mm_rollout_composed    (weak)
+  c1_closed  the same sizes as a closed drift-only rollout (d=D=6)                   (weak)
   c2  configs[1] shaped: N=1000, d=D=5, H=40, B=64, fp64, closed rollout      (weak)
   c3  configs[2]: N=2000, d=D=8, H=40, B=256 per GPU, fp32, closed rollout    (weak; THE metric's config)
   c4  configs[3]: N=4000, d=16, D=32, H=50, B=256 sharded over the ranks, fp32; d != D, so the step kernel runs on
@@ -45,9 +47,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# BASELINE.json configs[0]: the cartpole example's own wiring, run by mm_rollout_composed (csrc/mm_compose.hip)
+CARTPOLE = dict(M=100, Mpol=30, H=30, B=1, dtype="f64", seed=1000, scaling="weak",
+                label="C1 (BASELINE configs[0]): cartpole_swingup wiring x(4) -> trig encoder e(5) -> policy SVGP(M=30) + "
+                      "Chain[Scale,Shift,NormalCDF] u(1) -> drift SVGP(N=100, d=6 -> D=4) -> Euler -> cost; H=30, B=1, fp64")
 CONFIGS = {
-    "c1": dict(L=6, M=100, d=6, H=30, B=1, dtype="f64", seed=1000, scaling="weak", recipe="pilco", closed=True,
-               label="C1-shaped (BASELINE configs[0]): N=100 d=6 D=6 H=30 B=1 fp64 closed drift rollout"),
+    "c1_closed": dict(L=6, M=100, d=6, H=30, B=1, dtype="f64", seed=1000, scaling="weak", recipe="pilco", closed=True,
+               label="C1-shaped closed drift rollout: N=100 d=6 D=6 H=30 B=1 fp64 (no encoder / policy)"),
     "c2": dict(L=5, M=1000, d=5, H=40, B=64, dtype="f64", seed=1001, scaling="weak", recipe="pilco", closed=True,
                label="C2-shaped (BASELINE configs[1]): N=1000 d=5 D=5 H=40 B=64 fp64 closed drift rollout"),
     "c3": dict(L=8, M=2000, d=8, H=40, B=256, dtype="f32", seed=1002, scaling="weak", recipe="pilco", closed=True,
@@ -81,7 +87,7 @@ def parse():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=80)
   ap.add_argument("--warmup", type=int, default=8)
-  ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c5"])
+  ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c5"])
   ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                   help="weak: the config's B (or S) per GPU; strong: the config's B (or S) sharded over the ranks "
                        "(default: weak for c1..c3, strong for c4/c5 -- BASELINE.json shards those)")
@@ -137,30 +143,39 @@ def pmc_kernel(pmc, prefix):
   return None if best is None else (best[1], best[2])
 
 
-def executed_ceiling(ent, mfma_cost):
-  """Executed-work ceiling of one dispatch from its hardware counters: cycles per SIMD =
-  (MFMA instructions x pipe cycles + VALU instructions x measured issue cost by class) / 1024 SIMDs, priced at the
-  2.4 GHz peak clock.  tools/ubench_gap.hip (profiles/r02_ubench_gap.txt): on a gfx950 SIMD the f32 FMA-class VALU
-  serialises with the bf16 MFMA, and the f64 FMA with the f64 MFMA, beyond the first ~3 instructions per MFMA, so
-  the two add; only that small free quota is credited back."""
+def executed_ceiling(ent, kind):
+  """Executed-work ceiling of one dispatch from its hardware counters, priced with the per-SIMD issue costs and the
+  overlap rules MEASURED by tools/ubench_gap.hip (profiles/r02_ubench_gap.txt):
+
+    kind "bf16" (v_mfma_f32_32x32x16_bf16, 32 pipe cycles): f32 FMA-class VALU (4 cycles, packed) serialises with the
+         MFMA beyond the first 3 instructions per MFMA; f64 FMAs (5 cycles) co-execute up to 5 per MFMA; every other
+         VALU instruction (v_max3, compares, moves, integer: 4 cycles) co-executes up to 24 cycles per MFMA;
+    kind "f64"  (v_mfma_f64_16x16x4_f64, 64 pipe cycles): nothing co-executes -- MFMA, f64 VALU (5), the rest (4) add.
+
+  cycles per SIMD = (MFMA pipe cycles + VALU issue cycles that cannot hide) / 1024, at the 2.4 GHz peak clock."""
   c = ent["counters"]
   n_mfma = c.get("SQ_INSTS_MFMA", 0.0)
-  n_valu = max(0.0, c.get("SQ_INSTS_VALU", 0.0) - n_mfma)
+  n_valu = max(0.0, c.get("SQ_INSTS_VALU", 0.0) - n_mfma)              # SQ_INSTS_VALU counts the MFMAs too
   f32 = c.get("SQ_INSTS_VALU_FMA_F32", 0.0) + c.get("SQ_INSTS_VALU_MUL_F32", 0.0) + c.get("SQ_INSTS_VALU_ADD_F32", 0.0)
   f64 = c.get("SQ_INSTS_VALU_FMA_F64", 0.0) + c.get("SQ_INSTS_VALU_MUL_F64", 0.0) + c.get("SQ_INSTS_VALU_ADD_F64", 0.0)
   trans = c.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
-  have_classes = "SQ_INSTS_VALU_FMA_F32" in c
-  if not have_classes:
-    f32, f64, trans = n_valu, 0.0, 0.0
+  if "SQ_INSTS_VALU_FMA_F32" not in c:
+    f32, f64, trans = (n_valu, 0.0, 0.0) if kind == "bf16" else (0.0, n_valu, 0.0)
   other = max(0.0, n_valu - f32 - f64 - trans)
-  free = min(n_valu, 3.0 * n_mfma)                        # instructions hidden in the MFMA issue gaps
-  valu_cyc = f32 * ISSUE["valu_f32"] + f64 * ISSUE["valu_f64"] + trans * ISSUE["valu_trans"] + other * ISSUE["valu_other"]
-  valu_cyc *= (1.0 - free / n_valu) if n_valu else 1.0
-  mfma_cyc = c.get("SQ_VALU_MFMA_BUSY_CYCLES", n_mfma * mfma_cost)
+  mfma_cyc = c.get("SQ_VALU_MFMA_BUSY_CYCLES", n_mfma * ISSUE["mfma_bf16_32x32x16" if kind == "bf16" else "mfma_f64_16x16x4"])
+  if kind == "bf16":
+    f32_cyc = max(0.0, f32 - 3.0 * n_mfma) * ISSUE["valu_f32"]
+    f64_cyc = max(0.0, f64 - 5.0 * n_mfma) * ISSUE["valu_f64"]
+    oth_cyc = max(0.0, (other * ISSUE["valu_other"] + trans * ISSUE["valu_trans"]) - 24.0 * n_mfma)
+  else:
+    f32_cyc = f32 * 2.0
+    f64_cyc = f64 * ISSUE["valu_f64"]
+    oth_cyc = other * ISSUE["valu_other"] + trans * ISSUE["valu_trans"]
+  valu_cyc = f32_cyc + f64_cyc + oth_cyc
   cyc_per_simd = (mfma_cyc + valu_cyc) / N_SIMD
   return {"ceiling_ms": cyc_per_simd / PEAK_CLOCK_HZ * 1e3,
           "mix": {"mfma": n_mfma, "valu_f32": f32, "valu_f64": f64, "valu_trans": trans, "valu_other": other,
-                  "mfma_pipe_cycles_per_simd": mfma_cyc / N_SIMD, "valu_issue_cycles_per_simd": valu_cyc / N_SIMD}}
+                  "mfma_pipe_cycles_per_simd": mfma_cyc / N_SIMD, "valu_issue_cycles_per_simd_not_hidden": valu_cyc / N_SIMD}}
 
 
 def main():
@@ -196,6 +211,8 @@ def main():
 
   if args.config == "c5":
     return pathwise_bench(args, rank, world, dev, dist)
+  if args.config == "c1":
+    return composed_bench(args, rank, world, dev, dist)
   cfg = dict(CONFIGS[args.config])
   scaling = args.scaling or cfg["scaling"]
   recipe_name = args.recipe or cfg["recipe"]
@@ -360,7 +377,7 @@ def main():
       r.update({"achieved": None, "frac": None, "pmc": pmc_src})
       return r
     name, ent = got
-    ce = executed_ceiling(ent, ISSUE["mfma_bf16_32x32x16" if f32k else "mfma_f64_16x16x4"])
+    ce = executed_ceiling(ent, "bf16" if f32k else "f64")
     # counters are per dispatch of the profiled run; scale to this run's launch by entries (same config => factor 1)
     scale = entries / ent["entries"] if ent.get("entries") else 1.0
     ceiling_ms = ce["ceiling_ms"] * scale
@@ -368,8 +385,8 @@ def main():
     r.update({"kernel": name, "frac": round(frac, 4), "achieved": round(peak * frac, 2),
               "ceiling_ms": round(ceiling_ms, 4),
               "frac_definition": "executed-work ceiling / measured kernel time; ceiling = (MFMA pipe cycles + VALU issue cycles "
-                                 "by class, first 3 VALU per MFMA gap free) / 1024 SIMDs / 2.4 GHz from the kernel's own hardware "
-                                 "counters; `achieved` = peak x frac",
+                                 "that cannot hide beside the MFMAs, by instruction class: tools/ubench_gap.hip) / 1024 SIMDs / 2.4 GHz "
+                                 "from the kernel's own hardware counters; `achieved` = peak x frac",
               "instruction_mix_per_launch": {k: round(v, 1) for k, v in ce["mix"].items()},
               "traffic": ent["counters"].get("hbm_bytes"), "pmc": pmc_src})
     c = ent["counters"]
@@ -483,6 +500,119 @@ def main():
         out["parity"]["step_f32_vs_f64_mode"] = {
             "B": Br, "max_abs_diff": {k: float((a.double() - b).abs().max()) for k, a, b in zip(("f1", "Sff", "cross_pre"), g32, g64)},
             "max_abs": {k: float(b.abs().max()) for k, b in zip(("f1", "Sff", "cross_pre"), g64)}}
+  if rank == 0:
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def composed_bench(args, rank, world, dev, dist):
+  """configs[0]: one step = one COMPOSED rollout step (encoder, policy match + head, drift match, cross-covariance
+  bookkeeping, Euler update, expected cost) of the local batch; a rollout = one mm_rollout_composed call."""
+  import numpy as np
+  import torch
+  from gpflowpilco_amd import ops
+  from gpflowpilco_amd.synthetic import make_cartpole_like, make_inputs
+  c = dict(CARTPOLE)
+  H, dtype = c["H"], torch.float64
+  B = args.batch or c["B"]
+  steps = max(H, -(-args.steps // H) * H)
+  drift_s, pol_s = make_cartpole_like(c["M"], c["Mpol"], c["seed"], device=str(dev))
+  drift, pol = drift_s.to_model(dev), pol_s.to_model(dev)
+  rng = np.random.default_rng(2000 + c["seed"] + rank)
+  mu_np = np.array([0.4, 0.2, 0.5, 0.3])[None] + 0.05 * rng.standard_normal((B, 4))
+  _, S_np = make_inputs(B, 4, seed=3000 + rank, scale=0.05)
+  target = np.array([0.0, 1.0, 0.0, 0.0, 0.0])
+  precis = 16 * np.array([[0.25, 0, -0.5, 0, 0], [0, 0.25, 0, 0, 0], [-0.5, 0, 1, 0, 0], [0] * 5, [0] * 5], dtype=float)
+  t = lambda a: torch.tensor(np.asarray(a), dtype=dtype, device=dev)
+  scale, shift, active = 2.0, -0.5, (1,)
+  roll = ops.ComposedRollout(drift.packed(dtype, True, dev), pol.packed(dtype, False, dev), nx=4, active_dims=active,
+                             head_scale=scale, head_shift=shift, target=t(target), precis=t(precis))
+  mx, Sxx = t(mu_np), t(S_np)
+  # the rollout is captured once into a HIP graph and replayed (the reference traces its closure once under
+  # tf.function, loops/pilco.py:219-220): at B = 1 the eager path is paced by the host enqueueing ~16 launches per step
+  eager_roll = roll
+  graphed = ops.GraphedComposedRollout(roll, B, H)
+  roll = lambda m, S, h: graphed(m, S)
+  gathered = [torch.empty(B, H, dtype=dtype, device=dev) for _ in range(world)] if world > 1 else None
+
+  def fence():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for _ in range(max(1, -(-args.warmup // H))):
+    out = roll(mx, Sxx, H)
+  if world > 1:
+    dist.all_gather(gathered, out[2].contiguous())
+  fence()
+  e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+  t0 = time.perf_counter()
+  e0.record()
+  for _ in range(steps // H):
+    m_H, S_H, cost = roll(mx, Sxx, H)
+    if world > 1:
+      dist.all_gather(gathered, cost.contiguous())
+  e1.record()
+  fence()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+  eager_roll.drift.check_status(B)
+  if not (torch.isfinite(cost).all() and torch.isfinite(S_H).all()):
+    raise SystemExit("non-finite composed rollout")
+  dev_ms = e0.elapsed_time(e1) / steps
+  # the same rollouts enqueued eagerly (one mm_rollout_composed call each), for the record
+  torch.cuda.synchronize()
+  te = time.perf_counter()
+  for _ in range(steps // H):
+    eager_roll(mx, Sxx, H)
+  torch.cuda.synchronize()
+  eager_ms = 1e3 * (time.perf_counter() - te) / steps
+  model_bytes = float(drift.packed(dtype, True, dev).nbytes + pol.packed(dtype, False, dev).nbytes)
+  out = {"metric": "moment_matched_rollout_step_elements_per_sec", "value": round(B * world * steps / elapsed, 2),
+         "unit": "rollout step-elements/s (B*H per rollout second)", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+         "ms_per_step": round(1e3 * elapsed / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+         "dtype": "f64", "data": "synthetic",
+         "config": {"workload": c["label"], "N": c["M"], "N_policy": c["Mpol"], "d": 6, "D": 4, "H": H, "B_per_gpu": B, "B_total": B * world,
+                    "parallelism": f"dp{world} over B (weak)", "rollouts_timed": steps // H,
+                    "collectives_timed": steps // H if world > 1 else 0, "steps_requested": args.steps,
+                    "launch": "HIP graph replay of one mm_rollout_composed call per rollout", "eager_ms_per_step": round(eager_ms, 4)},
+         "roofline": {"bound": "hbm", "kernel": "mm_rollout_composed: chain of ~16 dependent launches per step (2 GP moment matches + 4 composition kernels + cost)",
+                      "achieved": round(model_bytes / (dev_ms * 1e-3) / 1e9, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                      "frac": round(model_bytes / (dev_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6), "traffic": None, "kernel_ms": round(dev_ms, 4),
+                      "bytes_per_launch": model_bytes,
+                      "note": "B = 1: every kernel runs for a few microseconds on a fraction of one XCD; the step is bound by the "
+                              "dependency chain of its launches (MI355X_MICROARCH.md 'boundary': ~1.5-1.9 us each), not by a "
+                              "bandwidth or issue ceiling.  `achieved` = packed model bytes touched once per step / step time"}}
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    from oracle import mm_compose_oracle as co
+    from oracle import mm_oracle as mo
+    po_d = mo.SVGPParams(Z=np.broadcast_to(drift_s.Z, (4, c["M"], 6)).copy(), lengthscales=drift_s.lengthscales, variance=drift_s.variance,
+                         q_mu=drift_s.q_mu, q_sqrt=drift_s.q_sqrt, whiten=True)
+    po_p = mo.SVGPParams(Z=pol_s.Z[None].copy(), lengthscales=pol_s.lengthscales, variance=pol_s.variance, q_mu=pol_s.q_mu,
+                         q_sqrt=pol_s.q_sqrt, whiten=True)
+    pol_fn = lambda st: co.mm_policy(st, po_p, scale, shift)
+    t0 = time.perf_counter()
+    nroll = 0
+    while True:
+      loss_o, traj_o = co.policy_rollout_loss(mu_np[:1], S_np[:1], po_d, pol_fn, active, target, precis, H, keep=True)
+      nroll += 1
+      if time.perf_counter() - t0 > 10.0:
+        break
+    tc = time.perf_counter() - t0
+    out["cpu_baseline"] = {"value": round(nroll * H / tc, 3), "unit": out["unit"], "cores": os.cpu_count(), "kind": "port",
+                           "sample": f"the whole config on the host: oracle/mm_compose_oracle.py policy_rollout_loss (literal reference "
+                                     f"algorithm per GP match, numpy), B=1, {nroll} rollout(s) of H={H} steps, {tc:.1f}s"}
+    out["parity"] = {"vs": "fp64 CPU oracle rollout, same inputs, element 0",
+                     "max_abs_err": {"mu_H": float(np.abs(m_H[:1].cpu().numpy() - traj_o[-1][0]).max()),
+                                     "Sigma_H": float(np.abs(S_H[:1].cpu().numpy() - traj_o[-1][1]).max()),
+                                     "loss": float(np.abs(cost[:1].sum(1).cpu().numpy() - loss_o).max())},
+                     "max_abs": {"mu_H": float(np.abs(traj_o[-1][0]).max()), "Sigma_H": float(np.abs(traj_o[-1][1]).max()),
+                                 "loss": float(np.abs(loss_o).max())}}
   if rank == 0:
     print(json.dumps(out))
   if world > 1:

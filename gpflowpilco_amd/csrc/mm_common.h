@@ -29,6 +29,13 @@ static inline long long mm_binom(int n, int k) {
 // number of monomials of degree exactly n in d variables, and of degree < n (offset of the degree-n block)
 static inline int mm_mono_count(int n, int d) { return (int)mm_binom(d + n - 1, n); }
 static inline int mm_mono_offset(int n, int d) { int o = 0; for (int m = 0; m < n; ++m) o += mm_mono_count(m, d); return o; }
+// entries of the rank table: sum_{k=1..deg} DK^k with DK = 8 (d <= 8) or 32
+static inline size_t mm_rank_table_entries(int d) {
+  const int dk = d <= 8 ? 8 : 32, deg = mm_moment_deg(d);
+  size_t n = 0, p = 1;
+  for (int k = 1; k <= deg; ++k) { p *= dk; n += p; }
+  return n;
+}
 // columns of the table, rounded up to the 16-wide MFMA tile
 static inline int mm_moment_cols(int d) { return mm_round_up_int(mm_mono_offset(mm_moment_deg(d) + 1, d), 16); }
 
@@ -49,6 +56,9 @@ struct MMModelLayout {
   size_t Zm;      // [L][Mp][KMp] f64: the monomials of zc up to degree mm_moment_deg(d) per inducing point (graded colex,
                   // zero padded) -- the table the weight moments sum_m what_m zc_m^alpha are taken against (f32 mode only)
   size_t zmax2;   // [L] f64 max_m |zc_m|^2 (Cauchy-Schwarz bound on |b_ij| that admits a (b, pair) to the collapse)
+  size_t rtab;    // int16: for k = 1..deg the rank (inside the degree-k block of the moment table) of every index tuple
+                  // encoded base DK = 8 (d <= 8) or 32 in a flat position, -1 where a digit is >= d; blocks of DK^k
+                  // entries one after another (k_spoly's lookups: no integer arithmetic per tensor entry)
   size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
                   // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
@@ -77,6 +87,7 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   o.Zm = off;
   if (dtype != MM_F64) off = mm_align_up(off + (size_t)L * o.Mp * o.KMp * 8, A);
   o.zmax2 = off;  off = mm_align_up(off + (size_t)L * 8, A);
+  o.rtab = off;   off = mm_align_up(off + mm_rank_table_entries(d) * 2, A);
   o.Cm = off;
   if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;

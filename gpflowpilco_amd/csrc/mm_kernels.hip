@@ -63,8 +63,10 @@ __device__ __forceinline__ double mm_expm1(double x) { return expm1(x); }
 // In-place inverse of a symmetric positive definite d x d matrix held in LDS (row stride dp),
 // by one 64-lane workgroup.  A: in SPD (full storage) -> out inverse (full).  Y: scratch.
 // Returns log det(A) (same value in every lane); *ok is cleared if a pivot is not positive.
+// Several waves of a workgroup may call it at once, each on its own (A, Y): the barriers are workgroup barriers, and
+// every wave executes the same number of them.
 __device__ double mm_spd_inverse(double* A, double* Y, int d, int dp, bool* ok) {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   for (int k = 0; k < d; ++k) {
     __syncthreads();
     const double akk = A[k * dp + k];
@@ -175,6 +177,24 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
       }
       Zm[idx] = v;
     }
+    // rank table of k_spoly (latent 0 writes it): position = index tuple base DK, value = colex rank or -1
+    if (a == 0) {
+      short* rt = (short*)(packed + lay.rtab);
+      const int lb = d <= 8 ? 3 : 5;
+      size_t base = 0;
+      for (int kk = 1; kk <= deg; ++kk) {
+        const int sz = 1 << (lb * kk);
+        for (int idx = tid; idx < sz; idx += 256) {
+          int dg[4] = {0, 0, 0, 0};
+          bool in = true;
+          for (int t = 0; t < kk; ++t) { dg[t] = (idx >> (lb * t)) & ((1 << lb) - 1); in = in && dg[t] < d; }
+          for (int i = 1; i < kk; ++i)
+            for (int j = i; j > 0 && dg[j - 1] > dg[j]; --j) { const int t2 = dg[j]; dg[j] = dg[j - 1]; dg[j - 1] = t2; }
+          rt[base + idx] = in ? (short)mm_mono_rank(dg, kk) : (short)-1;
+        }
+        base += sz;
+      }
+    }
     // max_m |zc_m|^2 (the column side of the Cauchy-Schwarz bound on |b_ij|)
     double zm2 = 0.0;
     for (int m = tid; m < M; m += 256) {
@@ -227,15 +247,17 @@ __global__ void k_pack_C(char* packed, MMModelLayout lay, int L, int M, const do
 // k_prep: per (b, pair) and per (b, latent) d x d algebra, f64, one wave each
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, const double* __restrict__ var,
-                                             int L, int d, int P,
-                                             const T* __restrict__ mu, const T* __restrict__ Sigma,
-                                             double* __restrict__ pairmat, double* __restrict__ latmat,
-                                             unsigned int* __restrict__ amax, int32_t* status, int pairs_pass) {
+__global__ __launch_bounds__(192) void k_prep(const double* __restrict__ ls2, const double* __restrict__ var,
+                                              int L, int d, int P,
+                                              const T* __restrict__ mu, const T* __restrict__ Sigma,
+                                              double* __restrict__ pairmat, double* __restrict__ latmat,
+                                              unsigned int* __restrict__ amax, int32_t* status, int pairs_pass) {
   // pairs_pass == 0: the L latent items (blockIdx.x = a); pairs_pass == 1: the P pair items, which take
   // (Sigma + Lambda_a)^-1 and its log-determinant from the latent pass instead of refactorising them (one
-  // Cholesky-inverse per pair instead of three); pairs_pass == 2: all P + L items in ONE launch, pairs
-  // self-contained -- for small problems, where a launch boundary costs more than the factorisations
+  // Cholesky-inverse per pair instead of three) -- both with 64 threads; pairs_pass == 2: all P + L items in ONE launch,
+  // pairs self-contained -- for small problems, where a launch boundary costs more than the factorisations: 192
+  // threads, the three factorisations of a pair item run CONCURRENTLY, one per wave (B = 1 rollouts are a chain of
+  // dependent launches: the critical path of this kernel is their step time)
   extern __shared__ double smem[];
   const int dp = d + 1, msz = d * dp;
   double* Sg = smem;            // Sigma_b (symmetrised from the lower triangle)
@@ -243,34 +265,46 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
   double* A1 = A0 + msz;        // (Sigma + Lambda_a)^-1
   double* A2 = A1 + msz;        // (Sigma + Lambda_a')^-1
   double* Tm = A2 + msz;        // T
-  double* Y = Tm + msz;         // scratch
-  const int lane = threadIdx.x, item = pairs_pass == 0 ? P + blockIdx.x : blockIdx.x, b = blockIdx.y;
+  double* Y = Tm + msz;         // scratch of wave 0; waves 1, 2 (single-launch mode): Y + msz, Y + 2 msz
+  __shared__ double lds3[3];
+  __shared__ int okw[3];
+  const int tid = threadIdx.x, nt = blockDim.x, wv = tid >> 6;
+  const int item = pairs_pass == 0 ? P + blockIdx.x : blockIdx.x, b = blockIdx.y;
   bool ok = true;
   const T* Sb = Sigma + (size_t)b * d * d;
-  for (int idx = lane; idx < d * d; idx += 64) {
+  for (int idx = tid; idx < d * d; idx += nt) {
     const int i = idx / d, j = idx - i * d;
     Sg[i * dp + j] = (double)(i >= j ? Sb[i * d + j] : Sb[j * d + i]);
   }
+  if (tid < 3) okw[tid] = 1;
   __syncthreads();
   if (item >= P) {
     // latent item: P_a = (Sigma + Lambda_a)^-1, lognorm_a = log var + sum log ls - 0.5 logdet
     const int a = item - P;
     const double* la = ls2 + a * d;
-    for (int idx = lane; idx < d * d; idx += 64) {
+    for (int idx = tid; idx < d * d; idx += nt) {
       const int i = idx / d, j = idx - i * d;
       A1[i * dp + j] = Sg[i * dp + j] + (i == j ? la[i] : 0.0);
+      A0[i * dp + j] = i == j ? 1.0 : 0.0;                   // (waves 1, 2 of the single-launch mode factorise an identity)
+      A2[i * dp + j] = i == j ? 1.0 : 0.0;
     }
-    const double ld = mm_spd_inverse(A1, Y, d, dp, &ok);
+    double* Aw = wv == 0 ? A1 : wv == 1 ? A0 : A2;
+    const double ldw = mm_spd_inverse(Aw, Y + wv * msz, d, dp, &ok);
+    if (wv == 0 && !ok) okw[0] = 0;
+    if (tid == 0) lds3[0] = ldw;
+    __syncthreads();
+    ok = okw[0] != 0;
+    const double ld = lds3[0];
     double* out = latmat + ((size_t)b * L + a) * (2 * d * d + 2);
-    for (int idx = lane; idx < d * d; idx += 64) { const int i = idx / d, j = idx - i * d; out[idx] = A1[i * dp + j]; }
-    if (lane == 0) {
+    for (int idx = tid; idx < d * d; idx += nt) { const int i = idx / d, j = idx - i * d; out[idx] = A1[i * dp + j]; }
+    if (tid == 0) {
       double sl = 0.0;
       for (int k = 0; k < d; ++k) sl += log(la[k]);
       out[d * d] = log(var[a]) + 0.5 * sl - 0.5 * ld;
       out[d * d + 1] = ld;
     }
     // E_a = sym(Lambda_a^-1 Sigma P_a) (= Lambda_a^-1 - P_a, in product form: no cancellation for small Sigma)
-    for (int idx = lane; idx < d * d; idx += 64) {
+    for (int idx = tid; idx < d * d; idx += nt) {
       const int i = idx / d, j = idx - i * d;
       double s1 = 0.0, t1 = 0.0;
       for (int k = 0; k < d; ++k) {
@@ -282,10 +316,10 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
   } else {
     int a, a2;
     mm_decode_pair(item, L, a, a2);
-    if (amax && item >= L && lane == 0) amax[(size_t)b * (P - L) + (item - L)] = 0u;   // k_pairvec max-es |A_i|^2 into it
+    if (amax && item >= L && tid == 0) amax[(size_t)b * (P - L) + (item - L)] = 0u;   // k_pairvec max-es |A_i|^2 into it
     const double* la = ls2 + a * d;
     const double* lb = ls2 + a2 * d;
-    for (int idx = lane; idx < d * d; idx += 64) {
+    for (int idx = tid; idx < d * d; idx += nt) {
       const int i = idx / d, j = idx - i * d;
       const double s = Sg[i * dp + j];
       const double v = la[i] * lb[i] / (la[i] + lb[i]);   // kernel_expectation.py:119
@@ -295,35 +329,40 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
         A2[i * dp + j] = s + (i == j ? lb[i] : 0.0);
       }
     }
-    const double ldS = mm_spd_inverse(A0, Y, d, dp, &ok);
-    double ldA, ldB;
+    double ldS, ldA, ldB;
     if (pairs_pass == 1) {
+      ldS = mm_spd_inverse(A0, Y, d, dp, &ok);
       ldA = latmat[((size_t)b * L + a) * (2 * d * d + 2) + d * d + 1];
       ldB = latmat[((size_t)b * L + a2) * (2 * d * d + 2) + d * d + 1];
-    } else {                       // single-launch mode (small problems): self-contained, three factorisations
-      ldA = mm_spd_inverse(A1, Y, d, dp, &ok);
-      ldB = mm_spd_inverse(A2, Y, d, dp, &ok);
+    } else {                       // single-launch mode (small problems): self-contained, one factorisation per wave
+      double* Aw = wv == 0 ? A0 : wv == 1 ? A1 : A2;
+      const double ldw = mm_spd_inverse(Aw, Y + wv * msz, d, dp, &ok);
+      if (!ok) okw[wv] = 0;
+      if ((tid & 63) == 0) lds3[wv] = ldw;
+      __syncthreads();
+      ok = okw[0] && okw[1] && okw[2];
+      ldS = lds3[0]; ldA = lds3[1]; ldB = lds3[2];
     }
     // T = V S^-1 Sigma (product form: no cancellation), symmetrised below
-    for (int idx = lane; idx < d * d; idx += 64) {
+    for (int idx = tid; idx < d * d; idx += nt) {
       const int i = idx / d, j = idx - i * d;
       double s = 0.0;
       for (int k = 0; k < d; ++k) s += A0[i * dp + k] * Sg[k * dp + j];
       Y[i * dp + j] = (la[i] * lb[i] / (la[i] + lb[i])) * s;
     }
     __syncthreads();
-    for (int idx = lane; idx < d * d; idx += 64) {
+    for (int idx = tid; idx < d * d; idx += nt) {
       const int i = idx / d, j = idx - i * d;
       Tm[i * dp + j] = 0.5 * (Y[i * dp + j] + Y[j * dp + i]);
     }
     __syncthreads();
     double* out = pairmat + ((size_t)b * P + item) * (d * d + 1);
     // G = Lambda_a^-1 T Lambda_a'^-1   (rho_i, gamma_j follow from G and the per-latent E_a: k_pairvec)
-    for (int idx = lane; idx < d * d; idx += 64) {
+    for (int idx = tid; idx < d * d; idx += nt) {
       const int i = idx / d, j = idx - i * d;
       out[idx] = Tm[i * dp + j] / (la[i] * lb[j]);
     }
-    if (lane == 0) {
+    if (tid == 0) {
       double lv = 0.0, sla = 0.0, slb = 0.0;
       for (int k = 0; k < d; ++k) {
         lv += log(la[k] * lb[k] / (la[k] + lb[k]));
@@ -333,7 +372,7 @@ __global__ __launch_bounds__(64) void k_prep(const double* __restrict__ ls2, con
       out[d * d] = -0.5 * ldS + 0.5 * lv - 0.5 * sla - 0.5 * slb + 0.5 * ldA + 0.5 * ldB;
     }
   }
-  if (!ok && lane == 0 && status) {
+  if (!ok && tid == 0 && status) {
     atomicMax(status, (int)gridDim.y - b);   // B - b: the host decodes the smallest failing b
     status[1] = item;
   }
@@ -941,10 +980,10 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   const double* Z64 = (const double*)(packed + ml.Z64);
   double* pairmat = (double*)(ws + wl.pairmat);
   double* latmat = (double*)(ws + wl.latmat);
-  const size_t shm = (size_t)6 * d * (d + 1) * sizeof(double);
+  const size_t shm = (size_t)8 * d * (d + 1) * sizeof(double);
   unsigned int* amax = (sizeof(T) == 4 && wl.Po > 0) ? (unsigned int*)(ws + wl.amax) : nullptr;
   if ((long long)(wl.P + L) * B <= 4096) {
-    hipLaunchKernelGGL((k_prep<T>), dim3(wl.P + L, B), dim3(64), shm, s,
+    hipLaunchKernelGGL((k_prep<T>), dim3(wl.P + L, B), dim3(192), shm, s,
                        ls2, var, L, d, wl.P, mu, Sigma, pairmat, latmat, amax, status, 2);
     MM_CHECK_LAUNCH();
   } else {

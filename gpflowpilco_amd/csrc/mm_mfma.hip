@@ -49,8 +49,15 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
 #ifndef MM_F32_WAVES
 #define MM_F32_WAVES 2
 #endif
+// 1: one column sweep for collapsed and dense (b, pair) items alike (the (l | h) parts always prefetched);
+// 0: a second instantiation for collapsed items that fetches them on demand
+#ifndef MM_F32_SINGLE_SWEEP
+#define MM_F32_SINGLE_SWEEP 0
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+struct mm_true { static constexpr bool value = true; };
+struct mm_false { static constexpr bool value = false; };
 
 __device__ __forceinline__ unsigned int mm_f2bf(float x) {
   const __bf16 b = (__bf16)x;                                  // v_cvt_pk_bf16_f32, round to nearest even
@@ -159,10 +166,14 @@ __device__ __forceinline__ float mm_rem_p5(float x) {       // r(x) on [-1, 1]
 //   stationary operand (registers, split once per sweep): A_i = G^T zeta_i of the wave's 64 rows and
 //   their factored weights what_i; streaming operand: the model's pre-split centred inducing inputs
 //   of latent a' (b-independent, L2-resident) and what'_j per column.
-template <int ND8>
+// LDSZ: the (h, m) parts of the column latent's split inputs -- all the screening product and the 2-way product read --
+// are staged ONCE per workgroup in LDS (Mp * 32 ND8 bytes: 64 KB at C3) and shared by its four waves: a collapsed
+// (b, pair) is a sweep of one MFMA + one range check per 32 x 32 block, which from L2 would be bound by the
+// 1 KB per wave tile of operand traffic (measured 2.0 ms at C3 against 0.4 ms of MFMA time).
+template <int ND8, bool LDSZ>
 __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32_mfma(const unsigned short* __restrict__ Zs3,
                                                           int L, int Mp, int d, int P, int Po, int NS,
-                                                          int npanel, int nwork, int force_worst,
+                                                          int npanel, int ppw, int nwork, int force_worst,
                                                           const unsigned int* __restrict__ amax,
                                                           const double* __restrict__ zmax2,
                                                           const float* __restrict__ rowO,
@@ -174,14 +185,44 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
   const int xcd = orig & 7, slot = orig >> 3;
   const int qn = nwork >> 3, rn = nwork & 7;
   const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
-  const int panel = wi % npanel;
-  const int t = wi / npanel;
+  // a workgroup owns ppw consecutive row panels of one (b, pair) (all of them when the operand image is staged in
+  // LDS: the 64 KB fill is then paid once per (b, pair)); npw = ceil(npanel / ppw) workgroups per (b, pair)
+  const int npw = (npanel + ppw - 1) / ppw;
+  const int pgrp = wi % npw;
+  const int t = wi / npw;
   const int lp = t % Po, b = t / Po;
   const int p = L + lp;
   int a, a2;
   mm_decode_pair_o(p, L, a, a2);
 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  extern __shared__ __align__(16) char zlds[];     // LDSZ: [Mp/32 tiles][2 parts (h, m)][32 columns][16 ND8 bytes]
+  if constexpr (LDSZ) {
+    // the first two parts of every tile are contiguous in the packed model ([tile][h, m, l][32][16 ND8]): copy
+    // 1024 ND8 of every 1536 ND8 bytes, 16 bytes per thread and pass
+    const char* src = reinterpret_cast<const char*>(Zs3 + (size_t)a2 * Mp * (24 * ND8));
+    const int nchunk = (Mp >> 5) * 64 * ND8;         // 16-byte chunks
+    // batches of 8 chunks per thread: all loads of a batch are issued before its LDS stores (a load -> store loop
+    // would pay one memory latency per chunk)
+    for (int c0 = 0; c0 < nchunk; c0 += 8 * 256) {
+      u32x4 tmp[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        int c = c0 + u * 256 + (int)threadIdx.x;
+        c = c < nchunk ? c : nchunk - 1;
+        const int tile = c / (64 * ND8), within = c - tile * (64 * ND8);
+        tmp[u] = *reinterpret_cast<const u32x4*>(src + (size_t)tile * (1536 * ND8) + (size_t)within * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u * 256 + (int)threadIdx.x;
+        if (c < nchunk) *reinterpret_cast<u32x4*>(zlds + (size_t)c * 16) = tmp[u];
+      }
+    }
+    __syncthreads();
+  }
+  __shared__ double red[4];
+  for (int panel = pgrp * ppw; panel < npanel && panel < (pgrp + 1) * ppw; ++panel) {
   const int row0 = panel * MM_PANEL_ROWS + wv * 64;
   double sum = 0.0;
   if (row0 < Mp) {   // Mp % 128 == 0, so a wave's 64 rows are all inside or all outside
@@ -249,14 +290,18 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     const char* zbase = reinterpret_cast<const char*>(zs);
     const int nct = Mp >> 5;                     // Mp % 128 == 0: nct is a multiple of 4
 
-    auto load_tile = [&](int ct, u32x4 (&zA)[ND8], u32x4 (&zB)[ND8], float& wc) {
-      const char* tb = zbase + (size_t)ct * tile_bytes;
+    // zA: the (m | h) parts (from LDS when staged); zB: the (l | h) parts, always from L2 -- prefetched with the tile
+    // for a (b, pair) that is not collapsed, fetched on demand for a collapsed one (where few tiles get that far)
+    auto load_zA = [&](int ct, u32x4 (&zA)[ND8]) {
 #pragma unroll
       for (int nb = 0; nb < ND8; ++nb) {
-        zA[nb] = *reinterpret_cast<const u32x4*>(tb + offA + nb * 16);
-        zB[nb] = *reinterpret_cast<const u32x4*>(tb + offB + nb * 16);
+        if constexpr (LDSZ) zA[nb] = *reinterpret_cast<const u32x4*>(zlds + (size_t)ct * (1024 * ND8) + offA + nb * 16);
+        else zA[nb] = *reinterpret_cast<const u32x4*>(zbase + (size_t)ct * tile_bytes + offA + nb * 16);
       }
-      wc = wcf[ct * 32 + l31];
+    };
+    auto load_zB = [&](int ct, u32x4 (&zB)[ND8]) {
+#pragma unroll
+      for (int nb = 0; nb < ND8; ++nb) zB[nb] = *reinterpret_cast<const u32x4*>(zbase + (size_t)ct * tile_bytes + offB + nb * 16);
     };
 
     // b_ij in two stages.  Stage 1: the 2-way split product (h + m parts, 2^-17 relative): enough when the
@@ -296,11 +341,12 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     };
     // max |b| of a finished tile: one v_max3_f32 |a|, |b|, m per entry pair (needs -fno-honor-nans)
     auto tile_max = [&](const f32x16 (&acc)[2]) {
-      float mx = 0.0f;
+      // four independent v_max3 chains (a single chain of 16 dependent ops is the critical path of a skipped tile)
+      float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        mx = fmaxf(fmaxf(mx, fabsf(acc[r >> 3][2 * (r & 7)])), fabsf(acc[r >> 3][2 * (r & 7) + 1]));
-      return mx;
+        m4[r & 3] = fmaxf(fmaxf(m4[r & 3], fabsf(acc[r >> 3][2 * (r & 7)])), fabsf(acc[r >> 3][2 * (r & 7) + 1]));
+      return fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
     };
     // b_ij = acc: a pure bilinear form (rho'_i, gamma_j live in the weights); tile range -> tier.
     // (sub0, sub1) = (c0, c1) of the first tier for a collapsed (b, pair) -- already in the moments -- else (0, 0).
@@ -340,40 +386,60 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     };
     // one wave tile: screening product; a collapsed (b, pair) stops here when the whole tile is inside the collapsed
     // range; else the rest of the split product, the range tier and the weighted reduction
-    auto process_tile = [&](const u32x4 (&zA)[ND8], const u32x4 (&zB)[ND8], float wc) {
+    auto process_tile = [&](auto collc, int ct, const u32x4 (&zA)[ND8], u32x4 (&zB)[ND8], float wc) __attribute__((always_inline)) {
+      // (a collapsed (b, pair) prefetches neither the column weight nor the (l | h) parts: few of its tiles need them,
+      // and a prefetched global load would put its latency on every tile of a sweep that is otherwise 2 MFMAs long)
+      constexpr bool CM = decltype(collc)::value;
+      const bool cm = CM || (MM_F32_SINGLE_SWEEP && coll);
       f32x16 acc[2];
       mfma_tile_screen(zA, acc);
-      if (coll) {
+      if (cm) {
         const float ms = tile_max(acc);
         if (!__any(ms > thr_skip)) return;
       }
       mfma_tile_m(zA, acc);
       const float mx = force_worst ? 2.0f : tile_max(acc);       // MM_FORCE_WORST_TIER: wave-uniform override
-      if (coll && !__any(mx > 0.0625f)) return;                  // first tier of a collapsed pair: all in the moments
-      if (__any(mx > MM_TWO_WAY_MAX)) mfma_tile_l(zB, acc);
+      if (cm) {
+        if (!__any(mx > 0.0625f)) return;                        // first tier of a collapsed pair: all in the moments
+      }
+      if constexpr (CM) wc = wcf[ct * 32 + l31];
+      if (__any(mx > MM_TWO_WAY_MAX)) {
+        if constexpr (CM) load_zB(ct, zB);
+        mfma_tile_l(zB, acc);
+      }
       reduce_tile(acc, mx, wc);
     };
 
     // two-stage register ping-pong: tile ct + 1 is in flight while tile ct is reduced.  (Issuing the MFMAs
     // of tile ct + 1 interleaved with the v_max3 range check of tile ct -- a second accumulator set,
     // 182 VGPRs -- was measured: 4.27 ms against 4.25 ms; three waves per SIMD already overlap the two.)
-    u32x4 zA0[ND8], zB0[ND8], zA1[ND8], zB1[ND8];
-    float w0, w1;
-    load_tile(0, zA0, zB0, w0);
-    for (int ct = 0; ct < nct; ct += 2) {
-      load_tile(ct + 1, zA1, zB1, w1);
-      process_tile(zA0, zB0, w0);
-      load_tile(ct + 2 < nct ? ct + 2 : ct, zA0, zB0, w0);      // clamped: the last pass re-reads its own tile
-      process_tile(zA1, zB1, w1);
-    }
+    auto sweep = [&](auto collc) __attribute__((always_inline)) {
+      constexpr bool CM = decltype(collc)::value;
+      u32x4 zA0[ND8], zB0[ND8], zA1[ND8], zB1[ND8];
+      float w0, w1;
+      w0 = w1 = 0.0f;
+      load_zA(0, zA0);
+      if constexpr (!CM) { load_zB(0, zB0); w0 = wcf[l31]; }
+      for (int ct = 0; ct < nct; ct += 2) {
+        load_zA(ct + 1, zA1);
+        if constexpr (!CM) { load_zB(ct + 1, zB1); w1 = wcf[(ct + 1) * 32 + l31]; }
+        process_tile(collc, ct, zA0, zB0, w0);
+        const int cn = ct + 2 < nct ? ct + 2 : ct;               // clamped: the last pass re-reads its own tile
+        load_zA(cn, zA0);
+        if constexpr (!CM) { load_zB(cn, zB0); w0 = wcf[cn * 32 + l31]; }
+        process_tile(collc, ct + 1, zA1, zB1, w1);
+      }
+    };
+    if (!MM_F32_SINGLE_SWEEP && coll) sweep(mm_true{}); else sweep(mm_false{});
   }
   // workgroup reduction -> slab
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-  __shared__ double red[4];
+  __syncthreads();                               // (the previous panel's red[] has been read)
   if (lane == 0) red[wv] = sum;
   __syncthreads();
   if (threadIdx.x == 0) partB[((size_t)b * P + p) * NS + panel] = red[0] + red[1] + red[2] + red[3];
+  }
 }
 
 extern "C" int mm_mfma_supported(int d) { return d >= 1 && d <= 32; }
@@ -386,21 +452,28 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
   const int force_worst = (flags & MM_FORCE_WORST_TIER) ? 1 : 0;
   const unsigned int* amax = (const unsigned int*)(ws + wl.amax);
   const double* zmax2 = mm_moment_deg(d) >= 4 ? (const double*)(packed + ml.zmax2) : nullptr;
-  const long long nwork_ll = (long long)npanel * wl.Po * B;
+  // the (h, m) parts of one latent in LDS when they fit beside a second workgroup (<= 64 KB): d <= 8 and M <= 2048
+  const size_t zbytes = (size_t)wl.Mp * 32 * ml.nd8;
+  const bool ldsz = ml.nd8 == 1 && zbytes <= 65536;
+  // LDS-staged: one workgroup per (b, pair) (the fill is paid once) as long as that still leaves >= 8 rounds of
+  // 512 resident workgroups; else one per panel
+  int ppw = 1;
+  if (ldsz && (long long)wl.Po * B >= 4096) ppw = npanel;
+  const long long nwork_ll = (long long)((npanel + ppw - 1) / ppw) * wl.Po * B;
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const int nwork = (int)nwork_ll;
   const unsigned short* Zs3 = (const unsigned short*)(packed + ml.Zs3);
   const float* rowO = (const float*)(ws + wl.rowO);
   const float* colO = (const float*)(ws + wl.colO);
   double* partB = (double*)(ws + wl.partB);
-#define MM_LAUNCH_ND(ND_)                                                                         \
-  hipLaunchKernelGGL((k_qred_f32_mfma<ND_>), dim3(nwork), dim3(256), 0, stream, Zs3, L, wl.Mp, d, \
-                     wl.P, wl.Po, wl.NS, npanel, nwork, force_worst, amax, zmax2, rowO, colO, partB)
+#define MM_LAUNCH_ND(ND_, LZ_, SH_)                                                                          \
+  hipLaunchKernelGGL((k_qred_f32_mfma<ND_, LZ_>), dim3(nwork), dim3(256), SH_, stream, Zs3, L, wl.Mp, d,    \
+                     wl.P, wl.Po, wl.NS, npanel, ppw, nwork, force_worst, amax, zmax2, rowO, colO, partB)
   switch (ml.nd8) {
-    case 1: MM_LAUNCH_ND(1); break;
-    case 2: MM_LAUNCH_ND(2); break;
-    case 3: MM_LAUNCH_ND(3); break;
-    default: MM_LAUNCH_ND(4); break;
+    case 1: if (ldsz) MM_LAUNCH_ND(1, true, zbytes); else MM_LAUNCH_ND(1, false, 0); break;
+    case 2: MM_LAUNCH_ND(2, false, 0); break;
+    case 3: MM_LAUNCH_ND(3, false, 0); break;
+    default: MM_LAUNCH_ND(4, false, 0); break;
   }
 #undef MM_LAUNCH_ND
   hipError_t e = hipGetLastError();

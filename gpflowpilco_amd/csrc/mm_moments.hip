@@ -39,7 +39,9 @@ __device__ __forceinline__ void mm_decode_pair_m(int p, int L, int& a, int& a2) 
   a = i; a2 = i + 1 + r;
 }
 
-__global__ __launch_bounds__(256, 2) void k_wmom_gemm(const double* __restrict__ whR, const double* __restrict__ whC,
+// (54 KB of LDS admit two workgroups per CU = two waves per SIMD: pin the register budget to that occupancy, else the
+// compiler aims at three waves and spills the A prefetch registers inside the K loop)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wmom_gemm(const double* __restrict__ whR, const double* __restrict__ whC,
                                                       const double* __restrict__ Zm, int KMp, int L, int Mp, int B, int Po,
                                                       int nrb, int ncb, int nwork, int col_deg3,
                                                       const unsigned int* __restrict__ amax, const double* __restrict__ zmax2,
@@ -148,27 +150,8 @@ __global__ __launch_bounds__(256, 2) void k_wmom_gemm(const double* __restrict__
 //   (T symmetric), k runs from n down to 0: dot of the leading-k-index tensor with the packed row moments of
 //   degree k, then the last index is contracted with dmu.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int mm_flat_rank(int flat, int n, int d) {
-  // rank (inside the degree-n block) of the index tuple encoded base d in `flat`
-  int k0 = flat % d; flat /= d;
-  int k1 = flat % d; flat /= d;
-  int k2 = flat % d; flat /= d;
-  int k3 = flat % d;
-  if (n < 4) k3 = 1 << 20;
-  if (n < 3) k2 = 1 << 20;
-  if (n < 2) k1 = 1 << 20;
-  // sorting network on (k0, k1, k2, k3); absent slots hold a large value and stay on top
-  int t;
-#define MM_CX(x_, y_) t = min(x_, y_); y_ = max(x_, y_); x_ = t
-  MM_CX(k0, k1); MM_CX(k2, k3); MM_CX(k0, k2); MM_CX(k1, k3); MM_CX(k1, k2);
-#undef MM_CX
-  int r = k0;                                              // C(k0, 1)
-  if (n >= 2) r += k1 * (k1 + 1) / 2;                      // C(k1 + 1, 2)
-  if (n >= 3) r += k2 * (k2 + 1) * (k2 + 2) / 6;           // C(k2 + 2, 3)
-  if (n >= 4) r += k3 * (k3 + 1) * (k3 + 2) * (k3 + 3) / 24;
-  return r;
-}
-
+// Tensors are held with the power-of-two extent DK per index (d <= DK; entries with an index >= d are zero); the
+// rank of an index tuple inside its degree block comes from a table written at pack time (MMModelLayout::rtab).
 __device__ __forceinline__ double mm_block_sum256m(double v, double* red) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -178,25 +161,29 @@ __device__ __forceinline__ double mm_block_sum256m(double v, double* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-template <int DK>
+// DK = 8 (d <= 8, degree <= 4) or 32 (d <= 32, degree 2); LB = log2 DK; offs[n] = first column of the degree-n block
+template <int DK, int LB>
 __global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, int KMp, const double* __restrict__ pairmat,
                                                const double* __restrict__ zbar, const double* __restrict__ zmax2,
                                                const unsigned int* __restrict__ amax, const float* __restrict__ mu,
                                                int L, int d, int P, int deg, int allow_collapse,
+                                               int off1, int off2, int off3, int off4, const short* __restrict__ rtab,
                                                double c0, double c1, double* __restrict__ s12) {
   extern __shared__ double sm[];
   const int po = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int Po = P - L, p = L + po;
   int a, a2;
   mm_decode_pair_m(p, L, a, a2);
-  int dn = 1;                                              // d^deg
-  for (int i = 0; i < deg; ++i) dn *= d;
-  double* T = sm;                      // [d^deg]
-  double* U = T + dn;                  // [d^(deg-1)]
-  double* nh = U + dn / d;             // [KMp] row-side moments
+  const int dn = 1 << (LB * deg);                          // DK^deg
+  // T / U are stored with one pad double per 32 (position i lives at i + (i >> 5)): the fibre passes read
+  // DK entries 8^t doubles apart from every lane, which unpadded lands 8 lanes on one LDS bank
+#define MM_PADI(i_) ((i_) + ((i_) >> 5))
+  double* T = sm;                      // [DK^deg], padded
+  double* U = T + MM_PADI(dn);         // [DK^(deg-1)], padded
+  double* nh = U + MM_PADI(dn >> LB);  // [KMp] row-side moments
   double* qh = nh + KMp;               // [KMp] column-side moments
-  double* Gs = qh + KMp;               // [d][d]
-  double* dmu = Gs + d * d;            // [d]
+  double* Gs = qh + KMp;               // [DK][DK], zero padded
+  double* dmu = Gs + DK * DK;          // [DK], zero padded
   __shared__ double red[4];
   {
     const double* nm = mom + (((size_t)b * Po + po) * 2 + 0) * MM_MOM_SPLIT * KMp;
@@ -208,41 +195,63 @@ __global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, i
       nh[k] = sn; qh[k] = sq;
     }
     const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
-    for (int idx = tid; idx < d * d; idx += 256) Gs[idx] = pm[idx];
-    if (tid < d) dmu[tid] = (double)mu[(size_t)b * d + tid] - zbar[a * d + tid];
+    for (int idx = tid; idx < DK * DK; idx += 256) {
+      const int i = idx >> LB, j = idx & (DK - 1);
+      Gs[idx] = (i < d && j < d) ? pm[i * d + j] : 0.0;
+    }
+    if (tid < DK) dmu[tid] = tid < d ? (double)mu[(size_t)b * d + tid] - zbar[a * d + tid] : 0.0;
   }
   __syncthreads();
   const bool coll = allow_collapse && deg >= 4 &&
                     mm_collapse_bound2(amax[(size_t)b * Po + po], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
   const int nmax = coll ? 4 : 2;
+  double Gr[DK == 8 ? 64 : 1];
+  if constexpr (DK == 8) {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) Gr[i] = Gs[i];
+  }
   double total = 0.0;                                      // per-thread partial of the final sum
   for (int n = nmax; n >= 1; --n) {
     const double an = n == 1 ? 1.0 : n == 2 ? 0.5 : n == 3 ? c0 : c1;
-    int dsz = 1;
-    for (int i = 0; i < n; ++i) dsz *= d;
-    const int offn = mm_mono_off(n, d);
-    for (int idx = tid; idx < dsz; idx += 256) T[idx] = qh[offn + mm_flat_rank(idx, n, d)];
+    const int dsz = 1 << (LB * n);
+    const int offn = n == 1 ? off1 : n == 2 ? off2 : n == 3 ? off3 : off4;
+    // rank-table blocks: degree k starts at sum_{j<k} DK^j - 1 ... = (DK^k - DK) / (DK - 1)
+    const short* rtn = rtab + (((1 << (LB * n)) - DK) / (DK - 1));
+    for (int idx = tid; idx < dsz; idx += 256) {
+      const int r = rtn[idx];
+      T[MM_PADI(idx)] = r >= 0 ? qh[offn + r] : 0.0;
+    }
     __syncthreads();
-    // T <- G applied along every index: axis t has stride d^t; a fibre = the d entries along that axis,
-    // owned by one thread (registers), so the transform is in place
-    int stride = 1;
+    // T <- G applied along every index: axis t has stride DK^t; a fibre = the DK entries along that axis,
+    // owned by one thread (registers), so the transform is in place.  DK = 8: G itself sits in registers
+    // (one LDS read per FMA would make the passes LDS-issue bound)
     for (int t = 0; t < n; ++t) {
-      const int nfib = dsz / d;
+      const int sh = LB * t, nfib = dsz >> LB;
       for (int f = tid; f < nfib; f += 256) {
-        const int lo = f % stride, hi = f / stride;
-        double* base = T + (size_t)hi * stride * d + lo;
+        const int lo = f & ((1 << sh) - 1), hi = f >> sh;
+        const int base = (hi << (sh + LB)) + lo;
         double v[DK];
 #pragma unroll
-        for (int l = 0; l < DK; ++l) v[l] = l < d ? base[(size_t)l * stride] : 0.0;
-        for (int k = 0; k < d; ++k) {
-          double s = 0.0;
+        for (int l = 0; l < DK; ++l) v[l] = T[MM_PADI(base + (l << sh))];
+        if constexpr (DK == 8) {
 #pragma unroll
-          for (int l = 0; l < DK; ++l) s = fma(l < d ? Gs[k * d + l] : 0.0, v[l], s);
-          base[(size_t)k * stride] = s;
+          for (int k = 0; k < 8; ++k) {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) s = fma(Gr[k * 8 + l], v[l], s);
+            T[MM_PADI(base + (k << sh))] = s;
+          }
+        } else {
+#pragma unroll 2
+          for (int k = 0; k < DK; ++k) {
+            double s = 0.0;
+#pragma unroll
+            for (int l = 0; l < DK; ++l) s = fma(Gs[k * DK + l], v[l], s);
+            T[MM_PADI(base + (k << sh))] = s;
+          }
         }
       }
       __syncthreads();
-      stride *= d;
     }
     // k = n .. 0: dot with the row moments of degree k, then contract the last (highest-stride) index with dmu
     double* cur = T;
@@ -250,16 +259,21 @@ __global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, i
     int ksz = dsz;
     double sign_binom = 1.0;                               // C(n, k) (-1)^(n-k), starting at k = n
     for (int k = n; k >= 0; --k) {
-      const int offk = mm_mono_off(k, d);
+      const int offk = k == 0 ? 0 : k == 1 ? off1 : k == 2 ? off2 : k == 3 ? off3 : off4;
       double part = 0.0;
-      for (int idx = tid; idx < ksz; idx += 256) part = fma(cur[idx], nh[offk + (k ? mm_flat_rank(idx, k, d) : 0)], part);
+      const short* rtk = rtab + (k ? (((1 << (LB * k)) - DK) / (DK - 1)) : 0);
+      for (int idx = tid; idx < ksz; idx += 256) {
+        const int r = k ? rtk[idx] : 0;
+        if (r >= 0) part = fma(cur[MM_PADI(idx)], nh[offk + r], part);
+      }
       total = fma(an * sign_binom, part, total);
       if (k == 0) break;
-      const int nsz = ksz / d;                             // contract the highest index (stride nsz) with dmu
+      const int nsz = ksz >> LB;                           // contract the highest index (stride nsz) with dmu
       for (int idx = tid; idx < nsz; idx += 256) {
         double s = 0.0;
-        for (int l = 0; l < d; ++l) s = fma(cur[(size_t)l * nsz + idx], dmu[l], s);
-        oth[idx] = s;
+#pragma unroll
+        for (int l = 0; l < DK; ++l) s = fma(cur[MM_PADI(l * nsz + idx)], dmu[l], s);
+        oth[MM_PADI(idx)] = s;
       }
       __syncthreads();
       double* tsw = cur; cur = oth; oth = tsw;
@@ -270,6 +284,7 @@ __global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, i
   }
   const double tot = mm_block_sum256m(total, red);
   if (tid == 0) s12[(size_t)b * Po + po] = tot + nh[0] * qh[0];
+#undef MM_PADI
 }
 
 int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
@@ -290,14 +305,19 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
                      (const double*)(packed + ml.zmax2), mom);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  int dn = 1;
-  for (int i = 0; i < deg; ++i) dn *= d;
-  const size_t shm = (size_t)(dn + dn / d + 2 * ml.KMp + d * d + d) * sizeof(double);
-#define MM_SPOLY(DK_) hipLaunchKernelGGL((k_spoly<DK_>), dim3(wl.Po, B), dim3(256), shm, stream, (const double*)mom, ml.KMp, \
-                     (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), (const double*)(packed + ml.zmax2),    \
-                     (const unsigned int*)(ws + wl.amax), (const float*)mu_f32, L, d, wl.P, deg, allow,                          \
-                     (double)MM_REM1_C0, (double)MM_REM1_C1, (double*)(ws + wl.s12))
-  if (d <= 8) MM_SPOLY(8); else MM_SPOLY(32);
+  const int off1 = mm_mono_offset(1, d), off2 = mm_mono_offset(2, d), off3 = mm_mono_offset(3, d), off4 = mm_mono_offset(4, d);
+#define MM_SPOLY(DK_, LB_)                                                                                                       \
+  do {                                                                                                                          \
+    const int dn_ = 1 << (LB_ * deg);                                                                                           \
+    const int up_ = dn_ >> LB_;                                                                                                 \
+    const size_t shm_ = (size_t)(dn_ + (dn_ >> 5) + up_ + (up_ >> 5) + 2 * ml.KMp + DK_ * DK_ + DK_ + 8) * sizeof(double);      \
+    hipLaunchKernelGGL((k_spoly<DK_, LB_>), dim3(wl.Po, B), dim3(256), shm_, stream, (const double*)mom, ml.KMp,                \
+                       (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), (const double*)(packed + ml.zmax2), \
+                       (const unsigned int*)(ws + wl.amax), (const float*)mu_f32, L, d, wl.P, deg, allow, off1, off2, off3, off4, \
+                       (const short*)(packed + ml.rtab),                                                                        \
+                       (double)MM_REM1_C0, (double)MM_REM1_C1, (double*)(ws + wl.s12));                                         \
+  } while (0)
+  if (d <= 8) MM_SPOLY(8, 3); else MM_SPOLY(32, 5);
 #undef MM_SPOLY
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

@@ -48,12 +48,49 @@ def check_capture_status(device):
                         "replaced by NaN, so every value computed from it in that replay is NaN")
 
 
+# rocSOLVER's BLOCKED potrf (what torch.linalg.cholesky_ex reaches for n beyond a few hundred) is not safe when a
+# second process uses the same GPU: tools/potrf_probe.py (profiles/r02_potrf_probe.txt) factorises one fixed
+# K + 1e-6 I (n = 2000; host LAPACK and a lone GPU process factorise it to 1e-11) from two processes on one device
+# and gets a failed minor at a random position in ~10 % of the calls -- on the default stream, on a side stream and
+# with device synchronisations around the call alike -- and once a factor that is silently wrong by 5e-4.  The same
+# factorisation composed of the UNBLOCKED kernel on <= 256-wide diagonal blocks + triangular solves + GEMMs never
+# failed there.  That composition is what the set-up uses; its result is verified (below) instead of trusted.
+_BLOCK = 256
+
+
+def _blocked_cholesky_ex(A: torch.Tensor, nb: int = _BLOCK):
+  """Right-looking blocked Cholesky out of small ``cholesky_ex`` calls, ``solve_triangular`` and matmuls (any
+  leading batch dims).  -> (L, info) with info = 1-based position of the first failed minor (0 = none)."""
+  n = A.shape[-1]
+  L = A.clone()
+  info = torch.zeros(A.shape[:-2], dtype=torch.int32, device=A.device)
+  for j in range(0, n, nb):
+    e = min(j + nb, n)
+    Ljj, inf = torch.linalg.cholesky_ex(L[..., j:e, j:e])
+    info = torch.where((info == 0) & (inf != 0), inf + j, info)
+    L[..., j:e, j:e] = Ljj
+    if e < n:
+      P = torch.linalg.solve_triangular(Ljj, L[..., e:, j:e].transpose(-1, -2), upper=False).transpose(-1, -2)
+      L[..., e:, j:e] = P
+      L[..., e:, e:] -= P @ P.transpose(-1, -2)
+  return torch.tril(L), info
+
+
+def _residual(A: torch.Tensor, L: torch.Tensor) -> float:
+  """max |L (L^T v) - A v| / (n |A|_max |v|_max) on two fixed probe vectors: O(n^2), catches a silently wrong factor."""
+  n = A.shape[-1]
+  g = torch.Generator(device="cpu").manual_seed(1234)
+  v = torch.randn(n, 2, generator=g, dtype=A.dtype).to(A.device)
+  r = L @ (L.transpose(-1, -2) @ v) - A @ v
+  return float(r.abs().max() / (n * A.abs().max() * v.abs().max()))
+
+
 def cholesky(A: torch.Tensor) -> torch.Tensor:
   """Lower Cholesky factor of the model set-up matrices (Kuu + jitter, K + s2 I); never on the per-step path.
 
-  Eager: a device factorisation that reports ``info != 0`` RAISES ``CholeskyError`` with the failing item, the
-  symmetry defect and the diagonal range in the message and, when ``GPFLOWPILCO_DUMP_DIR`` is set, the matrix
-  saved there.  There is no host retry and no CPU fallback.
+  Eager: a factorisation that reports ``info != 0`` -- or whose factor does not reproduce A on two probe vectors --
+  RAISES ``CholeskyError`` with the failing item, the symmetry defect and the diagonal range in the message and,
+  when ``GPFLOWPILCO_DUMP_DIR`` is set, the matrix saved there.  There is no retry and no CPU fallback.
 
   Inside a HIP-graph capture (the trainable policy of ``loops.GraphedPolicyLoss`` is re-factorised from its
   parameters on every replay) the host cannot look at ``info``; the check moves onto the device instead of
@@ -61,15 +98,24 @@ def cholesky(A: torch.Tensor) -> torch.Tensor:
   garbage factor -- and ``info`` is max-ed into ``capture_status(device)``, which ``GraphedPolicyLoss`` checks
   after each replay (``check_capture_status``).
   """
-  L, info = torch.linalg.cholesky_ex(A)
+  big = A.is_cuda and A.shape[-1] > _BLOCK
+  L, info = _blocked_cholesky_ex(A) if big else torch.linalg.cholesky_ex(A)
   if A.is_cuda and torch.cuda.is_current_stream_capturing():
     bad = info != 0
     L = torch.where(bad.reshape(bad.shape + (1, 1)), torch.full_like(L, float("nan")), L)
     st = capture_status(A.device)
     st.copy_(torch.maximum(st, info.abs().max().reshape(1).to(torch.int32)))
     return L
-  if bool((info != 0).any()):
+  failed = bool((info != 0).any())
+  msg = None
+  if failed:
     msg = _describe(A, info)
+  elif A.is_cuda and A.shape[-1] > 64:
+    res = _residual(A, L)
+    if not res < 1e-9:                                       # also catches NaN
+      failed = True
+      msg = f"info = 0 but the factor does not reproduce the matrix: probe residual {res:.3e} (n={A.shape[-1]}, device={A.device})"
+  if failed:
     import os
     dump = os.environ.get("GPFLOWPILCO_DUMP_DIR")
     if dump:

@@ -122,3 +122,24 @@ def make_inputs(B: int, d: int, seed: int, scale: float = 0.1, lo: float = 0.0, 
   mu = rng.uniform(lo, hi, size=(B, d))
   Sigma = generate_covariance(rng, d, (B,), scale)
   return mu, Sigma
+
+
+def make_policy(M: int, d: int, seed: int, scale: float = 0.3, ls_bounds=(0.7, 2.0)) -> SyntheticSVGP:
+  """A one-latent SVGP policy regressor on d encoded inputs (the reference's KernelRegressor policy with M = 30
+  kernel centres, ``examples/cartpole_swingup/settings.py``): random centres in the unit cube, random q_mu of the
+  given scale.  Only its mean is used (models/core.py:60-62), so q_sqrt is the identity."""
+  rng = np.random.default_rng(seed)
+  Z = rng.uniform(size=(M, d))
+  ls = np.exp(rng.uniform(np.log(ls_bounds[0]), np.log(ls_bounds[1]), size=(1, d)))
+  var = np.full(1, 0.89 ** 2)
+  return SyntheticSVGP(Z=Z, lengthscales=ls, variance=var, noise=1e-2 * var, q_mu=scale * rng.standard_normal((M, 1)),
+                       q_sqrt=np.eye(M)[None].copy())
+
+
+def make_cartpole_like(M_drift: int = 100, M_policy: int = 30, seed: int = 1000, device: str = "cpu"):
+  """BASELINE configs[0] wiring (examples/cartpole_swingup/swingup_loops.py:41-91): state x (4) -> trig encoder on the
+  angle (dim 1) -> e (5) -> policy u (1) -> drift input d = (e, u) (6) -> dx (4).  Returns (drift, policy) as
+  SyntheticSVGP; the drift's action axis (input 5) is stretched to [-2, 2], the range of u = 2 (2 Phi(f) - 1)."""
+  drift = make_svgp(4, M_drift, 6, seed=seed, device=device, ls_bounds=(0.8, 3.0))
+  drift.Z = drift.Z * np.array([1, 1, 1, 1, 1, 4.0]) - np.array([0, 0, 0, 0, 0, 2.0])
+  return drift, make_policy(M_policy, 5, seed + 1)

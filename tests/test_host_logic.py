@@ -210,3 +210,22 @@ def test_synthetic_posterior_is_exact_and_pd_by_construction():
     S = Lk @ qs @ qs.T @ Lk.T
     ref = K - K @ np.linalg.solve(K + syn.noise[a] * np.eye(40), K)
     assert np.abs(S - ref).max() < 1e-8
+
+
+def test_blocked_cholesky_equals_lapack_and_reports_the_failing_minor():
+  """linalg._blocked_cholesky_ex (the composition the GPU set-up uses instead of rocSOLVER's blocked potrf, which
+  tools/potrf_probe.py shows to be unsafe beside a second process on the device): same factor as LAPACK, batched,
+  and info = position of the first failed leading minor."""
+  import torch
+  from gpflowpilco_amd.linalg import _blocked_cholesky_ex, _residual
+  g = torch.Generator().manual_seed(3)
+  X = torch.randn(2, 150, 40, generator=g, dtype=torch.float64)
+  A = X @ X.transpose(1, 2) + 1e-3 * torch.eye(150, dtype=torch.float64)
+  L, info = _blocked_cholesky_ex(A, nb=32)
+  assert int(info.abs().max()) == 0 and torch.allclose(L, torch.linalg.cholesky(A), rtol=1e-9, atol=1e-10)
+  assert _residual(A[0], L[0]) < 1e-12 and not _residual(A[0], L[0] * 1.001) < 1e-9
+  B = A.clone()
+  B[1, 70, 70] = -1.0                                         # minor 71 of item 1 is the first non-positive one
+  _, info = _blocked_cholesky_ex(B, nb=32)
+  ref = torch.linalg.cholesky_ex(B)[1]
+  assert info.tolist() == ref.tolist() == [0, 71]
