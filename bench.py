@@ -178,6 +178,25 @@ def executed_ceiling(ent, kind):
                   "mfma_pipe_cycles_per_simd": mfma_cyc / N_SIMD, "valu_issue_cycles_per_simd_not_hidden": valu_cyc / N_SIMD}}
 
 
+def one_rank_at_a_time(fn, rank, world, dist, rehearsal):
+  """Model set-up.  Production (one process per GPU): every rank simply runs it.  The --rehearse-gloo mode puts all
+  ranks on ONE GPU, and on this driver stack large f64 library kernels are not reliable while two processes
+  time-slice a device (tools/potrf_probe.py, profiles/r02_potrf_probe.txt: rocSOLVER potrf fails at a random minor
+  in ~10 % of the calls and once returned a wrong factor with info = 0; a lone process never does): there the ranks
+  take turns, so that no two of them run the set-up's factorisations at the same time.  linalg.cholesky verifies
+  every large factor it returns either way."""
+  if not (rehearsal and world > 1):
+    return fn()
+  import torch
+  out = None
+  for turn in range(world):
+    if turn == rank:
+      out = fn()
+      torch.cuda.synchronize()
+    dist.barrier()
+  return out
+
+
 def main():
   args = parse()
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -235,9 +254,11 @@ def main():
     raise SystemExit(f"rank {rank} got an empty shard of B={B_total}")
   steps = args.steps if args.pmc_run else max(H, -(-args.steps // H) * H)     # whole rollouts (see module docstring)
 
-  syn = make_svgp(L, M, d, seed=cfg["seed"], device=str(dev), ls_bounds=rec["ls_bounds"], stable=rec["stable"])
-  model = syn.to_model(dev)
-  pm = model.packed(dtype, True, dev)
+  def build_model():
+    syn_ = make_svgp(L, M, d, seed=cfg["seed"], device=str(dev), ls_bounds=rec["ls_bounds"], stable=rec["stable"])
+    model_ = syn_.to_model(dev)
+    return syn_, model_, model_.packed(dtype, True, dev)
+  syn, model, pm = one_rank_at_a_time(build_model, rank, world, dist, args.rehearse_gloo)
   if rec["independent"]:
     # the step kernel on H independent draws of the whole batch; rank-independent global draw so that
     # a strong-scaling run processes the same B_total inputs at every N
@@ -337,7 +358,12 @@ def main():
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
   pm.check_status(B)
-  collapsed = ops.offdiag_stats(pm, B, base) if dtype == torch.float32 else (0, 0)      # of the last timed step
+  # regime of the off-diagonal reduce over one (untimed) rollout: its kernels' time depends on it
+  collapsed = [0, 0, 0]
+  if dtype == torch.float32 and not args.pmc_run:
+    for _ in range(H):
+      one_step(False)
+      collapsed = [x + y for x, y in zip(collapsed, ops.offdiag_stats(pm, B, base))]
   if cfg["closed"] and not torch.isfinite(state["S"]).all():
     raise SystemExit("non-finite state in the timed rollout")
   if not args.pmc_run:
@@ -419,9 +445,11 @@ def main():
                  "rollouts_timed": state["rollouts"], "collectives_timed": state["rollouts"] if world > 1 else 0,
                  "steps_requested": args.steps,
                  "diag_pairs": "f64", "offdiag_pairs": cfg["dtype"],
-                 "offdiag_items_collapsed_last_step": {"collapsed": collapsed[0], "total": collapsed[1],
-                                                       "meaning": "(b, off-diagonal pair) items whose cubic + quartic remainder terms come from "
-                                                                  "f64 moments and whose tiles with max|b| <= 1/16 are skipped (csrc/mm_moments.hip)"}},
+                 "offdiag_items_one_rollout": {"collapsed": collapsed[0], "wholly_inside": collapsed[2], "total": collapsed[1],
+                                               "meaning": "(b, off-diagonal pair, step) items of one rollout; collapsed: cubic + quartic "
+                                                          "remainder terms from f64 moments, tiles with max|b| <= 1/16 skipped after a "
+                                                          "screening MFMA; wholly_inside: the Cauchy-Schwarz bound alone puts every |b| <= 1/16, "
+                                                          "no tile work (csrc/mm_moments.hip, mm_mfma.hip)"}},
       "segments_ms": {k: round(v, 4) for k, v in seg.items()},
       "roofline": roofs[dominant],
       "roofline_other": roofs["diag" if dominant == "offdiag" else "offdiag"],
@@ -636,12 +664,15 @@ def pathwise_bench(args, rank, world, dev, dist):
   else:
     S, S_total = Scfg, Scfg * world
   steps = max(H, -(-args.steps // H) * H)
-  syn = make_svgp(L, M, d, seed=c["seed"], device=str(dev), ls_bounds=(0.7, 3.0))
-  base = syn.to_model(dev)
-  model = PathwiseSVGP(kernel=base.kernel, inducing_variable=base.inducing_variable, q_mu=base.q_mu,
-                       q_sqrt=base.q_sqrt, whiten=True, num_latent_gps=L)
   g = torch.Generator(device=dev).manual_seed(c["seed"] + rank)
-  paths = model.generate_paths(S, K, dtype=dtype, device=dev, generator=g)
+
+  def build_paths():
+    syn = make_svgp(L, M, d, seed=c["seed"], device=str(dev), ls_bounds=(0.7, 3.0))
+    base = syn.to_model(dev)
+    model = PathwiseSVGP(kernel=base.kernel, inducing_variable=base.inducing_variable, q_mu=base.q_mu,
+                         q_sqrt=base.q_sqrt, whiten=True, num_latent_gps=L)
+    return model.generate_paths(S, K, dtype=dtype, device=dev, generator=g)
+  paths = one_rank_at_a_time(build_paths, rank, world, dist, args.rehearse_gloo)
   x0 = 0.3 + 0.4 * torch.rand(S, d, dtype=dtype, device=dev, generator=g)
   target = torch.full((d,), 0.5, dtype=dtype, device=dev)
   Smax = -(-S_total // world)

@@ -99,6 +99,9 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 // a (b, pair) is collapsed (cubic + quartic term of the remainder taken from moments, tiles with max|b| <= 1/16
 // skipped) when max_i |A_i|^2 * max_j |zc_j|^2 <= MM_COLLAPSE_BOUND2, i.e. every |b_ij| <= 1 by Cauchy-Schwarz
 #define MM_COLLAPSE_BOUND2 1.0f
+// ... and when the bound itself says every |b_ij| <= 1/16 (bound2 <= 0.0039 < 1/256), the whole remainder of the
+// (b, pair) is inside the collapsed range: the tile kernel's workgroup writes zero partials and leaves
+#define MM_INSIDE_BOUND2 0.0039f
 // first-tier near-minimax approximant of the remainder r(x) = expm1(x) - x - x^2/2 ~ x^3 (C0 + C1 x), |x| <= 1/16,
 // error <= 5e-8 |x| (tools/minimax_remainder.py): the polynomial the collapse takes from the moments
 #define MM_REM1_C0 1.666936278e-01f

@@ -529,20 +529,33 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   Ops cur, nxt;
   if (PF) load_ops(blockIdx.x, cur);
   __shared__ double Gs[GREG ? 1 : DK * DK];
-  __shared__ double vecs[5][DK];                             // mu, mu - zbar_a, mu - zbar_a', Lam_a'/Lam_a, Lam_a/Lam_a'
+  __shared__ double vecs[7][DK];                             // mu, mu - zbar_a, mu - zbar_a', Lam_a'/Lam_a, Lam_a/Lam_a', 1/Lam_a, 1/Lam_a'
   const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
-  double Gr[GREG ? DK * DK : 1];
+  // GREG: G = Lam_a^-1 T Lam_a'^-1 with T SYMMETRIC, so the thread keeps the DK (DK + 1) / 2 distinct entries of
+  // T = Lam_a G Lam_a' (72 VGPRs at d = 8 instead of 128 for G) and scales the vectors instead:
+  //   A_i = (1 / Lam_a',i) sum_k T_ki (zeta_k / Lam_a,k),   g_i = (1 / Lam_a,i) sum_k T_ik (zeta'_k / Lam_a',k)
+  constexpr int NT = DK * (DK + 1) / 2;
+  double Tr[GREG ? NT : 1];
+  auto tsym = [](int i, int k) { return i <= k ? i * DK - i * (i - 1) / 2 + (k - i) : k * DK - k * (k - 1) / 2 + (i - k); };
   if (GREG) {
-    // lane l of every wave loads padded entry l (one coalesced load), then the DK * DK <= 64 values are
-    // broadcast with v_readlane.  (Uniform-address loads pm[in ? i * d + k : 0] compiled to 64 serialised
-    // s_load + s_waitcnt pairs behind ~1200 SGPR spill moves: microseconds of prologue per workgroup.)
+    // lane l of every wave loads padded entry l (one coalesced load), then the values are broadcast with v_readlane.
+    // (Uniform-address loads pm[in ? i * d + k : 0] compiled to 64 serialised s_load + s_waitcnt pairs behind ~1200
+    // SGPR spill moves: microseconds of prologue per workgroup.)
     const int ln = tid & 63, li = ln / DK, lk = ln - li * DK;
     const bool lin = li < d && lk < d && ln < DK * DK;
-    const double mine = lin ? pm[li * d + lk] : 0.0;
+    const double mine = lin ? pm[li * d + lk] * ls2[a * d + li] * ls2[a2 * d + lk] : 0.0;
     const int mlo = __double2loint(mine), mhi = __double2hiint(mine);
 #pragma unroll
-    for (int idx = 0; idx < DK * DK; ++idx)
-      Gr[idx] = __hiloint2double(__builtin_amdgcn_readlane(mhi, idx), __builtin_amdgcn_readlane(mlo, idx));
+    for (int i = 0; i < DK; ++i)
+#pragma unroll
+      for (int k = i; k < DK; ++k) {
+        double t = __hiloint2double(__builtin_amdgcn_readlane(mhi, i * DK + k), __builtin_amdgcn_readlane(mlo, i * DK + k));
+        // pinned to VECTOR registers: left uniform, the doubles want SGPRs the kernel does not have, and the compiler
+        // re-broadcasts them inside the chunk loop instead (290 v_readlane + 106 hazard s_nop per chunk against
+        // 250 f64 FMAs)
+        asm volatile("" : "+v"(t));
+        Tr[GREG ? tsym(i, k) : 0] = t;
+      }
   } else {
     for (int idx = tid; idx < DK * DK; idx += 256) {
       const int i = idx / DK, k = idx - i * DK;
@@ -560,6 +573,8 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
     vecs[2][tid] = tid < d ? mv - zbar[a2 * d + k] : 0.0;
     vecs[3][tid] = tid < d ? lb / la : 0.0;                  // Lam_a',k / Lam_a,k
     vecs[4][tid] = tid < d ? la / lb : 0.0;
+    vecs[5][tid] = tid < d ? 1.0 / la : 0.0;
+    vecs[6][tid] = tid < d ? 1.0 / lb : 0.0;
   }
   __syncthreads();
   const double cst = pm[d * d];
@@ -614,15 +629,19 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
       }
     };
     if (GREG) {
+      double zrs[DK], zcs[DK];
+#pragma unroll
+      for (int k = 0; k < DK; ++k) { zrs[k] = zr[k] * vecs[5][k]; zcs[k] = zc[k] * vecs[6][k]; }
 #pragma unroll
       for (int i = 0; i < DK; ++i) {
         double av = 0.0, gv = 0.0;
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
-          gv = fma(Gr[(GREG ? i * DK + k : 0)], zc[k], gv);
-          av = fma(Gr[(GREG ? k * DK + i : 0)], zr[k], av);
+          const double t = Tr[GREG ? tsym(i, k) : 0];
+          gv = fma(t, zcs[k], gv);
+          av = fma(t, zrs[k], av);
         }
-        row(i, av, gv);
+        row(i, av * vecs[6][i], gv * vecs[5][i]);
       }
     } else {
 #pragma unroll 2      // not fully: the compiler would hoist all the LDS reads (> 256 VGPRs)
@@ -670,6 +689,250 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
     for (int off = 32; off > 0; off >>= 1) a2max = fmaxf(a2max, __shfl_down(a2max, off, 64));
     if ((tid & 63) == 0) atomicMax(amax + (size_t)b * Po + (p - L), __float_as_uint(a2max));
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_pairvec_reg: k_pairvec for d <= 8, the pair's matrix in REGISTERS.  grid (nsplit, P, B), 256 threads.
+//
+// G = Lam_a^-1 T Lam_a'^-1 with T symmetric: a thread keeps the DK (DK + 1) / 2 distinct entries of T = Lam_a G Lam_a'
+// (72 VGPRs at d = 8; G itself would take 128, which the compiler answered by re-broadcasting it with v_readlane in
+// every chunk) and works on SCALED vectors, s = zeta / Lam_a (row side), s' = zeta' / Lam_a' (column side):
+//     u = T s,  v = T s';    A_i = u_i / Lam_a',i,  g_i = v_i / Lam_a,i,
+//     zeta^T (Lam_a^-1 T Lam_a^-1) zeta = s . u,     zeta'^T (Lam_a'^-1 T Lam_a'^-1) zeta' = s' . v = s'^T T s',
+// so a quadratic form whose vector is not an output costs 36 products instead of 64 + 8.  The three modes (diagonal
+// pair; f32 off-diagonal pair; f64 off-diagonal pair) are straight-line code behind a workgroup-uniform branch;
+// the chunk loop is unrolled twice over two operand sets (the next chunk's loads are in flight, no register copies);
+// the per-latent vectors stay in LDS (laundered pointer: hoisted, the 5 x 8 doubles cost 80 VGPRs).
+// ---------------------------------------------------------------------------------------------
+// MODE 0: diagonal pair; 1: f32 off-diagonal pair; 2: f64 off-diagonal pair.  One instantiation per mode behind the
+// kernel's workgroup-uniform branch: operand pointers and temporaries of the other modes are never live.
+template <typename T, int DK, int MODE>
+__device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Zt64, const double* __restrict__ zbar,
+                                                    const double* __restrict__ ls2, int L, int M, int Mp, int d, int P,
+                                                    const T* __restrict__ mu, const double* __restrict__ pairmat,
+                                                    const double* __restrict__ rho1,
+                                                    double* __restrict__ rowD, double* __restrict__ colD,
+                                                    T* __restrict__ rowO, T* __restrict__ colO,
+                                                    const double* __restrict__ w64, double* __restrict__ whR,
+                                                    double* __restrict__ whC, unsigned int* __restrict__ amax,
+                                                    const double* __restrict__ q64, double* __restrict__ qhR,
+                                                    double* __restrict__ qhC, int with_unc, int nblk, int a, int a2,
+                                                    double (*vecs)[DK]) {
+  constexpr bool diag = MODE == 0;
+  const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int Po = P - L;
+  const double* zA = Zt64 + (size_t)a * d * Mp;
+  const double* zB = Zt64 + (size_t)a2 * d * Mp;
+  const double* r1a = rho1 + ((size_t)b * L + a) * Mp;
+  const double* r1b = rho1 + ((size_t)b * L + a2) * Mp;
+  const double* wa = w64 + ((size_t)b * L + a) * Mp;
+  const double* wb = w64 + ((size_t)b * L + a2) * Mp;
+  const double* qa = q64 + ((size_t)b * L + a) * Mp;
+  struct Ops { double zr[DK], zc[diag ? 1 : DK], r1r, r1c, wr, wc; };
+  auto load_ops = [&](int mblk, Ops& o) {
+    int m = mblk * 256 + tid;
+    m = m < Mp ? m : Mp - 1;
+#pragma unroll
+    for (int k = 0; k < DK; ++k) {
+      const unsigned off = (unsigned)((k < d ? k : 0) * Mp + m);   // index-clamped: the scale vectors are zero beyond d
+      o.zr[k] = zA[off];                                     // dimension-major: coalesced over m
+      if constexpr (!diag) o.zc[k] = zB[off];
+    }
+    o.r1r = r1a[m];
+    o.wr = wa[m];
+    if constexpr (!diag) { o.r1c = r1b[m]; o.wc = wb[m]; }
+    else if (with_unc) o.wc = qa[m];                         // diagonal pair: the weight of the fused sum is q, not w
+  };
+  Ops oA, oB;
+  load_ops(blockIdx.x, oA);
+  const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
+  constexpr int NT = DK * (DK + 1) / 2;
+  double Tr[NT];
+  auto tsym = [](int i, int k) { return i <= k ? i * DK - i * (i - 1) / 2 + (k - i) : k * DK - k * (k - 1) / 2 + (i - k); };
+  {
+    // lane l of every wave loads padded entry l (one coalesced load), then the values are broadcast with v_readlane
+    // and pinned to vector registers
+    const int ln = tid & 63, li = ln / DK, lk = ln - li * DK;
+    const bool lin = li < d && lk < d && ln < DK * DK;
+    const double mine = lin ? pm[li * d + lk] * ls2[a * d + li] * ls2[a2 * d + lk] : 0.0;
+    const int mlo = __double2loint(mine), mhi = __double2hiint(mine);
+#pragma unroll
+    for (int i = 0; i < DK; ++i)
+#pragma unroll
+      for (int k = i; k < DK; ++k) {
+        double t = __hiloint2double(__builtin_amdgcn_readlane(mhi, i * DK + k), __builtin_amdgcn_readlane(mlo, i * DK + k));
+        asm volatile("" : "+v"(t));
+        Tr[tsym(i, k)] = t;
+      }
+  }
+  if (tid < DK) {
+    const int k = tid < d ? tid : 0;
+    const double mv = (double)mu[(size_t)b * d + k];
+    const double la = ls2[a * d + k], lb = ls2[a2 * d + k];
+    vecs[0][tid] = tid < d ? mv : 0.0;
+    vecs[1][tid] = tid < d ? 1.0 / la : 0.0;
+    vecs[2][tid] = tid < d ? 1.0 / lb : 0.0;
+    vecs[3][tid] = tid < d ? (mv - zbar[a2 * d + k]) / lb : 0.0;   // the A operand is centred at zbar_a', not at mu_b
+    vecs[4][tid] = tid < d ? (mv - zbar[a * d + k]) / la : 0.0;
+  }
+  __syncthreads();
+  const double cst = pm[d * d];
+  float a2max = 0.0f;                                         // max_i |A_i|^2 over this thread's rows (f32 off-diagonal pairs)
+  typedef const __attribute__((address_space(3))) double* lds_cptr;
+  // rows i >= d of a (d + 1)-row operand do not exist: their (zero) value goes to row d, which the chunk's last
+  // store overwrites -- no branch per row, and no extra store at all when d == DK
+  auto rowi = [&](int i) { return (unsigned)((i < d ? i : d) * Mp); };
+  const unsigned rowd = (unsigned)(d * Mp);
+
+  auto body = [&](int mblk, const Ops& o) {
+    const int m = mblk * 256 + tid;
+    if (m >= Mp) return;
+    lds_cptr vl = (lds_cptr)&vecs[0][0];
+    asm volatile("" : "+v"(vl));
+    const bool live = m < M;
+    if constexpr (MODE == 0) {
+      double* cbD = colD + ((size_t)b * L + p) * (size_t)(d + 1) * Mp;
+      double* raD = rowD + ((size_t)b * L + p) * Mp;
+      double* qR = qhR + ((size_t)b * L + p) * Mp;
+      double* qC = qhC + ((size_t)b * L + p) * Mp;
+      if (live) {
+        double sv[DK];
+#pragma unroll
+        for (int k = 0; k < DK; ++k) sv[k] = (o.zr[k] - vl[k]) * vl[DK + k];
+        double tq = 0.0, corr = 0.0;
+#pragma unroll
+        for (int i = 0; i < DK; ++i) {
+          double u = 0.0;
+#pragma unroll
+          for (int k = 0; k < DK; ++k) u = fma(Tr[tsym(i, k)], sv[k], u);
+          tq = fma(sv[i], u, tq);
+          corr = fma(vl[4 * DK + i], u, corr);               // (mu - zbar_a) . g
+          cbD[rowi(i) + m] = u * vl[DK + i];                 // g_i
+        }
+        // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j
+        const double rowv = -0.5 * (o.r1r - tq);
+        const double colv = rowv + cst - corr;
+        // factored weights of the f64 MFMA reduce (mm_f64.hip): e^{delta_ij} = e^{rho_i} e^{gamma'_j} e^{zc_i . g_j};
+        // u = q with model uncertainty (the fused sum runs over q_i q_j D_ij e^{delta}), w without
+        const double uw = with_unc ? o.wc : o.wr;
+        raD[m] = rowv; cbD[rowd + m] = colv;
+        qR[m] = uw * exp(rowv); qC[m] = uw * exp(colv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < DK; ++i) cbD[rowi(i) + m] = 0.0;
+        raD[m] = 0.0; cbD[rowd + m] = 0.0; qR[m] = 0.0; qC[m] = 0.0;
+      }
+    } else if constexpr (MODE == 1) {
+      // f32 off-diagonal format (mm_mfma.hip).  With b_ij = A_i . zc^{a'}_j,
+      //   delta_ij = rho'_i + gamma_j + b_ij,  rho'_i = rho_i + const - A_i . (mu - zbar_a'),
+      // exp(delta) - 1 = e^{rho'_i} e^{gamma_j} (expm1(b_ij) + 1) - 1: the M x M tile is a pure bilinear form in
+      // what_i = w_i e^{rho'_i}, what'_j = w'_j e^{gamma_j}; the f64 weights feed the moment GEMM (mm_moments.hip).
+      T* rO = rowO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
+      T* cO = colO + ((size_t)b * Po + (p - L)) * Mp;
+      double* hR = whR + ((size_t)b * Po + (p - L)) * Mp;
+      double* hC = whC + ((size_t)b * Po + (p - L)) * Mp;
+      if (live) {
+        double sr[DK], sc[DK];
+#pragma unroll
+        for (int k = 0; k < DK; ++k) { const double muk = vl[k]; sr[k] = (o.zr[k] - muk) * vl[DK + k]; sc[k] = (o.zc[k] - muk) * vl[2 * DK + k]; }
+        double tA = 0.0, tg = 0.0, corrA = 0.0, asq = 0.0;
+#pragma unroll
+        for (int i = 0; i < DK; ++i) {
+          double u = 0.0, vh = 0.0;
+#pragma unroll
+          for (int k = 0; k < DK; ++k) {
+            const double t = Tr[tsym(i, k)];
+            u = fma(t, sr[k], u);
+            if (k > i) vh = fma(t, sc[k], vh);               // s'^T T s' from the upper triangle
+          }
+          tA = fma(sr[i], u, tA);
+          tg = fma(sc[i], fma(2.0, vh, Tr[tsym(i, i)] * sc[i]), tg);
+          const double av = u * vl[2 * DK + i];
+          asq = fma(av, av, asq);
+          corrA = fma(vl[3 * DK + i], u, corrA);
+          rO[rowi(i) + m] = (T)av;
+        }
+        a2max = fmaxf(a2max, (float)asq * 1.000001f);        // rounded up: the bound must not be under-estimated
+        const double whr = o.wr * exp(-0.5 * (o.r1r - tA) + cst - corrA);
+        const double whc = o.wc * exp(-0.5 * (o.r1c - tg));
+        rO[rowd + m] = (T)whr; cO[m] = (T)whc; hR[m] = whr; hC[m] = whc;
+      } else {
+#pragma unroll
+        for (int i = 0; i < DK; ++i) rO[rowi(i) + m] = (T)0;  // zero rows: b = 0 in the padding
+        rO[rowd + m] = (T)0; cO[m] = (T)0; hR[m] = 0.0; hC[m] = 0.0;
+      }
+    } else {
+      // off-diagonal pair of the f64 mode: rho_i (row), g_j and gamma'_j (column)
+      T* raO = rowO + ((size_t)b * Po + (p - L)) * Mp;
+      T* cbO = colO + ((size_t)b * Po + (p - L)) * (size_t)(d + 1) * Mp;
+      if (live) {
+        double sr[DK], sc[DK];
+#pragma unroll
+        for (int k = 0; k < DK; ++k) { const double muk = vl[k]; sr[k] = (o.zr[k] - muk) * vl[DK + k]; sc[k] = (o.zc[k] - muk) * vl[2 * DK + k]; }
+        double tA = 0.0, tg = 0.0, corrg = 0.0;
+#pragma unroll
+        for (int i = 0; i < DK; ++i) {
+          double v = 0.0, uh = 0.0;
+#pragma unroll
+          for (int k = 0; k < DK; ++k) {
+            const double t = Tr[tsym(i, k)];
+            v = fma(t, sc[k], v);
+            if (k > i) uh = fma(t, sr[k], uh);
+          }
+          tg = fma(sc[i], v, tg);
+          tA = fma(sr[i], fma(2.0, uh, Tr[tsym(i, i)] * sr[i]), tA);
+          corrg = fma(vl[4 * DK + i], v, corrg);
+          cbO[rowi(i) + m] = (T)(v * vl[DK + i]);            // g_i
+        }
+        raO[m] = (T)(-0.5 * (o.r1r - tA));
+        cbO[rowd + m] = (T)(-0.5 * (o.r1c - tg) + cst - corrg);
+      } else {
+#pragma unroll
+        for (int i = 0; i < DK; ++i) cbO[rowi(i) + m] = (T)0;
+        raO[m] = (T)0; cbO[rowd + m] = (T)0;
+      }
+    }
+  };
+
+  const int step = (int)gridDim.x;
+  for (int mblk = blockIdx.x; mblk < nblk; mblk += 2 * step) {
+    // unconditional (clamped) prefetch: past the end it re-reads the current chunk
+    load_ops(mblk + step < nblk ? mblk + step : mblk, oB);
+    body(mblk, oA);
+    if (mblk + step >= nblk) break;
+    load_ops(mblk + 2 * step < nblk ? mblk + 2 * step : mblk + step, oA);
+    body(mblk + step, oB);
+  }
+  if (MODE == 1 && amax) {
+    // one atomicMax per wave: non-negative floats are ordered like their bit patterns (max is order independent)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a2max = fmaxf(a2max, __shfl_down(a2max, off, 64));
+    if ((tid & 63) == 0) atomicMax(amax + (size_t)b * Po + (p - L), __float_as_uint(a2max));
+  }
+}
+
+template <typename T, int DK>
+__global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict__ Zt64, const double* __restrict__ zbar,
+                                                        const double* __restrict__ ls2, int L, int M, int Mp, int d, int P,
+                                                        const T* __restrict__ mu, const double* __restrict__ pairmat,
+                                                        const double* __restrict__ rho1,
+                                                        double* __restrict__ rowD, double* __restrict__ colD,
+                                                        T* __restrict__ rowO, T* __restrict__ colO,
+                                                        const double* __restrict__ w64, double* __restrict__ whR,
+                                                        double* __restrict__ whC, unsigned int* __restrict__ amax,
+                                                        const double* __restrict__ q64, double* __restrict__ qhR,
+                                                        double* __restrict__ qhC, int with_unc, int nblk) {
+  static_assert(DK <= 8, "register form: d <= 8");
+  __shared__ double vecs[5][DK];      // mu | 1/Lam_a | 1/Lam_a' | (mu - zbar_a') / Lam_a' | (mu - zbar_a) / Lam_a
+  int a, a2;
+  mm_decode_pair((int)blockIdx.y, L, a, a2);
+#define MM_PV_BODY(MODE_)                                                                                           \
+  mm_pairvec_reg_body<T, DK, MODE_>(Zt64, zbar, ls2, L, M, Mp, d, P, mu, pairmat, rho1, rowD, colD, rowO, colO, w64, \
+                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs)
+  if ((int)blockIdx.y < L) MM_PV_BODY(0);
+  else if (sizeof(T) == 4) MM_PV_BODY(1);
+  else MM_PV_BODY(2);
+#undef MM_PV_BODY
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1005,13 +1268,17 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     int nsplit = (int)((4096 + per - 1) / per);            // >= 16 workgroups per CU, else one per (b, pair)
     if (nsplit > nblk) nsplit = nblk;
     if (nsplit < 1) nsplit = 1;
-    hipLaunchKernelGGL((k_pairvec<T, DK>), dim3(nsplit, wl.P, B), dim3(256), 0, s,
-                       (const double*)(packed + ml.Zt64), (const double*)(packed + ml.zbar), ls2, L, M, wl.Mp, d, wl.P, mu, pairmat,
-                       (const double*)(ws + wl.rho1),
-                       (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO),
-                       (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), amax,
-                       (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC),
-                       (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk);
+#define MM_PAIRVEC_ARGS                                                                                                     \
+    (const double*)(packed + ml.Zt64), (const double*)(packed + ml.zbar), ls2, L, M, wl.Mp, d, wl.P, mu, pairmat,            \
+    (const double*)(ws + wl.rho1), (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO), \
+    (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), amax,                                      \
+    (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC), (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk
+    if constexpr (DK <= 8) {
+      hipLaunchKernelGGL((k_pairvec_reg<T, DK>), dim3(nsplit, wl.P, B), dim3(256), 0, s, MM_PAIRVEC_ARGS);
+    } else {
+      hipLaunchKernelGGL((k_pairvec<T, DK>), dim3(nsplit, wl.P, B), dim3(256), 0, s, MM_PAIRVEC_ARGS);
+    }
+#undef MM_PAIRVEC_ARGS
   }
   MM_CHECK_LAUNCH();
   if (sizeof(T) == 4 && wl.Po > 0) {

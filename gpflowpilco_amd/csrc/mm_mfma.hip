@@ -196,6 +196,15 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
   mm_decode_pair_o(p, L, a, a2);
 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  if constexpr (ND8 == 1) {
+    // Cauchy-Schwarz already bounds every |b_ij| of this (b, pair) by 1/16: the remainder is the first tier's
+    // c0 x^3 + c1 x^4 everywhere, which the moments carry (k_spoly) -- every tile would be skipped: no sweep at all
+    if (!force_worst && zmax2 && mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) <= MM_INSIDE_BOUND2) {
+      for (int panel = pgrp * ppw + (int)threadIdx.x; panel < npanel && panel < (pgrp + 1) * ppw; panel += 256)
+        partB[((size_t)b * P + p) * NS + panel] = 0.0;
+      return;
+    }
+  }
   extern __shared__ __align__(16) char zlds[];     // LDSZ: [Mp/32 tiles][2 parts (h, m)][32 columns][16 ND8 bytes]
   if constexpr (LDSZ) {
     // the first two parts of every tile are contiguous in the packed model ([tile][h, m, l][32][16 ND8]): copy

@@ -325,19 +325,23 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
 
 // ---------------------------------------------------------------------------------------------
 // mm_offdiag_stats: how many (b, off-diagonal pair) items of the last mm_q_forward are collapsed (bench.py reports
-// it with the timing: the reduce kernels' time depends on the regime).  out: device int32[2] = {collapsed, total}.
+// it with the timing: the reduce kernels' time depends on the regime).  out: device int32[4] = {collapsed, total,
+// wholly inside the collapsed range (no tile work at all), 0}.
 // ---------------------------------------------------------------------------------------------
 __global__ void k_offdiag_stats(const unsigned int* __restrict__ amax, const double* __restrict__ zmax2, int L, int Po, int n,
                                 int32_t* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  bool c = false;
+  bool c = false, in = false;
   if (idx < n) {
     int a, a2;
     mm_decode_pair_m(L + idx % Po, L, a, a2);
-    c = mm_collapse_bound2(amax[idx], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
+    const float b2 = mm_collapse_bound2(amax[idx], zmax2[a2]);
+    c = b2 <= MM_COLLAPSE_BOUND2;
+    in = b2 <= MM_INSIDE_BOUND2;
   }
-  const unsigned long long m = __ballot(c);
+  const unsigned long long m = __ballot(c), mi = __ballot(in);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (int)__popcll(m));
+  if ((threadIdx.x & 63) == 0 && mi) atomicAdd(out + 2, (int)__popcll(mi));
   if (idx == 0) out[1] = n;
 }
 
@@ -348,7 +352,7 @@ extern "C" int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, 
   const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
   if (packed_bytes < ml.Cm || workspace_bytes < wl.total) return MM_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(int32_t), s);
+  hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(int32_t), s);
   if (e != hipSuccess) return (int)e;
   if (dtype != MM_F32 || wl.Po == 0 || mm_moment_deg(d) < 4 || (flags & MM_FORCE_WORST_TIER)) return 0;   // nothing collapses
   const int n = B * wl.Po;

@@ -179,15 +179,17 @@ def Q_reduce_forward(pm: PackedModel, B: int, flags: int, jitter: float = 0.0):
 
 
 def offdiag_stats(pm: PackedModel, B: int, flags: int):
-  """(collapsed, total) (b, off-diagonal pair) items of the last ``q_forward`` / ``moment_match`` with this B and flags
-  (f32 models with d <= 8; (0, 0) otherwise).  Synchronises."""
+  """(collapsed, total, wholly inside) (b, off-diagonal pair) items of the last ``q_forward`` / ``moment_match`` with
+  this B and flags (f32 models with d <= 8; zeros otherwise): items whose cubic + quartic remainder terms come from
+  the f64 moments, all items, and collapsed items whose Cauchy-Schwarz bound puts every |b| <= 1/16 (the tile kernel
+  does nothing for them).  Synchronises."""
   ws = pm.workspace(B, flags)
-  out = torch.zeros(2, dtype=torch.int32, device=pm.device)
+  out = torch.zeros(4, dtype=torch.int32, device=pm.device)
   rc = lib().mm_offdiag_stats(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, flags,
                               ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(pm.device))
   check(rc, "mm_offdiag_stats")
-  c, n = out.tolist()
-  return c, n
+  c, n, inside, _ = out.tolist()
+  return c, n, inside
 
 
 def euler_update(mu, Sigma, f1, Sff, cross_pre, dt: float = 1.0):

@@ -136,7 +136,8 @@ int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
 
 /* Diagnostic: after mm_q_forward (f32 model, d <= 8), how many (batch element, off-diagonal pair) items take the
  * moment collapse of csrc/mm_moments.hip (cubic + quartic term of the remainder from f64 moments, tiles with
- * max |b| <= 1/16 skipped).  out: device int32[2] = {collapsed, total}; {0, 0} where the collapse does not apply. */
+ * max |b| <= 1/16 skipped), and for how many of those the Cauchy-Schwarz bound alone puts every |b| <= 1/16 (no tile
+ * work at all).  out: device int32[4] = {collapsed, total, wholly inside, 0}; zeros where the collapse does not apply. */
 int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
                      const void* workspace, size_t workspace_bytes, int32_t* out, void* stream);
 
