@@ -46,6 +46,13 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
 #ifndef MM_TWO_WAY_MAX
 #define MM_TWO_WAY_MAX 0.03125f
 #endif
+// LDS-staged sweep: workgroups per (b, pair), each paying the 64 KB fill for its share of the row panels.  Measured
+// at C3 (off-diagonal segment, pilco / BASELINE recipe): 1 -> 0.574 / 6.66 ms, 2 -> 0.444 / 6.27, 4 -> 0.380 / 6.19,
+// 8 -> 0.420 / 6.31: with most (b, pair) items leaving at once (wholly inside the collapsed range) the few that sweep
+// are the grid's tail, and finer items balance it
+#ifndef MM_F32_PPW_DIV
+#define MM_F32_PPW_DIV 4
+#endif
 #ifndef MM_F32_WAVES
 #define MM_F32_WAVES 2
 #endif
@@ -467,7 +474,7 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
   // LDS-staged: one workgroup per (b, pair) (the fill is paid once) as long as that still leaves >= 8 rounds of
   // 512 resident workgroups; else one per panel
   int ppw = 1;
-  if (ldsz && (long long)wl.Po * B >= 4096) ppw = npanel;
+  if (ldsz && (long long)wl.Po * B >= 4096) ppw = (npanel + MM_F32_PPW_DIV - 1) / MM_F32_PPW_DIV;
   const long long nwork_ll = (long long)((npanel + ppw - 1) / ppw) * wl.Po * B;
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const int nwork = (int)nwork_ll;

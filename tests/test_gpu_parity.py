@@ -422,24 +422,26 @@ def test_latents_with_different_active_dims_match_quadrature(device):
 
 
 def test_offdiag_regimes_inside_collapsed_dense(device):
-  """The three regimes of the f32 off-diagonal reduce (csrc/mm_mfma.hip, mm_moments.hip) on one model, each against
-  the oracle: a narrow state (the Cauchy-Schwarz bound puts every |b| <= 1/16: no tile work, all of the remainder in
-  the f64 moments), a medium one (collapsed, tiles screened) and a wide one (not collapsed: every tile reduced).
-  ops.offdiag_stats must report the regime that the inputs were built for."""
+  """The three regimes of the f32 off-diagonal reduce (csrc/mm_mfma.hip, mm_moments.hip), each against the oracle:
+  a narrow state (the Cauchy-Schwarz bound puts every |b| <= 1/16: no tile work, all of the remainder in the f64
+  moments), wider ones (collapsed, tiles screened) and -- with short lengthscales, where G = Lam^-1 T Lam'^-1 is
+  large -- items that are not collapsed (every tile reduced).  ops.offdiag_stats reports the regime."""
   L, M, d, B = 3, 300, 4, 4
-  syn = make_svgp(L, M, d, seed=4242, ls_bounds=(0.7, 2.0))
-  pm = syn.to_model(device).packed(torch.float32, True, device)
+  n = B * (L * (L - 1) // 2)
   flags = ops.make_flags(True, True, False)
-  Po = L * (L - 1) // 2
   seen = []
-  for scale in (0.01, 0.12, 1.2):
-    mu, Sigma = make_inputs(B, d, seed=11, scale=scale, lo=0.3, hi=0.7)
-    _, Sffo, _ = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
-    _, Sff, _ = ops.moment_match(pm, to_dev(mu, device, torch.float32), to_dev(Sigma, device, torch.float32))
-    collapsed, total, inside = ops.offdiag_stats(pm, B, flags)
-    assert total == B * Po and inside <= collapsed <= total
-    seen.append((collapsed, inside))
-    assert scale_err(Sff, Sffo) < (TOL[torch.float32]["Sff"] if scale < 1.0 else 2e-3), (scale, collapsed, inside)
-  assert seen[0] == (B * Po, B * Po), seen          # narrow: every item wholly inside
-  assert seen[1][0] == B * Po and seen[1][1] < B * Po, seen      # medium: collapsed, tiles screened
-  assert seen[2][0] < B * Po and seen[2][1] == 0, seen           # wide: some item is reduced densely
+  for ls_bounds, scales, tol in (((0.7, 2.0), (0.01, 0.12, 0.25, 0.6), TOL[torch.float32]["Sff"]),
+                                 ((0.2, 0.45), (0.3, 0.8), 2e-3)):     # |delta| > 1: the exp2 branch, as test_large_delta_slow_path_f32
+    syn = make_svgp(L, M, d, seed=4242, ls_bounds=ls_bounds)
+    pm = syn.to_model(device).packed(torch.float32, True, device)
+    for scale in scales:
+      mu, Sigma = make_inputs(B, d, seed=11, scale=scale, lo=0.3, hi=0.7)
+      _, Sffo, _ = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
+      _, Sff, _ = ops.moment_match(pm, to_dev(mu, device, torch.float32), to_dev(Sigma, device, torch.float32))
+      collapsed, total, inside = ops.offdiag_stats(pm, B, flags)
+      assert total == n and inside <= collapsed <= total
+      seen.append((collapsed, inside))
+      assert scale_err(Sff, Sffo) < tol, (ls_bounds, scale, collapsed, inside)
+  assert seen[0] == (n, n), seen                                  # narrow: every item wholly inside
+  assert any(c == n and i < n for c, i in seen), seen             # collapsed, tiles screened
+  assert any(c < n for c, i in seen), seen                        # some item reduced densely
