@@ -35,6 +35,9 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define MM_LOWP_D1 8
 #define MM_LOWP_D2 10
 #endif
+#ifndef MM_F64_TARGET_WGS
+#define MM_F64_TARGET_WGS 8192
+#endif
 #define MM_F64_NB 16      // batch elements whose partial sums are staged in LDS between workgroup reductions
 // diagonal pairs with the rank-one terms factored into the weights need ~100 fewer VGPRs: three waves per SIMD
 // up to this many K = 4 steps (d <= 4 MM_F64_3WAVE_KS4)
@@ -380,7 +383,7 @@ int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double*
   if (nslots > NS) return MM_E_WORKSPACE;
   // batch chunk: enough workgroups to fill the chip evenly (>= ~32 per CU), as few C re-reads as possible
   long long per_chunk = (long long)nslots * npairs;
-  int nchunk = (int)((8192 + per_chunk - 1) / per_chunk);    // >= 16 rounds of 512 resident workgroups: short tail
+  int nchunk = (int)((MM_F64_TARGET_WGS + per_chunk - 1) / per_chunk);    // >= 16 rounds of 512 resident workgroups: short tail
   if (nchunk > B / 16) nchunk = B / 16;      // keep >= 16 batch elements per C tile load
   if (nchunk < 1) nchunk = 1;
   if (!diag) {                               // no C reuse to protect: ~24 workgroups per CU, but chunks long
