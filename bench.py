@@ -130,6 +130,19 @@ def load_pmc(tag):
   return pmc, os.path.relpath(path, ROOT)
 
 
+def pmc_scale(pmc, pmc_src, units_now, units_default):
+  """Counters are per launch of the profiled run.  Every grid of a step is linear in the per-rank batch (B or S), so a
+  run with another batch scales them by units_now / units_profiled -- and says so in the `pmc` field."""
+  if pmc is None:
+    return 1.0, pmc_src
+  import re
+  m = re.search(r"--batch\s+(\d+)", pmc.get("bench_args", ""))
+  prof = int(m.group(1)) if m else units_default
+  if prof == units_now:
+    return 1.0, pmc_src
+  return units_now / prof, f"{pmc_src} (collected at {prof} batch units per launch, scaled x{units_now / prof:g}: every grid of the step is linear in the batch)"
+
+
 def pmc_kernel(pmc, prefix):
   """Counters of the kernel whose short name starts with ``prefix`` (the instantiation with the most time)."""
   if pmc is None:
@@ -358,6 +371,7 @@ def main():
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
   pm.check_status(B)
+  rollouts_timed = state["rollouts"]
   # regime of the off-diagonal reduce over one (untimed) rollout: its kernels' time depends on it
   collapsed = [0, 0, 0]
   if dtype == torch.float32 and not args.pmc_run:
@@ -378,6 +392,7 @@ def main():
   Po = L * (L - 1) // 2
   f32_mode = dtype == torch.float32
   pmc, pmc_src = load_pmc(args.config if recipe_name == cfg["recipe"] else f"{args.config}_{recipe_name}")
+  pscale, pmc_src = pmc_scale(pmc, pmc_src, B, cfg["B"])
   e_off = float(B) * Po * M * M
   e_diag = float(B) * L * M * (M + 1) / 2
 
@@ -404,17 +419,15 @@ def main():
       return r
     name, ent = got
     ce = executed_ceiling(ent, "bf16" if f32k else "f64")
-    # counters are per dispatch of the profiled run; scale to this run's launch by entries (same config => factor 1)
-    scale = entries / ent["entries"] if ent.get("entries") else 1.0
-    ceiling_ms = ce["ceiling_ms"] * scale
+    ceiling_ms = ce["ceiling_ms"] * pscale
     frac = ceiling_ms / k_ms if k_ms > 0 else None
     r.update({"kernel": name, "frac": round(frac, 4), "achieved": round(peak * frac, 2),
               "ceiling_ms": round(ceiling_ms, 4),
               "frac_definition": "executed-work ceiling / measured kernel time; ceiling = (MFMA pipe cycles + VALU issue cycles "
                                  "that cannot hide beside the MFMAs, by instruction class: tools/ubench_gap.hip) / 1024 SIMDs / 2.4 GHz "
                                  "from the kernel's own hardware counters; `achieved` = peak x frac",
-              "instruction_mix_per_launch": {k: round(v, 1) for k, v in ce["mix"].items()},
-              "traffic": ent["counters"].get("hbm_bytes"), "pmc": pmc_src})
+              "instruction_mix_per_launch": {k: round(v * pscale, 1) for k, v in ce["mix"].items()},
+              "traffic": ent["counters"]["hbm_bytes"] * pscale if "hbm_bytes" in ent["counters"] else None, "pmc": pmc_src})
     c = ent["counters"]
     if "SQ_BUSY_CYCLES" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
       r["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / (c["GRBM_GUI_ACTIVE"] / 8.0), 4) if c.get("GRBM_GUI_ACTIVE") else None
@@ -429,7 +442,7 @@ def main():
     for pre in ("k_qvec", "k_pairvec", "k_wmom_gemm", "k_spoly"):
       got = pmc_kernel(pmc, pre)
       if got and "hbm_bytes" in got[1]["counters"]:
-        qroof["per_kernel"][got[0]] = {"hbm_bytes": got[1]["counters"]["hbm_bytes"]}
+        qroof["per_kernel"][got[0]] = {"hbm_bytes": got[1]["counters"]["hbm_bytes"] * pscale}
 
   out = {
       "metric": "moment_matched_rollout_step_elements_per_sec",
@@ -442,7 +455,7 @@ def main():
       "config": {"workload": f"{cfg['label']}; recipe={recipe_name}: {rec['text']}",
                  "N": M, "d": d, "D": L, "H": H, "B_per_gpu": B if scaling == "weak" else None, "B_total": B_total,
                  "B_this_rank": B, "parallelism": f"dp{world} over B ({scaling})", "recipe": recipe_name,
-                 "rollouts_timed": state["rollouts"], "collectives_timed": state["rollouts"] if world > 1 else 0,
+                 "rollouts_timed": rollouts_timed, "collectives_timed": rollouts_timed if world > 1 else 0,
                  "steps_requested": args.steps,
                  "diag_pairs": "f64", "offdiag_pairs": cfg["dtype"],
                  "offdiag_items_one_rollout": {"collapsed": collapsed[0], "wholly_inside": collapsed[2], "total": collapsed[1],
@@ -719,6 +732,7 @@ def pathwise_bench(args, rank, world, dev, dist):
   bytes_per_launch = float(S) * L * (K + M) * 4
   achieved = bytes_per_launch / (k_ms * 1e-3) / 1e9
   pmc, pmc_src = load_pmc("c5")
+  pscale, pmc_src = pmc_scale(pmc, pmc_src, S, c["S"])
   got = pmc_kernel(pmc, "k_pathwise")
   out = {"metric": "pathwise_rollout_sample_steps_per_sec", "value": round(S_total * steps / elapsed, 1),
          "unit": "sample step-elements/s (S*H per rollout second)", "n_gpus": world, "steps": steps,
@@ -729,7 +743,7 @@ def pathwise_bench(args, rank, world, dev, dist):
                     "steps_requested": args.steps},
          "roofline": {"bound": "hbm", "kernel": "k_pathwise", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS,
                       "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 4),
-                      "traffic": got[1]["counters"].get("hbm_bytes") if got else None, "pmc": pmc_src,
+                      "traffic": got[1]["counters"]["hbm_bytes"] * pscale if got and "hbm_bytes" in got[1]["counters"] else None, "pmc": pmc_src,
                       "kernel_ms": round(k_ms, 4), "bytes_per_launch": bytes_per_launch,
                       "note": "achieved = algorithmic bytes S*L*(K+M)*4 per step / step time (the step time includes the small cost kernels "
                               "between launches)"}}

@@ -68,3 +68,15 @@ def test_bench_ceiling_and_staleness(tmp_path, monkeypatch):
   pmc, src = bench.load_pmc("c3")
   assert pmc is not None and bench.pmc_kernel(pmc, "k_x")[0] == "k_x<1>" and bench.pmc_kernel(pmc, "k_y") is None
   assert bench.load_pmc("c9")[0] is None
+
+
+def test_pmc_counters_scale_with_the_batch_of_the_run():
+  """bench.pmc_scale: counters collected at another per-rank batch are scaled linearly and the `pmc` field says so."""
+  import bench
+  pmc = {"bench_args": "--config c4 --batch 32"}
+  assert bench.pmc_scale(pmc, "profiles/x.json", 32, 256) == (1.0, "profiles/x.json")
+  sc, note = bench.pmc_scale(pmc, "profiles/x.json", 256, 256)
+  assert sc == 8.0 and "scaled x8" in note and "collected at 32" in note
+  assert bench.pmc_scale({"bench_args": "--config c3"}, "p", 256, 256) == (1.0, "p")
+  assert bench.pmc_scale({"bench_args": "--config c3"}, "p", 64, 256)[0] == 0.25
+  assert bench.pmc_scale(None, "not collected", 64, 256) == (1.0, "not collected")
