@@ -53,14 +53,15 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
 #ifndef MM_F32_PPW_DIV
 #define MM_F32_PPW_DIV 4
 #endif
+// collapsed items with bound^2 above this sweep without screening (see the kernel)
+#ifndef MM_SCREEN_BOUND2
+#define MM_SCREEN_BOUND2 0.0225f
+#endif
 #ifndef MM_F32_WAVES
 #define MM_F32_WAVES 2
 #endif
 // 1: one column sweep for collapsed and dense (b, pair) items alike (the (l | h) parts always prefetched);
 // 0: a second instantiation for collapsed items that fetches them on demand
-#ifndef MM_F32_SINGLE_SWEEP
-#define MM_F32_SINGLE_SWEEP 0
-#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct mm_true { static constexpr bool value = true; };
@@ -249,7 +250,6 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // collapsed (b, pair)?  Cauchy-Schwarz: |b_ij| <= |A_i| |zc_j| <= sqrt(bound2); the same predicate as k_spoly
     const float bound2 = zmax2 ? mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) : 3.0e38f;
     const bool coll = (ND8 == 1) && !force_worst && bound2 <= MM_COLLAPSE_BOUND2;
-    const float sub0 = coll ? MM_REM1_C0 : 0.0f, sub1 = coll ? MM_REM1_C1 : 0.0f;
     // a tile is skipped on the screening product alone: its error is <= 2^-9 sum_k |A_k||Z_k| <= 2^-9 sqrt(bound2)
     const float thr_skip = 0.0625f - 0.00390625f * __builtin_sqrtf(bound2) - 1e-6f;
 
@@ -366,16 +366,20 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     };
     // b_ij = acc: a pure bilinear form (rho'_i, gamma_j live in the weights); tile range -> tier.
     // (sub0, sub1) = (c0, c1) of the first tier for a collapsed (b, pair) -- already in the moments -- else (0, 0).
-    auto reduce_tile = [&](const f32x16 (&acc)[2], float mx, float wc) {
+    // collm (compile time): the (b, pair) is collapsed -- the moments already carry c0 x^3 + c1 x^4 of the first tier
+    auto reduce_tile = [&](auto collm, const f32x16 (&acc)[2], float mx, float wc) {
+      constexpr bool CC = decltype(collm)::value;
+      constexpr float sub0 = CC ? MM_REM1_C0 : 0.0f, sub1 = CC ? MM_REM1_C1 : 0.0f;
       f32x2 xx[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
       f32x2 part2;
       // wave-uniform tier choice (ballots, no cross-lane reduction)
       if (!__any(mx > 0.0625f)) {
-        // reached only by a (b, pair) that is not collapsed (a collapsed one has nothing left to add in this tier)
+        // a collapsed (b, pair) has nothing left to add in this tier (the moments carry c0 x^3 + c1 x^4)
         // (the folded coefficients cost 64 more VGPRs: only where the operand registers leave room, d <= 8)
-        if constexpr (ND8 == 1) part2 = mm_weighted_rem1(xx, wc0, wc1);
+        if constexpr (CC) part2 = (f32x2){0.0f, 0.0f};
+        else if constexpr (ND8 == 1) part2 = mm_weighted_rem1(xx, wc0, wc1);
         else part2 = mm_weighted_rem<1>(xx, wrow, 0.0f, 0.0f);
       } else if (!__any(mx > 0.25f)) {
         part2 = mm_weighted_rem<3>(xx, wrow, sub0, sub1);
@@ -394,7 +398,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
             const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
             const float big = (__builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f) - fmaf(0.5f * x, x, x);
             float e = (fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big;
-            if (coll) e -= (x * x) * x * fmaf(sub1, x, sub0);    // wave-uniform; a collapsed pair has |b| <= 1 + rounding
+            if constexpr (CC) e -= (x * x) * x * fmaf(sub1, x, sub0);    // a collapsed pair has |b| <= 1 + rounding
             part2[e2] = fmaf(wrow[r >> 3][r & 7][e2], e, part2[e2]);
           }
       }
@@ -402,20 +406,20 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     };
     // one wave tile: screening product; a collapsed (b, pair) stops here when the whole tile is inside the collapsed
     // range; else the rest of the split product, the range tier and the weighted reduction
-    auto process_tile = [&](auto collc, int ct, const u32x4 (&zA)[ND8], u32x4 (&zB)[ND8], float wc) __attribute__((always_inline)) {
-      // (a collapsed (b, pair) prefetches neither the column weight nor the (l | h) parts: few of its tiles need them,
-      // and a prefetched global load would put its latency on every tile of a sweep that is otherwise 2 MFMAs long)
+    // collc (compile time): SCREENED sweep -- the screening check, and neither the column weight nor the (l | h) parts
+    // prefetched (few tiles of such an item need them, and a prefetched global load would put its latency on every tile
+    // of a sweep that is otherwise 2 MFMAs long); collm: collapsed coefficients (reduce_tile)
+    auto process_tile = [&](auto collc, auto collm, int ct, const u32x4 (&zA)[ND8], u32x4 (&zB)[ND8], float wc) __attribute__((always_inline)) {
       constexpr bool CM = decltype(collc)::value;
-      const bool cm = CM || (MM_F32_SINGLE_SWEEP && coll);
       f32x16 acc[2];
       mfma_tile_screen(zA, acc);
-      if (cm) {
+      if constexpr (CM) {
         const float ms = tile_max(acc);
         if (!__any(ms > thr_skip)) return;
       }
       mfma_tile_m(zA, acc);
       const float mx = force_worst ? 2.0f : tile_max(acc);       // MM_FORCE_WORST_TIER: wave-uniform override
-      if (cm) {
+      if constexpr (CM) {
         if (!__any(mx > 0.0625f)) return;                        // first tier of a collapsed pair: all in the moments
       }
       if constexpr (CM) wc = wcf[ct * 32 + l31];
@@ -423,13 +427,13 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
         if constexpr (CM) load_zB(ct, zB);
         mfma_tile_l(zB, acc);
       }
-      reduce_tile(acc, mx, wc);
+      reduce_tile(collm, acc, mx, wc);
     };
 
     // two-stage register ping-pong: tile ct + 1 is in flight while tile ct is reduced.  (Issuing the MFMAs
     // of tile ct + 1 interleaved with the v_max3 range check of tile ct -- a second accumulator set,
     // 182 VGPRs -- was measured: 4.27 ms against 4.25 ms; three waves per SIMD already overlap the two.)
-    auto sweep = [&](auto collc) __attribute__((always_inline)) {
+    auto sweep = [&](auto collc, auto collm) __attribute__((always_inline)) {
       constexpr bool CM = decltype(collc)::value;
       u32x4 zA0[ND8], zB0[ND8], zA1[ND8], zB1[ND8];
       float w0, w1;
@@ -439,14 +443,22 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
       for (int ct = 0; ct < nct; ct += 2) {
         load_zA(ct + 1, zA1);
         if constexpr (!CM) { load_zB(ct + 1, zB1); w1 = wcf[(ct + 1) * 32 + l31]; }
-        process_tile(collc, ct, zA0, zB0, w0);
+        process_tile(collc, collm, ct, zA0, zB0, w0);
         const int cn = ct + 2 < nct ? ct + 2 : ct;               // clamped: the last pass re-reads its own tile
         load_zA(cn, zA0);
         if constexpr (!CM) { load_zB(cn, zB0); w0 = wcf[cn * 32 + l31]; }
-        process_tile(collc, ct + 1, zA1, zB1, w1);
+        process_tile(collc, collm, ct + 1, zA1, zB1, w1);
       }
     };
-    if (!MM_F32_SINGLE_SWEEP && coll) sweep(mm_true{}); else sweep(mm_false{});
+    // a collapsed (b, pair) whose bound is well above 1/16 skips almost no tile (measured on the BASELINE recipe,
+    // scratch statistics in DESIGN.md: bound <= 0.12 -> < 12 % of the tiles exceed 1/16, bound >= 0.18 -> > 90 %):
+    // it takes the prefetching sweep -- no screening check, operands of the next tile always in flight -- with the
+    // collapsed coefficients
+    // (three instantiations: a non-collapsed item must not pay for the collapsed coefficients -- as a run-time flag
+    // they cost the exp2 branch 4 more ops per entry: forced-worst C3 12.5 -> 16.8 ms)
+    if (coll && bound2 <= MM_SCREEN_BOUND2) sweep(mm_true{}, mm_true{});
+    else if (coll) sweep(mm_false{}, mm_true{});
+    else sweep(mm_false{}, mm_false{});
   }
   // workgroup reduction -> slab
 #pragma unroll

@@ -158,11 +158,12 @@ def test_gpu_policy_rollout_matches_oracle(dtype, device):
   system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=encoder,
                                     solver=dynamics.MomentMatchingEuler())
   x = _mom(mu, S, device, dtype)
-  tol = 1e-7 if dtype == torch.float64 else 5e-3
+  tol = 1e-7 if dtype == torch.float64 else 5e-4
   md, _ = system.forward(0.0, x)
   assert md.cross[1] is False
-  assert scale_err(md.y.mean(), mo_["y"][0]) < tol and scale_err(md.y.covariance(), co.covariance(mo_["y"])) < tol
-  assert scale_err(md.cross[0], mo_["cross"][0]) < tol
+  errs = [scale_err(md.y.mean(), mo_["y"][0]), scale_err(md.y.covariance(), co.covariance(mo_["y"])),
+          scale_err(md.cross[0], mo_["cross"][0])]
+  assert max(errs) < tol, errs
 
   def accumulate(t, state, loss):                                    # loops/pilco.py:199-205
     e = moment_matching(GaussianMoments(state, centered=True), encoder).y
@@ -171,8 +172,8 @@ def test_gpu_policy_rollout_matches_oracle(dtype, device):
                              solution_times=np.arange(1.0, H + 1.0), iterator="foldl",
                              callbacks_and_initializers=[(accumulate, torch.zeros(2, dtype=dtype, device=device))])
   (m_H, S_H), loss = out[0], out[1]
-  assert scale_err(m_H, traj_o[-1][0]) < tol and scale_err(S_H, traj_o[-1][1]) < tol
-  assert scale_err(loss, loss_o) < tol
+  errs = [scale_err(m_H, traj_o[-1][0]), scale_err(S_H, traj_o[-1][1]), scale_err(loss, loss_o)]
+  assert max(errs) < tol, errs
   # the same through the MomentMatchingPILCO harness (loops/pilco.py:176-220)
   from gpflowpilco_amd.loops import get_state_initializer, policy_loss_closure
   closure = policy_loss_closure(system, objective, get_state_initializer(x.mean(), x.covariance()), H, native=False)

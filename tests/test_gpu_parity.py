@@ -445,3 +445,29 @@ def test_offdiag_regimes_inside_collapsed_dense(device):
   assert seen[0] == (n, n), seen                                  # narrow: every item wholly inside
   assert any(c == n and i < n for c, i in seen), seen             # collapsed, tiles screened
   assert any(c < n for c, i in seen), seen                        # some item reduced densely
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_diagonal_operator_input_covariance(dtype, device):
+  """Row a-2 (`_moments_to_gpflow_distrib`, moment_matching/models.py:302-311): an input whose covariance is a
+  diagonal LINEAR OPERATOR (what the diagonal-output handlers and the NormalCDF head return) enters a GP handler;
+  the reference re-expands it with tf.linalg.diag (kernel_expectation.py:100-103).  Same outputs as the dense
+  diagonal matrix, and equal to the oracle."""
+  from gpflowpilco_amd.moment_matching import LinearOperatorDiag
+  L, M, d, B = 3, 70, 4, 3
+  syn = make_svgp(L, M, d, seed=909)
+  rng = np.random.default_rng(5)
+  mu = rng.uniform(0.2, 0.8, size=(B, d))
+  var = rng.uniform(0.01, 0.06, size=(B, d))
+  Sigma = np.stack([np.diag(v) for v in var])
+  f1o, Sffo, cro = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
+  model = syn.to_model(device)
+  x_op = GaussianMoments((to_dev(mu, device, dtype), LinearOperatorDiag(to_dev(var, device, dtype))), centered=True)
+  x_dn = GaussianMoments((to_dev(mu, device, dtype), to_dev(Sigma, device, dtype)), centered=True)
+  m_op, m_dn = moment_matching(x_op, model), moment_matching(x_dn, model)
+  tol = TOL[dtype]
+  assert torch.equal(m_op.y.mean(), m_dn.y.mean()) and torch.equal(m_op.y.covariance(), m_dn.y.covariance())
+  assert torch.equal(m_op.cross[0], m_dn.cross[0])
+  assert scale_err(m_op.y.mean(), f1o) < tol["f1"] and scale_err(m_op.y.covariance(), Sffo) < tol["Sff"]
+  assert scale_err(m_op.cross[0], cro) < tol["cross"]
+  assert scale_err(m_op.cross_covariance(), Sigma @ cro) < tol["cross"]
