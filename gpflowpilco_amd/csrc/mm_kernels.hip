@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_pairvec: streamed operands of the reduce.  grid (Mp/256, P, B)
+// k_pairvec: streamed operands of the reduce for d > 8 (d <= 8: k_pairvec_reg below).  grid (nsplit, P, B)
 // ---------------------------------------------------------------------------------------------
 template <typename T, int DK>
 __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64, const double* __restrict__ zbar,
@@ -492,6 +492,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
                                                  double* __restrict__ whC, unsigned int* __restrict__ amax,
                                                  const double* __restrict__ q64, double* __restrict__ qhR,
                                                  double* __restrict__ qhC, int with_unc, int nblk) {
+  static_assert(DK > 8, "d <= 8 takes k_pairvec_reg");
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
   // pair's matrix is fetched once per workgroup, not once per chunk
   const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
@@ -501,93 +502,36 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   //   zeta_i^T D_row zeta_i   = rho1_a[i]  - sum_k zeta_ik  A_ik Lam_a',k / Lam_a,k
   //   zeta'_j^T D_col zeta'_j = rho1_a'[j] - sum_k zeta'_jk g_jk Lam_a,k  / Lam_a',k
   // (D_row = E_a - Lam_a^-1 T Lam_a^-1, T Lam_a^-1 zeta = Lam_a' A; rho1 = zeta^T E zeta comes from k_qvec),
-  // so only G is needed per pair.  For d <= 8 every thread keeps G in registers (128 VGPRs): the two
-  // mat-vecs per row are then pure register FMAs (staged in LDS, each FMA needed a broadcast ds_read and
-  // the loop was LDS-issue bound); for larger d, G is read from LDS row by row.
-  constexpr bool GREG = DK <= 8;
-  // the chunk loop is a load -> compute -> store chain per wave.  For d <= 8 the next chunk's operands are
-  // loaded (unconditionally, index-clamped) before the current chunk is processed, and the first chunk's
-  // before the workgroup's prologue (G fetch, LDS vectors, barrier); for larger d the extra live registers
-  // would halve the occupancy, so chunks are loaded in place.
-  constexpr bool PF = GREG;
+  // so only G is needed per pair.  As in k_pairvec_reg the SYMMETRIC T = Lam_a G Lam_a' is used on scaled vectors
+  // (s = zeta / Lam_a, s' = zeta' / Lam_a'; u = T s, v = T s'; A_i = u_i / Lam_a',i, g_i = v_i / Lam_a,i): one row of
+  // T read from LDS feeds both mat-vecs, where G needed a row for g and a (strided) column for A -- the loop was
+  // bound by those broadcast reads (C4 shard: 289 LDS instructions per 256-row chunk and wave).  In registers T would
+  // take DK (DK + 1) VGPRs, and a prefetched second operand set halves the occupancy at these d: loads are in place.
   const double* r1a = rho1 + ((size_t)b * L + a) * Mp;
   const double* r1b = rho1 + ((size_t)b * L + a2) * Mp;
-  struct Ops { double zr[DK], zc[DK], r1r, r1c, wr, wc; };
-  auto load_ops = [&](int mblk, Ops& o) {
-    int m = mblk * 256 + tid;
-    m = m < Mp ? m : Mp - 1;
-#pragma unroll
-    for (int k = 0; k < DK; ++k) {
-      const int kk = k < d ? k : 0;
-      o.zr[k] = Zt64[((size_t)a * d + kk) * Mp + m];        // dimension-major: coalesced over m
-      o.zc[k] = Zt64[((size_t)a2 * d + kk) * Mp + m];
-    }
-    o.r1r = r1a[m]; o.r1c = r1b[m];
-    o.wr = w64[((size_t)b * L + a) * Mp + m];
-    o.wc = w64[((size_t)b * L + a2) * Mp + m];
-  };
-  Ops cur, nxt;
-  if (PF) load_ops(blockIdx.x, cur);
-  __shared__ double Gs[GREG ? 1 : DK * DK];
-  __shared__ double vecs[7][DK];                             // mu, mu - zbar_a, mu - zbar_a', Lam_a'/Lam_a, Lam_a/Lam_a', 1/Lam_a, 1/Lam_a'
+  __shared__ __align__(16) double Ts[DK * DK];
+  __shared__ double vecs[5][DK];      // mu | 1/Lam_a | 1/Lam_a' | (mu - zbar_a') / Lam_a' | (mu - zbar_a) / Lam_a
   const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
-  // GREG: G = Lam_a^-1 T Lam_a'^-1 with T SYMMETRIC, so the thread keeps the DK (DK + 1) / 2 distinct entries of
-  // T = Lam_a G Lam_a' (72 VGPRs at d = 8 instead of 128 for G) and scales the vectors instead:
-  //   A_i = (1 / Lam_a',i) sum_k T_ki (zeta_k / Lam_a,k),   g_i = (1 / Lam_a,i) sum_k T_ik (zeta'_k / Lam_a',k)
-  constexpr int NT = DK * (DK + 1) / 2;
-  double Tr[GREG ? NT : 1];
-  auto tsym = [](int i, int k) { return i <= k ? i * DK - i * (i - 1) / 2 + (k - i) : k * DK - k * (k - 1) / 2 + (i - k); };
-  if (GREG) {
-    // lane l of every wave loads padded entry l (one coalesced load), then the values are broadcast with v_readlane.
-    // (Uniform-address loads pm[in ? i * d + k : 0] compiled to 64 serialised s_load + s_waitcnt pairs behind ~1200
-    // SGPR spill moves: microseconds of prologue per workgroup.)
-    const int ln = tid & 63, li = ln / DK, lk = ln - li * DK;
-    const bool lin = li < d && lk < d && ln < DK * DK;
-    const double mine = lin ? pm[li * d + lk] * ls2[a * d + li] * ls2[a2 * d + lk] : 0.0;
-    const int mlo = __double2loint(mine), mhi = __double2hiint(mine);
-#pragma unroll
-    for (int i = 0; i < DK; ++i)
-#pragma unroll
-      for (int k = i; k < DK; ++k) {
-        double t = __hiloint2double(__builtin_amdgcn_readlane(mhi, i * DK + k), __builtin_amdgcn_readlane(mlo, i * DK + k));
-        // pinned to VECTOR registers: left uniform, the doubles want SGPRs the kernel does not have, and the compiler
-        // re-broadcasts them inside the chunk loop instead (290 v_readlane + 106 hazard s_nop per chunk against
-        // 250 f64 FMAs)
-        asm volatile("" : "+v"(t));
-        Tr[GREG ? tsym(i, k) : 0] = t;
-      }
-  } else {
-    for (int idx = tid; idx < DK * DK; idx += 256) {
-      const int i = idx / DK, k = idx - i * DK;
-      const bool in = i < d && k < d;
-      const double g = pm[in ? i * d + k : 0];
-      Gs[idx] = in ? g : 0.0;
-    }
+  for (int idx = tid; idx < DK * DK; idx += 256) {
+    const int i = idx / DK, k = idx - i * DK;
+    const bool in = i < d && k < d;
+    Ts[idx] = in ? pm[i * d + k] * ls2[a * d + i] * ls2[a2 * d + k] : 0.0;
   }
   if (tid < DK) {
     const int k = tid < d ? tid : 0;
     const double mv = (double)mu[(size_t)b * d + k];
     const double la = ls2[a * d + k], lb = ls2[a2 * d + k];
     vecs[0][tid] = tid < d ? mv : 0.0;
-    vecs[1][tid] = tid < d ? mv - zbar[a * d + k] : 0.0;    // the A operand is centred at zbar_a, not at mu_b
-    vecs[2][tid] = tid < d ? mv - zbar[a2 * d + k] : 0.0;
-    vecs[3][tid] = tid < d ? lb / la : 0.0;                  // Lam_a',k / Lam_a,k
-    vecs[4][tid] = tid < d ? la / lb : 0.0;
-    vecs[5][tid] = tid < d ? 1.0 / la : 0.0;
-    vecs[6][tid] = tid < d ? 1.0 / lb : 0.0;
+    vecs[1][tid] = tid < d ? 1.0 / la : 0.0;
+    vecs[2][tid] = tid < d ? 1.0 / lb : 0.0;
+    vecs[3][tid] = tid < d ? (mv - zbar[a2 * d + k]) / lb : 0.0;   // the A operand is centred at zbar_a', not at mu_b
+    vecs[4][tid] = tid < d ? (mv - zbar[a * d + k]) / la : 0.0;
   }
   __syncthreads();
   const double cst = pm[d * d];
   const bool diag = p < L;
   const int Po = P - L;
-  // f32 off-diagonal format (mm_mfma.hip).  With b_ij = A_i . zc^{a'}_j,
-  //   delta_ij = rho'_i + gamma_j + b_ij,  rho'_i = rho_i + const - A_i . (mu - zbar_a'),
-  // exp(delta) - 1 = e^{rho'_i} e^{gamma_j} (expm1(b_ij) + 1) - 1, hence
-  //   S = sum_ij what_i what'_j expm1(b_ij) + (sum_i what_i)(sum_j what'_j) - (sum_i w_i)(sum_j w'_j)
-  // with what_i = w_i e^{rho'_i}, what'_j = w'_j e^{gamma_j}: the M x M tile is a pure bilinear form.
-  // The f64 weights are kept as well: their moments against (1, zc, zc zc^T) give the O(M) correction
-  // and the linear + quadratic part of the sum exactly (k_wmoments / k_s12); the tile kernel only
-  // reduces the remainder expm1(b) - b - b^2/2 in f32.
+  // f32 off-diagonal format (mm_mfma.hip): see k_pairvec_reg
   const bool f32off = !diag && sizeof(T) == 4;
   T* rO = rowO + ((size_t)b * Po + (f32off ? p - L : 0)) * (size_t)(d + 1) * Mp;
   T* cO = colO + ((size_t)b * Po + (f32off ? p - L : 0)) * Mp;
@@ -600,59 +544,45 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   T* cbO = colO + ((size_t)b * Po + (diag ? 0 : p - L)) * (size_t)(d + 1) * Mp;
   float a2max = 0.0f;                                         // max_i |A_i|^2 over this thread's rows (f32 off-diagonal pairs)
   for (int mblk = blockIdx.x; mblk < nblk; mblk += gridDim.x) {
-    if (PF) load_ops(mblk + (int)gridDim.x < nblk ? mblk + (int)gridDim.x : mblk, nxt);
-    else load_ops(mblk, cur);
     const int m = mblk * 256 + tid;
-    // centred inducing inputs of row / column index m (zero beyond d or M)
+    if (m >= Mp) continue;
+    // (laundered LDS pointers: hoisted out of the chunk loop, the five vectors alone take 10 DK VGPRs)
+    typedef const __attribute__((address_space(3))) double* lds_cptr;
+    lds_cptr vl = (lds_cptr)&vecs[0][0], tl = (lds_cptr)Ts;
+    asm volatile("" : "+v"(vl), "+v"(tl));
+    // scaled centred inducing inputs of row / column index m (zero beyond d -- the scale vectors are -- or M)
     double zr[DK], zc[DK];
 #pragma unroll
     for (int k = 0; k < DK; ++k) {
-      zr[k] = (k < d && m < M) ? cur.zr[k] - vecs[0][k] : 0.0;
-      zc[k] = (k < d && m < M) ? cur.zc[k] - vecs[0][k] : 0.0;
+      const int kk = k < d ? k : 0;
+      const double vr = Zt64[((size_t)a * d + kk) * Mp + m];     // dimension-major: coalesced over m
+      const double vc = Zt64[((size_t)a2 * d + kk) * Mp + m];
+      zr[k] = (m < M) ? (vr - vl[k]) * vl[DK + k] : 0.0;
+      zc[k] = (m < M) ? (vc - vl[k]) * vl[2 * DK + k] : 0.0;
     }
-    const double r1r = cur.r1r, r1c = cur.r1c, wrv = cur.wr, wcv = cur.wc;
-    if (PF) cur = nxt;
-    if (m >= Mp) continue;
-    // A = G^T zr, g = G zc (for a diagonal pair G is symmetric and zr == zc: A == g)
+    const double r1r = r1a[m], r1c = r1b[m];
+    const double wrv = w64[((size_t)b * L + a) * Mp + m], wcv = w64[((size_t)b * L + a2) * Mp + m];
     double tA = 0.0, tg = 0.0, corrA = 0.0, corrg = 0.0;
     double asq = 0.0;
-    auto row = [&](int i, double av, double gv) {
+#pragma unroll 2      // not fully: the compiler would hoist all the LDS reads (> 256 VGPRs)
+    for (int i = 0; i < DK; ++i) {
+      double u = 0.0, v = 0.0;
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        const double t = tl[i * DK + k];
+        u = fma(t, zr[k], u);
+        v = fma(t, zc[k], v);
+      }
+      tA = fma(zr[i], u, tA);
+      tg = fma(zc[i], v, tg);
+      corrA = fma(vl[3 * DK + i], u, corrA);
+      corrg = fma(vl[4 * DK + i], v, corrg);
+      const double av = u * vl[2 * DK + i], gv = v * vl[DK + i];
       asq = fma(av, av, asq);
-      tA = fma(zr[i] * vecs[3][i], av, tA);
-      tg = fma(zc[i] * vecs[4][i], gv, tg);
-      corrA = fma(vecs[2][i], av, corrA);
-      corrg = fma(vecs[1][i], gv, corrg);
       if (i < d) {
         if (f32off) rO[(size_t)i * Mp + m] = (T)av;           // zero for the padding rows m >= M
         else if (diag) cbD[(size_t)i * Mp + m] = gv;
         else cbO[(size_t)i * Mp + m] = (T)gv;
-      }
-    };
-    if (GREG) {
-      double zrs[DK], zcs[DK];
-#pragma unroll
-      for (int k = 0; k < DK; ++k) { zrs[k] = zr[k] * vecs[5][k]; zcs[k] = zc[k] * vecs[6][k]; }
-#pragma unroll
-      for (int i = 0; i < DK; ++i) {
-        double av = 0.0, gv = 0.0;
-#pragma unroll
-        for (int k = 0; k < DK; ++k) {
-          const double t = Tr[GREG ? tsym(i, k) : 0];
-          gv = fma(t, zcs[k], gv);
-          av = fma(t, zrs[k], av);
-        }
-        row(i, av * vecs[6][i], gv * vecs[5][i]);
-      }
-    } else {
-#pragma unroll 2      // not fully: the compiler would hoist all the LDS reads (> 256 VGPRs)
-      for (int i = 0; i < DK; ++i) {
-        double av = 0.0, gv = 0.0;
-#pragma unroll
-        for (int k = 0; k < DK; ++k) {
-          gv = fma(Gs[(GREG ? 0 : i * DK + k)], zc[k], gv);
-          av = fma(Gs[(GREG ? 0 : k * DK + i)], zr[k], av);
-        }
-        row(i, av, gv);
       }
     }
     const double rho_q = (m < M) ? r1r - tA : 0.0;              // zeta_i^T D_row zeta_i

@@ -46,8 +46,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                       int nrb, int ncb, int nwork, int col_deg3,
                                                       const unsigned int* __restrict__ amax, const double* __restrict__ zmax2,
                                                       double* __restrict__ mom) {
-  // work item -> (pair, side, column block, k slice, row block); consecutive items (one XCD after the remap)
-  // share the table slice [k slice][column block] of one latent
+  // The GEMM of latent a: rows = every weight vector taken against a's table -- (L - 1) B of them: for partner
+  // a' > a the ROW side of pair (a, a'), for a' < a the COLUMN side of pair (a', a) -- so a 64-row block is full
+  // whatever B is (rows used to be the B elements of ONE (pair, side): half-empty blocks at the C4 shard's B = 32).
+  // work item -> (latent, column block, k slice, row block); consecutive items (one XCD after the remap) share the
+  // table slice [k slice][column block] of one latent
   const int orig = blockIdx.x;
   const int xcd = orig & 7, slot = orig >> 3;
   const int qn = nwork >> 3, rn = nwork & 7;
@@ -55,18 +58,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int rb = wi % nrb; wi /= nrb;
   const int ks = wi % MM_MOM_SPLIT; wi /= MM_MOM_SPLIT;
   const int cb = wi % ncb; wi /= ncb;
-  const int side = wi & 1, po = wi >> 1;
-  int a, a2;
-  mm_decode_pair_m(L + po, L, a, a2);
-  const double* W = side ? whC : whR;
-  const double* tab = Zm + (size_t)(side ? a2 : a) * Mp * KMp;
+  const int a = wi;
+  const int R = (L - 1) * B;                                // rows of this latent's GEMM
+  // row r -> (batch element, off-diagonal pair index, side, column latent of that pair)
+  auto row_item = [&](int r, int& b, int& po, int& side, int& acol) {
+    const int which = r / B;
+    b = r - which * B;
+    const int ap = which < a ? which : which + 1;           // partner latent
+    const int lo = ap < a ? ap : a, hi = ap < a ? a : ap;
+    po = lo * (L - 1) - lo * (lo - 1) / 2 + (hi - lo - 1);  // pairs (lo, hi), lo < hi, in mm_decode_pair order
+    side = ap < a ? 1 : 0;
+    acol = hi;
+  };
+  const double* tab = Zm + (size_t)a * Mp * KMp;
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, l15 = lane & 15, kq = lane >> 4;
   // a column block made of cubic / quartic monomials only is needed by collapsed (b, pair) items alone: the
-  // workgroup leaves when none of its 64 batch elements is collapsed (k_spoly then never reads those columns)
+  // workgroup leaves when none of its 64 rows belongs to one (k_spoly then never reads those columns)
   if (cb * MM_GEMM_NB >= col_deg3) {
-    const int bb = rb * MM_GEMM_RB + lane;
-    const bool c = amax != nullptr && bb < B && mm_collapse_bound2(amax[(size_t)bb * Po + po], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
-    if (!__any(c)) return;                                  // every wave evaluates the same 64 elements: uniform exit
+    const int r = rb * MM_GEMM_RB + lane;
+    bool c = false;
+    if (amax != nullptr && r < R) {
+      int b, po, side, acol;
+      row_item(r, b, po, side, acol);
+      c = mm_collapse_bound2(amax[(size_t)b * Po + po], zmax2[acol]) <= MM_COLLAPSE_BOUND2;
+    }
+    if (!__any(c)) return;                                  // every wave evaluates the same 64 rows: uniform exit
   }
   const int kslice = Mp / MM_MOM_SPLIT;                     // Mp % 128 == 0: a multiple of MM_GEMM_KB
   const int k_begin = ks * kslice, nkb = kslice / MM_GEMM_KB;
@@ -76,9 +92,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // global -> register staging: A: row ar, 8 consecutive k;  B: table row bk, 16 consecutive columns
   const int ar = tid >> 2, ak = (tid & 3) * 8;
-  int brow = rb * MM_GEMM_RB + ar;
-  brow = brow < B ? brow : B - 1;                           // rows past the batch recompute the last one (not stored)
-  const double* aptr = W + ((size_t)brow * Po + po) * Mp + k_begin + ak;
+  int arow = rb * MM_GEMM_RB + ar;
+  arow = arow < R ? arow : R - 1;                           // rows past the end recompute the last one (not stored)
+  int ab, apo, aside, aacol;
+  row_item(arow, ab, apo, aside, aacol);
+  const double* aptr = (aside ? whC : whR) + ((size_t)ab * Po + apo) * Mp + k_begin + ak;
   const int bk = tid >> 3, bc = (tid & 7) * 16;
   const int col0 = cb * MM_GEMM_NB + bc;
   const bool bvalid = col0 < KMp;                           // KMp % 16 == 0: a 16-column chunk is all in or all out
@@ -131,8 +149,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int b = rb * MM_GEMM_RB + rt * 16 + kq + 4 * r;
-      if (b >= B) continue;
+      const int row = rb * MM_GEMM_RB + rt * 16 + kq + 4 * r;
+      if (row >= R) continue;
+      int b, po, side, acol;
+      row_item(row, b, po, side, acol);
       double* o = mom + ((((size_t)b * Po + po) * 2 + side) * MM_MOM_SPLIT + ks) * KMp;
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) {
@@ -291,8 +311,9 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
                       int B, int L, int d, const void* mu_f32, int flags, hipStream_t stream) {
   const double* Zm = (const double*)(packed + ml.Zm);
   double* mom = (double*)(ws + wl.mom);
-  const int nrb = (B + MM_GEMM_RB - 1) / MM_GEMM_RB, ncb = (ml.KMp + MM_GEMM_NB - 1) / MM_GEMM_NB;
-  const long long nwork_ll = (long long)wl.Po * 2 * ncb * MM_MOM_SPLIT * nrb;
+  // per latent a GEMM with (L - 1) B rows (k_wmom_gemm): row blocks, column blocks, k slices
+  const int nrb = ((L - 1) * B + MM_GEMM_RB - 1) / MM_GEMM_RB, ncb = (ml.KMp + MM_GEMM_NB - 1) / MM_GEMM_NB;
+  const long long nwork_ll = (long long)L * ncb * MM_MOM_SPLIT * nrb;
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const int nwork = (int)nwork_ll;
   const int deg = mm_moment_deg(d);
