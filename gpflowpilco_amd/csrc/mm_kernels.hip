@@ -393,7 +393,6 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
   // P_a = (Sigma + Lambda_a)^-1 and E_a, zero padded to DK x DK: compile-time LDS offsets (wide broadcast reads)
   __shared__ double Pa[DK * DK], Ea[DK * DK];
   __shared__ double mub[DK];
-  __shared__ double red[4];
   __shared__ double sv[DK + 1];
   const double* lm = latmat + ((size_t)b * L + a) * (2 * d * d + 2);
   for (int idx = tid; idx < DK * DK; idx += 256) {
@@ -406,6 +405,28 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
   if (tid < DK) mub[tid] = tid < d ? (double)mu[(size_t)b * d + tid] : 0.0;
   __syncthreads();
   const double lognorm = lm[d * d];
+  // d <= 8: the two SYMMETRIC matrices live in registers as their upper triangles (2 x 36 doubles at d = 8), broadcast
+  // once per workgroup with v_readlane; a quadratic form is then sum_i z_i (M_ii z_i + 2 sum_{k>i} M_ik z_k):
+  // 44 register FMAs instead of 72 with one broadcast LDS read each (the loop was bound by those reads)
+  constexpr bool QREG = DK <= 8;
+  constexpr int NT = DK * (DK + 1) / 2;
+  double Pr[QREG ? NT : 1], Er[QREG ? NT : 1];
+  if constexpr (QREG) {
+    const int ln = tid & 63;
+    const double pmine = ln < DK * DK ? Pa[ln] : 0.0, emine = ln < DK * DK ? Ea[ln] : 0.0;
+    const int plo = __double2loint(pmine), phi = __double2hiint(pmine);
+    const int elo = __double2loint(emine), ehi = __double2hiint(emine);
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < DK; ++i)
+#pragma unroll
+      for (int k = i; k < DK; ++k, ++t) {
+        double pv = __hiloint2double(__builtin_amdgcn_readlane(phi, i * DK + k), __builtin_amdgcn_readlane(plo, i * DK + k));
+        double ev = __hiloint2double(__builtin_amdgcn_readlane(ehi, i * DK + k), __builtin_amdgcn_readlane(elo, i * DK + k));
+        asm volatile("" : "+v"(pv), "+v"(ev));                 // vector registers (see k_pairvec_reg)
+        Pr[QREG ? t : 0] = pv; Er[QREG ? t : 0] = ev;
+      }
+  }
   double acc_f = 0.0;
   double acc_s[DK];
 #pragma unroll
@@ -440,9 +461,18 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
         maha = fma(z[i], t, maha);
         rv = fma(z[i], te, rv);                              // zeta^T E_a zeta
       };
-      if constexpr (DK <= 8) {
+      if constexpr (QREG) {
+        int t = 0;
 #pragma unroll
-        for (int i = 0; i < DK; ++i) row(i);
+        for (int i = 0; i < DK; ++i) {
+          const double pd = Pr[QREG ? t : 0] * z[i], ed = Er[QREG ? t : 0] * z[i];
+          ++t;
+          double tp = 0.0, te = 0.0;
+#pragma unroll
+          for (int k = i + 1; k < DK; ++k, ++t) { tp = fma(Pr[QREG ? t : 0], z[k], tp); te = fma(Er[QREG ? t : 0], z[k], te); }
+          maha = fma(z[i], fma(2.0, tp, pd), maha);
+          rv = fma(z[i], fma(2.0, te, ed), rv);                // zeta^T E_a zeta
+        }
       } else {
 #pragma unroll 2
         for (int i = 0; i < DK; ++i) row(i);
@@ -459,15 +489,25 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
     r1[m] = rv;
     if (sizeof(T) != 8) wb[m] = (T)wv;
   }
-  const double f = mm_block_sum256(acc_f, red);
-  if (tid == 0) sv[DK] = f;
+  // the DK + 1 workgroup sums together: wave butterflies, one LDS stage, one barrier (fixed order: reproducible)
+  __shared__ double red9[4][DK + 1];
+  {
+    double v[DK + 1];
 #pragma unroll
-  for (int k = 0; k < DK; ++k) {
-    if (k < d) {
-      const double s = mm_block_sum256(acc_s[k], red);
-      if (tid == 0) sv[k] = s;
+    for (int k = 0; k < DK; ++k) v[k] = acc_s[k];
+    v[DK] = acc_f;
+#pragma unroll
+    for (int k = 0; k <= DK; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    }
+    if ((tid & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k <= DK; ++k) red9[tid >> 6][k] = v[k];
     }
   }
+  __syncthreads();
+  if (tid <= DK) sv[tid] = (red9[0][tid] + red9[1][tid]) + (red9[2][tid] + red9[3][tid]);
   __syncthreads();
   if (tid == 0) { f1[(size_t)b * L + a] = (T)(sv[DK] + meanc[a]); f1raw[(size_t)b * L + a] = sv[DK]; }
   if (tid < d) {
