@@ -80,3 +80,19 @@ def test_pmc_counters_scale_with_the_batch_of_the_run():
   assert bench.pmc_scale({"bench_args": "--config c3"}, "p", 256, 256) == (1.0, "p")
   assert bench.pmc_scale({"bench_args": "--config c3"}, "p", 64, 256)[0] == 0.25
   assert bench.pmc_scale(None, "not collected", 64, 256) == (1.0, "not collected")
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+  """`python bench.py` on a host without a GPU: a one-line refusal and a non-zero exit code -- no CPU fallback, no
+  traceback from a half-initialised run."""
+  import os
+  import subprocess
+  import sys
+  import torch
+  if torch.cuda.is_available():
+    import pytest
+    pytest.skip("a GPU is present")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c1_closed", "--steps", "1"],
+                     capture_output=True, text=True, timeout=300)
+  assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout) and "Traceback" not in r.stderr
