@@ -67,6 +67,9 @@ __device__ __forceinline__ double mm_expm1(double x) { return expm1(x); }
 // every wave executes the same number of them.
 __device__ double mm_spd_inverse(double* A, double* Y, int d, int dp, bool* ok) {
   const int lane = threadIdx.x & 63;
+  // d <= 8: lane owns entry (li, lj) for the whole factorisation (one integer division instead of one per step)
+  const bool one = d * d <= 64;
+  const int li = lane / d, lj = lane - li * d;
   for (int k = 0; k < d; ++k) {
     __syncthreads();
     const double akk = A[k * dp + k];
@@ -76,14 +79,20 @@ __device__ double mm_spd_inverse(double* A, double* Y, int d, int dp, bool* ok) 
     if (lane > k && lane < d) A[lane * dp + k] /= lkk;
     if (lane == k) A[k * dp + k] = lkk;
     __syncthreads();
-    for (int idx = lane; idx < d * d; idx += 64) {
-      const int i = idx / d, j = idx - i * d;
-      if (j > k && i >= j) A[i * dp + j] -= A[i * dp + k] * A[j * dp + k];
+    if (one) {
+      if (li < d && lj > k && li >= lj) A[li * dp + lj] -= A[li * dp + k] * A[lj * dp + k];
+    } else {
+      for (int idx = lane; idx < d * d; idx += 64) {
+        const int i = idx / d, j = idx - i * d;
+        if (j > k && i >= j) A[i * dp + j] -= A[i * dp + k] * A[j * dp + k];
+      }
     }
   }
   __syncthreads();
-  double logdet = 0.0;
-  for (int k = 0; k < d; ++k) logdet += log(A[k * dp + k]);
+  // log det = 2 sum_k log L_kk: lane k takes one logarithm (d <= 32 <= 64 lanes), then a wave sum
+  double logdet = lane < d ? log(A[lane * dp + lane]) : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) logdet += __shfl_xor(logdet, off, 64);
   logdet *= 2.0;
   // Y = L^-1 (lower): lane c owns column c.
   if (lane < d) {
@@ -297,11 +306,14 @@ __global__ __launch_bounds__(192) void k_prep(const double* __restrict__ ls2, co
     const double ld = lds3[0];
     double* out = latmat + ((size_t)b * L + a) * (2 * d * d + 2);
     for (int idx = tid; idx < d * d; idx += nt) { const int i = idx / d, j = idx - i * d; out[idx] = A1[i * dp + j]; }
-    if (tid == 0) {
-      double sl = 0.0;
-      for (int k = 0; k < d; ++k) sl += log(la[k]);
-      out[d * d] = log(var[a]) + 0.5 * sl - 0.5 * ld;
-      out[d * d + 1] = ld;
+    {
+      double sl = (tid < d) ? log(la[tid]) : 0.0;            // wave 0: one logarithm per lane, wave sum
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) sl += __shfl_xor(sl, off, 64);
+      if (tid == 0) {
+        out[d * d] = log(var[a]) + 0.5 * sl - 0.5 * ld;
+        out[d * d + 1] = ld;
+      }
     }
     // E_a = sym(Lambda_a^-1 Sigma P_a) (= Lambda_a^-1 - P_a, in product form: no cancellation for small Sigma)
     for (int idx = tid; idx < d * d; idx += nt) {
@@ -362,14 +374,13 @@ __global__ __launch_bounds__(192) void k_prep(const double* __restrict__ ls2, co
       const int i = idx / d, j = idx - i * d;
       out[idx] = Tm[i * dp + j] / (la[i] * lb[j]);
     }
-    if (tid == 0) {
-      double lv = 0.0, sla = 0.0, slb = 0.0;
-      for (int k = 0; k < d; ++k) {
-        lv += log(la[k] * lb[k] / (la[k] + lb[k]));
-        sla += log(la[k]); slb += log(lb[k]);
-      }
+    {
+      // 0.5 sum_k [log V_k - log Lam_a,k - log Lam_a',k] = -0.5 sum_k log(Lam_a,k + Lam_a',k): one logarithm per lane
+      double lsum = (tid < d) ? log(la[tid] + lb[tid]) : 0.0;
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) lsum += __shfl_xor(lsum, off, 64);
       // log kappa_ab - lognorm_a - lognorm_a'  (the variances cancel)
-      out[d * d] = -0.5 * ldS + 0.5 * lv - 0.5 * sla - 0.5 * slb + 0.5 * ldA + 0.5 * ldB;
+      if (tid == 0) out[d * d] = -0.5 * ldS - 0.5 * lsum + 0.5 * ldA + 0.5 * ldB;
     }
   }
   if (!ok && tid == 0 && status) {
