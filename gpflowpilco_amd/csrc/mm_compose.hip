@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
+#include "mm_cost.h"
 
 #define MMC_NX 16          // largest state dimension
 #define MMC_NA 8           // largest number of encoded (angle) dimensions
@@ -67,9 +68,8 @@ static inline MMComposeLayout mm_compose_layout(int B, int nx, int na, int dtype
 // k_compose_encode: (mx, Sxx) -> moments of e = [sin a, cos a, x_inactive] and Cov(x, e)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void k_compose_encode(MMComposeDims D, const T* __restrict__ mx, const T* __restrict__ Sxx,
-                                                       T* __restrict__ me, T* __restrict__ See, double* __restrict__ Sxe) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void mmc_encode_body(const MMComposeDims& D, const T* mx, const T* Sxx, T* me, T* See, double* Sxe,
+                                                int b, int lane) {
   const int nx = D.nx, na = D.na, nb = D.nb, ne = D.ne, n2 = 2 * na;
   __shared__ double m[MMC_NX], S[MMC_NX * MMC_NX];
   __shared__ double s1[MMC_NA], c1[MMC_NA];
@@ -124,6 +124,12 @@ __global__ __launch_bounds__(64) void k_compose_encode(MMComposeDims D, const T*
     const int r = idx / ne, k = idx - r * ne;
     Sxeb[idx] = k < n2 ? Sxy[r * n2 + k] : S[r * nx + D.inactive[k - n2]];
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_compose_encode(MMComposeDims D, const T* __restrict__ mx, const T* __restrict__ Sxx,
+                                                       T* __restrict__ me, T* __restrict__ See, double* __restrict__ Sxe) {
+  mmc_encode_body<T>(D, mx, Sxx, me, See, Sxe, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -185,12 +191,9 @@ __global__ __launch_bounds__(64) void k_compose_policy(MMComposeDims D, double s
 // k_compose_step: Cov(x, f) bookkeeping of forward_sde.py:105-131 and the Euler moment update
 // ---------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void k_compose_step(MMComposeDims D, double dt, const double* __restrict__ Sxe,
-                                                     const double* __restrict__ cpol, const T* __restrict__ Sdd,
-                                                     const T* __restrict__ df1, const T* __restrict__ dSff,
-                                                     const T* __restrict__ dcross, T* mx, T* Sxx,
-                                                     T* traj_mu, T* traj_S) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void mmc_step_body(const MMComposeDims& D, double dt, const double* Sxe, const double* cpol, const T* Sdd,
+                                              const T* df1, const T* dSff, const T* dcross, T* mx, T* Sxx,
+                                              T* traj_mu, T* traj_S, int b, int lane) {
   const int nx = D.nx, na = D.na, ne = D.ne, nd = D.nd, n2 = 2 * na;
   __shared__ double Sxd[MMC_NX * MMC_ND], Sxf[MMC_NX * MMC_NX];
   const double* Sxeb = Sxe + (size_t)b * nx * ne;
@@ -234,6 +237,29 @@ __global__ __launch_bounds__(64) void k_compose_step(MMComposeDims D, double dt,
     const double v = (double)mx[(size_t)b * nx + lane] + dt * (double)df1[(size_t)b * nx + lane];
     mx[(size_t)b * nx + lane] = (T)v;
     if (traj_mu) traj_mu[(size_t)b * nx + lane] = (T)v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_compose_tail: the end of a step in ONE launch -- Euler update (k_compose_step's body), the encoding of the new
+// state (the next step's policy input and this step's cost argument) and the expected cost of the encoded state
+// (mm_expected_cost's arithmetic).  At cartpole sizes every kernel of the chain runs for ~5 us, most of it launch and
+// dependency latency: two launches fewer per step.  One wave per batch element; the stages communicate through the
+// wave's own global writes (visible after the workgroup barrier).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void k_compose_tail(MMComposeDims D, double dt, const double* cpol, const T* Sdd,
+                                                     const T* df1, const T* dSff, const T* dcross, T* mx, T* Sxx,
+                                                     T* traj_mu, T* traj_S, T* me, T* See, double* Sxe,
+                                                     const T* target, const T* precis, T* cost) {
+  extern __shared__ double csm[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  mmc_step_body<T>(D, dt, Sxe, cpol, Sdd, df1, dSff, dcross, mx, Sxx, traj_mu, traj_S, b, lane);
+  __syncthreads();
+  mmc_encode_body<T>(D, mx, Sxx, me, See, Sxe, b, lane);
+  if (cost) {
+    __syncthreads();
+    mm_expected_cost_body<T>(D.ne, me, See, target, precis, cost, b, lane, csm);
   }
 }
 
@@ -287,18 +313,14 @@ static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, 
     rc = mm_moment_match(drift, drift_bytes, nx, Md, nd, dtype, B, md, Sdd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY, 0.0,
                          df1, dSff, dcross, ws_drift, ws_drift_bytes, status, (void*)s);
     if (rc) return rc;
-    hipLaunchKernelGGL((k_compose_step<T>), dim3(B), dim3(64), 0, s, D, dt, (const double*)Sxe, (const double*)cpol,
+    // Euler update, the new state's encoding (the cost statistic of this step, pilco.py:199-205, and the next step's
+    // policy input) and the expected cost: one launch
+    hipLaunchKernelGGL((k_compose_tail<T>), dim3(B), dim3(64), mm_cost_lds_bytes(ne), s, D, dt, (const double*)cpol,
                        (const T*)Sdd, (const T*)df1, (const T*)dSff, (const T*)dcross, mx, Sxx,
                        traj_mu ? traj_mu + (size_t)h * B * nx : (T*)nullptr,
-                       traj_S ? traj_S + (size_t)h * B * nx * nx : (T*)nullptr);
+                       traj_S ? traj_S + (size_t)h * B * nx * nx : (T*)nullptr, me, See, Sxe, target, precis,
+                       cost ? cost + (size_t)h * B : (T*)nullptr);
     MMC_CHECK();
-    // the new state's encoding: the cost statistic of this step (pilco.py:199-205) and the next step's policy input
-    hipLaunchKernelGGL((k_compose_encode<T>), dim3(B), dim3(64), 0, s, D, (const T*)mx, (const T*)Sxx, me, See, Sxe);
-    MMC_CHECK();
-    if (cost) {
-      rc = mm_expected_cost(B, ne, dtype, me, See, target, precis, cost + (size_t)h * B, (void*)s);
-      if (rc) return rc;
-    }
   }
 #undef MMC_CHECK
   return 0;

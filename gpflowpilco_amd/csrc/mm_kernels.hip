@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
+#include "mm_cost.h"
 #include "mm_mono.h"
 
 #define MM_ABI_VERSION 1
@@ -1086,64 +1087,7 @@ __global__ __launch_bounds__(64) void k_expected_cost(int d, const T* __restrict
                                                       const T* __restrict__ target, const T* __restrict__ precis,
                                                       T* __restrict__ cost) {
   extern __shared__ double smem[];
-  const int dp = d + 2;
-  double* A = smem;               // [d][d+2]: I + S W | err | (pad)
-  double* W = A + d * dp;         // [d][d]
-  double* e0 = W + d * d;         // [d] err
-  __shared__ int piv;
-  __shared__ double detv;
-  const int n = blockIdx.x, lane = threadIdx.x;
-  for (int idx = lane; idx < d * d; idx += 64) W[idx] = (double)precis[idx];
-  if (lane < d) e0[lane] = (double)mean[(size_t)n * d + lane] - (double)target[lane];
-  if (lane == 0) detv = 1.0;
-  __syncthreads();
-  for (int idx = lane; idx < d * d; idx += 64) {
-    const int i = idx / d, j = idx - i * d;
-    double s = (i == j) ? 1.0 : 0.0;
-    for (int k = 0; k < d; ++k) s += (double)cov[((size_t)n * d + i) * d + k] * W[k * d + j];
-    A[i * dp + j] = s;
-  }
-  if (lane < d) A[lane * dp + d] = e0[lane];
-  __syncthreads();
-  for (int k = 0; k < d; ++k) {
-    if (lane == 0) {
-      int p = k; double best = fabs(A[k * dp + k]);
-      for (int i = k + 1; i < d; ++i) { const double v = fabs(A[i * dp + k]); if (v > best) { best = v; p = i; } }
-      piv = p;
-    }
-    __syncthreads();
-    const int p = piv;
-    if (p != k) {
-      for (int j = lane; j <= d; j += 64) { const double t = A[k * dp + j]; A[k * dp + j] = A[p * dp + j]; A[p * dp + j] = t; }
-      if (lane == 0) detv = -detv;
-    }
-    __syncthreads();
-    const double akk = A[k * dp + k];
-    if (lane == 0) detv *= akk;
-    // eliminate rows below k: entries (i, j), i > k, j > k (incl. the rhs column)
-    const int nr = d - 1 - k, nc = d - k;       // columns k+1 .. d
-    __syncthreads();
-    for (int idx = lane; idx < nr * nc; idx += 64) {
-      const int i = k + 1 + idx / nc, j = k + 1 + idx % nc;
-      A[i * dp + j] -= (A[i * dp + k] / akk) * A[k * dp + j];
-    }
-    __syncthreads();
-  }
-  // back substitution (serial, d <= 32): y = (I + S W)^-1 err
-  if (lane == 0) {
-    for (int i = d - 1; i >= 0; --i) {
-      double s = A[i * dp + d];
-      for (int j = i + 1; j < d; ++j) s -= A[i * dp + j] * A[j * dp + d];
-      A[i * dp + d] = s / A[i * dp + i];
-    }
-    double dist2 = 0.0;
-    for (int i = 0; i < d; ++i) {
-      double s = 0.0;
-      for (int j = 0; j < d; ++j) s += W[i * d + j] * A[j * dp + d];
-      dist2 += e0[i] * s;
-    }
-    cost[n] = (T)(-rsqrt(detv) * exp(-0.5 * dist2));
-  }
+  mm_expected_cost_body<T>(d, mean, cov, target, precis, cost, (int)blockIdx.x, (int)threadIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1483,7 +1427,7 @@ extern "C" int mm_expected_cost(int N, int d, int dtype, const void* mean, const
   if (dtype != MM_F32 && dtype != MM_F64) return MM_E_DTYPE;
   if (!mean || !cov || !target || !precis || !cost) return MM_E_ARG;
   hipStream_t s = (hipStream_t)stream;
-  const size_t shm = (size_t)(d * (d + 2) + d * d + d) * sizeof(double);
+  const size_t shm = mm_cost_lds_bytes(d);
   if (dtype == MM_F64)
     hipLaunchKernelGGL((k_expected_cost<double>), dim3(N), dim3(64), shm, s, d, (const double*)mean, (const double*)cov,
                        (const double*)target, (const double*)precis, (double*)cost);
