@@ -18,6 +18,7 @@
 #include <math.h>
 #include "mm_common.h"
 #include "mm_cost.h"
+#include "mm_dev.h"
 
 #define MMC_NX 16          // largest state dimension
 #define MMC_NA 8           // largest number of encoded (angle) dimensions
@@ -264,6 +265,170 @@ __global__ __launch_bounds__(64) void k_compose_tail(MMComposeDims D, double dt,
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_policy_match_small: the policy's moment match in ONE launch.  The policy of the composed rollout is a one-latent,
+// mean-only regressor (KernelRegressor: model_uncertainty = False, moment_matching/models.py:34-41) with a few tens of
+// kernel centres; through the general path its match is five dependent launches of a few microseconds each.  Here one
+// 256-thread workgroup per batch element does all of it in f64 (the general path reduces diagonal pairs in f64 too):
+//   (Sigma + Lambda)^-1 and (Sigma + Lambda / 2)^-1 by two waves at once (mm_spd_inverse), E = sym(Lambda^-1 Sigma P),
+//   T = V S^-1 Sigma, G = Lambda^-1 T Lambda^-1, const;  per centre m (thread m): zeta, q, w = beta q, r = -(zeta^T E zeta
+//   - zeta^T G zeta) / 2, g = G zeta;  f1 = sum w + c,  cross = P sum w zeta;
+//   Sff = sum_ij w_i expm1(r_i + r_j + const + zeta_i . g_j) w_j   (256 / M threads per column j).
+// Requires L == 1, M <= 128, d <= 8 (else the general mm_moment_match is used).  A non-PD Sigma + V sets the status
+// word exactly as k_prep does.
+// ---------------------------------------------------------------------------------------------
+#define MMS_MMAX 128
+template <typename T>
+__global__ __launch_bounds__(256) void k_policy_match_small(const double* __restrict__ Z64, const double* __restrict__ beta64,
+                                                            const double* __restrict__ ls2, const double* __restrict__ var,
+                                                            const double* __restrict__ meanc, int M, int d,
+                                                            const T* __restrict__ mu, const T* __restrict__ Sigma, double jitter,
+                                                            T* __restrict__ f1, T* __restrict__ Sff, T* __restrict__ cross,
+                                                            int32_t* status) {
+  constexpr int DK = 8, DP = DK + 1;
+  const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  __shared__ double Sg[DK * DP], Am[4][DK * DP], Ym[4][DK * DP], Em[DK * DK], Gm[DK * DK];
+  __shared__ double zs[MMS_MMAX][DK], gs[MMS_MMAX][DK];
+  __shared__ double ws[MMS_MMAX], rs[MMS_MMAX];
+  __shared__ double red[4][DK + 2], sv[DK + 2], lds4[4];
+  __shared__ int okw[4];
+  const T* Sb = Sigma + (size_t)b * d * d;
+  for (int idx = tid; idx < d * d; idx += 256) {
+    const int i = idx / d, j = idx - i * d;
+    Sg[i * DP + j] = (double)(i >= j ? Sb[i * d + j] : Sb[j * d + i]);     // symmetrised from the lower triangle (k_prep)
+  }
+  if (tid < 4) okw[tid] = 1;
+  __syncthreads();
+  // wave 0: Sigma + Lambda; wave 1: Sigma + Lambda / 2 (V of the pair (a, a), kernel_expectation.py:119); waves 2, 3: identity
+  for (int idx = lane; idx < d * d; idx += 64) {
+    const int i = idx / d, j = idx - i * d;
+    const double add = wv == 0 ? ls2[i] : wv == 1 ? 0.5 * ls2[i] : 1.0;
+    Am[wv][i * DP + j] = (wv < 2 ? Sg[i * DP + j] : 0.0) + (i == j ? add : 0.0);
+  }
+  bool ok = true;
+  const double ldw = mm_spd_inverse(Am[wv], Ym[wv], d, DP, &ok);
+  if (!ok && wv < 2) okw[wv] = 0;
+  if (lane == 0) lds4[wv] = ldw;
+  __syncthreads();
+  ok = okw[0] && okw[1];
+  const double ldA = lds4[0], ldS = lds4[1];
+  const double* Pm = Am[0];            // (Sigma + Lambda)^-1
+  const double* S0 = Am[1];            // (Sigma + V)^-1
+  // E = sym(Lambda^-1 Sigma P)  (k_prep);  T = V S0 Sigma (into Ym[0]), symmetrised;  G = Lambda^-1 T Lambda^-1
+  for (int idx = tid; idx < d * d; idx += 256) {
+    const int i = idx / d, j = idx - i * d;
+    double s1 = 0.0, t1 = 0.0, tt = 0.0;
+    for (int k = 0; k < d; ++k) {
+      s1 += Sg[i * DP + k] * Pm[k * DP + j];
+      t1 += Sg[j * DP + k] * Pm[k * DP + i];
+      tt += S0[i * DP + k] * Sg[k * DP + j];
+    }
+    Em[i * DK + j] = 0.5 * (s1 / ls2[i] + t1 / ls2[j]);
+    Ym[0][i * DP + j] = 0.5 * ls2[i] * tt;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < d * d; idx += 256) {
+    const int i = idx / d, j = idx - i * d;
+    Gm[i * DK + j] = 0.5 * (Ym[0][i * DP + j] + Ym[0][j * DP + i]) / (ls2[i] * ls2[j]);
+  }
+  // log-normaliser of q and the pair constant (k_prep: -0.5 ldS - 0.5 sum log(2 Lambda_k) + ldA)
+  double sl = (tid < d) ? log(ls2[tid]) : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) sl += __shfl_xor(sl, off, 64);
+  sl = __shfl(sl, 0, 64);
+  __syncthreads();
+  // (every wave needs the wave-0 sum: through LDS)
+  if (tid == 0) lds4[2] = sl;
+  __syncthreads();
+  sl = lds4[2];
+  const double lognorm = log(var[0]) + 0.5 * sl - 0.5 * ldA;
+  const double cst = -0.5 * ldS - 0.5 * (sl + d * 0.6931471805599453) + ldA;
+  // ---- per centre -------------------------------------------------------------------------------------------------
+  double wv_m = 0.0, acc[DK];
+#pragma unroll
+  for (int k = 0; k < DK; ++k) acc[k] = 0.0;
+  if (tid < M) {
+    double z[DK];
+#pragma unroll
+    for (int k = 0; k < DK; ++k) z[k] = k < d ? Z64[(size_t)tid * d + k] - (double)mu[(size_t)b * d + k] : 0.0;
+    double maha = 0.0, r1 = 0.0, tq = 0.0;
+#pragma unroll
+    for (int i = 0; i < DK; ++i) {
+      double tp = 0.0, te = 0.0, tg = 0.0;
+#pragma unroll
+      for (int k = 0; k < DK; ++k) {
+        const bool in = i < d && k < d;
+        tp = fma(in ? Pm[i * DP + k] : 0.0, z[k], tp);
+        te = fma(in ? Em[i * DK + k] : 0.0, z[k], te);
+        tg = fma(in ? Gm[i * DK + k] : 0.0, z[k], tg);
+      }
+      maha = fma(z[i], tp, maha);
+      r1 = fma(z[i], te, r1);
+      tq = fma(z[i], tg, tq);
+      gs[tid][i] = tg;
+      zs[tid][i] = z[i];
+    }
+    const double qv = exp(lognorm - 0.5 * maha);
+    wv_m = beta64[tid] * qv;
+    ws[tid] = wv_m;
+    rs[tid] = -0.5 * (r1 - tq);
+#pragma unroll
+    for (int k = 0; k < DK; ++k) acc[k] = wv_m * z[k];
+  }
+  __syncthreads();
+  // ---- the M x M sum: 256 / M threads share a column (rows interleaved); every partial goes into the workgroup sum ----
+  double colsum = 0.0;
+  {
+    const int nsub = 256 / M;                               // >= 2 (M <= 128)
+    const int j = tid % M, i0 = tid / M;
+    if (i0 < nsub) {
+      double g[DK];
+#pragma unroll
+      for (int k = 0; k < DK; ++k) g[k] = gs[j][k];
+      const double base = rs[j] + cst;
+      for (int i = i0; i < M; i += nsub) {
+        double delta = rs[i] + base;
+#pragma unroll
+        for (int k = 0; k < DK; ++k) delta = fma(zs[i][k], g[k], delta);
+        colsum = fma(ws[i], expm1(delta), colsum);
+      }
+      colsum *= ws[j];
+    }
+  }
+  // ---- the d + 2 workgroup sums (f1, sum w zeta, Sff) together -----------------------------------------------------
+  {
+    double v[DK + 2];
+#pragma unroll
+    for (int k = 0; k < DK; ++k) v[k] = acc[k];
+    v[DK] = wv_m; v[DK + 1] = colsum;
+#pragma unroll
+    for (int k = 0; k < DK + 2; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < DK + 2; ++k) red[wv][k] = v[k];
+    }
+  }
+  __syncthreads();
+  if (tid < DK + 2) sv[tid] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+  __syncthreads();
+  if (tid == 0) {
+    f1[b] = (T)(sv[DK] + meanc[0]);
+    Sff[b] = (T)(sv[DK + 1] + jitter);
+  }
+  if (tid < d) {
+    double s = 0.0;
+    for (int k = 0; k < d; ++k) s += Pm[tid * DP + k] * sv[k];     // Sigma^-1 Cov(x, f) = P sum_i w_i zeta_i  (models.py:263-277)
+    cross[(size_t)b * d + tid] = (T)s;
+  }
+  if (!ok && tid == 0 && status) {
+    atomicMax(status, (int)gridDim.x - b);                          // B - b: the host decodes the smallest failing b
+    status[1] = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
 static int mm_compose_dims(int nx, int na, const int32_t* active_dims, MMComposeDims& D) {
@@ -304,9 +469,19 @@ static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, 
   MMC_CHECK();
   for (int h = 0; h < H; ++h) {
     // policy: mean-only regressor (models.py:34-41: model_uncertainty = False), one latent
-    int rc = mm_moment_match(policy, policy_bytes, 1, Mpol, ne, dtype, B, me, See, MM_FULL_OUTPUT_COV, 0.0,
-                             pf1, pSff, pcross, ws_policy, ws_policy_bytes, status, (void*)s);
-    if (rc) return rc;
+    int rc = 0;
+    if (Mpol <= MMS_MMAX && ne <= 8) {
+      const MMModelLayout pl = mm_model_layout(1, Mpol, ne, dtype, 1);
+      const char* pp = (const char*)policy;
+      hipLaunchKernelGGL((k_policy_match_small<T>), dim3(B), dim3(256), 0, s, (const double*)(pp + pl.Z64),
+                         (const double*)(pp + pl.beta64), (const double*)(pp + pl.ls2), (const double*)(pp + pl.var),
+                         (const double*)(pp + pl.meanc), Mpol, ne, (const T*)me, (const T*)See, 0.0, pf1, pSff, pcross, status);
+      MMC_CHECK();
+    } else {
+      rc = mm_moment_match(policy, policy_bytes, 1, Mpol, ne, dtype, B, me, See, MM_FULL_OUTPUT_COV, 0.0,
+                           pf1, pSff, pcross, ws_policy, ws_policy_bytes, status, (void*)s);
+      if (rc) return rc;
+    }
     hipLaunchKernelGGL((k_compose_policy<T>), dim3(B), dim3(64), 0, s, D, scale, shift, (const T*)me, (const T*)See,
                        (const T*)pf1, (const T*)pSff, (const T*)pcross, md, Sdd, cpol);
     MMC_CHECK();
