@@ -435,7 +435,7 @@ def main():
 
   roofs = {"offdiag": reduce_roofline("offdiag") if Po else None, "diag": reduce_roofline("diag")}
   dominant = "offdiag" if (Po and seg["offdiag"] >= seg["diag"]) else "diag"
-  # q stage: HBM-bound operand producers (k_qvec, k_pairvec, k_wmoments): bytes from the counters
+  # q stage: HBM-bound operand producers (k_qvec, k_pairvec, k_wmom_gemm): bytes from the counters
   qroof = {"bound": "hbm", "kernels": "k_prep + k_qvec + k_pairvec (+ k_wmom_gemm [f64 MFMA GEMM] + k_spoly)", "segment_ms": round(seg["q_stage"], 4),
            "peak": PEAK_HBM_GBS, "unit": "GB/s", "per_kernel": {}}
   if pmc is not None:

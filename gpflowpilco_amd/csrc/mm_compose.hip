@@ -12,8 +12,9 @@
 //   k_compose_policy : moment_matching/bijectors.py:39-69 (NormalCDF: Owen's T by 48-point Gauss-Legendre, the
 //                      quadrature gpflowpilco_amd/special.py uses), Shift, Scale, the chain rule
 //                      (gaussian.py:66-83) and GaussianMatch.joint (gaussian.py:53-63)
-//   k_compose_step   : forward_sde.py:105-131 bookkeeping + solvers.py:110-135
-// mm_rollout_composed enqueues the whole H-step rollout (4 small kernels + 2 GP matches + the cost per step).
+//   k_compose_tail   : forward_sde.py:105-131 bookkeeping + solvers.py:110-135, then the new state's encoding and the
+//                      expected cost, one launch;  k_policy_match_small: the policy's whole moment match in one launch
+// mm_rollout_composed enqueues the whole H-step rollout (per step: policy match, k_compose_policy, drift match, k_compose_tail).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(64) void k_compose_policy(MMComposeDims D, double s
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_compose_step: Cov(x, f) bookkeeping of forward_sde.py:105-131 and the Euler moment update
+// mmc_step_body: Cov(x, f) bookkeeping of forward_sde.py:105-131 and the Euler moment update (first stage of k_compose_tail)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void mmc_step_body(const MMComposeDims& D, double dt, const double* Sxe, const double* cpol, const T* Sdd,
@@ -242,7 +243,7 @@ __device__ __forceinline__ void mmc_step_body(const MMComposeDims& D, double dt,
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_compose_tail: the end of a step in ONE launch -- Euler update (k_compose_step's body), the encoding of the new
+// k_compose_tail: the end of a step in ONE launch -- Euler update (mmc_step_body), the encoding of the new
 // state (the next step's policy input and this step's cost argument) and the expected cost of the encoded state
 // (mm_expected_cost's arithmetic).  At cartpole sizes every kernel of the chain runs for ~5 us, most of it launch and
 // dependency latency: two launches fewer per step.  One wave per batch element; the stages communicate through the

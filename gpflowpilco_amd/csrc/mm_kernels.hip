@@ -17,7 +17,8 @@
 // Stages per moment match (all enqueue-only):
 //   k_prep      one wave per (b, pair) / (b, latent): d x d Cholesky algebra in f64 (LDS)
 //   k_qvec      one workgroup per (b, latent): q_i, w_i, f1, Sigma^-1 Cov(x,f)
-//   k_pairvec   per (b, pair, m): rho_m, g_m = G zeta_m, gamma'_m  (streamed operands of the reduce)
+//   k_pairvec   per (b, pair, m): rho_m, g_m = G zeta_m, gamma'_m  (streamed operands of the reduce; k_pairvec_reg for d <= 8)
+//   k_wmom_gemm, k_spoly (mm_moments.hip; f32 models): the polynomial part of the off-diagonal sums from f64 moments
 //   k_qred_*    the M x M fused reduce: diagonal pairs (a == a', incl. the C-weighted term) always in
 //               f64, off-diagonal pairs in T (generic VALU kernel here; f32 MFMA kernel in mm_mfma.hip)
 //   k_finalize  deterministic sum of the partial slabs -> Sff
@@ -913,7 +914,7 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
     for (int k = 0; k < DK; ++k)
       if (k < d) delta += (ROWVEC ? ra[(size_t)k * Mp + i] : zrow[(size_t)i * Kz + k]) * g[k];
     // ROWVEC (f32 off-diagonal pairs): only the remainder expm1(b) - b - b^2/2 is reduced here, the
-    // rest comes from the f64 weight moments (k_s12); evaluated in f64 (portable cross-check kernel)
+    // rest comes from the f64 weight moments (k_spoly); evaluated in f64 (portable cross-check kernel)
     const double dd = (double)delta;
     const T e = ROWVEC ? (T)(expm1(dd) - dd - 0.5 * dd * dd - dd * dd * dd * fma(sub1, dd, sub0))
                        : mm_expm1(delta);
@@ -964,7 +965,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (lane != 0) return;
-  // f32 mode: the tile kernel reduced only the remainder; the moments supply 1 + b + b^2/2 (k_s12)
+  // f32 mode: the tile kernel reduced only the remainder; the moments supply 1 + b + b^2/2, and c0 b^3 + c1 b^4 of a collapsed item (k_spoly)
   if (a != a2 && s12) s += s12[(size_t)b * (P - L) + (p - L)] - f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a2];
   if (a == a2) {
     // factored f64 reduce: the slabs hold sum_ij u_i u_j [D_ij] e^{delta_ij}; minus (sum_i w_i)^2 gives the centred sum
