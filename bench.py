@@ -6,36 +6,43 @@
 
 One "step" = one pass of the hot path over the local batch: q stage + fused Q reduce (+ Euler moment update
 where the state is closed, d == L).  Per-step expected costs are evaluated and all-gathered once per H-step
-rollout, so K is rounded UP to a whole number of rollouts: the cost kernel and the collective are
-always inside the timed region.  value = B_total * K / wall time ("rollout step-elements per second").
+rollout, and once more for the partial rollout at the end of the timed region when K is not a multiple
+of H: EXACTLY K steps are timed, and the cost kernel and the collective are always inside the timed region.
+value = B_total * K / wall time ("rollout step-elements per second").
 
 Configurations (BASELINE.json configs; `config.workload` names what ran):
   c1  configs[0]: the cartpole wiring x(4) -> encoder -> policy SVGP(30) + NormalCDF head -> drift SVGP(N=100, d=6 -> D=4)
       -> Euler -> cost, H=30, B=1, fp64: the whole rollout in mm_rollout_composed    (weak)
   c1_closed  the same sizes as a closed drift-only rollout (d=D=6)                   (weak)
   c2  configs[1] shaped: N=1000, d=D=5, H=40, B=64, fp64, closed rollout      (weak)
-  c3  configs[2]: N=2000, d=D=8, H=40, B=256 per GPU, fp32, closed rollout    (weak; THE metric's config)
+  c3  configs[2]: N=2000, d=D=8, H=40, B=256 per GPU, fp32                    (weak; THE metric's config)
   c4  configs[3]: N=4000, d=16, D=32, H=50, B=256 sharded over the ranks, fp32; d != D, so the step kernel runs on
       H independent (mu, Sigma) draws per rollout                 (strong)
   c5  configs[4]: pathwise sample rollout, S=65536 sharded over the ranks, N=2000, K=1024, H=50, fp32 (strong)
 Recipes (the reduce kernels choose range tiers per tile, so their time depends on the data):
+  baseline  BASELINE.md's own recipe (SURVEY 8d "Synthetic inputs"): lengthscales log-uniform [0.3, 3], GP-prior
+            targets; a closed dt = 1 rollout leaves the support within a few steps there, so every step takes a
+            fresh (mu, Sigma) draw (mu ~ U[0,1]^d, Sigma std 0.1) -- the step kernel on H independent draws, as
+            SURVEY 8d allows.  Default for c3 and c4: `value` is measured on it;
   pilco     lengthscales log-uniform [0.7, 3], contracting targets: the state stays inside the data's support for
-            the whole closed rollout (DESIGN.md section 5) -- default for c1..c3;
-  baseline  BASELINE.md's own recipe: lengthscales log-uniform [0.3, 3], GP-prior targets; a closed dt = 1 rollout
-            leaves the support within a few steps there, so every step takes a fresh (mu, Sigma) draw
-            (mu ~ U[0,1]^d, Sigma std 0.1) -- default for c4;
+            the whole closed rollout (DESIGN.md section 5) -- default for c1_closed, c2;
   worst     the pilco data with MM_FORCE_WORST_TIER: every tile takes its most expensive tier.
+The default N = 1 run of c3 times all three in one process (each with the same --steps / --warmup) and reports them
+under `regimes`; `value`, `ms_per_step`, `segments_ms`, `roofline`, `parity`, `cpu_baseline` describe the baseline one.
 
 The JSON line carries
   roofline     -- the kernel with the largest measured share of the step, HIP-event timed inside the timed region on
-                  the launch stream.  `frac` = executed-work ceiling / measured time: the ceiling is the kernel's OWN
-                  executed instruction mix (hardware counters of the same workload, profiles/r02_pmc_<config>.json,
-                  collected by tools/collect_pmc.sh and accepted only if they were taken on the kernel sources
-                  now in the tree) priced with the issue costs measured by tools/ubench_gap.hip at the peak clock;
-                  the SURVEY 8d algorithmic figure is reported beside it as `algorithmic_*` and never as `frac`;
+                  the launch stream: `achieved` = SURVEY 8d ALGORITHMIC flops per launch (E (2d + 12)) / that time,
+                  `frac` = achieved / dense peak of the dtype (null with a reason where the algorithmic rate exceeds
+                  the peak, i.e. the launch does not execute 8d's per-entry work); `issue_frac` = the kernel's OWN
+                  executed instruction mix (hardware counters of the same workload, profiles/r*_pmc_<config>_<recipe>.json,
+                  collected by tools/collect_pmc.sh and accepted only if taken on the kernel sources now in the tree)
+                  priced with the issue costs of tools/ubench_gap.hip, over the measured time -- a diagnostic, never `frac`;
+  roofline_step -- the same 8d flop model over the whole step (cross-check);
   cpu_baseline -- the literal fp64 CPU oracle (reference algorithm: materialised eKuffu + triangular solves) timed on
                   this host on a bounded sample (rank 0, N=1);
-  parity       -- max abs error of one GPU step against that oracle on the same inputs.
+  parity       -- max abs error of one GPU step against that oracle on the same inputs (+ per regime: against the
+                  algorithm-matched fp64 restatement, and f32 mode vs f64 mode of the same kernels).
 """
 import argparse
 import json
@@ -56,8 +63,11 @@ CONFIGS = {
                label="C1-shaped closed drift rollout: N=100 d=6 D=6 H=30 B=1 fp64 (no encoder / policy)"),
     "c2": dict(L=5, M=1000, d=5, H=40, B=64, dtype="f64", seed=1001, scaling="weak", recipe="pilco", closed=True,
                label="C2-shaped (BASELINE configs[1]): N=1000 d=5 D=5 H=40 B=64 fp64 closed drift rollout"),
-    "c3": dict(L=8, M=2000, d=8, H=40, B=256, dtype="f32", seed=1002, scaling="weak", recipe="pilco", closed=True,
-               label="C3 (BASELINE configs[2]): N=2000 d=8 D=8 H=40 fp32 closed drift rollout"),
+    # the headline config: `value` is BASELINE.md's own recipe (SURVEY 8d "Synthetic inputs"); the default N = 1 run also
+    # times the two other data regimes of the range-tiered reduce kernels and reports them under `regimes`
+    "c3": dict(L=8, M=2000, d=8, H=40, B=256, dtype="f32", seed=1002, scaling="weak", recipe="baseline", closed=True,
+               also=("pilco", "worst"),
+               label="C3 (BASELINE configs[2]): N=2000 d=8 D=8 H=40 fp32 drift moment-match step / closed rollout"),
     "c4": dict(L=32, M=4000, d=16, H=50, B=256, dtype="f32", seed=1003, scaling="strong", recipe="baseline", closed=False,
                label="C4 (BASELINE configs[3]): N=4000 d=16 D=32 H=50 B=256 total fp32, step kernel on H independent draws"),
 }
@@ -91,7 +101,11 @@ def parse():
   ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                   help="weak: the config's B (or S) per GPU; strong: the config's B (or S) sharded over the ranks "
                        "(default: weak for c1..c3, strong for c4/c5 -- BASELINE.json shards those)")
-  ap.add_argument("--recipe", default=None, choices=sorted(RECIPES))
+  ap.add_argument("--recipe", default=None, choices=sorted(RECIPES),
+                  help="the regime `value` is measured on (default: the config's; c3: baseline); given explicitly, only it runs")
+  ap.add_argument("--regimes", default=None,
+                  help="comma-separated recipes to time after the primary one in the same process and report under `regimes` "
+                       "(default at N = 1: the config's list -- c3: pilco,worst; none at N > 1)")
   ap.add_argument("--batch", type=int, default=None, help="override B (or S): per GPU if weak, total if strong")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--force-generic", action="store_true")
@@ -117,17 +131,25 @@ def src_hash():
   return h(ROOT)
 
 
-def load_pmc(tag):
-  """profiles/r02_pmc_<tag>.json if it was collected on the kernel sources now in the tree, else (None, reason)."""
-  path = os.path.join(ROOT, "profiles", f"r02_pmc_{tag}.json")
-  if not os.path.exists(path):
-    return None, f"profiles/r02_pmc_{tag}.json not collected"
-  with open(path) as fh:
-    pmc = json.load(fh)
+def load_pmc(tag, fallback=None):
+  """The newest profiles/r*_pmc_<tag>.json (then <fallback>) collected on the kernel sources now in the tree, else
+  (None, reason)."""
+  import glob
   cur = src_hash()
-  if pmc.get("src_hash") != cur:
-    return None, f"profiles/r02_pmc_{tag}.json is stale (collected on kernel sources {pmc.get('src_hash')}, tree has {cur})"
-  return pmc, os.path.relpath(path, ROOT)
+  why = []
+  for t in (tag, fallback):
+    if t is None:
+      continue
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9]*_pmc_{t}.json")), reverse=True)
+    if not paths:
+      why.append(f"profiles/r*_pmc_{t}.json not collected")
+    for path in paths:
+      with open(path) as fh:
+        pmc = json.load(fh)
+      if pmc.get("src_hash") == cur:
+        return pmc, os.path.relpath(path, ROOT)
+      why.append(f"{os.path.relpath(path, ROOT)} is stale (collected on kernel sources {pmc.get('src_hash')}, tree has {cur})")
+  return None, "; ".join(why)
 
 
 def pmc_scale(pmc, pmc_src, units_now, units_default):
@@ -210,6 +232,45 @@ def one_rank_at_a_time(fn, rank, world, dist, rehearsal):
   return out
 
 
+def roofline_block(kernel, k_ms, flops, peak, pmc, pmc_src, pscale, kind, prefix, why_flops):
+  """`roofline` of one reduce kernel, SURVEY 8d accounting:
+       achieved = ALGORITHMIC flops per launch (E * (2d + 12)) / the kernel's live duration      [TFLOP/s]
+       frac     = achieved / the dense peak of the dtype (null where the algorithmic figure exceeds the peak: the
+                  kernel then replaced part of the per-entry work -- moment collapse, skipped tiles -- and the
+                  8d flop model does not describe it)
+       issue_frac = executed-work ceiling / measured time (the kernel's OWN instruction mix from the counters,
+                  priced with tools/ubench_gap.hip's issue costs): an issue-efficiency diagnostic, NOT a fraction of
+                  the peak and never reported as `frac` or in TFLOP/s."""
+  ach = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else None
+  r = {"bound": "mfma", "kernel": kernel, "kernel_ms": round(k_ms, 4), "algorithmic_flops_per_launch": flops,
+       "flops_model": why_flops, "achieved": None if ach is None else round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+       "frac": None, "traffic": None}
+  if ach is not None:
+    if ach <= peak:
+      r["frac"] = round(ach / peak, 4)
+    else:
+      r["frac_null_reason"] = ("algorithmic rate exceeds the dense peak: the launch does not execute SURVEY 8d's per-entry work "
+                               "(cubic + quartic remainder from f64 moments, tiles with max|b| <= 1/16 skipped; config.offdiag_items)")
+  got = pmc_kernel(pmc, prefix)
+  if got is None:
+    r["pmc"] = pmc_src
+    return r
+  name, ent = got
+  ce = executed_ceiling(ent, kind)
+  ceiling_ms = ce["ceiling_ms"] * pscale
+  r.update({"kernel": name, "issue_frac": round(ceiling_ms / k_ms, 4) if k_ms > 0 else None,
+            "issue_ceiling_ms": round(ceiling_ms, 4),
+            "issue_frac_definition": "executed-work ceiling / measured kernel time; ceiling = (MFMA pipe cycles + VALU issue cycles that "
+                                     "cannot hide beside the MFMAs, by instruction class: tools/ubench_gap.hip) / 1024 SIMDs / 2.4 GHz, "
+                                     "from the kernel's own hardware counters -- issue efficiency, not a fraction of the flop peak",
+            "instruction_mix_per_launch": {k: round(v * pscale, 1) for k, v in ce["mix"].items()},
+            "traffic": ent["counters"]["hbm_bytes"] * pscale if "hbm_bytes" in ent["counters"] else None, "pmc": pmc_src})
+  c = ent["counters"]
+  if "SQ_VALU_MFMA_BUSY_CYCLES" in c and c.get("GRBM_GUI_ACTIVE"):
+    r["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / (c["GRBM_GUI_ACTIVE"] / 8.0), 4)
+  return r
+
+
 def main():
   args = parse()
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -247,15 +308,9 @@ def main():
     return composed_bench(args, rank, world, dev, dist)
   cfg = dict(CONFIGS[args.config])
   scaling = args.scaling or cfg["scaling"]
-  recipe_name = args.recipe or cfg["recipe"]
-  rec = dict(RECIPES[recipe_name])
-  if not cfg["closed"] and not rec["independent"]:
-    # d != D: no closed rollout exists; the recipe's model on H independent (mu, Sigma) draws (mu in [0.3, 0.7]^d)
-    rec["independent"] = True
-    rec["text"] += "; d != D, so every step takes a fresh draw mu~U[0.3,0.7]^d / Sigma std 0.1"
-    rec["mu_range"] = (0.3, 0.7)
   L, M, d, H = cfg["L"], cfg["M"], cfg["d"], cfg["H"]
   dtype = torch.float32 if cfg["dtype"] == "f32" else torch.float64
+  f32_mode = dtype == torch.float32
   Bcfg = args.batch or cfg["B"]
   if scaling == "strong":
     B_total = Bcfg
@@ -265,69 +320,77 @@ def main():
     B, B_total, lo = Bcfg, Bcfg * world, rank * Bcfg
   if B <= 0:
     raise SystemExit(f"rank {rank} got an empty shard of B={B_total}")
-  steps = args.steps if args.pmc_run else max(H, -(-args.steps // H) * H)     # whole rollouts (see module docstring)
-
-  def build_model():
-    syn_ = make_svgp(L, M, d, seed=cfg["seed"], device=str(dev), ls_bounds=rec["ls_bounds"], stable=rec["stable"])
-    model_ = syn_.to_model(dev)
-    return syn_, model_, model_.packed(dtype, True, dev)
-  syn, model, pm = one_rank_at_a_time(build_model, rank, world, dist, args.rehearse_gloo)
-  if rec["independent"]:
-    # the step kernel on H independent draws of the whole batch; rank-independent global draw so that
-    # a strong-scaling run processes the same B_total inputs at every N
-    lo_mu, hi_mu = rec.get("mu_range", (0.0, 1.0))
-    mu_np, S_np = make_inputs(B_total * H, d, seed=2000 + cfg["seed"], scale=0.1, lo=lo_mu, hi=hi_mu)
-    mu_np = mu_np.reshape(H, B_total, d)[:, lo:lo + B]
-    S_np = S_np.reshape(H, B_total, d, d)[:, lo:lo + B]
-    draws_mu = torch.tensor(np.ascontiguousarray(mu_np), dtype=dtype, device=dev)
-    draws_S = torch.tensor(np.ascontiguousarray(S_np), dtype=dtype, device=dev)
-    mu0_np, S0_np = mu_np[0], S_np[0]
+  steps = args.steps                                       # EXACTLY --steps timed steps (see one_step / finish_rollout)
+  primary = args.recipe or cfg["recipe"]
+  # the regimes of one run: the primary recipe gives `value`; the others are timed in the same process after it and
+  # reported under `regimes` (N = 1 only unless --regimes says otherwise)
+  if args.regimes:
+    names = [primary] + [r for r in args.regimes.split(",") if r and r != primary]
+  elif args.recipe is None and not args.pmc_run and world == 1:
+    names = [primary] + [r for r in cfg.get("also", ()) if r != primary]
   else:
-    mu_all, S_all = make_inputs(B_total, d, seed=2000 + cfg["seed"], scale=0.1, lo=0.3, hi=0.7)
-    mu0_np, S0_np = mu_all[lo:lo + B], S_all[lo:lo + B]
-  mu0 = torch.tensor(mu0_np, dtype=dtype, device=dev)
-  S0 = torch.tensor(S0_np, dtype=dtype, device=dev)
-  dc = d if cfg["closed"] else L                           # dimension of the per-step cost statistic's argument
-  target = torch.full((dc,), 0.5 if cfg["closed"] else 0.0, dtype=dtype, device=dev)
-  precis = torch.eye(dc, dtype=dtype, device=dev) * 4.0
-
+    names = [primary]
+  for n in names:
+    if n not in RECIPES:
+      raise SystemExit(f"unknown recipe {n}")
   F = _lib
-  base = ops.make_flags(True, True, args.force_generic) | (F.MM_FORCE_WORST_TIER if rec["worst"] else 0)
-  traj_mu = torch.empty(H, B, dc, dtype=dtype, device=dev)
-  traj_S = torch.empty(H, B, dc, dc, dtype=dtype, device=dev)
-  Bmax = -(-B_total // world)
-  gathered = [torch.empty(Bmax, H, dtype=dtype, device=dev) for _ in range(world)] if world > 1 else None
-  pad_cost = torch.zeros(Bmax, H, dtype=dtype, device=dev)
-  ev = []
-  state = {"mu": mu0.clone(), "S": S0.clone(), "h": 0, "cost": None, "rollouts": 0}
-  Ev = lambda: torch.cuda.Event(enable_timing=True)
+  Po = L * (L - 1) // 2
+  e_off = float(B) * Po * M * M
+  e_diag = float(B) * L * M * (M + 1) / 2
+  models = {}
 
-  def one_step(timed):
-    h = state["h"]
+  def model_for(rec):
+    key = (rec["ls_bounds"], rec["stable"])
+    if key not in models:
+      def build_model():
+        syn_ = make_svgp(L, M, d, seed=cfg["seed"], device=str(dev), ls_bounds=rec["ls_bounds"], stable=rec["stable"])
+        model_ = syn_.to_model(dev)
+        return syn_, model_, model_.packed(dtype, True, dev)
+      models[key] = one_rank_at_a_time(build_model, rank, world, dist, args.rehearse_gloo)
+    return models[key]
+
+  def run_regime(recipe_name, is_primary):
+    rec = dict(RECIPES[recipe_name])
+    if not cfg["closed"] and not rec["independent"]:
+      # d != D: no closed rollout exists; the recipe's model on H independent (mu, Sigma) draws (mu in [0.3, 0.7]^d)
+      rec["independent"] = True
+      rec["text"] += "; d != D, so every step takes a fresh draw mu~U[0.3,0.7]^d / Sigma std 0.1"
+      rec["mu_range"] = (0.3, 0.7)
+    syn, model, pm = model_for(rec)
     if rec["independent"]:
-      state["mu"], state["S"] = draws_mu[h], draws_S[h]
-    elif h == 0:
-      state["mu"], state["S"] = mu0.clone(), S0.clone()
-    e = [Ev() for _ in range(5)] if timed else None
-    if timed: e[0].record()
-    f1, cross, _ = ops.q_forward(pm, state["mu"], state["S"], base)
-    if timed: e[1].record()
-    ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_DIAG)
-    if timed: e[2].record()
-    ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_OFFDIAG)
-    if timed: e[3].record()
-    Sff = ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_FINALIZE)
-    if cfg["closed"]:
-      state["mu"], state["S"] = ops.euler_update(state["mu"], state["S"], f1, Sff, cross, 1.0)
-      traj_mu[h].copy_(state["mu"]); traj_S[h].copy_(state["S"])
+      # the step kernel on H independent draws of the whole batch; rank-independent global draw so that
+      # a strong-scaling run processes the same B_total inputs at every N
+      lo_mu, hi_mu = rec.get("mu_range", (0.0, 1.0))
+      mu_np, S_np = make_inputs(B_total * H, d, seed=2000 + cfg["seed"], scale=0.1, lo=lo_mu, hi=hi_mu)
+      mu_np = mu_np.reshape(H, B_total, d)[:, lo:lo + B]
+      S_np = S_np.reshape(H, B_total, d, d)[:, lo:lo + B]
+      draws_mu = torch.tensor(np.ascontiguousarray(mu_np), dtype=dtype, device=dev)
+      draws_S = torch.tensor(np.ascontiguousarray(S_np), dtype=dtype, device=dev)
+      mu0_np, S0_np = mu_np[0], S_np[0]
     else:
-      traj_mu[h].copy_(f1); traj_S[h].copy_(Sff)            # the predicted increment's moments carry the cost statistic
-    if timed:
-      e[4].record(); ev.append(e)
-    state["h"] = h + 1
-    if state["h"] == H:
-      # per-step cost statistic of the finished rollout, [B_local, H] -> all ranks: ONE collective
-      cost = expected_gaussian_cost(traj_mu, traj_S, target, precis).T.contiguous()
+      mu_all, S_all = make_inputs(B_total, d, seed=2000 + cfg["seed"], scale=0.1, lo=0.3, hi=0.7)
+      mu0_np, S0_np = mu_all[lo:lo + B], S_all[lo:lo + B]
+    mu0 = torch.tensor(mu0_np, dtype=dtype, device=dev)
+    S0 = torch.tensor(S0_np, dtype=dtype, device=dev)
+    dc = d if cfg["closed"] else L                           # dimension of the per-step cost statistic's argument
+    target = torch.full((dc,), 0.5 if cfg["closed"] else 0.0, dtype=dtype, device=dev)
+    precis = torch.eye(dc, dtype=dtype, device=dev) * 4.0
+    base = ops.make_flags(True, True, args.force_generic) | (F.MM_FORCE_WORST_TIER if rec["worst"] else 0)
+    traj_mu = torch.empty(H, B, dc, dtype=dtype, device=dev)
+    traj_S = torch.empty(H, B, dc, dc, dtype=dtype, device=dev)
+    Bmax = -(-B_total // world)
+    gathered = [torch.empty(Bmax, H, dtype=dtype, device=dev) for _ in range(world)] if world > 1 else None
+    pad_cost = torch.zeros(Bmax, H, dtype=dtype, device=dev)
+    ev = []
+    state = {"mu": mu0.clone(), "S": S0.clone(), "h": 0, "cost": None, "rollouts": 0, "collectives": 0}
+    Ev = lambda: torch.cuda.Event(enable_timing=True)
+
+    def finish_rollout(h_done):
+      """Per-step cost statistic of the h_done steps just taken, [B_local, H] -> all ranks: ONE collective
+      per rollout.  Called at every rollout boundary and once more at the end of the timed region when --steps is not
+      a whole number of rollouts, so the cost kernel and the collective are inside the timed region for every K."""
+      cost = torch.zeros(B, H, dtype=dtype, device=dev)
+      cost[:, :h_done] = expected_gaussian_cost(traj_mu[:h_done], traj_S[:h_done], target, precis).T
       if world > 1:
         pad_cost[:B].copy_(cost)
         if args.rehearse_gloo:
@@ -337,6 +400,7 @@ def main():
         else:
           dist.all_gather(gathered, pad_cost)
           full = gathered
+        state["collectives"] += 1
         if scaling == "strong":
           sizes = [shard_range(B_total, r, world) for r in range(world)]
           state["cost"] = torch.cat([t[:b - a] for t, (a, b) in zip(full, sizes)], 0)
@@ -347,133 +411,219 @@ def main():
       state["h"] = 0
       state["rollouts"] += 1
 
-  def fence():
-    torch.cuda.synchronize()
-    if world > 1:
-      dist.barrier()
-    torch.cuda.synchronize()
+    def one_step(timed):
+      h = state["h"]
+      if rec["independent"]:
+        state["mu"], state["S"] = draws_mu[h], draws_S[h]
+      elif h == 0:
+        state["mu"], state["S"] = mu0.clone(), S0.clone()
+      e = [Ev() for _ in range(5)] if timed else None
+      if timed: e[0].record()
+      f1, cross, _ = ops.q_forward(pm, state["mu"], state["S"], base)
+      if timed: e[1].record()
+      ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_DIAG)
+      if timed: e[2].record()
+      ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_OFFDIAG)
+      if timed: e[3].record()
+      Sff = ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_FINALIZE)
+      if cfg["closed"]:
+        state["mu"], state["S"] = ops.euler_update(state["mu"], state["S"], f1, Sff, cross, 1.0)
+        traj_mu[h].copy_(state["mu"]); traj_S[h].copy_(state["S"])
+      else:
+        traj_mu[h].copy_(f1); traj_S[h].copy_(Sff)            # the predicted increment's moments carry the cost statistic
+      if timed:
+        e[4].record(); ev.append(e)
+      state["h"] = h + 1
+      if state["h"] == H:
+        finish_rollout(H)
 
-  for _ in range(args.warmup):
-    one_step(False)
-  state["h"] = 0
-  state["rollouts"] = 0
-  if world > 1 and not args.rehearse_gloo:
-    # the warm-up steps need not reach the end of a rollout: bring up the collective's channels untimed
-    dist.all_gather(gathered, pad_cost)
-  fence()
-  t0 = time.perf_counter()
-  for _ in range(steps):
-    one_step(True)
-  fence()
-  elapsed = time.perf_counter() - t0
-  if world > 1:
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_gloo else dev)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
-  pm.check_status(B)
-  rollouts_timed = state["rollouts"]
-  # regime of the off-diagonal reduce over one (untimed) rollout: its kernels' time depends on it
-  collapsed = [0, 0, 0]
-  if dtype == torch.float32 and not args.pmc_run:
-    for _ in range(H):
+    def fence():
+      torch.cuda.synchronize()
+      if world > 1:
+        dist.barrier()
+      torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
       one_step(False)
-      collapsed = [x + y for x, y in zip(collapsed, ops.offdiag_stats(pm, B, base))]
-  if cfg["closed"] and not torch.isfinite(state["S"]).all():
-    raise SystemExit("non-finite state in the timed rollout")
-  if not args.pmc_run:
-    if state["cost"] is None or tuple(state["cost"].shape) != (B_total, H):
-      raise SystemExit(f"gathered cost matrix has shape {None if state['cost'] is None else tuple(state['cost'].shape)}, "
-                       f"expected {(B_total, H)}")
-    if not torch.isfinite(state["cost"]).all():
-      raise SystemExit("non-finite per-step costs")
+    state["h"] = 0
+    state["rollouts"] = 0
+    state["collectives"] = 0
+    if world > 1 and not args.rehearse_gloo:
+      # the warm-up steps need not reach the end of a rollout: bring up the collective's channels untimed
+      dist.all_gather(gathered, pad_cost)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+      one_step(True)
+    if state["h"] != 0 and not args.pmc_run:
+      finish_rollout(state["h"])                             # the partial last rollout's costs + collective
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+      tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_gloo else dev)
+      dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+      elapsed = float(tmax.item())
+    pm.check_status(B)
+    rollouts_timed, collectives_timed = state["rollouts"], state["collectives"]
+    # regime of the off-diagonal reduce over one (untimed) rollout: its kernels' time depends on it
+    collapsed = [0, 0, 0]
+    if f32_mode and not args.pmc_run:
+      state["h"] = 0
+      for _ in range(H):
+        one_step(False)
+        collapsed = [x + y for x, y in zip(collapsed, ops.offdiag_stats(pm, B, base))]
+    if cfg["closed"] and not torch.isfinite(state["S"]).all():
+      raise SystemExit(f"non-finite state in the timed rollout (recipe {recipe_name})")
+    if not args.pmc_run:
+      if state["cost"] is None or tuple(state["cost"].shape) != (B_total, H):
+        raise SystemExit(f"gathered cost matrix has shape {None if state['cost'] is None else tuple(state['cost'].shape)}, "
+                         f"expected {(B_total, H)}")
+      if not torch.isfinite(state["cost"]).all():
+        raise SystemExit("non-finite per-step costs")
 
-  # ---- per-segment device time (HIP events on the launch stream, inside the timed region) -------------------
-  seg = {k: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i, k in enumerate(("q_stage", "diag", "offdiag", "tail"))}
-  Po = L * (L - 1) // 2
-  f32_mode = dtype == torch.float32
-  pmc, pmc_src = load_pmc(args.config if recipe_name == cfg["recipe"] else f"{args.config}_{recipe_name}")
-  pscale, pmc_src = pmc_scale(pmc, pmc_src, B, cfg["B"])
-  e_off = float(B) * Po * M * M
-  e_diag = float(B) * L * M * (M + 1) / 2
+    # ---- per-segment device time (HIP events on the launch stream, inside the timed region) -------------------
+    seg = {k: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i, k in enumerate(("q_stage", "diag", "offdiag", "tail"))}
+    pmc, pmc_src = load_pmc(f"{args.config}_{recipe_name}", fallback=args.config if (recipe_name == cfg["recipe"] and args.config != "c3") else None)
+    pscale, pmc_src = pmc_scale(pmc, pmc_src, B, cfg["B"])
+    kdim = (d + 3) // 4 if (d + 3) // 4 <= 4 else (6 if (d + 3) // 4 <= 6 else 8)
 
-  def reduce_roofline(which):
-    entries = e_off if which == "offdiag" else e_diag
-    k_ms = seg[which]
-    f32k = which == "offdiag" and f32_mode and not args.force_generic
-    prefix = "k_qred_generic" if args.force_generic else ("k_qred_f32_mfma" if f32k else "k_qred_f64_mfma")
-    if which == "diag" and not args.force_generic:
-      prefix = "k_qred_f64_mfma<" + str((d + 3) // 4 if (d + 3) // 4 <= 4 else (6 if (d + 3) // 4 <= 6 else 8)) + ", true"
-    elif which == "offdiag" and not f32k and not args.force_generic:
-      prefix = "k_qred_f64_mfma<" + str((d + 3) // 4 if (d + 3) // 4 <= 4 else (6 if (d + 3) // 4 <= 6 else 8)) + ", false"
-    flops = entries * (2 * d + 12)                      # E * (2d + 12)
-    peak = PEAK_TFLOPS["f32" if f32k else "f64"]
-    r = {"bound": "mfma", "kernel": prefix, "kernel_ms": round(k_ms, 4), "entries_per_launch": entries,
-         "algorithmic_flops_per_launch": flops,
-         "algorithmic_tflops": round(flops / (k_ms * 1e-3) / 1e12, 2) if k_ms > 0 else None,
-         "algorithmic_note": "SURVEY 8d E*(2d+12) flops / kernel time: NOT a utilisation -- the kernel executes a different, "
-                             "cheaper instruction mix (bf16 split-product MFMAs, range-tiered polynomials, low orders from f64 moments)",
-         "unit": "TFLOP/s", "peak": peak, "traffic": None}
-    got = pmc_kernel(pmc, prefix)
-    if got is None:
-      r.update({"achieved": None, "frac": None, "pmc": pmc_src})
+    def reduce_roofline(which):
+      entries = e_off if which == "offdiag" else e_diag
+      f32k = which == "offdiag" and f32_mode and not args.force_generic
+      if args.force_generic:
+        prefix = "k_qred_generic"
+      elif f32k:
+        prefix = "k_qred_f32_mfma"
+      else:
+        prefix = f"k_qred_f64_mfma<{kdim}, " + ("true" if which == "diag" else "false")
+      why = (f"SURVEY 8d: E * (2d + 12) with E = B*{'Po*M^2' if which == 'offdiag' else 'L*M(M+1)/2'} = {entries:.4g} entries "
+             f"({'off-diagonal' if which == 'offdiag' else 'diagonal'} pairs of one step), d = {d}")
+      r = roofline_block(prefix, seg[which], entries * (2 * d + 12), PEAK_TFLOPS["f32" if f32k else "f64"], pmc, pmc_src, pscale,
+                         "bf16" if f32k else "f64", prefix, why)
+      r["entries_per_launch"] = entries
       return r
-    name, ent = got
-    ce = executed_ceiling(ent, "bf16" if f32k else "f64")
-    ceiling_ms = ce["ceiling_ms"] * pscale
-    frac = ceiling_ms / k_ms if k_ms > 0 else None
-    r.update({"kernel": name, "frac": round(frac, 4), "achieved": round(peak * frac, 2),
-              "ceiling_ms": round(ceiling_ms, 4),
-              "frac_definition": "executed-work ceiling / measured kernel time; ceiling = (MFMA pipe cycles + VALU issue cycles "
-                                 "that cannot hide beside the MFMAs, by instruction class: tools/ubench_gap.hip) / 1024 SIMDs / 2.4 GHz "
-                                 "from the kernel's own hardware counters; `achieved` = peak x frac",
-              "instruction_mix_per_launch": {k: round(v * pscale, 1) for k, v in ce["mix"].items()},
-              "traffic": ent["counters"]["hbm_bytes"] * pscale if "hbm_bytes" in ent["counters"] else None, "pmc": pmc_src})
-    c = ent["counters"]
-    if "SQ_BUSY_CYCLES" in c and "SQ_VALU_MFMA_BUSY_CYCLES" in c:
-      r["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / (c["GRBM_GUI_ACTIVE"] / 8.0), 4) if c.get("GRBM_GUI_ACTIVE") else None
-    return r
 
-  roofs = {"offdiag": reduce_roofline("offdiag") if Po else None, "diag": reduce_roofline("diag")}
-  dominant = "offdiag" if (Po and seg["offdiag"] >= seg["diag"]) else "diag"
-  # q stage: HBM-bound operand producers (k_qvec, k_pairvec, k_wmom_gemm): bytes from the counters
-  qroof = {"bound": "hbm", "kernels": "k_prep + k_qvec + k_pairvec (+ k_wmom_gemm [f64 MFMA GEMM] + k_spoly)", "segment_ms": round(seg["q_stage"], 4),
-           "peak": PEAK_HBM_GBS, "unit": "GB/s", "per_kernel": {}}
-  if pmc is not None:
-    for pre in ("k_qvec", "k_pairvec", "k_wmom_gemm", "k_spoly"):
-      got = pmc_kernel(pmc, pre)
-      if got and "hbm_bytes" in got[1]["counters"]:
-        qroof["per_kernel"][got[0]] = {"hbm_bytes": got[1]["counters"]["hbm_bytes"] * pscale}
+    roofs = {"offdiag": reduce_roofline("offdiag") if Po else None, "diag": reduce_roofline("diag")}
+    dominant = "offdiag" if (Po and seg["offdiag"] >= seg["diag"]) else "diag"
+    # step-level cross-check of the same model: all pairs' 8d flops over the whole step, against the f32/f64 peak
+    step_ms = 1e3 * elapsed / steps
+    step_flops = (e_off + e_diag) * (2 * d + 12) + e_diag * 2
+    step_tf = step_flops / (step_ms * 1e-3) / 1e12
+    step_peak = PEAK_TFLOPS["f32" if f32_mode else "f64"]
+    roof_step = {"flops_per_step": step_flops, "achieved": round(step_tf, 2), "peak": step_peak, "unit": "TFLOP/s",
+                 "frac": round(step_tf / step_peak, 4) if step_tf <= step_peak else None,
+                 "note": "SURVEY 8d F_Q per step / ms_per_step (q stage included in the time); diagonal pairs run in f64 in both modes"}
+    if step_tf > step_peak:
+      roof_step["frac_null_reason"] = "exceeds the peak: the step does not execute 8d's per-entry work in this data regime (see roofline.frac_null_reason)"
+    # q stage: HBM-bound operand producers: bytes from the counters / the HIP-event segment is the whole stage
+    qroof = {"bound": "hbm", "kernels": "k_prep + k_qvec + k_pairvec (+ k_wmom_gemm [f64 MFMA GEMM] + k_spoly)", "segment_ms": round(seg["q_stage"], 4),
+             "peak": PEAK_HBM_GBS, "unit": "GB/s", "per_kernel": {}}
+    if pmc is not None:
+      for pre in ("k_qvec", "k_pairvec", "k_wmom_gemm", "k_spoly"):
+        got = pmc_kernel(pmc, pre)
+        if got and "hbm_bytes" in got[1]["counters"]:
+          qroof["per_kernel"][got[0]] = {"hbm_bytes": got[1]["counters"]["hbm_bytes"] * pscale}
 
+    res = {
+        "recipe": recipe_name, "recipe_text": rec["text"],
+        "value": round(B_total * steps / elapsed, 2), "ms_per_step": round(step_ms, 4), "steps": steps,
+        "rollouts_timed": rollouts_timed, "collectives_timed": collectives_timed if world > 1 else 0,
+        "segments_ms": {k: round(v, 4) for k, v in seg.items()},
+        "offdiag_items_one_rollout": {"collapsed": collapsed[0], "wholly_inside": collapsed[2], "total": collapsed[1]},
+        "roofline": roofs[dominant], "roofline_other": roofs["diag" if dominant == "offdiag" else "offdiag"],
+        "roofline_step": roof_step, "roofline_q_stage": qroof,
+    }
+
+    # ---- parity of THIS regime (rank 0, N == 1): GPU step vs the CPU restatements on the same element ------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pmc_run:
+      from oracle import mm_oracle as mo
+      Bc = 1 if M >= 1000 else min(B, 4)
+      err = lambda g, w: float(np.abs(g.double().cpu().numpy() - w).max())
+
+      def gpu_step(pm_, mu_t, S_t, flags):
+        f1_, cross_, _ = ops.q_forward(pm_, mu_t, S_t, flags)
+        Sff_ = ops.Q_reduce_forward(pm_, mu_t.shape[0], flags)
+        pm_.check_status(mu_t.shape[0])
+        return f1_, Sff_, cross_
+      po_full = mo.SVGPParams(Z=np.broadcast_to(syn.Z, (L, M, d)).copy(), lengthscales=syn.lengthscales, variance=syn.variance,
+                              q_mu=syn.q_mu, q_sqrt=syn.q_sqrt, whiten=True)
+      par = {}
+      g = gpu_step(pm, mu0[:Bc].contiguous(), S0[:Bc].contiguous(), base)
+      if 8.0 * Bc * L * M * M * 3 < 4e9:
+        # algorithm-matched fp64 restatement (O(M^2) per pair): affordable for every regime
+        from oracle import mm_fused_ref as fr
+        key = ("fused_pre", rec["ls_bounds"], rec["stable"])
+        if key not in models:
+          models[key] = fr.precompute(po_full)
+        t0c = time.perf_counter()
+        fm = fr.moment_match(mu0_np[:Bc], S0_np[:Bc], po_full, *models[key])
+        tm = time.perf_counter() - t0c
+        par["vs_fused_restatement"] = {"B": Bc, "max_abs_err": {"f1": err(g[0], fm[0]), "Sff": err(g[1], fm[1]), "cross_pre": err(g[2], fm[2])},
+                                       "max_abs": {"f1": float(np.abs(fm[0]).max()), "Sff": float(np.abs(fm[1]).max()),
+                                                   "cross_pre": float(np.abs(fm[2]).max())},
+                                       "vs": "oracle/mm_fused_ref.py (fp64 numpy, same algorithm as the kernels), first step, same inputs"}
+        res["_fused"] = (fm, tm, Bc)
+      if f32_mode:
+        # f32 mode against the same kernels in f64 mode on a larger sample of THIS regime's inputs
+        Br = min(B, 8)
+        pm64 = model.packed(torch.float64, True, dev)
+        if cfg["closed"] and not rec["independent"] and not rec["worst"]:
+          m32, S32 = ops.rollout_closed(pm, mu0[:Br].contiguous(), S0[:Br].contiguous(), H)
+          m64, S64 = ops.rollout_closed(pm64, mu0[:Br].double().contiguous(), S0[:Br].double().contiguous(), H)
+          pm64.check_status(Br)
+          par["rollout_f32_vs_f64_mode"] = {
+              "B": Br, "H": H, "max_abs_diff": {"mu_H": float((m32.double() - m64).abs().max()),
+                                                "Sigma_H": float((S32.double() - S64).abs().max())},
+              "max_abs": {"mu_H": float(m64.abs().max()), "Sigma_H": float(S64.abs().max())}}
+        else:
+          g32 = gpu_step(pm, mu0[:Br].contiguous(), S0[:Br].contiguous(), base)
+          g64 = gpu_step(pm64, mu0[:Br].double().contiguous(), S0[:Br].double().contiguous(), ops.make_flags(True, True, False))
+          par["step_f32_vs_f64_mode"] = {
+              "B": Br, "max_abs_diff": {k: float((a.double() - b).abs().max()) for k, a, b in zip(("f1", "Sff", "cross_pre"), g32, g64)},
+              "max_abs": {k: float(b.abs().max()) for k, b in zip(("f1", "Sff", "cross_pre"), g64)}}
+      res["parity"] = par
+      if is_primary:
+        res["_ctx"] = dict(syn=syn, pm=pm, mu0=mu0, S0=S0, mu0_np=mu0_np, S0_np=S0_np, rec=rec, base=base, gpu_first=g, Bc=Bc)
+    return res
+
+  results = {}
+  for i, n in enumerate(names):
+    results[n] = run_regime(n, i == 0)
+  pr = results[primary]
+  rec_p = RECIPES[primary]
   out = {
       "metric": "moment_matched_rollout_step_elements_per_sec",
-      "value": round(B_total * steps / elapsed, 2),
+      "value": pr["value"],
       "unit": "rollout step-elements/s (B*H per rollout second)",
       "n_gpus": world, "steps": steps, "warmup": args.warmup,
-      "ms_per_step": round(1e3 * elapsed / steps, 4),
+      "ms_per_step": pr["ms_per_step"],
       "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
       "dtype": cfg["dtype"], "data": "synthetic",
-      "config": {"workload": f"{cfg['label']}; recipe={recipe_name}: {rec['text']}",
+      "config": {"workload": f"{cfg['label']}; recipe={primary}: {rec_p['text']}",
                  "N": M, "d": d, "D": L, "H": H, "B_per_gpu": B if scaling == "weak" else None, "B_total": B_total,
-                 "B_this_rank": B, "parallelism": f"dp{world} over B ({scaling})", "recipe": recipe_name,
-                 "rollouts_timed": rollouts_timed, "collectives_timed": rollouts_timed if world > 1 else 0,
+                 "B_this_rank": B, "parallelism": f"dp{world} over B ({scaling})", "recipe": primary,
+                 "value_is": f"the `{primary}` regime; every other entry of `regimes` was timed in the same process with the same --steps/--warmup",
+                 "rollouts_timed": pr["rollouts_timed"], "collectives_timed": pr["collectives_timed"],
                  "steps_requested": args.steps,
                  "diag_pairs": "f64", "offdiag_pairs": cfg["dtype"],
-                 "offdiag_items_one_rollout": {"collapsed": collapsed[0], "wholly_inside": collapsed[2], "total": collapsed[1],
-                                               "meaning": "(b, off-diagonal pair, step) items of one rollout; collapsed: cubic + quartic "
-                                                          "remainder terms from f64 moments, tiles with max|b| <= 1/16 skipped after a "
-                                                          "screening MFMA; wholly_inside: the Cauchy-Schwarz bound alone puts every |b| <= 1/16, "
-                                                          "no tile work (csrc/mm_moments.hip, mm_mfma.hip)"}},
-      "segments_ms": {k: round(v, 4) for k, v in seg.items()},
-      "roofline": roofs[dominant],
-      "roofline_other": roofs["diag" if dominant == "offdiag" else "offdiag"],
-      "roofline_q_stage": qroof,
+                 "offdiag_items_one_rollout": dict(pr["offdiag_items_one_rollout"],
+                                                   meaning="(b, off-diagonal pair, step) items of one rollout; collapsed: cubic + quartic "
+                                                           "remainder terms from f64 moments, tiles with max|b| <= 1/16 skipped after a "
+                                                           "screening MFMA; wholly_inside: the Cauchy-Schwarz bound alone puts every |b| <= 1/16, "
+                                                           "no tile work (csrc/mm_moments.hip, mm_mfma.hip)")},
+      "segments_ms": pr["segments_ms"],
+      "roofline": pr["roofline"],
+      "roofline_other": pr["roofline_other"],
+      "roofline_step": pr["roofline_step"],
+      "roofline_q_stage": pr["roofline_q_stage"],
   }
+  ctx = pr.pop("_ctx", None)
 
-  # ---- CPU baseline + parity (rank 0, N == 1 only) -----------------------------------------
-  if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pmc_run:
+  # ---- CPU baseline + parity vs the literal oracle (rank 0, N == 1 only, primary regime) --------------------------
+  if ctx is not None:
     from oracle import mm_oracle as mo
+    syn, mu0_np, S0_np, rec, Bc = ctx["syn"], ctx["mu0_np"], ctx["S0_np"], ctx["rec"], ctx["Bc"]
     small = M <= 256
-    Bc = 1 if M >= 1000 else min(B, 4)
     # the literal algorithm materialises eKuffu [B,L,M,L,M] (8 B L^2 M^2 bytes) and needs 2 L^2 M^3 flops per element:
     # where that does not fit a bounded sample (C4: 131 GB), the sample is the sub-problem of the first Lc latents
     # (latents are independent: f1, Sff[:Lc,:Lc], cross[:,:Lc] of the full model ARE the sub-model's outputs)
@@ -501,46 +651,29 @@ def main():
     out["cpu_baseline"] = {"value": round(Bc * nst / tc, 4), "unit": out["unit"] + ("" if Lc == L else f" [{Lc}-latent sub-problem]"),
                            "cores": os.cpu_count(), "kind": "port",
                            "sample": f"literal fp64 oracle (materialised eKuffu [B,L,M,L,M] + triangular solves, "
-                                     f"numpy/OpenBLAS threads), B={Bc}, {nst} step(s) of the same workload{sub}, {tc:.1f}s"}
-    if M >= 1000 and Lc == L:
+                                     f"numpy/OpenBLAS threads), B={Bc}, {nst} step(s) of the same workload ({primary} recipe){sub}, {tc:.1f}s"}
+    fused = pr.pop("_fused", None)
+    if fused is not None and M >= 1000 and Lc == L:
       # second CPU figure: the algorithm-matched restatement -- beta / C hoisted out of the
       # step, O(M^2) per kernel pair -- so the ratio to the GPU is not merely the O(M^3) -> O(M^2) change
-      from oracle import mm_fused_ref as fr
-      beta_c, C_c = fr.precompute(po)                        # not timed: once per model, like mm_pack_model
-      t0 = time.perf_counter()
-      fm = fr.moment_match(mu0_np[:Bc], S0_np[:Bc], po, beta_c, C_c)
-      tm = time.perf_counter() - t0
-      out["cpu_baseline_matched"] = {"value": round(Bc / tm, 4), "unit": out["unit"], "cores": os.cpu_count(), "kind": "port",
+      fm, tm, Bf = fused
+      out["cpu_baseline_matched"] = {"value": round(Bf / tm, 4), "unit": out["unit"], "cores": os.cpu_count(), "kind": "port",
                                      "sample": f"algorithm-matched fp64 restatement (oracle/mm_fused_ref.py: numpy, O(M^2) per pair, "
-                                               f"precompute excluded), B={Bc}, 1 step without the Euler update, {tm:.1f}s",
+                                               f"precompute excluded), B={Bf}, 1 step without the Euler update, {tm:.1f}s",
                                      "max_abs_diff_vs_literal": {"f1": float(np.abs(fm[0] - first[0]).max()),
                                                                  "Sff": float(np.abs(fm[1] - first[1]).max())}}
-    f1, Sff, cross = ops.moment_match(pm, mu0[:Bc].contiguous(), S0[:Bc].contiguous())
+    f1, Sff, cross = ctx["gpu_first"]
     f1, Sff, cross = f1[:, :Lc], Sff[:, :Lc, :Lc], cross[:, :, :Lc]
     err = lambda g, w: float(np.abs(g.double().cpu().numpy() - w).max())
-    out["parity"] = {"vs": "fp64 CPU oracle, first step, same inputs" + ("" if Lc == L else f" (first {Lc} latents)"), "B": Bc,
-                     "max_abs_err": {"f1": err(f1, first[0]), "Sff": err(Sff, first[1]), "cross_pre": err(cross, first[2])},
-                     "max_abs": {"f1": float(np.abs(first[0]).max()), "Sff": float(np.abs(first[1]).max()),
-                                 "cross_pre": float(np.abs(first[2]).max())}}
-    if f32_mode:
-      # f32 mode against the same kernels in f64 mode on a larger sample of THIS workload's inputs
-      Br = min(B, 8)
-      pm64 = model.packed(torch.float64, True, dev)
-      if cfg["closed"] and not rec["independent"]:
-        m32, S32 = ops.rollout_closed(pm, mu0[:Br].contiguous(), S0[:Br].contiguous(), H)
-        m64, S64 = ops.rollout_closed(pm64, mu0[:Br].double().contiguous(), S0[:Br].double().contiguous(), H)
-        pm64.check_status(Br)
-        out["parity"]["rollout_f32_vs_f64_mode"] = {
-            "B": Br, "H": H, "max_abs_diff": {"mu_H": float((m32.double() - m64).abs().max()),
-                                              "Sigma_H": float((S32.double() - S64).abs().max())},
-            "max_abs": {"mu_H": float(m64.abs().max()), "Sigma_H": float(S64.abs().max())}}
-      else:
-        g32 = ops.moment_match(pm, mu0[:Br].contiguous(), S0[:Br].contiguous(), force_generic=False)
-        g64 = ops.moment_match(pm64, mu0[:Br].double().contiguous(), S0[:Br].double().contiguous())
-        pm64.check_status(Br)
-        out["parity"]["step_f32_vs_f64_mode"] = {
-            "B": Br, "max_abs_diff": {k: float((a.double() - b).abs().max()) for k, a, b in zip(("f1", "Sff", "cross_pre"), g32, g64)},
-            "max_abs": {k: float(b.abs().max()) for k, b in zip(("f1", "Sff", "cross_pre"), g64)}}
+    out["parity"] = dict({"vs": "fp64 CPU oracle (literal reference algorithm), first step, same inputs" + ("" if Lc == L else f" (first {Lc} latents)"), "B": Bc,
+                          "recipe": primary,
+                          "max_abs_err": {"f1": err(f1, first[0]), "Sff": err(Sff, first[1]), "cross_pre": err(cross, first[2])},
+                          "max_abs": {"f1": float(np.abs(first[0]).max()), "Sff": float(np.abs(first[1]).max()),
+                                      "cross_pre": float(np.abs(first[2]).max())}}, **pr.get("parity", {}))
+  for r in results.values():
+    r.pop("_fused", None); r.pop("_ctx", None)
+  if len(results) > 1 or args.regimes:
+    out["regimes"] = {n: {k: v for k, v in r.items() if k not in ("roofline_q_stage",)} for n, r in results.items()}
   if rank == 0:
     print(json.dumps(out))
   if world > 1:

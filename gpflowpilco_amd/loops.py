@@ -49,21 +49,32 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
   bj = head.bijectors if isinstance(head, tfb.Chain) else None
   if not (bj and len(bj) == 3 and isinstance(bj[0], tfb.Scale) and isinstance(bj[1], tfb.Shift) and isinstance(bj[2], tfb.NormalCDF)):
     return None
+  def head_constants():
+    return float(bj[0].scale), float(bj[1].shift)
   try:
-    scale, shift = float(bj[0].scale), float(bj[1].shift)
+    head_constants()
   except (TypeError, ValueError):
     return None
   cache = {}
 
   def run(mx: torch.Tensor, Sxx: torch.Tensor):
+    # Everything the rollout reads is looked up on EVERY call: ``packed()`` re-packs a model whose parameters were
+    # updated in place (optimiser step, refit between episodes: _PackCache keys on the tensors' versions), and the
+    # head / objective constants are read from their owners.  Only the compose workspace is kept across calls.
     key = (mx.dtype, str(mx.device))
-    roll = cache.get(key)
-    if roll is None:
-      nx = mx.shape[-1]
-      roll = ops.ComposedRollout(drift.packed(mx.dtype, True, mx.device), pm_.packed(mx.dtype, False, mx.device), nx=nx,
-                                 active_dims=enc.active_dims, head_scale=scale, head_shift=shift,
-                                 target=objective.target, precis=objective.precis)
-      cache[key] = roll
+    pd, pp = drift.packed(mx.dtype, True, mx.device), pm_.packed(mx.dtype, False, mx.device)
+    scale, shift = head_constants()
+    ent = cache.get(key)
+    roll = None if ent is None else ent[0]
+    if (roll is None or roll.drift is not pd or roll.policy is not pp or roll.scale != scale or roll.shift != shift
+        or ent[1] is not objective.target or ent[2] is not objective.precis
+        or ent[3] != (objective.target._version, objective.precis._version)):
+      new = ops.ComposedRollout(pd, pp, nx=mx.shape[-1], active_dims=enc.active_dims, head_scale=scale, head_shift=shift,
+                                target=objective.target, precis=objective.precis)
+      if roll is not None:
+        new._wsc = roll._wsc                               # same shapes: the workspace carries over
+      roll = new
+      cache[key] = (roll, objective.target, objective.precis, (objective.target._version, objective.precis._version))
     _, _, cost = roll(mx, Sxx, num_steps, dt=dt)
     return cost.sum(1)
   return run

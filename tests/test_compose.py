@@ -227,3 +227,49 @@ def test_native_composed_rollout_matches_oracle_and_torch_path(dtype, device):
   assert scale_err(loss_n, loss_t.double().cpu().numpy()) < (1e-9 if dtype == torch.float64 else 2e-4)
   assert torch.allclose(loss_n, cost.sum(1))
   assert native_policy_loss(system, objective, H) is not None
+
+
+@pytest.mark.gpu
+def test_native_closure_follows_in_place_parameter_updates(device):
+  """The native rollout reads the models through their packed snapshots: an in-place update of a policy parameter
+  (an optimiser step), of a drift parameter (a refit between episodes), of the head constants or of the objective
+  must show up in the next call -- no stale ComposedRollout (loops.native_policy_loss)."""
+  from gpflowpilco_amd.loops import get_state_initializer, policy_loss_closure
+  dtype = F64
+  drift_o = oracle_params(make_svgp(4, 48, 6, seed=20, ls_bounds=(0.8, 3.0)))
+  pol_o = random_svgp_params(seed=21, L=1, M=16, d=5, whiten=True, ls_bounds=(0.7, 2.0), mean=False)
+  pol_o.q_mu = 0.3 * pol_o.q_mu
+  rng = np.random.default_rng(22)
+  mu = np.array([[0.4, 0.2, 0.5, 0.3], [0.6, -0.1, 0.4, 0.5]])
+  S = generate_covariance(rng, 4, (2,), 0.05)
+  target = np.array([0.0, 1.0, 0, 0, 0]); precis = 4.0 * np.eye(5)
+  drift = gp_model_from_oracle(drift_o, device)
+  pol_model = gp_model_from_oracle(pol_o, device)
+  head = tfb.Chain([tfb.Scale(2.0), tfb.Shift(-0.5), tfb.NormalCDF()])
+  policy = gp.InverseLinkWrapper(gp.KernelRegressor(pol_model), invlink=head)
+  objective = GaussianObjective(target=to_dev(target, device, dtype), precis=to_dev(precis, device, dtype))
+  system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=TrigonometricEncoder(active_dims=(1,)),
+                                    solver=dynamics.MomentMatchingEuler())
+  init = get_state_initializer(to_dev(mu, device, dtype), to_dev(S, device, dtype))
+  H = 5
+  native = policy_loss_closure(system, objective, init, H, native=True)
+  torch_path = policy_loss_closure(system, objective, init, H, native=False)
+  pol_model.q_mu.requires_grad_(True)                       # a trainable policy evaluated under no_grad (metrics, line search)
+
+  def both():
+    with torch.no_grad():
+      return native(), torch_path()
+  n0, t0 = both()
+  assert scale_err(n0, t0.cpu().numpy()) < 1e-9
+  with torch.no_grad():
+    pol_model.q_mu.mul_(1.5)                                # optimiser step on the policy
+  n1, t1 = both()
+  assert scale_err(n1, t1.cpu().numpy()) < 1e-9 and (n1 - n0).abs().max() > 1e-6
+  with torch.no_grad():
+    drift.q_mu.mul_(0.9)                                    # drift refit in place between episodes
+  n2, t2 = both()
+  assert scale_err(n2, t2.cpu().numpy()) < 1e-9 and (n2 - n1).abs().max() > 1e-6
+  head.bijectors[0].scale = 1.5                             # head constant
+  objective.target.add_(0.1)                                # objective, in place
+  n3, t3 = both()
+  assert scale_err(n3, t3.cpu().numpy()) < 1e-9 and (n3 - n2).abs().max() > 1e-6

@@ -159,3 +159,36 @@ def test_wide_sigma_short_lengthscales_f32_is_finite_and_bounded(device):
     pm.check_status(5)
     assert torch.isfinite(f1).all() and torch.isfinite(Sff).all() and torch.isfinite(cross).all()
     assert scale_err(Sff, Sffo) < tol and scale_err(f1, f1o) < tol
+
+
+@pytest.mark.parametrize("recipe", ["baseline", "pilco"])
+def test_c3_at_the_configs_own_batch_256(recipe, device):
+  """BASELINE configs[2] at ITS batch, B = 256 (what bench.py times), on both data recipes: two elements -- the first
+  and the last of the batch -- against the fused fp64 restatement, shard invariance of a slice from the middle and
+  of the last element (the tail of every grid), symmetry, positive definiteness; one closed Euler step on top."""
+  L = d = 8
+  M, B = 2000, 256
+  kw = dict(ls_bounds=(0.3, 3.0), stable=False) if recipe == "baseline" else dict(ls_bounds=(0.7, 3.0), stable=True)
+  syn = make_svgp(L, M, d, seed=1002, device=str(device), **kw)
+  lo, hi = (0.0, 1.0) if recipe == "baseline" else (0.3, 0.7)
+  mu, Sigma = make_inputs(B, d, seed=3002, scale=0.1, lo=lo, hi=hi)
+  pm = syn.to_model(device).packed(torch.float32, True, device)
+  mu_t, S_t = to_dev(mu, device, torch.float32), to_dev(Sigma, device, torch.float32)
+  f1, Sff, cross = ops.moment_match(pm, mu_t, S_t)
+  pm.check_status(B)
+  po = oracle_params(syn)
+  beta, C = fr.precompute(po)
+  sel = [0, B - 1]
+  f1o, Sffo, cro = fr.moment_match(mu[sel], Sigma[sel], po, beta, C)
+  assert scale_err(f1[sel], f1o) < 2e-6 and scale_err(cross[sel], cro) < 2e-6
+  assert scale_err(Sff[sel], Sffo) < 5e-5
+  for a, b in ((100, 104), (B - 1, B)):
+    f1s, Sffs, crs = ops.moment_match(pm, mu_t[a:b].contiguous(), S_t[a:b].contiguous())
+    assert torch.equal(f1s, f1[a:b]) and torch.equal(Sffs, Sff[a:b]) and torch.equal(crs, cross[a:b])
+  assert torch.equal(Sff, Sff.transpose(1, 2))
+  assert torch.linalg.eigvalsh(Sff.double()).min() > 0
+  m1, S1 = ops.euler_update(mu_t, S_t, f1, Sff, cross, 1.0)
+  m2, S2 = ops.rollout_closed(pm, mu_t, S_t, 1)
+  assert torch.equal(m1, m2) and torch.equal(S1, S2)
+  Sxf = Sigma[sel] @ cro
+  assert scale_err(S1[sel], Sigma[sel] + Sxf + np.swapaxes(Sxf, 1, 2) + Sffo) < 5e-5
