@@ -559,5 +559,5 @@ def test_disjoint_active_dims_under_a_diagonal_covariance(dtype, device):
   want01 = np.einsum('i,bij,j->b', betas[0], Q01, betas[1]) - per[0][1][:, 0] * per[1][1][:, 0]
   scale = float(np.abs(Sff.double().cpu().numpy()).max())
   got01 = Sff[:, 0, 1].double().cpu().numpy()
-  assert np.abs(want01).max() < 1e-12 * max(scale, 1.0)                 # the shortcut: independent outputs
+  assert np.abs(want01).max() < 1e-8 * max(scale, 1.0)    # the shortcut: independent outputs (beta carries cond(Kuu) eps)
   assert np.abs(got01 - want01).max() < tol["Sff"] * scale and torch.equal(Sff[:, 0, 1], Sff[:, 1, 0])
