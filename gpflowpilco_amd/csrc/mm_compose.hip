@@ -20,51 +20,10 @@
 #include "mm_common.h"
 #include "mm_cost.h"
 #include "mm_dev.h"
-
-#define MMC_NX 16          // largest state dimension
-#define MMC_NA 8           // largest number of encoded (angle) dimensions
-#define MMC_ND 32          // largest drift input dimension (= MM_DMAX)
-
-struct MMComposeDims {
-  int nx, na, nb, ne, nd;
-  int active[MMC_NA];
-  int inactive[MMC_NX];
-  int slot[MMC_NX];        // state dim r -> ia (< na) if active, else na + ib
-};
+#include "mm_compose.h"
 
 static __device__ const double MM_GL48_X[48] = {-9.98771007252426068e-01, -9.93530172266350764e-01, -9.84124583722826851e-01, -9.70591592546247273e-01, -9.52987703160430910e-01, -9.31386690706554332e-01, -9.05879136715569633e-01, -8.76572020274247854e-01, -8.43588261624393487e-01, -8.07066204029442624e-01, -7.67159032515740358e-01, -7.24034130923814634e-01, -6.77872379632663891e-01, -6.28867396776513599e-01, -5.77224726083972683e-01, -5.23160974722232996e-01, -4.66902904750958414e-01, -4.08686481990716721e-01, -3.48755886292160755e-01, -2.87362487355455554e-01, -2.24763790394689050e-01, -1.61222356068891709e-01, -9.70046992094626970e-02, -3.23801709628693674e-02, 3.23801709628693674e-02, 9.70046992094626970e-02, 1.61222356068891709e-01, 2.24763790394689050e-01, 2.87362487355455554e-01, 3.48755886292160755e-01, 4.08686481990716721e-01, 4.66902904750958414e-01, 5.23160974722232996e-01, 5.77224726083972683e-01, 6.28867396776513599e-01, 6.77872379632663891e-01, 7.24034130923814634e-01, 7.67159032515740358e-01, 8.07066204029442624e-01, 8.43588261624393487e-01, 8.76572020274247854e-01, 9.05879136715569633e-01, 9.31386690706554332e-01, 9.52987703160430910e-01, 9.70591592546247273e-01, 9.84124583722826851e-01, 9.93530172266350764e-01, 9.98771007252426068e-01};
 static __device__ const double MM_GL48_W[48] = {3.15334605230917957e-03, 7.32755390127649234e-03, 1.14772345792349736e-02, 1.55793157229429276e-02, 1.96161604573552965e-02, 2.35707608393240925e-02, 2.74265097083568818e-02, 3.11672278327983394e-02, 3.47772225647706573e-02, 3.82413510658306741e-02, 4.15450829434645535e-02, 4.46745608566940997e-02, 4.76166584924902839e-02, 5.03590355538542783e-02, 5.28901894851934867e-02, 5.51995036999840538e-02, 5.72772921004029295e-02, 5.91148396983954827e-02, 6.07044391658935825e-02, 6.20394231598924636e-02, 6.31141922862537841e-02, 6.39242385846479494e-02, 6.44661644359498381e-02, 6.47376968126836816e-02, 6.47376968126836816e-02, 6.44661644359498381e-02, 6.39242385846479494e-02, 6.31141922862537841e-02, 6.20394231598924636e-02, 6.07044391658935825e-02, 5.91148396983954827e-02, 5.72772921004029295e-02, 5.51995036999840538e-02, 5.28901894851934867e-02, 5.03590355538542783e-02, 4.76166584924902839e-02, 4.46745608566940997e-02, 4.15450829434645535e-02, 3.82413510658306741e-02, 3.47772225647706573e-02, 3.11672278327983394e-02, 2.74265097083568818e-02, 2.35707608393240925e-02, 1.96161604573552965e-02, 1.55793157229429276e-02, 1.14772345792349736e-02, 7.32755390127649234e-03, 3.15334605230917957e-03};
-
-// ---- workspace of the composition (caller-owned; sizes from mm_compose_workspace_bytes) ------------------------
-struct MMComposeLayout {
-  size_t me, See;            // [B][ne], [B][ne][ne] T   policy GP input
-  size_t pf1, pSff, pcross;  // [B][1], [B][1][1], [B][ne][1] T   policy GP output
-  size_t md, Sdd;            // [B][nd], [B][nd][nd] T   drift GP input
-  size_t df1, dSff, dcross;  // [B][nx], [B][nx][nx], [B][nd][nx] T   drift GP output
-  size_t Sxe, cpol;          // [B][nx][ne], [B][ne] f64   Cov(x, e);  Cov(e,e)^-1 Cov(e, u)
-  size_t total;
-};
-
-static inline MMComposeLayout mm_compose_layout(int B, int nx, int na, int dtype) {
-  MMComposeLayout o;
-  const size_t es = mm_elem_size(dtype), A = 256;
-  const int nb = nx - na, ne = 2 * na + nb, nd = ne + 1;
-  size_t off = 0;
-  o.me = off;     off = mm_align_up(off + (size_t)B * ne * es, A);
-  o.See = off;    off = mm_align_up(off + (size_t)B * ne * ne * es, A);
-  o.pf1 = off;    off = mm_align_up(off + (size_t)B * es, A);
-  o.pSff = off;   off = mm_align_up(off + (size_t)B * es, A);
-  o.pcross = off; off = mm_align_up(off + (size_t)B * ne * es, A);
-  o.md = off;     off = mm_align_up(off + (size_t)B * nd * es, A);
-  o.Sdd = off;    off = mm_align_up(off + (size_t)B * nd * nd * es, A);
-  o.df1 = off;    off = mm_align_up(off + (size_t)B * nx * es, A);
-  o.dSff = off;   off = mm_align_up(off + (size_t)B * nx * nx * es, A);
-  o.dcross = off; off = mm_align_up(off + (size_t)B * nd * nx * es, A);
-  o.Sxe = off;    off = mm_align_up(off + (size_t)B * nx * ne * 8, A);
-  o.cpol = off;   off = mm_align_up(off + (size_t)B * ne * 8, A);
-  o.total = off;
-  return o;
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_compose_encode: (mx, Sxx) -> moments of e = [sin a, cos a, x_inactive] and Cov(x, e)
@@ -251,12 +210,14 @@ __device__ __forceinline__ void mmc_step_body(const MMComposeDims& D, double dt,
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(64) void k_compose_tail(MMComposeDims D, double dt, const double* cpol, const T* Sdd,
-                                                     const T* df1, const T* dSff, const T* dcross, T* mx, T* Sxx,
+                                                     const T* df1, const T* dSff, const T* dcross, const double* Sxe_in, T* mx, T* Sxx,
                                                      T* traj_mu, T* traj_S, T* me, T* See, double* Sxe,
                                                      const T* target, const T* precis, T* cost) {
+  // (me, See, Sxe: the NEW state's encoding; Sxe_in: Cov(x, e) of the state the step started from -- the same buffer
+  // in an ordinary rollout, consecutive tape slots in a taped one)
   extern __shared__ double csm[];
   const int b = blockIdx.x, lane = threadIdx.x;
-  mmc_step_body<T>(D, dt, Sxe, cpol, Sdd, df1, dSff, dcross, mx, Sxx, traj_mu, traj_S, b, lane);
+  mmc_step_body<T>(D, dt, Sxe_in, cpol, Sdd, df1, dSff, dcross, mx, Sxx, traj_mu, traj_S, b, lane);
   __syncthreads();
   mmc_encode_body<T>(D, mx, Sxx, me, See, Sxe, b, lane);
   if (cost) {
@@ -432,74 +393,123 @@ __global__ __launch_bounds__(256) void k_policy_match_small(const double* __rest
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-static int mm_compose_dims(int nx, int na, const int32_t* active_dims, MMComposeDims& D) {
-  if (nx <= 0 || nx > MMC_NX || na <= 0 || na > MMC_NA || na > nx || !active_dims) return MM_E_DIM;
-  D.nx = nx; D.na = na; D.nb = nx - na; D.ne = 2 * na + D.nb; D.nd = D.ne + 1;
-  if (D.nd > MMC_ND) return MM_E_DIM;
-  bool used[MMC_NX] = {false};
-  for (int i = 0; i < na; ++i) {
-    const int r = active_dims[i];
-    if (r < 0 || r >= nx || used[r]) return MM_E_ARG;
-    used[r] = true; D.active[i] = r; D.slot[r] = i;
-  }
-  int ib = 0;
-  for (int r = 0; r < nx; ++r) if (!used[r]) { D.inactive[ib] = r; D.slot[r] = na + ib; ++ib; }   // sorted (components.py:66)
-  return 0;
-}
-
 extern "C" size_t mm_compose_workspace_bytes(int B, int nx, int na, int dtype) {
   if (B <= 0 || nx <= 0 || nx > MMC_NX || na <= 0 || na > MMC_NA || na > nx) return 0;
   if (2 * na + (nx - na) + 1 > MMC_ND) return 0;
   return mm_compose_layout(B, nx, na, dtype).total;
 }
 
+// one compose-workspace slot as typed pointers
+template <typename T>
+struct MMCSlot {
+  T *me, *See, *pf1, *pSff, *pcross, *md, *Sdd, *df1, *dSff, *dcross;
+  double *Sxe, *cpol;
+  MMCSlot(char* w, const MMComposeLayout& cl)
+      : me((T*)(w + cl.me)), See((T*)(w + cl.See)), pf1((T*)(w + cl.pf1)), pSff((T*)(w + cl.pSff)), pcross((T*)(w + cl.pcross)),
+        md((T*)(w + cl.md)), Sdd((T*)(w + cl.Sdd)), df1((T*)(w + cl.df1)), dSff((T*)(w + cl.dSff)), dcross((T*)(w + cl.dcross)),
+        Sxe((double*)(w + cl.Sxe)), cpol((double*)(w + cl.cpol)) {}
+};
+
 template <typename T>
 static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, const void* policy, size_t policy_bytes, int Mpol,
                                  int dtype, int B, int H, double dt, const MMComposeDims& D, double scale, double shift,
                                  const T* target, const T* precis, T* mx, T* Sxx, T* cost, T* traj_mu, T* traj_S,
                                  void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
-                                 char* wsc, const MMComposeLayout& cl, int32_t* status, hipStream_t s) {
+                                 char* wsc, const MMComposeLayout& cl, char* tape, int32_t* status, hipStream_t s) {
   const int nx = D.nx, ne = D.ne, nd = D.nd;
-  T* me = (T*)(wsc + cl.me); T* See = (T*)(wsc + cl.See);
-  T* pf1 = (T*)(wsc + cl.pf1); T* pSff = (T*)(wsc + cl.pSff); T* pcross = (T*)(wsc + cl.pcross);
-  T* md = (T*)(wsc + cl.md); T* Sdd = (T*)(wsc + cl.Sdd);
-  T* df1 = (T*)(wsc + cl.df1); T* dSff = (T*)(wsc + cl.dSff); T* dcross = (T*)(wsc + cl.dcross);
-  double* Sxe = (double*)(wsc + cl.Sxe); double* cpol = (double*)(wsc + cl.cpol);
+  // taped: step h works in tape slot h and the tail writes the next encoding into slot h + 1; the states x_0 .. x_H
+  // go to the tape's state block.  Untaped: every step reuses the one workspace.
+  const MMTapeLayout tl = mm_tape_layout(B, H, nx, D.na, dtype);
+  auto slot = [&](int h) { return MMCSlot<T>(tape ? tape + (size_t)h * tl.slot_bytes : wsc, cl); };
+  T* xm = tape ? (T*)(tape + tl.xm) : nullptr;
+  T* xS = tape ? (T*)(tape + tl.xS) : nullptr;
 #define MMC_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
-  hipLaunchKernelGGL((k_compose_encode<T>), dim3(B), dim3(64), 0, s, D, (const T*)mx, (const T*)Sxx, me, See, Sxe);
-  MMC_CHECK();
+  if (tape) {
+    hipError_t e1 = hipMemcpyAsync(xm, mx, (size_t)B * nx * sizeof(T), hipMemcpyDeviceToDevice, s);
+    hipError_t e2 = hipMemcpyAsync(xS, Sxx, (size_t)B * nx * nx * sizeof(T), hipMemcpyDeviceToDevice, s);
+    if (e1 != hipSuccess) return (int)e1;
+    if (e2 != hipSuccess) return (int)e2;
+  }
+  {
+    MMCSlot<T> c0 = slot(0);
+    hipLaunchKernelGGL((k_compose_encode<T>), dim3(B), dim3(64), 0, s, D, (const T*)mx, (const T*)Sxx, c0.me, c0.See, c0.Sxe);
+    MMC_CHECK();
+  }
   for (int h = 0; h < H; ++h) {
+    MMCSlot<T> c = slot(h), n = slot(h + 1);
     // policy: mean-only regressor (models.py:34-41: model_uncertainty = False), one latent
     int rc = 0;
     if (Mpol <= MMS_MMAX && ne <= 8) {
       const MMModelLayout pl = mm_model_layout(1, Mpol, ne, dtype, 1);
+      if (policy_bytes < pl.Cm) return MM_E_WORKSPACE;         // the packed buffer must hold everything the kernel reads
       const char* pp = (const char*)policy;
       hipLaunchKernelGGL((k_policy_match_small<T>), dim3(B), dim3(256), 0, s, (const double*)(pp + pl.Z64),
                          (const double*)(pp + pl.beta64), (const double*)(pp + pl.ls2), (const double*)(pp + pl.var),
-                         (const double*)(pp + pl.meanc), Mpol, ne, (const T*)me, (const T*)See, 0.0, pf1, pSff, pcross, status);
+                         (const double*)(pp + pl.meanc), Mpol, ne, (const T*)c.me, (const T*)c.See, 0.0, c.pf1, c.pSff, c.pcross, status);
       MMC_CHECK();
     } else {
-      rc = mm_moment_match(policy, policy_bytes, 1, Mpol, ne, dtype, B, me, See, MM_FULL_OUTPUT_COV, 0.0,
-                           pf1, pSff, pcross, ws_policy, ws_policy_bytes, status, (void*)s);
+      rc = mm_moment_match(policy, policy_bytes, 1, Mpol, ne, dtype, B, c.me, c.See, MM_FULL_OUTPUT_COV, 0.0,
+                           c.pf1, c.pSff, c.pcross, ws_policy, ws_policy_bytes, status, (void*)s);
       if (rc) return rc;
     }
-    hipLaunchKernelGGL((k_compose_policy<T>), dim3(B), dim3(64), 0, s, D, scale, shift, (const T*)me, (const T*)See,
-                       (const T*)pf1, (const T*)pSff, (const T*)pcross, md, Sdd, cpol);
+    hipLaunchKernelGGL((k_compose_policy<T>), dim3(B), dim3(64), 0, s, D, scale, shift, (const T*)c.me, (const T*)c.See,
+                       (const T*)c.pf1, (const T*)c.pSff, (const T*)c.pcross, c.md, c.Sdd, c.cpol);
     MMC_CHECK();
-    rc = mm_moment_match(drift, drift_bytes, nx, Md, nd, dtype, B, md, Sdd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY, 0.0,
-                         df1, dSff, dcross, ws_drift, ws_drift_bytes, status, (void*)s);
+    rc = mm_moment_match(drift, drift_bytes, nx, Md, nd, dtype, B, c.md, c.Sdd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY, 0.0,
+                         c.df1, c.dSff, c.dcross, ws_drift, ws_drift_bytes, status, (void*)s);
     if (rc) return rc;
     // Euler update, the new state's encoding (the cost statistic of this step, pilco.py:199-205, and the next step's
     // policy input) and the expected cost: one launch
-    hipLaunchKernelGGL((k_compose_tail<T>), dim3(B), dim3(64), mm_cost_lds_bytes(ne), s, D, dt, (const double*)cpol,
-                       (const T*)Sdd, (const T*)df1, (const T*)dSff, (const T*)dcross, mx, Sxx,
-                       traj_mu ? traj_mu + (size_t)h * B * nx : (T*)nullptr,
-                       traj_S ? traj_S + (size_t)h * B * nx * nx : (T*)nullptr, me, See, Sxe, target, precis,
+    T* tm = tape ? xm + (size_t)(h + 1) * B * nx : (traj_mu ? traj_mu + (size_t)h * B * nx : (T*)nullptr);
+    T* tS = tape ? xS + (size_t)(h + 1) * B * nx * nx : (traj_S ? traj_S + (size_t)h * B * nx * nx : (T*)nullptr);
+    hipLaunchKernelGGL((k_compose_tail<T>), dim3(B), dim3(64), mm_cost_lds_bytes(ne), s, D, dt, (const double*)c.cpol,
+                       (const T*)c.Sdd, (const T*)c.df1, (const T*)c.dSff, (const T*)c.dcross, (const double*)c.Sxe, mx, Sxx,
+                       tm, tS, n.me, n.See, n.Sxe, target, precis,
                        cost ? cost + (size_t)h * B : (T*)nullptr);
     MMC_CHECK();
+    if (tape && traj_mu) {
+      hipError_t e1 = hipMemcpyAsync(traj_mu + (size_t)h * B * nx, tm, (size_t)B * nx * sizeof(T), hipMemcpyDeviceToDevice, s);
+      if (e1 != hipSuccess) return (int)e1;
+    }
+    if (tape && traj_S) {
+      hipError_t e2 = hipMemcpyAsync(traj_S + (size_t)h * B * nx * nx, tS, (size_t)B * nx * nx * sizeof(T), hipMemcpyDeviceToDevice, s);
+      if (e2 != hipSuccess) return (int)e2;
+    }
   }
 #undef MMC_CHECK
   return 0;
+}
+
+static int mm_rollout_composed_impl(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
+                                    const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
+                                    int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
+                                    double head_scale, double head_shift, const void* target, const void* precis,
+                                    void* mx, void* Sxx, void* cost, void* traj_mu, void* traj_Sigma,
+                                    void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
+                                    void* ws_compose, size_t ws_compose_bytes, void* tape, size_t tape_bytes,
+                                    int32_t* status, void* stream) {
+  if (!drift_packed || !policy_packed || !mx || !Sxx || !ws_drift || !ws_policy) return MM_E_ARG;
+  if (!ws_compose && !tape) return MM_E_ARG;
+  if (B <= 0 || H <= 0 || drift_M <= 0 || policy_M <= 0) return MM_E_ARG;
+  if (dtype != MM_F32 && dtype != MM_F64) return MM_E_DTYPE;
+  if (cost && (!target || !precis)) return MM_E_ARG;
+  MMComposeDims D;
+  int rc = mm_compose_dims(nx, na, active_dims, D);
+  if (rc) return rc;
+  if (drift_L != nx || drift_d != D.nd || policy_d != D.ne) return MM_E_STATE;
+  const MMComposeLayout cl = mm_compose_layout(B, nx, na, dtype);
+  if (!tape && ws_compose_bytes < cl.total) return MM_E_WORKSPACE;
+  if (tape && tape_bytes < mm_tape_layout(B, H, nx, na, dtype).total) return MM_E_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MM_F64)
+    return mm_rollout_composed_t<double>(drift_packed, drift_bytes, drift_M, policy_packed, policy_bytes, policy_M, dtype, B, H, dt,
+                                         D, head_scale, head_shift, (const double*)target, (const double*)precis, (double*)mx,
+                                         (double*)Sxx, (double*)cost, (double*)traj_mu, (double*)traj_Sigma, ws_drift, ws_drift_bytes,
+                                         ws_policy, ws_policy_bytes, (char*)ws_compose, cl, (char*)tape, status, s);
+  return mm_rollout_composed_t<float>(drift_packed, drift_bytes, drift_M, policy_packed, policy_bytes, policy_M, dtype, B, H, dt,
+                                      D, head_scale, head_shift, (const float*)target, (const float*)precis, (float*)mx,
+                                      (float*)Sxx, (float*)cost, (float*)traj_mu, (float*)traj_Sigma, ws_drift, ws_drift_bytes,
+                                      ws_policy, ws_policy_bytes, (char*)ws_compose, cl, (char*)tape, status, s);
 }
 
 extern "C" int mm_rollout_composed(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
@@ -509,24 +519,30 @@ extern "C" int mm_rollout_composed(const void* drift_packed, size_t drift_bytes,
                                    void* mx, void* Sxx, void* cost, void* traj_mu, void* traj_Sigma,
                                    void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
                                    void* ws_compose, size_t ws_compose_bytes, int32_t* status, void* stream) {
-  if (!drift_packed || !policy_packed || !mx || !Sxx || !ws_drift || !ws_policy || !ws_compose) return MM_E_ARG;
-  if (B <= 0 || H <= 0 || drift_M <= 0 || policy_M <= 0) return MM_E_ARG;
-  if (dtype != MM_F32 && dtype != MM_F64) return MM_E_DTYPE;
-  if (cost && (!target || !precis)) return MM_E_ARG;
-  MMComposeDims D;
-  int rc = mm_compose_dims(nx, na, active_dims, D);
-  if (rc) return rc;
-  if (drift_L != nx || drift_d != D.nd || policy_d != D.ne) return MM_E_STATE;
-  const MMComposeLayout cl = mm_compose_layout(B, nx, na, dtype);
-  if (ws_compose_bytes < cl.total) return MM_E_WORKSPACE;
-  hipStream_t s = (hipStream_t)stream;
-  if (dtype == MM_F64)
-    return mm_rollout_composed_t<double>(drift_packed, drift_bytes, drift_M, policy_packed, policy_bytes, policy_M, dtype, B, H, dt,
-                                         D, head_scale, head_shift, (const double*)target, (const double*)precis, (double*)mx,
-                                         (double*)Sxx, (double*)cost, (double*)traj_mu, (double*)traj_Sigma, ws_drift, ws_drift_bytes,
-                                         ws_policy, ws_policy_bytes, (char*)ws_compose, cl, status, s);
-  return mm_rollout_composed_t<float>(drift_packed, drift_bytes, drift_M, policy_packed, policy_bytes, policy_M, dtype, B, H, dt,
-                                      D, head_scale, head_shift, (const float*)target, (const float*)precis, (float*)mx,
-                                      (float*)Sxx, (float*)cost, (float*)traj_mu, (float*)traj_Sigma, ws_drift, ws_drift_bytes,
-                                      ws_policy, ws_policy_bytes, (char*)ws_compose, cl, status, s);
+  return mm_rollout_composed_impl(drift_packed, drift_bytes, drift_L, drift_M, drift_d, policy_packed, policy_bytes, policy_M, policy_d,
+                                  dtype, B, H, dt, nx, na, active_dims, head_scale, head_shift, target, precis, mx, Sxx, cost,
+                                  traj_mu, traj_Sigma, ws_drift, ws_drift_bytes, ws_policy, ws_policy_bytes, ws_compose,
+                                  ws_compose_bytes, nullptr, 0, status, stream);
+}
+
+extern "C" size_t mm_compose_tape_bytes(int B, int H, int nx, int na, int dtype) {
+  if (B <= 0 || H <= 0 || nx <= 0 || nx > MMC_NX || na <= 0 || na > MMC_NA || na > nx) return 0;
+  if (2 * na + (nx - na) + 1 > MMC_ND) return 0;
+  return mm_tape_layout(B, H, nx, na, dtype).total;
+}
+
+// The same rollout, recorded: every per-step intermediate and the states x_0 .. x_H go to `tape`
+// (mm_compose_tape_bytes), which mm_rollout_composed_backward reads (csrc/mm_compose_bwd.hip).
+extern "C" int mm_rollout_composed_taped(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
+                                         const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
+                                         int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
+                                         double head_scale, double head_shift, const void* target, const void* precis,
+                                         void* mx, void* Sxx, void* cost, void* ws_drift, size_t ws_drift_bytes,
+                                         void* ws_policy, size_t ws_policy_bytes, void* tape, size_t tape_bytes,
+                                         int32_t* status, void* stream) {
+  if (!tape) return MM_E_ARG;
+  return mm_rollout_composed_impl(drift_packed, drift_bytes, drift_L, drift_M, drift_d, policy_packed, policy_bytes, policy_M, policy_d,
+                                  dtype, B, H, dt, nx, na, active_dims, head_scale, head_shift, target, precis, mx, Sxx, cost,
+                                  nullptr, nullptr, ws_drift, ws_drift_bytes, ws_policy, ws_policy_bytes, nullptr, 0, tape, tape_bytes,
+                                  status, stream);
 }
