@@ -64,6 +64,31 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_void_p]),
+    "mm_compose_tape_bytes": (C.c_size_t, [C.c_int] * 5),
+    "mm_rollout_composed_taped": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                            C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                            C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_void_p]),
+    "mm_compose_backward_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "mm_policy_grad_bytes": (C.c_size_t, [C.c_int] * 3),
+    "mm_rollout_composed_backward": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_size_t, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int32),
+                                               C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_size_t, C.c_void_p,
+                                               C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                               C.c_void_p, C.c_void_p]),
+    "mm_moment_match_backward_bytes": (C.c_size_t, [C.c_int] * 5),
+    "mm_moment_match_backward": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                           C.c_void_p, C.c_void_p]),
     "mm_backward_bytes": (C.c_size_t, [C.c_int] * 5),
     "mm_backward_sums": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),

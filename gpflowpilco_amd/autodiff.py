@@ -290,9 +290,9 @@ class MomentMatchFunction(torch.autograd.Function):
     full, unc = ctx.flags
     pmb = ctx.pm_bwd
     mu64, S64 = mu.to(torch.float64), Sigma.to(torch.float64)
-    gmu, gS = moment_match_backward(pmb, ctx.pre, mu64, S64, full, unc,
-                                    g_f1.to(torch.float64).contiguous(), g_Sff.to(torch.float64).contiguous(),
-                                    g_cross.to(torch.float64).contiguous())
+    # native: M x M sweeps, M-sized moments and the d x d chain rule all on the device (mm_moment_match_backward);
+    # moment_match_backward / _reference above are the torch forms it is tested against
+    gmu, gS = ops.moment_match_backward(pmb, mu64.contiguous(), S64.contiguous(), g_f1, g_Sff, g_cross, full, unc)
     return gmu.to(mu.dtype), gS.to(Sigma.dtype), None, None, None, None, None
 
 
@@ -344,3 +344,41 @@ def moment_match_torch(mu, Sigma, Z, ls, var, beta, C=None, mean_c=None, full_ou
     Sff[:, ia[L:], ib[L:]] = off
     Sff[:, ib[L:], ia[L:]] = off
   return f1, Sff, cross
+
+
+class ComposedRolloutFunction(torch.autograd.Function):
+  """The whole moment-matched policy rollout as ONE differentiable op: forward = ``mm_rollout_composed_taped``,
+  backward = ``mm_rollout_composed_backward`` (csrc/mm_compose_bwd.hip) -- the native counterpart of differentiating
+  ``policy_loss_closure`` with a gradient tape (gpflow_pilco/utils/optimizers.py:51-56, loops/pilco.py:192-220).
+
+  Inputs: the initial state (mx [B,nx], Sxx [B,nx,nx]) and the policy in PACKED coordinates -- Z [1,M,d],
+  lengthscales [1,d], variance [1], beta = Kuu^-1 u [1,M], mean_c [1] -- which the caller computes from the trainable
+  parameters with ordinary differentiable torch ops (``SVGP.precompute``: a 30 x 30 Cholesky), so autograd carries the
+  gradient the last step to (q_mu, Z, lengthscales, variance).  The drift is frozen.  Output: cost [B, H]."""
+
+  @staticmethod
+  def forward(ctx, mx, Sxx, Z, ls, var, beta, mean_c, roll, num_steps, dt):
+    f64 = torch.float64
+    det = lambda t: t.detach().to(f64)
+    pol = ops.pack_model(det(Z), det(ls), det(var), det(beta), None, det(mean_c), dtype=f64, sync=False)
+    m_H, S_H, cost, tape = roll.taped(mx.detach(), Sxx.detach(), num_steps, dt=dt, policy=pol)
+    ctx.roll, ctx.pol, ctx.tape, ctx.H, ctx.dt, ctx.B = roll, pol, tape, int(num_steps), float(dt), mx.shape[0]
+    ctx.save_for_backward(ls)
+    ctx.need_state = mx.requires_grad or Sxx.requires_grad
+    ctx.shapes = (Z.shape, ls.shape, var.shape, beta.shape, mean_c.shape)
+    return cost.T.contiguous()
+
+  @staticmethod
+  def backward(ctx, g_cost):
+    (ls,) = ctx.saved_tensors
+    g_pol, g_m, g_S = ctx.roll.backward(ctx.tape, g_cost.T.contiguous(), ctx.B, ctx.H, dt=ctx.dt, policy=ctx.pol,
+                                        want_state_grad=ctx.need_state)
+    M, d = ctx.pol.M, ctx.pol.d
+    g = g_pol.sum(0)
+    zs, lss, vs, bs, ms = ctx.shapes
+    gZ = g[:M * d].reshape(zs)
+    gbeta = g[M * d:M * d + M].reshape(bs)
+    gls = (2.0 * ls.detach().reshape(-1) * g[M * d + M:M * d + M + d]).reshape(lss)        # d/d ls = 2 ls d/d ls^2
+    gvar = g[M * d + M + d].reshape(vs)
+    gmean = g[M * d + M + d + 1].reshape(ms)
+    return g_m, g_S, gZ, gls, gvar, gbeta, gmean, None, None, None

@@ -1,0 +1,351 @@
+// Reverse sweep of the moment-matched policy rollout and of one GP moment match, as device code (gfx950) -- SURVEY.md
+// rows f-1 x f-2.  The reference gets these gradients from tf.GradientTape over the whole closure
+// (gpflow_pilco/utils/optimizers.py:51-56, loops/pilco.py:192-220); here the arithmetic of csrc/mm_adjoint.h runs one
+// workgroup per batch element (or per (element, latent | pair) item), f64 in LDS:
+//   k_gp_bwd_items + k_gp_bwd_sum : d(f1, Sff, cross)/d(mu, Sigma) of a frozen model from mm_backward_sums' M-sized sums
+//                                   (mm_moment_match_backward: the native form of autodiff.moment_match_backward)
+//   k_compose_tail_bwd            : cost + encoding adjoint at x_{h+1}, then the adjoint of forward_sde's bookkeeping + Euler
+//   k_policy_head_bwd_small       : NormalCDF head adjoint, then the policy match's adjoint w.r.t. its input moments AND the
+//                                   packed policy (Z, beta, Lambda, variance, mean) -- the policy-parameter gradient
+//   k_compose_encode_bwd0         : the encoding adjoint at x_0 (gradient w.r.t. the initial state)
+// mm_rollout_composed_backward replays the tape of mm_rollout_composed_taped backwards: per step 9 launches (the drift's
+// q stage again for its workspace, two sweeps of mm_backward_sums, items, sum, tail, head + policy).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "mm_common.h"
+#include "mm_compose.h"
+#include "mm_adjoint.h"
+
+#define MMB_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// GP match backward: items and their sum
+// ---------------------------------------------------------------------------------------------------------------------
+// grid (L + P, B), 256 threads.  items [B][L + P][d^2 + d]; cbuf [B][L][Mp].
+__global__ __launch_bounds__(256) void k_gp_bwd_items(int L, int M, int Mp, int d, int P, int with_unc, int full_cov,
+                                                      const double* __restrict__ Z, const double* __restrict__ ls2,
+                                                      const double* __restrict__ mu, const double* __restrict__ Sigma,
+                                                      const double* __restrict__ latmat, const double* __restrict__ w,
+                                                      const double* __restrict__ q, const double* __restrict__ col,
+                                                      const double* __restrict__ row, const double* __restrict__ g_f1,
+                                                      const double* __restrict__ g_Sff, const double* __restrict__ g_cross,
+                                                      double* __restrict__ items, double* __restrict__ cbuf, int32_t* status) {
+  extern __shared__ double sm[];
+  const int item = blockIdx.x, b = blockIdx.y, Po = P - L, nsff = full_cov ? L * L : L;
+  bool ok = true;
+  double* out = items + ((size_t)b * (L + P) + item) * (d * d + d);
+  mma_gp_item_bwd(MMADevCtx(), item, L, M, Mp, d, P, with_unc != 0, Z, ls2, mu + (size_t)b * d, Sigma + (size_t)b * d * d,
+                  latmat + (size_t)b * L * (2 * d * d + 2), w + (size_t)b * L * Mp, q + (size_t)b * L * Mp,
+                  col + (size_t)b * P * (3 + d) * Mp, row + (size_t)b * Po * 2 * Mp, g_f1 + (size_t)b * L,
+                  g_Sff + (size_t)b * nsff, full_cov, g_cross + (size_t)b * d * L, out, out + d * d,
+                  cbuf + ((size_t)b * L + (item < L ? item : 0)) * Mp, sm, &ok);
+  if (!ok && threadIdx.x == 0 && status) { atomicMax(status, (int)gridDim.y - b); status[1] = item; }
+}
+
+// grid B, 64 threads: gmu [B][d] = sum of the items; gS [B][d][d] (+)= the symmetrised sum.
+__global__ __launch_bounds__(64) void k_gp_bwd_sum(int nitems, int d, const double* __restrict__ items,
+                                                   double* __restrict__ gmu, double* __restrict__ gS, int accumulate_S) {
+  const int b = blockIdx.x, lane = threadIdx.x, st = d * d + d;
+  const double* it = items + (size_t)b * nitems * st;
+  for (int idx = lane; idx < d * d; idx += 64) {
+    const int i = idx / d, j = idx - i * d;
+    double s = 0.0;
+    for (int t = 0; t < nitems; ++t) s += 0.5 * (it[(size_t)t * st + i * d + j] + it[(size_t)t * st + j * d + i]);
+    if (accumulate_S) gS[(size_t)b * d * d + idx] += s; else gS[(size_t)b * d * d + idx] = s;
+  }
+  for (int k = lane; k < d; k += 64) {
+    double s = 0.0;
+    for (int t = 0; t < nitems; ++t) s += it[(size_t)t * st + d * d + k];
+    gmu[(size_t)b * d + k] = s;
+  }
+}
+
+struct MMGpBwdLayout {
+  size_t sums, items, cbuf, f1, cross, total;
+};
+static inline MMGpBwdLayout mm_gp_bwd_layout(int B, int L, int M, int d, int flags) {
+  MMGpBwdLayout o;
+  const size_t A = 256;
+  const int Mp = mm_round_up_int(M, MM_M_ALIGN), P = mm_num_pairs(L, flags);
+  size_t off = 0;
+  o.sums = off;  off = mm_align_up(off + mm_backward_bytes(B, L, M, d, flags), A);
+  o.items = off; off = mm_align_up(off + (size_t)B * (L + P) * (d * d + d) * 8, A);
+  o.cbuf = off;  off = mm_align_up(off + (size_t)B * L * Mp * 8, A);
+  o.f1 = off;    off = mm_align_up(off + (size_t)B * L * 8, A);
+  o.cross = off; off = mm_align_up(off + (size_t)B * d * L * 8, A);
+  o.total = off;
+  return o;
+}
+
+extern "C" size_t mm_moment_match_backward_bytes(int B, int L, int M, int d, int flags) {
+  if (B <= 0 || L <= 0 || M <= 0 || d <= 0 || d > MM_DMAX) return 0;
+  return mm_gp_bwd_layout(B, L, M, d, flags).total;
+}
+
+// (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> g_mu [B,d], g_Sigma [B,d,d] (symmetric; += if accumulate_Sigma).
+// f64 packs only.  Re-runs the q stage for (mu, Sigma) on `workspace`, then the M x M sweeps, the items and their sum.
+extern "C" int mm_moment_match_backward(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                        const void* mu, const void* Sigma, int flags,
+                                        const void* g_f1, const void* g_Sff, const void* g_cross,
+                                        void* g_mu, void* g_Sigma, int accumulate_Sigma,
+                                        void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
+                                        int32_t* status, void* stream) {
+  if (!packed || !mu || !Sigma || !g_f1 || !g_Sff || !g_cross || !g_mu || !g_Sigma || !workspace || !bwd_ws) return MM_E_ARG;
+  if (L <= 0 || M <= 0 || d <= 0 || B <= 0) return MM_E_ARG;
+  if (d > MM_DMAX) return MM_E_DIM;
+  if (dtype != MM_F64) return MM_E_DTYPE;
+  const MMGpBwdLayout bl = mm_gp_bwd_layout(B, L, M, d, flags);
+  if (bwd_ws_bytes < bl.total) return MM_E_WORKSPACE;
+  const MMModelLayout ml = mm_model_layout(L, M, d, dtype, 1);
+  const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
+  if (workspace_bytes < wl.total) return MM_E_WORKSPACE;
+  char* bw = (char*)bwd_ws; const char* pk = (const char*)packed; const char* ws = (const char*)workspace;
+  hipStream_t s = (hipStream_t)stream;
+  int rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, bw + bl.f1, bw + bl.cross, nullptr,
+                        workspace, workspace_bytes, status, stream);
+  if (rc) return rc;
+  rc = mm_backward_sums(packed, packed_bytes, L, M, d, dtype, B, mu, flags, workspace, workspace_bytes, bw + bl.sums,
+                        mm_backward_bytes(B, L, M, d, flags), stream);
+  if (rc) return rc;
+  const int P = wl.P, Mp = wl.Mp;
+  const double* col = (const double*)(bw + bl.sums);
+  const double* row = col + (size_t)B * P * (3 + d) * Mp;
+  const size_t shm = (size_t)mma_gp_item_scratch(d, 256) * sizeof(double);
+  hipLaunchKernelGGL(k_gp_bwd_items, dim3(L + P, B), dim3(256), shm, s, L, M, Mp, d, P, (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0,
+                     (flags & MM_FULL_OUTPUT_COV) ? 1 : 0, (const double*)(pk + ml.Z64), (const double*)(pk + ml.ls2),
+                     (const double*)mu, (const double*)Sigma, (const double*)(ws + wl.latmat), (const double*)(ws + wl.w64),
+                     (const double*)(ws + wl.q64), col, row, (const double*)g_f1, (const double*)g_Sff, (const double*)g_cross,
+                     (double*)(bw + bl.items), (double*)(bw + bl.cbuf), status);
+  MMB_CHECK();
+  hipLaunchKernelGGL(k_gp_bwd_sum, dim3(B), dim3(64), 0, s, L + P, d, (const double*)(bw + bl.items), (double*)g_mu,
+                     (double*)g_Sigma, accumulate_Sigma);
+  MMB_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// composed rollout: carry of adjoints between the kernels of the reverse sweep (per batch element, f64)
+// ---------------------------------------------------------------------------------------------------------------------
+struct MMCarryLayout {
+  size_t cm, cS;                  // [B][nx], [B][nx][nx]   adjoint of the state x_h (direct terms; total after the encoding adjoint)
+  size_t cme, cSee, cSxe;         // [B][ne], [B][ne][ne], [B][nx][ne]   adjoint of the encoding of x_h
+  size_t ccp, cSdd, cmd;          // [B][ne], [B][nd][nd], [B][nd]       adjoint of cpol and of the drift's input moments
+  size_t cdf1, cdSff, cdcross;    // [B][nx], [B][nx][nx], [B][nd][nx]   adjoint of the drift's outputs
+  size_t total;
+};
+static inline MMCarryLayout mm_carry_layout(int B, int nx, int na) {
+  MMCarryLayout o;
+  const size_t A = 256;
+  const int ne = nx + na, nd = ne + 1;
+  size_t off = 0;
+  o.cm = off;      off = mm_align_up(off + (size_t)B * nx * 8, A);
+  o.cS = off;      off = mm_align_up(off + (size_t)B * nx * nx * 8, A);
+  o.cme = off;     off = mm_align_up(off + (size_t)B * ne * 8, A);
+  o.cSee = off;    off = mm_align_up(off + (size_t)B * ne * ne * 8, A);
+  o.cSxe = off;    off = mm_align_up(off + (size_t)B * nx * ne * 8, A);
+  o.ccp = off;     off = mm_align_up(off + (size_t)B * ne * 8, A);
+  o.cSdd = off;    off = mm_align_up(off + (size_t)B * nd * nd * 8, A);
+  o.cmd = off;     off = mm_align_up(off + (size_t)B * nd * 8, A);
+  o.cdf1 = off;    off = mm_align_up(off + (size_t)B * nx * 8, A);
+  o.cdSff = off;   off = mm_align_up(off + (size_t)B * nx * nx * 8, A);
+  o.cdcross = off; off = mm_align_up(off + (size_t)B * nd * nx * 8, A);
+  o.total = off;
+  return o;
+}
+
+// k_compose_tail_bwd: grid B, 64 threads.  `first`: the last step of the rollout (no adjoint arrives from a later step).
+//   x1 = x_{h+1}; me1 / See1: its encoding (tape slot h + 1); Sxe, cp, Sdd, dcross: tape slot h.
+__global__ __launch_bounds__(64) void k_compose_tail_bwd(MMComposeDims D, double dt, int first, const double* __restrict__ x1m,
+                                                         const double* __restrict__ x1S, const double* __restrict__ me1,
+                                                         const double* __restrict__ See1, const double* __restrict__ target,
+                                                         const double* __restrict__ precis, const double* __restrict__ gcost,
+                                                         const double* __restrict__ Sxe, const double* __restrict__ cp,
+                                                         const double* __restrict__ Sdd, const double* __restrict__ dcross,
+                                                         double* cm, double* cS, double* cme, double* cSee, double* cSxe,
+                                                         double* ccp, double* cSdd, double* cdf1, double* cdSff, double* cdcross) {
+  extern __shared__ double sm[];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nx = D.nx, ne = D.ne, nd = D.nd;
+  MMADevCtx c;
+  double* gme = sm; double* gSee = gme + ne; double* gSxe = gSee + ne * ne; double* gm1 = gSxe + nx * ne; double* gS1 = gm1 + nx;
+  double* wk = gS1 + nx * nx;
+  cm += (size_t)b * nx; cS += (size_t)b * nx * nx; cme += (size_t)b * ne; cSee += (size_t)b * ne * ne; cSxe += (size_t)b * nx * ne;
+  for (int i = lane; i < ne; i += 64) gme[i] = first ? 0.0 : cme[i];
+  for (int i = lane; i < ne * ne; i += 64) gSee[i] = first ? 0.0 : cSee[i];
+  for (int i = lane; i < nx * ne; i += 64) gSxe[i] = first ? 0.0 : cSxe[i];
+  for (int i = lane; i < nx; i += 64) gm1[i] = first ? 0.0 : cm[i];
+  for (int i = lane; i < nx * nx; i += 64) gS1[i] = first ? 0.0 : cS[i];
+  __syncthreads();
+  // this step's cost statistic: the expected cost of the ENCODED new state (loops/pilco.py:199-205)
+  mma_cost_bwd(c, ne, me1 + (size_t)b * ne, See1 + (size_t)b * ne * ne, target, precis, gcost[b], gme, gSee, wk);
+  mma_encode_bwd(c, D, x1m + (size_t)b * nx, x1S + (size_t)b * nx * nx, gme, gSee, gSxe, gm1, gS1, wk);
+  mma_step_bwd(c, D, dt, Sxe + (size_t)b * nx * ne, cp + (size_t)b * ne, Sdd + (size_t)b * nd * nd, dcross + (size_t)b * nd * nx,
+               gm1, gS1, cSxe, ccp + (size_t)b * ne, cSdd + (size_t)b * nd * nd, cdf1 + (size_t)b * nx,
+               cdSff + (size_t)b * nx * nx, cdcross + (size_t)b * nd * nx, wk);
+  for (int i = lane; i < nx; i += 64) cm[i] = gm1[i];
+  for (int i = lane; i < nx * nx; i += 64) cS[i] = gS1[i];
+}
+static inline size_t mm_tail_bwd_lds(int nx, int ne, int nd) {
+  int wk = mma_cost_bwd_scratch(ne);
+  const int e = mma_encode_bwd_scratch(nx, ne - nx), st = mma_step_bwd_scratch(nx, nd);
+  if (e > wk) wk = e;
+  if (st > wk) wk = st;
+  return (size_t)(ne + ne * ne + nx * ne + nx + nx * nx + wk + 8) * sizeof(double);
+}
+
+// k_policy_head_bwd_small: grid B, 256 threads.  Reads cmd, cSdd, ccp; writes cme, cSee (the adjoint of the encoding of x_h
+// through the policy and the joint); accumulates the packed policy's gradient into gpar [B][mm_policy_grad_len].
+__global__ __launch_bounds__(256) void k_policy_head_bwd_small(int M, int ne, double scale, double shift,
+                                                               const double* __restrict__ Z, const double* __restrict__ beta,
+                                                               const double* __restrict__ ls2, const double* __restrict__ var,
+                                                               const double* __restrict__ me, const double* __restrict__ See,
+                                                               const double* __restrict__ pf1, const double* __restrict__ pSff,
+                                                               const double* __restrict__ pcross, const double* __restrict__ cmd,
+                                                               const double* __restrict__ cSdd, const double* __restrict__ ccp,
+                                                               double* __restrict__ cme, double* __restrict__ cSee,
+                                                               double* __restrict__ gpar, int32_t* status) {
+  extern __shared__ double sm[];
+  const int b = blockIdx.x, nd = ne + 1;
+  MMADevCtx c;
+  double* gme = sm; double* gSee = gme + ne; double* gpc = gSee + ne * ne; double* gmu = gpc + ne; double* gSig = gmu + ne;
+  double* hw = gSig + ne * ne;             // head scratch: ne + 4
+  double* wk = hw + ne + 4;
+  mma_head_bwd(c, ne, scale, shift, pf1[b], pSff[b], pcross + (size_t)b * ne, See + (size_t)b * ne * ne, cmd + (size_t)b * nd,
+               cSdd + (size_t)b * nd * nd, ccp + (size_t)b * ne, gme, gSee, gpc, hw);
+  const double gpf1 = hw[ne], gpSff = hw[ne + 1];
+  bool ok = true;
+  mma_policy_small_bwd(c, M, ne, Z, beta, ls2, var[0], me + (size_t)b * ne, See + (size_t)b * ne * ne, gpf1, gpSff, gpc, gmu, gSig,
+                       gpar + (size_t)b * ((size_t)M * ne + M + ne + 2), wk, &ok);
+  for (int k = threadIdx.x; k < ne; k += 256) cme[(size_t)b * ne + k] = gme[k] + gmu[k];
+  for (int idx = threadIdx.x; idx < ne * ne; idx += 256) cSee[(size_t)b * ne * ne + idx] = gSee[idx] + gSig[idx];
+  if (!ok && threadIdx.x == 0 && status) { atomicMax(status, (int)gridDim.x - b); status[1] = 0; }
+}
+static inline size_t mm_policy_bwd_lds(int M, int ne) {
+  return (size_t)(4 * ne + 2 * ne * ne + 4 + mma_policy_small_bwd_scratch(M, ne, 256) + 8) * sizeof(double);
+}
+
+// k_compose_encode_bwd0: grid B, 64 threads: the adjoint of the initial state.
+__global__ __launch_bounds__(64) void k_compose_encode_bwd0(MMComposeDims D, const double* __restrict__ x0m, const double* __restrict__ x0S,
+                                                            const double* __restrict__ cm, const double* __restrict__ cS,
+                                                            const double* __restrict__ cme, const double* __restrict__ cSee,
+                                                            const double* __restrict__ cSxe, double* __restrict__ g_mx0,
+                                                            double* __restrict__ g_Sxx0) {
+  extern __shared__ double sm[];
+  const int b = blockIdx.x, lane = threadIdx.x, nx = D.nx, ne = D.ne;
+  double* gm = sm; double* gS = gm + nx; double* wk = gS + nx * nx;
+  for (int i = lane; i < nx; i += 64) gm[i] = cm[(size_t)b * nx + i];
+  for (int i = lane; i < nx * nx; i += 64) gS[i] = cS[(size_t)b * nx * nx + i];
+  __syncthreads();
+  mma_encode_bwd(MMADevCtx(), D, x0m + (size_t)b * nx, x0S + (size_t)b * nx * nx, cme + (size_t)b * ne, cSee + (size_t)b * ne * ne,
+                 cSxe + (size_t)b * nx * ne, gm, gS, wk);
+  for (int i = lane; i < nx; i += 64) g_mx0[(size_t)b * nx + i] = gm[i];
+  for (int idx = lane; idx < nx * nx; idx += 64) {
+    const int r = idx / nx, cc = idx - r * nx;
+    g_Sxx0[(size_t)b * nx * nx + idx] = 0.5 * (gS[idx] + gS[cc * nx + r]);
+  }
+}
+
+__global__ void k_zero_f64(double* p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.0;
+}
+
+struct MMComposeBwdLayout { size_t carry, gp, total; };
+static inline MMComposeBwdLayout mm_compose_bwd_layout(int B, int nx, int na, int Md) {
+  MMComposeBwdLayout o;
+  const int nd = nx + na + 1;
+  o.carry = 0;
+  o.gp = mm_align_up(mm_carry_layout(B, nx, na).total, 256);
+  o.total = o.gp + mm_gp_bwd_layout(B, nx, Md, nd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY).total;
+  return o;
+}
+
+extern "C" size_t mm_compose_backward_workspace_bytes(int B, int nx, int na, int drift_M) {
+  if (B <= 0 || nx <= 0 || nx > MMC_NX || na <= 0 || na > MMC_NA || na > nx || drift_M <= 0) return 0;
+  if (2 * na + (nx - na) + 1 > MMC_ND) return 0;
+  return mm_compose_bwd_layout(B, nx, na, drift_M).total;
+}
+
+extern "C" size_t mm_policy_grad_bytes(int B, int policy_M, int policy_d) {
+  if (B <= 0 || policy_M <= 0 || policy_d <= 0) return 0;
+  return (size_t)B * mm_policy_grad_len(policy_M, policy_d) * sizeof(double);
+}
+
+// Reverse sweep over the tape of mm_rollout_composed_taped (same models, shapes and constants).  f64 only.
+//   g_cost   [H][B]: d loss / d cost[h][b] (the loss of pilco.py:199-205 is the plain sum: all ones)
+//   g_policy [B][M d + M + d + 2] (out, overwritten): per batch element, gradient w.r.t. the PACKED policy -- Z [M][d],
+//            beta [M], ls2 = lengthscales^2 [d], variance, mean_c; the chain to (q_mu, Z, lengthscales, ...) through
+//            beta = Kuu^-1 u is the caller's (gpflowpilco_amd/autodiff.py does it with autograd on the 30 x 30 precompute)
+//   g_mx0 [B][nx], g_Sxx0 [B][nx][nx] (out, optional): gradient w.r.t. the initial state (symmetric)
+// The policy must be the one-launch shape (M <= 128, ne <= 8); else MM_E_DIM.
+extern "C" int mm_rollout_composed_backward(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
+                                            const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
+                                            int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
+                                            double head_scale, double head_shift, const void* target, const void* precis,
+                                            const void* tape, size_t tape_bytes, const void* g_cost,
+                                            void* g_policy, void* g_mx0, void* g_Sxx0,
+                                            void* ws_drift, size_t ws_drift_bytes, void* ws_bwd, size_t ws_bwd_bytes,
+                                            int32_t* status, void* stream) {
+  if (!drift_packed || !policy_packed || !tape || !g_cost || !g_policy || !ws_drift || !ws_bwd || !target || !precis) return MM_E_ARG;
+  if (B <= 0 || H <= 0 || drift_M <= 0 || policy_M <= 0) return MM_E_ARG;
+  if (dtype != MM_F64) return MM_E_DTYPE;
+  if ((g_mx0 == nullptr) != (g_Sxx0 == nullptr)) return MM_E_ARG;
+  MMComposeDims D;
+  int rc = mm_compose_dims(nx, na, active_dims, D);
+  if (rc) return rc;
+  const int ne = D.ne, nd = D.nd;
+  if (drift_L != nx || drift_d != nd || policy_d != ne) return MM_E_STATE;
+  if (policy_M > 128 || ne > 8) return MM_E_DIM;
+  const MMTapeLayout tl = mm_tape_layout(B, H, nx, na, dtype);
+  if (tape_bytes < tl.total) return MM_E_WORKSPACE;
+  const MMComposeBwdLayout bl = mm_compose_bwd_layout(B, nx, na, drift_M);
+  if (ws_bwd_bytes < bl.total) return MM_E_WORKSPACE;
+  const MMModelLayout pl = mm_model_layout(1, policy_M, ne, dtype, 1);
+  if (policy_bytes < pl.Cm) return MM_E_WORKSPACE;
+  const MMComposeLayout cl = mm_compose_layout(B, nx, na, dtype);
+  const MMCarryLayout kl = mm_carry_layout(B, nx, na);
+  hipStream_t s = (hipStream_t)stream;
+  char* bw = (char*)ws_bwd; char* cw = bw + bl.carry; char* gw = bw + bl.gp;
+  const char* tp = (const char*)tape; const char* pp = (const char*)policy_packed;
+  auto cr = [&](size_t off) { return (double*)(cw + off); };
+  const double* xm = (const double*)(tp + tl.xm); const double* xS = (const double*)(tp + tl.xS);
+  const size_t npar = (size_t)B * mm_policy_grad_len(policy_M, ne);
+  hipLaunchKernelGGL(k_zero_f64, dim3((unsigned)((npar + 255) / 256)), dim3(256), 0, s, (double*)g_policy, npar);
+  MMB_CHECK();
+  const size_t lds_tail = mm_tail_bwd_lds(nx, ne, nd), lds_pol = mm_policy_bwd_lds(policy_M, ne);
+  if (lds_pol > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_policy_head_bwd_small, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pol);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int dflags = MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY;
+  const size_t gp_bytes = mm_gp_bwd_layout(B, nx, drift_M, nd, dflags).total;
+  for (int h = H - 1; h >= 0; --h) {
+    const char* sl = tp + (size_t)h * tl.slot_bytes; const char* sn = tp + (size_t)(h + 1) * tl.slot_bytes;
+    hipLaunchKernelGGL(k_compose_tail_bwd, dim3(B), dim3(64), lds_tail, s, D, dt, h == H - 1 ? 1 : 0,
+                       xm + (size_t)(h + 1) * B * nx, xS + (size_t)(h + 1) * B * nx * nx, (const double*)(sn + cl.me),
+                       (const double*)(sn + cl.See), (const double*)target, (const double*)precis,
+                       (const double*)g_cost + (size_t)h * B, (const double*)(sl + cl.Sxe), (const double*)(sl + cl.cpol),
+                       (const double*)(sl + cl.Sdd), (const double*)(sl + cl.dcross), cr(kl.cm), cr(kl.cS), cr(kl.cme),
+                       cr(kl.cSee), cr(kl.cSxe), cr(kl.ccp), cr(kl.cSdd), cr(kl.cdf1), cr(kl.cdSff), cr(kl.cdcross));
+    MMB_CHECK();
+    // the drift's match: (g df1, g dSff, g dcross) -> g md (assigned), g Sdd (accumulated onto the bookkeeping's part)
+    rc = mm_moment_match_backward(drift_packed, drift_bytes, nx, drift_M, nd, dtype, B, sl + cl.md, sl + cl.Sdd, dflags,
+                                  cr(kl.cdf1), cr(kl.cdSff), cr(kl.cdcross), cr(kl.cmd), cr(kl.cSdd), 1, ws_drift, ws_drift_bytes,
+                                  gw, gp_bytes, status, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_policy_head_bwd_small, dim3(B), dim3(256), lds_pol, s, policy_M, ne, head_scale, head_shift,
+                       (const double*)(pp + pl.Z64), (const double*)(pp + pl.beta64), (const double*)(pp + pl.ls2),
+                       (const double*)(pp + pl.var), (const double*)(sl + cl.me), (const double*)(sl + cl.See),
+                       (const double*)(sl + cl.pf1), (const double*)(sl + cl.pSff), (const double*)(sl + cl.pcross),
+                       (const double*)cr(kl.cmd), (const double*)cr(kl.cSdd), (const double*)cr(kl.ccp), cr(kl.cme), cr(kl.cSee),
+                       (double*)g_policy, status);
+    MMB_CHECK();
+  }
+  if (g_mx0) {
+    const size_t lds0 = (size_t)(nx + nx * nx + mma_encode_bwd_scratch(nx, na) + 8) * sizeof(double);
+    hipLaunchKernelGGL(k_compose_encode_bwd0, dim3(B), dim3(64), lds0, s, D, xm, xS, (const double*)cr(kl.cm), (const double*)cr(kl.cS),
+                       (const double*)cr(kl.cme), (const double*)cr(kl.cSee), (const double*)cr(kl.cSxe), (double*)g_mx0, (double*)g_Sxx0);
+    MMB_CHECK();
+  }
+  return 0;
+}

@@ -44,8 +44,9 @@ def check_capture_status(device):
   if t is not None and int(t.item()) != 0:
     v = int(t.item())
     t.zero_()
-    raise CholeskyError(f"a Cholesky factorisation inside a replayed HIP graph failed (info={v}): its factor was "
-                        "replaced by NaN, so every value computed from it in that replay is NaN")
+    raise CholeskyError(f"a Cholesky factorisation inside a replayed HIP graph failed (info={v}; n + 1 = the factor did not "
+                        "reproduce its matrix on the probe vectors): its factor was replaced by NaN, so every value computed "
+                        "from it in that replay is NaN")
 
 
 # rocSOLVER's BLOCKED potrf (what torch.linalg.cholesky_ex reaches for n beyond a few hundred) is not safe when a
@@ -102,9 +103,21 @@ def cholesky(A: torch.Tensor) -> torch.Tensor:
   L, info = _blocked_cholesky_ex(A) if big else torch.linalg.cholesky_ex(A)
   if A.is_cuda and torch.cuda.is_current_stream_capturing():
     bad = info != 0
+    code = info.abs().max().reshape(1).to(torch.int32)
+    if A.shape[-1] > 64:
+      # the probe-residual guard of the eager path, on the device: a factor that is silently wrong with info = 0 (seen
+      # once, tools/potrf_probe.py) is poisoned too, and recorded as code n + 1
+      n = A.shape[-1]
+      t = torch.arange(1, n + 1, dtype=A.dtype, device=A.device)
+      v = torch.stack([torch.cos(0.7 * t), torch.sin(1.3 * t) + 0.5], dim=-1)
+      r = L @ (L.transpose(-1, -2) @ v) - A @ v
+      res = r.abs().amax(dim=(-1, -2)) / (n * A.abs().amax(dim=(-1, -2)) * v.abs().max())
+      wrong = ~(res < 1e-9)                                  # also true for NaN
+      bad = bad | wrong
+      code = torch.maximum(code, (wrong.any().to(torch.int32) * (n + 1)).reshape(1))
     L = torch.where(bad.reshape(bad.shape + (1, 1)), torch.full_like(L, float("nan")), L)
     st = capture_status(A.device)
-    st.copy_(torch.maximum(st, info.abs().max().reshape(1).to(torch.int32)))
+    st.copy_(torch.maximum(st, code))
     return L
   failed = bool((info != 0).any())
   msg = None

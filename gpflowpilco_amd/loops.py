@@ -25,8 +25,8 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
   when the system is not the shape that entry point implements: TrigonometricEncoder, policy =
   InverseLinkWrapper(KernelRegressor(SVGP with one latent), Chain[Scale, Shift, NormalCDF]) with scalar scale and
   shift, SVGP drift, no diffusion, MomentMatchingEuler, GaussianObjective -- the cartpole wiring of
-  ``examples/cartpole_swingup/swingup_loops.py:41-91``.  Forward only: callers that differentiate (a trainable
-  policy under autograd) take the torch composition."""
+  ``examples/cartpole_swingup/swingup_loops.py:41-91``.  ``f.with_grad(mx, Sxx)`` is the same loss as a differentiable op
+  (native reverse sweep, csrc/mm_compose_bwd.hip) where ``f.supports_grad(mx)``."""
   from . import bijectors as tfb
   from . import ops
   from .components import TrigonometricEncoder
@@ -57,15 +57,18 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
     return None
   cache = {}
 
-  def run(mx: torch.Tensor, Sxx: torch.Tensor):
+  def current_roll(mx: torch.Tensor, fresh_policy: bool = True):
+    # (fresh_policy=False: the caller brings its own pack of the policy's current parameters -- the differentiable
+    # path -- and the rollout object only has to have the right shapes: no re-pack of the policy here)
     # Everything the rollout reads is looked up on EVERY call: ``packed()`` re-packs a model whose parameters were
     # updated in place (optimiser step, refit between episodes: _PackCache keys on the tensors' versions), and the
     # head / objective constants are read from their owners.  Only the compose workspace is kept across calls.
     key = (mx.dtype, str(mx.device))
-    pd, pp = drift.packed(mx.dtype, True, mx.device), pm_.packed(mx.dtype, False, mx.device)
-    scale, shift = head_constants()
     ent = cache.get(key)
     roll = None if ent is None else ent[0]
+    pd = drift.packed(mx.dtype, True, mx.device)
+    pp = roll.policy if (roll is not None and not fresh_policy) else pm_.packed(mx.dtype, False, mx.device)
+    scale, shift = head_constants()
     if (roll is None or roll.drift is not pd or roll.policy is not pp or roll.scale != scale or roll.shift != shift
         or ent[1] is not objective.target or ent[2] is not objective.precis
         or ent[3] != (objective.target._version, objective.precis._version)):
@@ -75,8 +78,28 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
         new._wsc = roll._wsc                               # same shapes: the workspace carries over
       roll = new
       cache[key] = (roll, objective.target, objective.precis, (objective.target._version, objective.precis._version))
-    _, _, cost = roll(mx, Sxx, num_steps, dt=dt)
+    return roll
+
+  def run(mx: torch.Tensor, Sxx: torch.Tensor):
+    _, _, cost = current_roll(mx)(mx, Sxx, num_steps, dt=dt)
     return cost.sum(1)
+
+  def run_with_grad(mx: torch.Tensor, Sxx: torch.Tensor):
+    """The same loss as a differentiable function of the policy's parameters (and of the initial state): forward =
+    the taped native rollout, backward = the native reverse sweep (autodiff.ComposedRolloutFunction); the policy enters
+    in packed coordinates computed from its parameters by differentiable torch ops (a 30 x 30 precompute)."""
+    from .autodiff import ComposedRolloutFunction
+    roll = current_roll(mx, fresh_policy=False)
+    Zp, lsp, varp, betap, _, mcp = pm_.precompute(mx.device)
+    if mcp is None:
+      mcp = torch.zeros(1, dtype=Zp.dtype, device=mx.device)
+    cost = ComposedRolloutFunction.apply(mx, Sxx, Zp, lsp, varp, betap, mcp, roll, num_steps, dt)
+    return cost.sum(1)
+
+  def supports_grad(mx: torch.Tensor) -> bool:
+    return mx.dtype == torch.float64 and current_roll(mx, fresh_policy=False).supports_backward()
+  run.with_grad = run_with_grad
+  run.supports_grad = supports_grad
   return run
 
 
@@ -87,9 +110,12 @@ def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_init
   """pilco.py:176-220.  Returns ``closure() -> loss [B]``; ``system.solver`` should be a
   ``MomentMatchingEuler`` (pilco.py:141-144).
 
-  ``native``: None (default) runs the rollout in one ``mm_rollout_composed`` call whenever the system has the shape it
-  implements (``native_policy_loss``), the state is on the GPU and nothing requires a gradient; False always takes
-  the torch composition (``forward_sde`` over ``moment_matching``); True insists on the native path."""
+  ``native``: None (default) runs the rollout natively whenever the system has the shape ``mm_rollout_composed``
+  implements (``native_policy_loss``) and the state is on the GPU: forward only (one ``mm_rollout_composed`` call) when
+  nothing requires a gradient, and as ONE differentiable op -- taped forward + native reverse sweep
+  (``autodiff.ComposedRolloutFunction``) -- when the policy's parameters or the initial state do (float64, frozen
+  drift); False always takes the torch composition (``forward_sde`` over ``moment_matching``); True insists on the
+  native path."""
   uniform = solution_times is None
   if solution_times is None:
     solution_times = np.arange(1, 1 + num_steps, dtype=np.float64)     # pilco.py:186
@@ -117,10 +143,21 @@ def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_init
       return False                       # a captured graph must evaluate a trainable model FROM its parameters, not
     return True                          # from a packed snapshot that goes stale at the next optimiser step
 
+  def _use_native_grad(mx, Sxx):
+    """Someone differentiates, and what is differentiated is what the native reverse sweep covers: the policy's
+    parameters and / or the initial state, with a frozen drift, in float64."""
+    if native is False or fast is None or not mx.is_cuda or mx.ndim != 2 or not torch.is_grad_enabled():
+      return False
+    if any(t.requires_grad for t in system.drift._parameters()):
+      return False
+    return fast.supports_grad(mx)
+
   def _closure():                                                      # pilco.py:207-217
     mx, Sxx = state_initializer()
     if _use_native(mx, Sxx):
       return fast(mx, Sxx)
+    if _use_native_grad(mx, Sxx):
+      return fast.with_grad(mx, Sxx)
     loss = torch.zeros(mx.shape[:-1], dtype=mx.dtype, device=mx.device)
     _, loss = system.solve_forward(iterator="foldl", initial_time=initial_time,
                                    initial_state=(mx, Sxx), solution_times=solution_times,

@@ -179,7 +179,10 @@ class _PackCache:
     if slot not in self._packed:
       from . import ops
       Z, ls, var, beta, C, mean_c = self._pre
-      self._packed[slot] = ops.pack_model(Z, ls, var, beta, C if with_C else None, mean_c, dtype=dtype)
+      capturing = Z.is_cuda and torch.cuda.is_current_stream_capturing()
+      det = lambda t: None if t is None else t.detach()
+      self._packed[slot] = ops.pack_model(det(Z), det(ls), det(var), det(beta), det(C) if with_C else None, det(mean_c),
+                                          dtype=dtype, sync=not capturing)
     return self._packed[slot]
 
 

@@ -59,6 +59,7 @@ class PackedModel:
   buf: torch.Tensor                      # uint8 [packed_bytes]
   _workspaces: Dict[Tuple[int, int], torch.Tensor] = field(default_factory=dict, repr=False)
   _status: Optional[torch.Tensor] = field(default=None, repr=False)
+  _keep: Optional[tuple] = field(default=None, repr=False)
 
   @property
   def device(self):
@@ -97,9 +98,10 @@ class PackedModel:
 def pack_model(Z: torch.Tensor, lengthscales: torch.Tensor, variance: torch.Tensor,
                beta: torch.Tensor, C: Optional[torch.Tensor] = None,
                mean_c: Optional[torch.Tensor] = None,
-               dtype: torch.dtype = torch.float32) -> PackedModel:
+               dtype: torch.dtype = torch.float32, sync: bool = True) -> PackedModel:
   """Z [L,M,d], lengthscales [L,d], variance [L], beta [L,M], C [L,M,M]|None, mean_c [L]|None
-  (all float64 on the GPU) -> PackedModel whose reduce operands are stored as ``dtype``."""
+  (all float64 on the GPU) -> PackedModel whose reduce operands are stored as ``dtype``.
+  ``sync=False`` (graph capture): no stream synchronisation; the f64 inputs are kept alive on the returned object."""
   _require_device(Z, lengthscales, variance, beta, C, mean_c)
   L, M, d = Z.shape
   f64 = lambda t: None if t is None else t.to(torch.float64).contiguous()
@@ -116,8 +118,12 @@ def pack_model(Z: torch.Tensor, lengthscales: torch.Tensor, variance: torch.Tens
                            _ptr(variance), _ptr(beta), _ptr(C), _ptr(mean_c), _stream(Z.device))
   check(rc, "mm_pack_model")
   # the f64 inputs must outlive the asynchronous pack kernels
-  torch.cuda.current_stream(Z.device).synchronize()
-  return PackedModel(L=L, M=M, d=d, dtype=dtype, with_C=C is not None, buf=buf)
+  pm = PackedModel(L=L, M=M, d=d, dtype=dtype, with_C=C is not None, buf=buf)
+  if sync:
+    torch.cuda.current_stream(Z.device).synchronize()
+  else:
+    pm._keep = (Z, lengthscales, variance, beta, C, mean_c)
+  return pm
 
 
 def _prep_state(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor):
@@ -349,6 +355,71 @@ class ComposedRollout:
     return out + (tmu, tS) if keep_trajectory else out
 
 
+  # ---- differentiable form: tape + reverse sweep (csrc/mm_compose_bwd.hip) -------------------------------------------
+  def supports_backward(self) -> bool:
+    """The native reverse sweep exists for f64 rollouts whose policy is the one-launch shape (M <= 128, ne <= 8)."""
+    return self.drift.dtype == torch.float64 and self.policy.M <= 128 and self.ne <= 8
+
+  def taped(self, mx: torch.Tensor, Sxx: torch.Tensor, num_steps: int, dt: float = 1.0, policy: Optional[PackedModel] = None):
+    """``mm_rollout_composed_taped``: -> (mx_H, Sxx_H, cost [H, B], tape).  ``policy``: another pack of the same shape
+    (the current parameters of a trainable policy)."""
+    pol = self.policy if policy is None else policy
+    _require_device(mx, Sxx)
+    dt_ = self.drift.dtype
+    B, H = mx.shape[0], int(num_steps)
+    if mx.dtype != dt_ or mx.shape != (B, self.nx) or Sxx.shape != (B, self.nx, self.nx):
+      raise ValueError(f"expected {dt_} mx [B,{self.nx}], Sxx [B,{self.nx},{self.nx}]")
+    mx, Sxx = mx.contiguous().clone(), Sxx.contiguous().clone()
+    cost = torch.empty(H, B, dtype=dt_, device=mx.device)
+    n = lib().mm_compose_tape_bytes(B, H, self.nx, self.na, _dtype_code(dt_))
+    tape = torch.empty(n, dtype=torch.uint8, device=mx.device)
+    wd = self.drift.workspace(B, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY)
+    wp = pol.workspace(B, MM_FULL_OUTPUT_COV)
+    rc = lib().mm_rollout_composed_taped(self.drift.buf.data_ptr(), self.drift.nbytes, self.drift.L, self.drift.M, self.drift.d,
+                                         pol.buf.data_ptr(), pol.nbytes, pol.M, pol.d, _dtype_code(dt_), B, H, float(dt),
+                                         self.nx, self.na, self._act, self.scale, self.shift, self.target.data_ptr(),
+                                         self.precis.data_ptr(), mx.data_ptr(), Sxx.data_ptr(), cost.data_ptr(),
+                                         wd.data_ptr(), wd.numel(), wp.data_ptr(), wp.numel(), tape.data_ptr(), tape.numel(),
+                                         self.drift.status().data_ptr(), _stream(mx.device))
+    check(rc, "mm_rollout_composed_taped")
+    return mx, Sxx, cost, tape
+
+  def backward(self, tape: torch.Tensor, g_cost: torch.Tensor, B: int, num_steps: int, dt: float = 1.0,
+               policy: Optional[PackedModel] = None, want_state_grad: bool = True):
+    """``mm_rollout_composed_backward``: g_cost [H, B] -> (g_policy [B, M d + M + d + 2], g_mx0 [B,nx] | None,
+    g_Sxx0 [B,nx,nx] | None): the gradient w.r.t. the packed policy (Z, beta, lengthscales^2, variance, mean) per batch
+    element and w.r.t. the initial state."""
+    pol = self.policy if policy is None else policy
+    dev = tape.device
+    H = int(num_steps)
+    f64 = torch.float64
+    g_cost = g_cost.to(f64).contiguous()
+    if g_cost.shape != (H, B):
+      raise ValueError(f"g_cost must be [H={H}, B={B}]")
+    npar = pol.M * pol.d + pol.M + pol.d + 2
+    g_pol = torch.empty(B, npar, dtype=f64, device=dev)
+    g_m = torch.empty(B, self.nx, dtype=f64, device=dev) if want_state_grad else None
+    g_S = torch.empty(B, self.nx, self.nx, dtype=f64, device=dev) if want_state_grad else None
+    wd = self.drift.workspace(B, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY)
+    key = ("bwd", B)
+    wb = self._wsc.get(key)
+    if wb is None:
+      n = lib().mm_compose_backward_workspace_bytes(B, self.nx, self.na, self.drift.M)
+      if n == 0:
+        raise ValueError("mm_compose_backward_workspace_bytes rejected the shape")
+      wb = torch.empty(n, dtype=torch.uint8, device=dev)
+      self._wsc[key] = wb
+    rc = lib().mm_rollout_composed_backward(self.drift.buf.data_ptr(), self.drift.nbytes, self.drift.L, self.drift.M, self.drift.d,
+                                            pol.buf.data_ptr(), pol.nbytes, pol.M, pol.d, _dtype_code(self.drift.dtype), B, H,
+                                            float(dt), self.nx, self.na, self._act, self.scale, self.shift,
+                                            self.target.data_ptr(), self.precis.data_ptr(), tape.data_ptr(), tape.numel(),
+                                            g_cost.data_ptr(), g_pol.data_ptr(), _ptr(g_m), _ptr(g_S),
+                                            wd.data_ptr(), wd.numel(), wb.data_ptr(), wb.numel(),
+                                            self.drift.status().data_ptr(), _stream(dev))
+    check(rc, "mm_rollout_composed_backward")
+    return g_pol, g_m, g_S
+
+
 class GraphedComposedRollout:
   """``ComposedRollout`` captured once into a HIP graph (``torch.cuda.CUDAGraph``) and replayed: at cartpole sizes
   (B = 1) a composed step is ~16 launches of a few microseconds each, and the eager path is paced by the host
@@ -393,3 +464,30 @@ def expected_cost(mean: torch.Tensor, cov: torch.Tensor, target: torch.Tensor, p
                               out.data_ptr(), _stream(mean.device))
   check(rc, "mm_expected_cost")
   return out.reshape(lead)
+
+
+def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor, g_f1: torch.Tensor, g_Sff: torch.Tensor,
+                          g_cross: torch.Tensor, full_output_cov: bool = True, model_uncertainty: bool = True):
+  """``mm_moment_match_backward``: the vector-Jacobian product of one moment match of a frozen f64 pack,
+  (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> (g_mu [B,d], g_Sigma [B,d,d] symmetric)."""
+  if pm.dtype != torch.float64:
+    raise NotImplementedError("the backward runs on a float64 pack")
+  B, mu, Sigma = _prep_state(pm, mu, Sigma)
+  flags = make_flags(full_output_cov, model_uncertainty)
+  f64 = torch.float64
+  g_f1, g_Sff, g_cross = (t.to(f64).contiguous() for t in (g_f1, g_Sff, g_cross))
+  ws = pm.workspace(B, flags)
+  key = ("bwd", B, flags)
+  wb = pm._workspaces.get(key)
+  if wb is None:
+    n = lib().mm_moment_match_backward_bytes(B, pm.L, pm.M, pm.d, flags)
+    wb = torch.empty(n, dtype=torch.uint8, device=pm.device)
+    pm._workspaces[key] = wb
+  g_mu = torch.empty(B, pm.d, dtype=f64, device=pm.device)
+  g_S = torch.empty(B, pm.d, pm.d, dtype=f64, device=pm.device)
+  rc = lib().mm_moment_match_backward(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, MM_F64, B, mu.data_ptr(), Sigma.data_ptr(),
+                                      flags, g_f1.data_ptr(), g_Sff.data_ptr(), g_cross.data_ptr(), g_mu.data_ptr(),
+                                      g_S.data_ptr(), 0, ws.data_ptr(), ws.numel(), wb.data_ptr(), wb.numel(),
+                                      pm.status().data_ptr(), _stream(pm.device))
+  check(rc, "mm_moment_match_backward")
+  return g_mu, g_S

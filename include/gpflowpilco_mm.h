@@ -166,6 +166,39 @@ int mm_rollout_composed(const void* drift_packed, size_t drift_bytes, int drift_
                         void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
                         void* ws_compose, size_t ws_compose_bytes, int32_t* status, void* stream);
 
+/* The same rollout, RECORDED for differentiation: every per-step intermediate and the states x_0 .. x_H are written into
+ * `tape` (mm_compose_tape_bytes) instead of a reused workspace; mx / Sxx / cost as above. */
+size_t mm_compose_tape_bytes(int B, int H, int nx, int na, int dtype);
+int mm_rollout_composed_taped(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
+                              const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
+                              int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
+                              double head_scale, double head_shift, const void* target, const void* precis,
+                              void* mx, void* Sxx, void* cost, void* ws_drift, size_t ws_drift_bytes,
+                              void* ws_policy, size_t ws_policy_bytes, void* tape, size_t tape_bytes,
+                              int32_t* status, void* stream);
+
+/* ---- gradient of the composed rollout: SURVEY.md rows f-1 x f-2 -----------------------------------------------
+ * What the only real caller needs: update_policy differentiates the whole closure with tf.GradientTape
+ * (gpflow_pilco/utils/optimizers.py:51-56, examples/cartpole_swingup/train_utils.py:91-105, loops/pilco.py:192-220).
+ * mm_rollout_composed_backward is the reverse sweep over the tape (f64 only; the policy must be the one-launch shape,
+ * M <= 128 and ne <= 8, else MM_E_DIM):
+ *   g_cost   [H][B]  (in)  d loss / d cost[h][b]  (all ones for the loss of pilco.py:199-205)
+ *   g_policy [B][M d + M + d + 2] (out, overwritten): per batch element the gradient w.r.t. the PACKED policy --
+ *            Z [M][d], beta = Kuu^-1 u [M], ls2 = lengthscales^2 [d], variance, mean_c; sum over B and chain through
+ *            beta(q_mu, Z, lengthscales, variance) on the host (a 30 x 30 precompute)
+ *   g_mx0 [B][nx], g_Sxx0 [B][nx][nx] (out, both or neither): gradient w.r.t. the initial state (symmetric)
+ * ws_bwd: mm_compose_backward_workspace_bytes; ws_drift: the drift's mm_workspace_bytes (full covariance + uncertainty). */
+size_t mm_compose_backward_workspace_bytes(int B, int nx, int na, int drift_M);
+size_t mm_policy_grad_bytes(int B, int policy_M, int policy_d);
+int mm_rollout_composed_backward(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
+                                 const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
+                                 int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
+                                 double head_scale, double head_shift, const void* target, const void* precis,
+                                 const void* tape, size_t tape_bytes, const void* g_cost,
+                                 void* g_policy, void* g_mx0, void* g_Sxx0,
+                                 void* ws_drift, size_t ws_drift_bytes, void* ws_bwd, size_t ws_bwd_bytes,
+                                 int32_t* status, void* stream);
+
 /* ---- backward w.r.t. the input moments, stage A (f64 mode) ---------------------
  * The M x M part of d(f1, Sff, cross)/d(mu, Sigma) reduced to M-sized sums (see csrc/mm_backward.hip);
  * gpflowpilco_amd/autodiff.py finishes the chain rule.  Must follow mm_moment_match / mm_q_forward +
@@ -175,6 +208,19 @@ size_t mm_backward_bytes(int B, int L, int M, int d, int flags);
 int mm_backward_sums(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
                      const void* mu, int flags, const void* workspace, size_t workspace_bytes,
                      void* out, size_t out_bytes, void* stream);
+
+/* ---- backward w.r.t. the input moments, complete (f64 packs): the vector-Jacobian product of one moment match
+ *   (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> g_mu [B,d], g_Sigma [B,d,d] (symmetric; += if accumulate_Sigma)
+ * for a frozen model: re-runs the q stage for (mu, Sigma) on `workspace`, the M x M sweeps of mm_backward_sums, then the
+ * M-sized moments and the d x d chain rule per (latent | pair) item and their sum (csrc/mm_compose_bwd.hip, mm_adjoint.h).
+ * bwd_ws: mm_moment_match_backward_bytes. */
+size_t mm_moment_match_backward_bytes(int B, int L, int M, int d, int flags);
+int mm_moment_match_backward(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                             const void* mu, const void* Sigma, int flags,
+                             const void* g_f1, const void* g_Sff, const void* g_cross,
+                             void* g_mu, void* g_Sigma, int accumulate_Sigma,
+                             void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
+                             int32_t* status, void* stream);
 
 /* ---- pathwise (decoupled-sampling) rollout: SURVEY.md row f-3, BASELINE.json configs[4] ---------
  * f[s,a] = scale_a sum_k w[s,a,k] cos(2 pi (omega_t[a,:,k].x_s + phase[a,k]))

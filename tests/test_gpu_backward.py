@@ -272,3 +272,107 @@ def test_graphed_policy_loss_replays_eager_values_and_gradients(device):
     with torch.no_grad():                      # an in-place parameter update and a new initial state
       pol_model.q_mu.mul_(0.9)
       m0.add_(0.01)
+
+
+@pytest.mark.parametrize("case", [(3, 90, 4, 3, True, True), (2, 130, 6, 2, True, False), (3, 40, 3, 4, False, True),
+                                  (1, 200, 8, 2, True, True), (4, 100, 6, 1, True, True), (2, 70, 16, 2, True, True)],
+                         ids=["L3d4", "L2d6nounc", "L3diagcov", "L1d8", "c1drift", "d16"])
+def test_native_match_backward_equals_the_torch_chain_rule(case, device):
+  """mm_moment_match_backward (M x M sweeps + k_gp_bwd_items + k_gp_bwd_sum: everything on the device) against
+  autodiff.moment_match_backward (the same sums, chain rule in torch) -- which the tests above pin to finite differences
+  of the oracle."""
+  from gpflowpilco_amd import autodiff as ad, ops
+  from gpflowpilco_amd.synthetic import make_inputs, make_svgp
+  L, M, d, B, full, unc = case
+  syn = make_svgp(L, M, d, seed=60 + L + d, device=str(device), ls_bounds=(0.7, 3.0), mean_c=True)
+  model = syn.to_model(device)
+  pm = model.packed(torch.float64, True, device)
+  pre = model._cache._pre
+  mu, S = make_inputs(B, d, seed=9, scale=0.2, lo=0.3, hi=0.7)
+  mu_t, S_t = to_dev(mu, device, torch.float64), to_dev(S, device, torch.float64)
+  g = torch.Generator(device="cpu").manual_seed(2)
+  g1 = torch.randn(B, L, generator=g, dtype=torch.float64).to(device)
+  g2 = (torch.randn(B, L, L, generator=g, dtype=torch.float64) if full else torch.randn(B, L, generator=g, dtype=torch.float64)).to(device)
+  g3 = torch.randn(B, d, L, generator=g, dtype=torch.float64).to(device)
+  want = ad.moment_match_backward(pm, pre, mu_t, S_t, full, unc, g1, g2, g3)
+  got = ops.moment_match_backward(pm, mu_t, S_t, g1, g2, g3, full, unc)
+  pm.check_status(B)
+  for a_, b_ in zip(got, want):
+    assert float((a_ - b_).abs().max()) < 1e-10 * max(1.0, float(b_.abs().max()))
+
+
+def test_native_policy_gradient_at_H30_all_parameters_and_initial_state(device):
+  """Rows f-1 x f-2: the gradient of the cartpole-shaped policy loss (drift M = 100, policy M = 30, H = 30) w.r.t. EVERY
+  policy parameter (q_mu, inducing inputs, lengthscales, variance) and the initial state through the native reverse sweep
+  (mm_rollout_composed_backward) against (i) autograd through the torch composition of the same kernels and (ii) central
+  finite differences of the CPU oracle rollout on sampled coordinates."""
+  from gpflowpilco_amd import bijectors as tfb, dynamics, models as gp
+  from gpflowpilco_amd.components import GaussianObjective, TrigonometricEncoder
+  from gpflowpilco_amd.loops import get_state_initializer, policy_loss_closure
+  from gpflowpilco_amd.synthetic import make_svgp
+  from oracle import mm_compose_oracle as co
+  from tests.helpers import oracle_params
+  F64 = torch.float64
+  drift_syn = make_svgp(4, 100, 6, seed=10, ls_bounds=(0.8, 3.0))
+  drift_o = oracle_params(drift_syn)
+  drift_o.Z = drift_o.Z * np.array([1, 1, 1, 1, 1, 4.0]) - np.array([0, 0, 0, 0, 0, 2.0])
+  pol_o = random_svgp_params(seed=11, L=1, M=30, d=5, whiten=True, ls_bounds=(0.7, 2.0), mean=False)
+  pol_o.q_mu = 0.3 * pol_o.q_mu
+  rng = np.random.default_rng(12)
+  mu = np.array([[0.4, 0.2, 0.5, 0.3], [0.6, -0.1, 0.4, 0.5]])
+  S = generate_covariance(rng, 4, (2,), 0.05)
+  target = np.array([0.0, 1.0, 0, 0, 0])
+  precis = 16 * np.array([[0.25, 0, -0.5, 0, 0], [0, 0.25, 0, 0, 0], [-0.5, 0, 1, 0, 0], [0] * 5, [0] * 5], dtype=float)
+  scale, shift, active, H = 2.0, -0.5, (1,), 30
+  drift = gp_model_from_oracle(drift_o, device)
+  pol_model = gp_model_from_oracle(pol_o, device)
+  kern = pol_model.kernel.kernels[0]
+  params = {"q_mu": pol_model.q_mu, "Z": pol_model.inducing_variable.inducing_variables[0].Z,
+            "lengthscales": kern.lengthscales, "variance": kern.variance}
+  for t in params.values():
+    t.requires_grad_(True)
+  policy = gp.InverseLinkWrapper(gp.KernelRegressor(pol_model),
+                                 invlink=tfb.Chain([tfb.Scale(scale), tfb.Shift(shift), tfb.NormalCDF()]))
+  system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=TrigonometricEncoder(active_dims=active),
+                                    solver=dynamics.MomentMatchingEuler())
+  objective = GaussianObjective(target=to_dev(target, device, F64), precis=to_dev(precis, device, F64))
+  m0 = to_dev(mu, device, F64).requires_grad_(True); S0 = to_dev(S, device, F64).requires_grad_(True)
+  init = get_state_initializer(m0, S0)
+  wts = to_dev(np.array([1.0, 0.6]), device, F64)
+
+  def grads(native):
+    for t in list(params.values()) + [m0, S0]:
+      t.grad = None
+    loss = policy_loss_closure(system, objective, init, H, native=native)()
+    (loss * wts).sum().backward()
+    out = {k: t.grad.detach().clone() for k, t in params.items()}
+    out["m0"], out["S0"] = m0.grad.detach().clone(), 0.5 * (S0.grad + S0.grad.transpose(1, 2)).detach()
+    return loss.detach().cpu().numpy(), out
+  loss_n, gn = grads(None)              # native: taped rollout + reverse sweep
+  loss_t, gt = grads(False)             # torch composition
+  drift.packed(F64, True, device).check_status(2)
+  assert np.abs(loss_n - loss_t).max() < 1e-9
+  for k in gn:
+    err = float((gn[k] - gt[k]).abs().max()) / max(1e-12, float(gt[k].abs().max()))
+    assert err < 1e-7, (k, err)
+
+  def loss_np(q_mu=None, Z=None, ls=None, var=None, mu0=None):
+    pol = mo.SVGPParams(Z=pol_o.Z if Z is None else Z, lengthscales=pol_o.lengthscales if ls is None else ls,
+                        variance=pol_o.variance if var is None else var, q_mu=pol_o.q_mu if q_mu is None else q_mu,
+                        q_sqrt=pol_o.q_sqrt, whiten=True)
+    l = co.policy_rollout_loss(mu if mu0 is None else mu0, S, drift_o, lambda s: co.mm_policy(s, pol, scale, shift), active,
+                               target, precis, H)
+    return float((l * np.array([1.0, 0.6])).sum())
+  assert abs(loss_np() - float((loss_n * np.array([1.0, 0.6])).sum())) < 1e-7
+  eps = 1e-5
+  def fd(**kw_pm):
+    (name, (arr, idx)), = kw_pm.items()
+    ap, am = arr.copy(), arr.copy(); ap[idx] += eps; am[idx] -= eps
+    return (loss_np(**{name: ap}) - loss_np(**{name: am})) / (2 * eps)
+  checks = [("q_mu", fd(q_mu=(pol_o.q_mu, (3, 0))), gn["q_mu"][3, 0]), ("q_mu", fd(q_mu=(pol_o.q_mu, (21, 0))), gn["q_mu"][21, 0]),
+            ("Z", fd(Z=(pol_o.Z, (0, 5, 2))), gn["Z"][5, 2]), ("Z", fd(Z=(pol_o.Z, (0, 17, 0))), gn["Z"][17, 0]),
+            ("ls", fd(ls=(pol_o.lengthscales, (0, 1))), gn["lengthscales"][1]),
+            ("var", fd(var=(pol_o.variance, (0,))), gn["variance"].reshape(-1)[0]),
+            ("m0", fd(mu0=(mu, (0, 1))), gn["m0"][0, 1]), ("m0", fd(mu0=(mu, (1, 3))), gn["m0"][1, 3])]
+  for name, want, got in checks:
+    assert abs(want - float(got)) < 2e-5 * max(1.0, abs(want)), (name, want, float(got))
