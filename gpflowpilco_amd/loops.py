@@ -96,6 +96,17 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
     cost = ComposedRolloutFunction.apply(mx, Sxx, Zp, lsp, varp, betap, mcp, roll, num_steps, dt)
     return cost.sum(1)
 
+  def run_from_parameters(mx: torch.Tensor, Sxx: torch.Tensor):
+    """Forward only, the policy packed from its parameters on the stream (no snapshot from outside): what a HIP-graph
+    capture of the loss of a trainable policy must record, so that replays follow the optimiser's in-place updates."""
+    with torch.no_grad():
+      roll = current_roll(mx, fresh_policy=False)
+      Zp, lsp, varp, betap, _, mcp = pm_.precompute(mx.device)
+      pol = ops.pack_model(Zp, lsp, varp, betap, None, mcp, dtype=mx.dtype, sync=False)
+      _, _, cost = roll(mx, Sxx, num_steps, dt=dt, policy=pol)
+    return cost.sum(1)
+  run.from_parameters = run_from_parameters
+
   def supports_grad(mx: torch.Tensor) -> bool:
     return mx.dtype == torch.float64 and current_roll(mx, fresh_policy=False).supports_backward()
   run.with_grad = run_with_grad
@@ -140,8 +151,10 @@ def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_init
     if torch.is_grad_enabled() and (trainable or mx.requires_grad or Sxx.requires_grad):
       return False                       # someone differentiates: the torch composition carries the autograd graph
     if trainable and torch.cuda.is_current_stream_capturing():
-      return False                       # a captured graph must evaluate a trainable model FROM its parameters, not
-    return True                          # from a packed snapshot that goes stale at the next optimiser step
+      # a captured graph must evaluate a trainable model FROM its parameters, not from a packed snapshot that goes
+      # stale at the next optimiser step: only the policy can be re-packed inside the graph (run.from_parameters)
+      return "from_parameters" if not any(t.requires_grad for t in system.drift._parameters()) else False
+    return True
 
   def _use_native_grad(mx, Sxx):
     """Someone differentiates, and what is differentiated is what the native reverse sweep covers: the policy's
@@ -154,7 +167,10 @@ def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_init
 
   def _closure():                                                      # pilco.py:207-217
     mx, Sxx = state_initializer()
-    if _use_native(mx, Sxx):
+    use = _use_native(mx, Sxx)
+    if use == "from_parameters":
+      return fast.from_parameters(mx, Sxx)
+    if use:
       return fast(mx, Sxx)
     if _use_native_grad(mx, Sxx):
       return fast.with_grad(mx, Sxx)

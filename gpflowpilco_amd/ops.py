@@ -327,7 +327,13 @@ class ComposedRollout:
       self._wsc[B] = ws
     return ws
 
-  def __call__(self, mx: torch.Tensor, Sxx: torch.Tensor, num_steps: int, dt: float = 1.0, keep_trajectory: bool = False):
+  def __call__(self, mx: torch.Tensor, Sxx: torch.Tensor, num_steps: int, dt: float = 1.0, keep_trajectory: bool = False,
+               policy: Optional[PackedModel] = None):
+    """``policy``: another pack of the same shape to evaluate instead of ``self.policy`` (the current parameters of a
+    trainable policy, packed by the caller)."""
+    pol = self.policy if policy is None else policy
+    if (pol.L, pol.M, pol.d, pol.dtype) != (self.policy.L, self.policy.M, self.policy.d, self.policy.dtype):
+      raise ValueError("the policy pack does not have the shape this rollout was built for")
     _require_device(mx, Sxx)
     dt_ = self.drift.dtype
     if mx.dtype != dt_ or Sxx.dtype != dt_:
@@ -341,10 +347,10 @@ class ComposedRollout:
     tmu = torch.empty(H, B, self.nx, dtype=dt_, device=mx.device) if keep_trajectory else None
     tS = torch.empty(H, B, self.nx, self.nx, dtype=dt_, device=mx.device) if keep_trajectory else None
     wd = self.drift.workspace(B, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY)
-    wp = self.policy.workspace(B, MM_FULL_OUTPUT_COV)
+    wp = pol.workspace(B, MM_FULL_OUTPUT_COV)
     wc = self._compose_ws(B)
     rc = lib().mm_rollout_composed(self.drift.buf.data_ptr(), self.drift.nbytes, self.drift.L, self.drift.M, self.drift.d,
-                                   self.policy.buf.data_ptr(), self.policy.nbytes, self.policy.M, self.policy.d,
+                                   pol.buf.data_ptr(), pol.nbytes, pol.M, pol.d,
                                    _dtype_code(dt_), B, H, float(dt), self.nx, self.na, self._act,
                                    self.scale, self.shift, self.target.data_ptr(), self.precis.data_ptr(),
                                    mx.data_ptr(), Sxx.data_ptr(), cost.data_ptr(), _ptr(tmu), _ptr(tS),
