@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     const float bound2 = zmax2 ? mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) : 3.0e38f;
     const bool coll = (ND8 == 1) && !force_worst && bound2 <= MM_COLLAPSE_BOUND2;
     // a tile is skipped on the screening product alone: its error is <= 2^-9 sum_k |A_k||Z_k| <= 2^-9 sqrt(bound2)
-    const float thr_skip = 0.0625f - 0.00390625f * __builtin_sqrtf(bound2) - 1e-6f;
+    const float thr_skip = MM_TIER1_MAX - 0.00390625f * __builtin_sqrtf(bound2) - 1e-6f;
 
     // ---- stationary operands --------------------------------------------------------------
     bf16x8 a1[2][ND8], a2v[2][ND8], a3[2][ND8];
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
       for (int r = 0; r < 16; ++r) xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
       f32x2 part2;
       // wave-uniform tier choice (ballots, no cross-lane reduction)
-      if (!__any(mx > 0.0625f)) {
+      if (!__any(mx > MM_TIER1_MAX)) {
         // a collapsed (b, pair) has nothing left to add in this tier (the moments carry c0 x^3 + c1 x^4)
         // (the folded coefficients cost 64 more VGPRs: only where the operand registers leave room, d <= 8)
         if constexpr (CC) part2 = (f32x2){0.0f, 0.0f};
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
       mfma_tile_m(zA, acc);
       const float mx = force_worst ? 2.0f : tile_max(acc);       // MM_FORCE_WORST_TIER: wave-uniform override
       if constexpr (CM) {
-        if (!__any(mx > 0.0625f)) return;                        // first tier of a collapsed pair: all in the moments
+        if (!__any(mx > MM_TIER1_MAX)) return;                        // first tier of a collapsed pair: all in the moments
       }
       if constexpr (CM) wc = wcf[ct * 32 + l31];
       if (__any(mx > MM_TWO_WAY_MAX)) {

@@ -68,10 +68,11 @@ def test_c3_rollout_stays_in_regime_and_matches_f64_mode(device):
     m, S = ops.rollout_closed(pm, to_dev(mu, device, dtype), to_dev(Sigma, device, dtype), 10)
     pm.check_status(8)
     out[dtype] = (m.double(), S.double())
-  # measured: 2.9e-6 / 2.3e-6 on this draw, whose state widens to std 0.19 (|b| up to 0.3) around step 6; the bench
-  # rollout (std <= 0.14) stays at 4e-8 -- the f32 error grows with the width of the state
-  assert (out[torch.float32][0] - out[torch.float64][0]).abs().max() < 1e-5
-  assert (out[torch.float32][1] - out[torch.float64][1]).abs().max() < 1e-5
+  # this draw's state widens to std 0.19 (|b| up to 0.3) around step 6: the regime where the f32 mode's error is set by
+  # the SYSTEMATIC error of the first-tier approximant the moment collapse uses (mm_common.h MM_TIER1_DIV): measured
+  # 2.9e-6 with the tier at |b| <= 1/16 (round 2, tolerance then widened to 1e-5), 1.2e-6 at 1/20 (now), 1.5e-7 at 1/32
+  assert (out[torch.float32][0] - out[torch.float64][0]).abs().max() < 2e-6
+  assert (out[torch.float32][1] - out[torch.float64][1]).abs().max() < 2e-6
   std = torch.diagonal(out[torch.float64][1], dim1=-2, dim2=-1).sqrt()
   assert 0.02 < std.mean() < 0.5            # the state stays inside the data's support
 

@@ -65,25 +65,23 @@ policy = gp.InverseLinkWrapper(gp.KernelRegressor(pol_model),
 system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=TrigonometricEncoder(active_dims=(1,)),
                                   solver=dynamics.MomentMatchingEuler())
 objective = GaussianObjective(target=to_dev(target, dev, F64), precis=to_dev(precis, dev, F64))
-closure = policy_loss_closure(system, objective,
-                              get_state_initializer(to_dev(mu[:1], dev, F64), to_dev(S[:1] * 0.04, dev, F64)), H)
+init = get_state_initializer(to_dev(mu[:1], dev, F64), to_dev(S[:1] * 0.04, dev, F64))
+for label, native in (("native (taped rollout + mm_rollout_composed_backward)", None), ("torch composition (native=False)", False)):
+  closure = policy_loss_closure(system, objective, init, H, native=native)
 
+  def eager_fwd():
+    with torch.no_grad(): closure()
 
-def eager_fwd():
-  with torch.no_grad(): closure()
+  def eager_bwd():
+    pol_model.q_mu.grad = None
+    closure().sum().backward()
 
-
-def eager_bwd():
-  pol_model.q_mu.grad = None
-  closure().sum().backward()
-
-
-e_f, e_b = timed(eager_fwd, 3), timed(eager_bwd, 3)
-graphed = GraphedPolicyLoss(closure, [pol_model.q_mu])
-g_f, g_b = timed(graphed.loss, 5), timed(graphed.loss_and_grad, 5)
-emit(row="f-2 composed policy loss", shape="cartpole-sized (x4 -> e5 -> u1 -> d6 -> dx4), B=1, fp64", H=H,
-     eager_forward_ms_per_step=round(e_f / H, 3), eager_forward_backward_ms_per_step=round(e_b / H, 3),
-     graph_forward_ms_per_step=round(g_f / H, 3), graph_forward_backward_ms_per_step=round(g_b / H, 3))
+  e_f, e_b = timed(eager_fwd, 3), timed(eager_bwd, 3)
+  graphed = GraphedPolicyLoss(closure, [pol_model.q_mu])
+  g_f, g_b = timed(graphed.loss, 5), timed(graphed.loss_and_grad, 5)
+  emit(row="f-2 composed policy loss", path=label, shape="cartpole-sized (x4 -> e5 -> u1 -> d6 -> dx4), B=1, fp64", H=H,
+       eager_forward_ms_per_step=round(e_f / H, 4), eager_forward_backward_ms_per_step=round(e_b / H, 4),
+       graph_forward_ms_per_step=round(g_f / H, 4), graph_forward_backward_ms_per_step=round(g_b / H, 4))
 
 # ---- C4 shard ---------------------------------------------------------------------------------
 if not args.skip_c4:
