@@ -45,6 +45,31 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 #define MM_F64_3WAVE_KS4 2
 #endif
 
+// LOWP tiers: near-minimax e^x ~ 1 + x (c[0] + c[1] x + ... + c[N-1] x^(N-1)) on |x| <= h, ONE DEGREE BELOW the Taylor
+// polynomial it replaces at the same 1e-15 level (tools/minimax_exp_f64.py; max |p - e^x| in the comments): one f64 FMA
+// less per entry in every tier (three in the last).  MM_LOWP_MINIMAX 0 restores the Taylor tiers.
+#ifndef MM_LOWP_MINIMAX
+#define MM_LOWP_MINIMAX 1
+#endif
+struct MMExpMM {
+  static constexpr double t0[5] = {1.00000000000000044e+00, 4.99999999964337805e-01, 1.66666666653991380e-01, 4.16671387780754715e-02,
+                                   8.33342673612048890e-03};                                           // h = 1/64: 7.8e-16
+  static constexpr double t1[6] = {1.00000000000002021e+00, 5.00000000000006217e-01, 1.66666666501118582e-01, 4.16666666339412517e-02,
+                                   8.33367240573600759e-03, 1.38894006327464504e-03};                  // 1/32: 9.1e-17
+  static constexpr double t2[7] = {1.00000000000000000e+00, 5.00000000000271227e-01, 1.66666666666765689e-01, 4.16666662452447947e-02,
+                                   8.33333324931659694e-03, 1.38907499636817516e-03, 1.98438976588123547e-04};   // 1/16: 5.5e-17
+  static constexpr double t3[8] = {9.99999999999994227e-01, 4.99999999999998057e-01, 1.66666666671587443e-01, 4.16666666676764191e-02,
+                                   8.33333219859749494e-03, 1.38888871922507188e-03, 1.98509570295033318e-04,
+                                   2.48131262574843270e-05};                                           // 1/8: 8.3e-17
+  static constexpr double t4[9] = {1.00000000000000044e+00, 4.99999999999706179e-01, 1.66666666666557495e-01, 4.16666667123390885e-02,
+                                   8.33333334251792034e-03, 1.38888668227472043e-03, 1.98412387042712872e-04, 2.48435978552550916e-05,
+                                   2.76035419601197339e-06};                                           // 1/4: 6.1e-16
+  static constexpr double t5[12] = {9.99999999999984124e-01, 4.99999999999993894e-01, 1.66666666667467184e-01, 4.16666666668425861e-02,
+                                    8.33333332188715588e-03, 1.38888888712763070e-03, 1.98412768356629729e-04, 2.48015956038952326e-05,
+                                    2.75552447171072000e-06, 2.75553088264872583e-07, 2.53470020964661828e-08,
+                                    2.11189104196695848e-09};                                          // 3/4: 9.6e-16
+};
+
 __device__ __forceinline__ void mm_decode_pair_f(int p, int L, int& a, int& a2) {
   if (p < L) { a = p; a2 = p; return; }
   int r = p - L, i = 0;
@@ -319,28 +344,51 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : (DIAG && KS4 <= MM_F64_3WAVE_K
       }                                                                                   \
       sv = fma(pa + pb, o.cw[ct], sv);                                                    \
     }
+    // the same with a coefficient table (near-minimax LOWP tiers): degree N_
+#define MM_F64_ACCUM_POLYC(N_, TBL_)                                                      \
+    _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                    \
+      double pp[8], xv[8];                                                                \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                     \
+        xv[i] = cacc[i >> 2][ct][i & 3];                                                  \
+        pp[i] = fma(MMExpMM::TBL_[N_ - 1], xv[i], MMExpMM::TBL_[N_ - 2]);                 \
+      }                                                                                   \
+      _Pragma("unroll") for (int k = N_ - 3; k >= 0; --k)                                 \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] = fma(pp[i], xv[i], MMExpMM::TBL_[k]); \
+      _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] = DIAG ? fma(pp[i], xv[i], 1.0) : pp[i] * xv[i]; \
+      double pa = 0.0, pb = 0.0;                                                          \
+      if (withC) {                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) pp[i] *= dreg[i >> 2][ct][i & 3];   \
+      }                                                                                   \
+      _Pragma("unroll") for (int i = 0; i < 8; i += 2) {                                  \
+        pa = fma(pp[i], o.rw[i >> 2][i & 3], pa);                                         \
+        pb = fma(pp[i + 1], o.rw[(i + 1) >> 2][(i + 1) & 3], pb);                         \
+      }                                                                                   \
+      sv = fma(pa + pb, o.cw[ct], sv);                                                    \
+    }
     // Taylor degree by range: absolute truncation |x|^(DEG+1) / (DEG+1)!
     //   LOWP (f32 model): 1/64 -> 6 (5e-17), 1/32 -> 7 (2e-17), 1/16 -> 8 (4e-17), 1/8 -> 9 (3e-16), 1/4 -> 10 (6e-15), 3/4 -> 15
     //   f64 model       : 1/64 -> 7 (7e-20), 1/32 -> 8 (1e-19), 1/16 -> 9 (3e-19), 1/8 -> 10 (2e-18), 1/4 -> 12 (2e-18), 1/2 -> 15
     // Along the C3 rollout the 32 x 32 wave tiles of the diagonal pairs have max |delta| in (1/64, 1/32] 22-33 %,
     // (1/32, 1/16] 12-20 %, (1/16, 1/8] 47-55 %, (1/8, 1/4] 0-12 %: the half steps save one FMA per entry on 80 %.
+    constexpr bool MMX = LOWP && MM_LOWP_MINIMAX;
     if (!__any(mxh >= MM_HI32(0.015625))) {
-      if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D0) } else { MM_F64_ACCUM_POLY(7) }
+      if (MMX) { MM_F64_ACCUM_POLYC(5, t0) } else if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D0) } else { MM_F64_ACCUM_POLY(7) }
     } else if (!__any(mxh >= MM_HI32(0.03125))) {
-      if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D0 + 1) } else { MM_F64_ACCUM_POLY(8) }
+      if (MMX) { MM_F64_ACCUM_POLYC(6, t1) } else if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D0 + 1) } else { MM_F64_ACCUM_POLY(8) }
     } else if (!__any(mxh >= MM_HI32(0.0625))) {
-      if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D1) } else { MM_F64_ACCUM_POLY(9) }
+      if (MMX) { MM_F64_ACCUM_POLYC(7, t2) } else if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D1) } else { MM_F64_ACCUM_POLY(9) }
     } else if (!__any(mxh >= MM_HI32(0.125))) {
-      if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D1 + 1) } else { MM_F64_ACCUM_POLY(10) }
+      if (MMX) { MM_F64_ACCUM_POLYC(8, t3) } else if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D1 + 1) } else { MM_F64_ACCUM_POLY(10) }
     } else if (!__any(mxh >= MM_HI32(0.25))) {
-      if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D2) } else { MM_F64_ACCUM_POLY(12) }
+      if (MMX) { MM_F64_ACCUM_POLYC(9, t4) } else if (LOWP) { MM_F64_ACCUM_POLY(MM_LOWP_D2) } else { MM_F64_ACCUM_POLY(12) }
     } else if (!__any(mxh >= (LOWP ? MM_HI32(0.75) : MM_HI32(0.5)))) {
-      MM_F64_ACCUM_POLY(15)
+      if (MMX) { MM_F64_ACCUM_POLYC(12, t5) } else { MM_F64_ACCUM_POLY(15) }
     } else {
       MM_F64_ACCUM(mm_expm1_f64)
     }
 #undef MM_F64_ACCUM
 #undef MM_F64_ACCUM_POLY
+#undef MM_F64_ACCUM_POLYC
 #undef MM_HI32
     // the workgroup reduction is deferred: per-thread partials of MM_F64_NB batch elements are
     // staged in LDS and reduced together (no cross-lane traffic or barrier per batch element)
