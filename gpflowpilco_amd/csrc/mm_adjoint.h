@@ -21,15 +21,65 @@
 
 #define MMA_FN template <class Ctx> __host__ __device__ inline
 
+// one wave of a workgroup working on its own data (d x d items handled by several waves at once): LDS traffic of a
+// single wave is processed in order, so a wave-scope fence (no reordering by the compiler) is all a phase boundary needs
+struct MMAWaveCtx {
+  __device__ void stamp(int) const {}
+  __device__ int lane() const { return (int)(threadIdx.x & 63u); }
+  __device__ int nl() const { return 64; }
+  __device__ void sync() const {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+};
 struct MMADevCtx {
+  // optional stage profile (tools/profile_small.py): cycles between consecutive stamp() calls, accumulated per stage id
+  long long* prof = nullptr;
+  long long* last = nullptr;
+  __device__ void stamp(int k) const {
+    if (prof && threadIdx.x == 0 && blockIdx.x == 0) { const long long t = clock64(); prof[k] += t - *last; *last = t; }
+  }
   __device__ int lane() const { return (int)threadIdx.x; }
   __device__ int nl() const { return (int)blockDim.x; }
   __device__ void sync() const { __syncthreads(); }
+  // groups = waves: independent small items are dealt to them and run concurrently in sub()
+  __device__ int group() const { return (int)(threadIdx.x >> 6); }
+  __device__ int ngroups() const { return (int)(blockDim.x >> 6); }
+  __device__ MMAWaveCtx sub() const { return MMAWaveCtx(); }
+  // sum of v[k] over all lanes of the workgroup, result in every lane; scratch: ngroups() * N doubles
+  template <int N>
+  __device__ void reduce(double (&v)[N], double* scratch) const {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+    }
+    const int g = group(), ng = ngroups();
+    if ((threadIdx.x & 63u) == 0) {
+#pragma unroll
+      for (int k = 0; k < N; ++k) scratch[g * N + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      double s = 0.0;
+      for (int t = 0; t < ng; ++t) s += scratch[t * N + k];
+      v[k] = s;
+    }
+    __syncthreads();
+  }
 };
 struct MMAHostCtx {
+  __host__ __device__ void stamp(int) const {}
   __host__ __device__ int lane() const { return 0; }
   __host__ __device__ int nl() const { return 1; }
   __host__ __device__ void sync() const {}
+  __host__ __device__ int group() const { return 0; }
+  __host__ __device__ int ngroups() const { return 1; }
+  __host__ __device__ MMAHostCtx sub() const { return MMAHostCtx(); }
+  template <int N>
+  __host__ __device__ void reduce(double (&)[N], double*) const {}
 };
 
 #define MMA_INV_SQRT_2PI 0.39894228040143267794
