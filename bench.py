@@ -762,6 +762,37 @@ def composed_bench(args, rank, world, dev, dist):
                       "note": "B = 1: every kernel runs for a few microseconds on a fraction of one XCD; the step is bound by the "
                               "dependency chain of its launches (MI355X_MICROARCH.md 'boundary': ~1.5-1.9 us each), not by a "
                               "bandwidth or issue ceiling.  `achieved` = packed model bytes touched once per step / step time"}}
+  if rank == 0 and world == 1:
+    # what the only real caller of this rollout does with it (examples/cartpole_swingup/train_utils.py:91-105): the
+    # gradient of the loss w.r.t. the policy's parameters -- taped native rollout + reverse sweep
+    # (mm_rollout_composed_backward), forward + backward replayed from one HIP graph; untimed by the metric, reported beside it
+    from gpflowpilco_amd import bijectors as tfb, dynamics, models as gpm
+    from gpflowpilco_amd.components import GaussianObjective, TrigonometricEncoder
+    from gpflowpilco_amd.loops import GraphedPolicyLoss, get_state_initializer, policy_loss_closure
+    kern = pol.latent_kernels[0]
+    prm = [pol.q_mu, pol.inducing_variable.inducing_variable.Z, kern.lengthscales, kern.variance]
+    for p_ in prm:
+      p_.requires_grad_(True)
+    policy = gpm.InverseLinkWrapper(gpm.KernelRegressor(pol), invlink=tfb.Chain([tfb.Scale(scale), tfb.Shift(shift), tfb.NormalCDF()]))
+    system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=TrigonometricEncoder(active_dims=active),
+                                      solver=dynamics.MomentMatchingEuler())
+    closure = policy_loss_closure(system, GaussianObjective(target=t(target), precis=t(precis)), get_state_initializer(mx, Sxx), H)
+    gl = GraphedPolicyLoss(closure, prm)
+    for _ in range(3):
+      gl.loss_and_grad()
+    torch.cuda.synchronize()
+    tg = time.perf_counter()
+    nrep = max(1, steps // H)
+    for _ in range(nrep):
+      gl.loss_and_grad()
+    torch.cuda.synchronize()
+    out["config"]["policy_gradient"] = {
+        "forward_backward_ms_per_step": round(1e3 * (time.perf_counter() - tg) / (nrep * H), 4),
+        "what": "loss + d loss / d (q_mu, Z, lengthscales, variance) of the policy, H-step rollout, one HIP graph replay per evaluation "
+                "(loops.GraphedPolicyLoss over mm_rollout_composed_taped + mm_rollout_composed_backward)",
+        "grad_norm": float(torch.sqrt(sum((g_ * g_).sum() for g_ in gl._grads)))}
+    for p_ in prm:
+      p_.requires_grad_(False)
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     from oracle import mm_compose_oracle as co
     from oracle import mm_oracle as mo
