@@ -177,6 +177,109 @@ MMA_FN double mma_solve_pivot(Ctx c, double* Aug, int n, int nr, int ld) {
   return det;
 }
 
+// ---- device fast paths for n <= 8: one matrix entry per lane of ONE wave (lane = 8 i + j), broadcasts by wave shuffles ----
+// The phase-per-barrier versions above are latency chains on the device (an SPD inverse of a 6 x 6 matrix: ~20 barrier
+// phases, 5 us); these take ~0.5 us.  Chosen by overload for the device contexts; the host context keeps the generic code.
+#if defined(__HIPCC__)
+// Gauss-Jordan inverse of an SPD matrix held in `a` (identity outside d x d); returns the entry of the inverse, sets *logdet
+__device__ inline double mma_gj_spd8(double a, int d, bool* ok, double* logdet) {
+  const int lane = (int)(threadIdx.x & 63u), i = lane >> 3, j = lane & 7;
+  double pk = 1.0;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    if (k < d) {
+      const double p = __shfl(a, 9 * k, 64);
+      if (!(p > 0.0)) *ok = false;
+      if (lane == k) pk = p;
+      const double ip = 1.0 / p;
+      const double rk = __shfl(a, 8 * k + j, 64), ci = __shfl(a, 8 * i + k, 64);
+      if (i == k) a = (j == k) ? ip : rk * ip;
+      else a = (j == k) ? -ci * ip : fma(-ci * ip, rk, a);
+    }
+  }
+  a = 0.5 * (a + __shfl(a, 8 * j + i, 64));
+  double ld = lane < d ? log(pk) : 0.0;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ld += __shfl_xor(ld, off, 64);
+  *logdet = ld;
+  return a;
+}
+
+__device__ inline double mma_spd_inverse(MMAWaveCtx c, double* A, double* Y, int d, int dp, bool* ok) {
+  if (d > 8) return mma_spd_inverse<MMAWaveCtx>(c, A, Y, d, dp, ok);
+  const int lane = c.lane(), i = lane >> 3, j = lane & 7;
+  const bool in = i < d && j < d;
+  c.sync();
+  double ld;
+  const double a = mma_gj_spd8(in ? A[i * dp + j] : (i == j ? 1.0 : 0.0), d, ok, &ld);
+  if (in) A[i * dp + j] = a;
+  c.sync();
+  return ld;
+}
+
+// whole workgroup: wave 0 does the work, the log-determinant reaches every lane through Y[0]
+__device__ inline double mma_spd_inverse(MMADevCtx c, double* A, double* Y, int d, int dp, bool* ok) {
+  if (d > 8) return mma_spd_inverse<MMADevCtx>(c, A, Y, d, dp, ok);
+  c.sync();
+  if (c.group() == 0) {
+    const int lane = c.lane(), i = lane >> 3, j = lane & 7;
+    const bool in = i < d && j < d;
+    double ld;
+    bool okw = true;
+    const double a = mma_gj_spd8(in ? A[i * dp + j] : (i == j ? 1.0 : 0.0), d, &okw, &ld);
+    if (in) A[i * dp + j] = a;
+    if (lane == 0) { Y[0] = ld; Y[1] = okw ? 1.0 : 0.0; }
+  }
+  c.sync();
+  const double ld = Y[0];
+  if (Y[1] == 0.0) *ok = false;
+  c.sync();
+  return ld;
+}
+
+// A X = R, n <= 8 unknowns and nr <= 8 right-hand sides, partial pivoting: wave 0, one entry of A and one of R per lane
+__device__ inline double mma_solve_pivot(MMADevCtx c, double* Aug, int n, int nr, int ld) {
+  if (n > 8 || nr > 8) return mma_solve_pivot<MMADevCtx>(c, Aug, n, nr, ld);
+  c.sync();
+  if (c.group() == 0) {
+    const int lane = c.lane(), i = lane >> 3, j = lane & 7;
+    double a = (i < n && j < n) ? Aug[i * ld + j] : (i == j ? 1.0 : 0.0);
+    double b = (i < n && j < nr) ? Aug[i * ld + n + j] : 0.0;
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (k < n) {
+        double best = fabs(__shfl(a, 9 * k, 64));
+        int p = k;
+#pragma unroll
+        for (int r = 1; r < 8; ++r) {
+          if (k + r < n) {
+            const double v = fabs(__shfl(a, 8 * (k + r) + k, 64));
+            if (v > best) { best = v; p = k + r; }
+          }
+        }
+        if (p != k) {
+          const int si = i == k ? p : (i == p ? k : i);
+          a = __shfl(a, 8 * si + j, 64); b = __shfl(b, 8 * si + j, 64);
+          det = -det;
+        }
+        const double piv = __shfl(a, 9 * k, 64), ip = 1.0 / piv;
+        det *= piv;
+        const double rk = __shfl(a, 8 * k + j, 64), bk = __shfl(b, 8 * k + j, 64), ci = __shfl(a, 8 * i + k, 64);
+        if (i == k) { a = rk * ip; b = bk * ip; }
+        else { a = fma(-ci * ip, rk, a); b = fma(-ci * ip, bk, b); }
+      }
+    }
+    if (i < n && j < nr) Aug[i * ld + n + j] = b;
+    if (lane == 0) Aug[0] = det;                          // (the eliminated left block is not read again: carries det)
+  }
+  c.sync();
+  const double det = Aug[0];
+  c.sync();
+  return det;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // mma_encode_bwd: adjoint of the trigonometric encoding (mmc_encode_body in mm_compose.hip)
 //   (m [nx], S [nx, nx])  ->  me = [sin a, cos a, x_inactive] [ne], See [ne, ne], Sxe [nx, ne]
@@ -436,10 +539,11 @@ MMA_FN void mma_head_bwd(Ctx c, int ne, double scale, double shift, double pf1, 
 __host__ __device__ inline int mma_policy_nsub(int M, int nl) { const int n = nl / M; return n < 1 ? 1 : n; }
 __host__ __device__ inline int mma_policy_small_bwd_scratch(int M, int d, int nl) {
   const int dp = d + 1, ns = mma_policy_nsub(M, nl);
-  return 12 * d * dp + M * (5 * d + 8) + ns * M * (d + 2) + 4 * d + 16;
+  return 12 * d * dp + M * (5 * d + 8) + ns * M * (d + 2) + 4 * d + 16 + 3 * (nl > d * d + 2 * d + 2 ? nl : d * d + 2 * d + 2) + 16;
 }
 
-MMA_FN void mma_policy_small_bwd(Ctx c, int M, int d, const double* Z, const double* beta, const double* ls2, double var,
+template <class Ctx, int DK>
+__host__ __device__ inline void mma_policy_small_bwd(Ctx c, int M, int d, const double* Z, const double* beta, const double* ls2, double var,
                                  const double* mu, const double* Sigma, double gf1, double gSff, const double* gcross,
                                  double* gmu, double* gSig, double* gpar, double* sm, bool* ok) {
   const int lane = c.lane(), nl = c.nl(), dp = d + 1, msz = d * dp, ns = mma_policy_nsub(M, nl);
@@ -458,7 +562,9 @@ MMA_FN void mma_policy_small_bwd(Ctx c, int M, int d, const double* Z, const dou
   double* sb = sv + d;                   // [d] adjoint of s = P gcross
   double* lamb = sb + d;                 // [d] adjoint of Lambda
   double* Vb = lamb + d;                 // [d] adjoint of V
-  double* sc = Vb + d;                   // scalars
+  double* sc = Vb + d;                   // scalars [16]
+  double* slc = sc + 16;                 // [slices][d * d][3] partial matrix sums over the centres
+
   for (int idx = lane; idx < d * d; idx += nl) {
     const int i = idx / d, j = idx - i * d;
     const double s = i >= j ? Sigma[i * d + j] : Sigma[j * d + i];
@@ -467,8 +573,10 @@ MMA_FN void mma_policy_small_bwd(Ctx c, int M, int d, const double* Z, const dou
     S0[i * dp + j] = s + (i == j ? 0.5 * ls2[i] : 0.0);
   }
   c.sync();
+  c.stamp(0);
   const double ldA = mma_spd_inverse(c, Pm, Yw, d, dp, ok);
   const double ldS = mma_spd_inverse(c, S0, Yw, d, dp, ok);
+  c.stamp(1);
   double sl = 0.0;
   for (int k = 0; k < d; ++k) sl += log(ls2[k]);
   const double lognorm = log(var) + 0.5 * sl - 0.5 * ldA;
@@ -496,6 +604,7 @@ MMA_FN void mma_policy_small_bwd(Ctx c, int M, int d, const double* Z, const dou
     sb[k] = s;
   }
   c.sync();
+  c.stamp(2);
   // ---- per centre: forward quantities ---------------------------------------------------------------------------------
   for (int m = lane; m < M; m += nl) {
     double maha = 0.0, r1 = 0.0;
@@ -515,6 +624,7 @@ MMA_FN void mma_policy_small_bwd(Ctx c, int M, int d, const double* Z, const dou
     rs[m] = -0.5 * r1;
   }
   c.sync();
+  c.stamp(3);
   // ---- M x M sweep: c_i = sum_j E_ij w_j, K_i = sum_j Omega_ij, U_i = sum_j Omega_ij zeta_j -----------------------------
   for (int idx = lane; idx < ns * M; idx += nl) {
     const int i = idx % M, sub = idx / M;
@@ -532,58 +642,77 @@ MMA_FN void mma_policy_small_bwd(Ctx c, int M, int d, const double* Z, const dou
     pu[d] = ci; pu[d + 1] = Ki;
   }
   c.sync();
-  for (int i = lane; i < M; i += nl) {                  // combine the sub-sweeps; per-centre adjoints
-    double ci = 0.0, Ki = 0.0, U[MMC_ND];
-    for (int k = 0; k < d; ++k) U[k] = 0.0;
-    for (int sub = 0; sub < ns; ++sub) {
-      const double* pu = part + (size_t)(sub * M + i) * (d + 2);
-      for (int k = 0; k < d; ++k) U[k] += pu[k];
-      ci += pu[d]; Ki += pu[d + 1];
-    }
+  c.stamp(4);
+  // combine the sub-sweeps (into the slot of sub-sweep 0): U_i [d], c_i, K_i
+  for (int idx = lane; idx < M * (d + 2); idx += nl) {
+    const int i = idx / (d + 2), k = idx - i * (d + 2);
+    double v = 0.0;
+    for (int sub = 0; sub < ns; ++sub) v += part[(size_t)(sub * M + i) * (d + 2) + k];
+    part[(size_t)i * (d + 2) + k] = v;
+  }
+  c.sync();
+  for (int i = lane; i < M; i += nl) {                  // per-centre scalar adjoints
+    const double ci = part[(size_t)i * (d + 2) + d], Ki = part[(size_t)i * (d + 2) + d + 1];
     cs[i] = ci; Ks[i] = Ki;
     double sz = 0.0;
     for (int k = 0; k < d; ++k) sz = fma(sb[k], zs[i * d + k], sz);
     const double wbar = gf1 + 2.0 * gSff * ci + sz;
-    const double mbar = -0.5 * wbar * ws[i];
-    const double rbar = 2.0 * gSff * Ki;
-    wb[i] = wbar; mb[i] = mbar; rb[i] = rbar;
-    for (int k = 0; k < d; ++k) {
-      double gu = 0.0;
-      for (int l = 0; l < d; ++l) gu = fma(Gm[k * dp + l], U[l], gu);
-      zb[i * d + k] = 2.0 * gSff * gu + ws[i] * sb[k] + 2.0 * mbar * Pz[i * d + k] - rbar * dz[i * d + k];
-    }
-    // X_i = zeta_i U_i^T is summed below: keep U in the (now free) partial slot of sub-sweep 0
-    double* pu0 = part + (size_t)i * (d + 2);
-    for (int k = 0; k < d; ++k) pu0[k] = U[k];
+    wb[i] = wbar; mb[i] = -0.5 * wbar * ws[i]; rb[i] = 2.0 * gSff * Ki;
   }
   c.sync();
-  // ---- sums over the centres ---------------------------------------------------------------------------------------------
-  for (int idx = lane; idx < d * d; idx += nl) {
-    const int a = idx / d, b = idx - a * d;
-    double pm_ = 0.0, rr = 0.0, xx = 0.0;
-    for (int i = 0; i < M; ++i) {
-      const double zz = zs[i * d + a] * zs[i * d + b];
-      pm_ = fma(mb[i], zz, pm_);
-      rr = fma(rb[i], zz, rr);
-      xx = fma(zs[i * d + a], part[(size_t)i * (d + 2) + b], xx);
-    }
-    Pb[a * dp + b] = pm_;            // sum mbar zeta zeta^T            (+ sym(gcross s^T) + from E, below)
-    Eb[a * dp + b] = -0.5 * rr;      // adjoint of E
-    Gb[a * dp + b] = 0.5 * rr;       // adjoint of G: + gSff sym(X), below
-    W1[a * dp + b] = xx;             // X
-  }
-  for (int k = lane; k < d; k += nl) {
-    double s = 0.0, mz = 0.0;
-    for (int i = 0; i < M; ++i) { s = fma(ws[i], zs[i * d + k], s); mz += zb[i * d + k]; }
-    sv[k] = s; gmu[k] = -mz;
-  }
-  if (lane == 0) {
-    double lb = 0.0, k0 = 0.0;
-    for (int i = 0; i < M; ++i) { lb = fma(wb[i], ws[i], lb); k0 += Ks[i]; }
-    sc[0] = lb;                      // adjoint of lognorm
-    sc[1] = gSff * k0;               // adjoint of cst
+  for (int idx = lane; idx < M * d; idx += nl) {        // adjoint of zeta_i, one (centre, dimension) per lane
+    const int i = idx / d, k = idx - i * d;
+    double gu = 0.0;
+    for (int l = 0; l < d; ++l) gu = fma(Gm[k * dp + l], part[(size_t)i * (d + 2) + l], gu);
+    zb[idx] = 2.0 * gSff * gu + ws[i] * sb[k] + 2.0 * mb[i] * Pz[idx] - rb[i] * dz[idx];
   }
   c.sync();
+  c.stamp(5);
+  // ---- sums over the centres, in slices of the centre range (one (entry, slice) per lane, then one lane per entry): the
+  // d x d matrices sum mbar zz^T, sum rbar zz^T, X = sum zeta U^T, the vectors s = sum w zeta, sum zbar, and two scalars ------
+  {
+    const int dd = d * d, ne_ = dd + 2 * d + 2, nsl = nl / ne_ < 1 ? 1 : nl / ne_;
+    for (int idx = lane; idx < nsl * ne_; idx += nl) {
+      const int e = idx % ne_, sl2 = idx / ne_;
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+      if (e < dd) {
+        const int a = e / d, b = e - a * d;
+        for (int i = sl2; i < M; i += nsl) {
+          const double zz = zs[i * d + a] * zs[i * d + b];
+          v0 = fma(mb[i], zz, v0); v1 = fma(rb[i], zz, v1);
+          v2 = fma(zs[i * d + a], part[(size_t)i * (d + 2) + b], v2);
+        }
+      } else if (e < dd + d) {
+        const int k = e - dd;
+        for (int i = sl2; i < M; i += nsl) v0 = fma(ws[i], zs[i * d + k], v0);
+      } else if (e < dd + 2 * d) {
+        const int k = e - dd - d;
+        for (int i = sl2; i < M; i += nsl) v0 += zb[i * d + k];
+      } else if (e == dd + 2 * d) {
+        for (int i = sl2; i < M; i += nsl) v0 = fma(wb[i], ws[i], v0);
+      } else {
+        for (int i = sl2; i < M; i += nsl) v0 += Ks[i];
+      }
+      slc[(size_t)idx * 3] = v0; slc[(size_t)idx * 3 + 1] = v1; slc[(size_t)idx * 3 + 2] = v2;
+    }
+    c.sync();
+    for (int e = lane; e < ne_; e += nl) {
+      double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+      for (int t = 0; t < nsl; ++t) { v0 += slc[(size_t)(t * ne_ + e) * 3]; v1 += slc[(size_t)(t * ne_ + e) * 3 + 1]; v2 += slc[(size_t)(t * ne_ + e) * 3 + 2]; }
+      if (e < dd) {
+        const int a = e / d, b = e - a * d;
+        Pb[a * dp + b] = v0;           // sum mbar zeta zeta^T            (+ sym(gcross s^T) + from E, below)
+        Eb[a * dp + b] = -0.5 * v1;    // adjoint of E
+        Gb[a * dp + b] = 0.5 * v1;     // adjoint of G: + gSff sym(X), below
+        W1[a * dp + b] = v2;           // X
+      } else if (e < dd + d) sv[e - dd] = v0;
+      else if (e < dd + 2 * d) gmu[e - dd - d] = -v0;
+      else if (e == dd + 2 * d) sc[0] = v0;              // adjoint of lognorm
+      else sc[1] = gSff * v0;                            // adjoint of cst
+    }
+  }
+  c.sync();
+  c.stamp(6);
   const double lbar = sc[0], cbar = sc[1];
   const double ldAb = -0.5 * lbar + cbar, ldSb = -0.5 * cbar;
   for (int idx = lane; idx < d * d; idx += nl) {
@@ -648,6 +777,7 @@ MMA_FN void mma_policy_small_bwd(Ctx c, int M, int d, const double* Z, const dou
     const int a = idx / d, b = idx - a * d;
     gSig[a * d + b] += 0.5 * (W2[a * dp + b] + W2[b * dp + a]) + ldSb * S0[a * dp + b];
   }
+  c.stamp(7);
   // ---- the packed model's gradient (accumulated over the steps of a rollout) ---------------------------------------------
   for (int idx = lane; idx < M * d; idx += nl) gpar[idx] += zb[idx];
   for (int i = lane; i < M; i += nl) gpar[M * d + i] += wb[i] * qs[i];
@@ -692,12 +822,20 @@ MMA_FN void mma_raw_moments(Ctx c, int M, int d, const double* Z, const double* 
   for (int idx = lane; idx < ns * nc; idx += nl) {
     const int k = idx % nc, s = idx / nc;
     const int i = k <= d ? k - 1 : (k - 1 - d) / d, j = k <= d ? 0 : (k - 1 - d) % d;
-    double acc = 0.0;
-    for (int m = s; m < M; m += ns) {
-      const double f = k == 0 ? 1.0 : k <= d ? Z[(size_t)m * d + i] : Z[(size_t)m * d + i] * Z[(size_t)m * d + j];
-      acc = fma(coef[m], f, acc);
+    // four independent chains: the loads of four centres are in flight together (a single chain is one global-memory
+    // latency per centre on the device)
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    auto term = [&](int m) -> double {
+      return k == 0 ? 1.0 : k <= d ? Z[(size_t)m * d + i] : Z[(size_t)m * d + i] * Z[(size_t)m * d + j];
+    };
+    int m = s;
+    for (; m + 3 * ns < M; m += 4 * ns) {
+      const double c0 = coef[m], c1 = coef[m + ns], c2 = coef[m + 2 * ns], c3 = coef[m + 3 * ns];
+      const double f0 = term(m), f1 = term(m + ns), f2 = term(m + 2 * ns), f3 = term(m + 3 * ns);
+      acc[0] = fma(c0, f0, acc[0]); acc[1] = fma(c1, f1, acc[1]); acc[2] = fma(c2, f2, acc[2]); acc[3] = fma(c3, f3, acc[3]);
     }
-    part[idx] = acc;
+    for (; m < M; m += ns) acc[0] = fma(coef[m], term(m), acc[0]);
+    part[idx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
   }
   c.sync();
   for (int k = lane; k < nc; k += nl) {
@@ -807,12 +945,15 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
     for (int idx = lane; idx < nsl * nq; idx += nl) {
       const int k = idx % nq, s = idx / nq;
       const int i = k < d * d ? k / d : k - d * d, j = k < d * d ? k % d : 0;
-      double acc = 0.0;
-      for (int m = s; m < M; m += nsl) {
-        const double U = colp[(size_t)(3 + i) * Mp + m];
-        acc = fma(U, k < d * d ? Zb[(size_t)m * d + j] : 1.0, acc);
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+      auto term = [&](int m) -> double { return colp[(size_t)(3 + i) * Mp + m] * (k < d * d ? Zb[(size_t)m * d + j] : 1.0); };
+      int m = s;
+      for (; m + 3 * nsl < M; m += 4 * nsl) {
+        const double t0 = term(m), t1 = term(m + nsl), t2 = term(m + 2 * nsl), t3 = term(m + 3 * nsl);
+        acc[0] += t0; acc[1] += t1; acc[2] += t2; acc[3] += t3;
       }
-      part[idx] = acc;
+      for (; m < M; m += nsl) acc[0] += term(m);
+      part[idx] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
     c.sync();
     for (int k = lane; k < nq; k += nl) {

@@ -22,6 +22,21 @@
 #include "mm_dev.h"
 #include "mm_compose.h"
 
+// Stage profile of block 0 (cycles between consecutive MM_STAMP calls, accumulated per id): only in a -DMM_STAGE_PROFILE
+// build (tools/profile_c1_stages.py); expands to nothing in the shipped library.
+#ifdef MM_STAGE_PROFILE
+__device__ long long* mm_stage_prof = nullptr;
+extern "C" void mm_stage_profile_set(void* device_buffer) {
+  hipMemcpyToSymbol(HIP_SYMBOL(mm_stage_prof), &device_buffer, sizeof(void*));
+}
+#define MM_STAMP_INIT() long long mm_t0_ = clock64()
+#define MM_STAMP(k_) do { if (mm_stage_prof && threadIdx.x == 0 && blockIdx.x == 0) { const long long t_ = clock64(); \
+                          mm_stage_prof[k_] += t_ - mm_t0_; mm_t0_ = t_; } } while (0)
+#else
+#define MM_STAMP_INIT() do {} while (0)
+#define MM_STAMP(k_) do {} while (0)
+#endif
+
 static __device__ const double MM_GL48_X[48] = {-9.98771007252426068e-01, -9.93530172266350764e-01, -9.84124583722826851e-01, -9.70591592546247273e-01, -9.52987703160430910e-01, -9.31386690706554332e-01, -9.05879136715569633e-01, -8.76572020274247854e-01, -8.43588261624393487e-01, -8.07066204029442624e-01, -7.67159032515740358e-01, -7.24034130923814634e-01, -6.77872379632663891e-01, -6.28867396776513599e-01, -5.77224726083972683e-01, -5.23160974722232996e-01, -4.66902904750958414e-01, -4.08686481990716721e-01, -3.48755886292160755e-01, -2.87362487355455554e-01, -2.24763790394689050e-01, -1.61222356068891709e-01, -9.70046992094626970e-02, -3.23801709628693674e-02, 3.23801709628693674e-02, 9.70046992094626970e-02, 1.61222356068891709e-01, 2.24763790394689050e-01, 2.87362487355455554e-01, 3.48755886292160755e-01, 4.08686481990716721e-01, 4.66902904750958414e-01, 5.23160974722232996e-01, 5.77224726083972683e-01, 6.28867396776513599e-01, 6.77872379632663891e-01, 7.24034130923814634e-01, 7.67159032515740358e-01, 8.07066204029442624e-01, 8.43588261624393487e-01, 8.76572020274247854e-01, 9.05879136715569633e-01, 9.31386690706554332e-01, 9.52987703160430910e-01, 9.70591592546247273e-01, 9.84124583722826851e-01, 9.93530172266350764e-01, 9.98771007252426068e-01};
 static __device__ const double MM_GL48_W[48] = {3.15334605230917957e-03, 7.32755390127649234e-03, 1.14772345792349736e-02, 1.55793157229429276e-02, 1.96161604573552965e-02, 2.35707608393240925e-02, 2.74265097083568818e-02, 3.11672278327983394e-02, 3.47772225647706573e-02, 3.82413510658306741e-02, 4.15450829434645535e-02, 4.46745608566940997e-02, 4.76166584924902839e-02, 5.03590355538542783e-02, 5.28901894851934867e-02, 5.51995036999840538e-02, 5.72772921004029295e-02, 5.91148396983954827e-02, 6.07044391658935825e-02, 6.20394231598924636e-02, 6.31141922862537841e-02, 6.39242385846479494e-02, 6.44661644359498381e-02, 6.47376968126836816e-02, 6.47376968126836816e-02, 6.44661644359498381e-02, 6.39242385846479494e-02, 6.31141922862537841e-02, 6.20394231598924636e-02, 6.07044391658935825e-02, 5.91148396983954827e-02, 5.72772921004029295e-02, 5.51995036999840538e-02, 5.28901894851934867e-02, 5.03590355538542783e-02, 4.76166584924902839e-02, 4.46745608566940997e-02, 4.15450829434645535e-02, 3.82413510658306741e-02, 3.47772225647706573e-02, 3.11672278327983394e-02, 2.74265097083568818e-02, 2.35707608393240925e-02, 1.96161604573552965e-02, 1.55793157229429276e-02, 1.14772345792349736e-02, 7.32755390127649234e-03, 3.15334605230917957e-03};
 
@@ -39,21 +54,26 @@ __device__ __forceinline__ void mmc_encode_body(const MMComposeDims& D, const T*
   for (int i = lane; i < nx; i += 64) m[i] = (double)mx[(size_t)b * nx + i];
   for (int i = lane; i < nx * nx; i += 64) S[i] = (double)Sxx[(size_t)b * nx * nx + i];
   __syncthreads();
+  __shared__ double sa[MMC_NA], ca[MMC_NA];        // sin a_i, cos a_i: ONE sincos per angle, the pair terms by angle addition
   if (lane < na) {                                 // maths.py:143-176: first moments
     const int r = D.active[lane];
     const double a = m[r], ev = exp(-0.5 * S[r * nx + r]);
-    s1[lane] = ev * sin(a); c1[lane] = ev * cos(a);
+    double sv, cv;
+    sincos(a, &sv, &cv);
+    sa[lane] = sv; ca[lane] = cv;
+    s1[lane] = ev * sv; c1[lane] = ev * cv;
   }
   __syncthreads();
   for (int idx = lane; idx < na * na; idx += 64) { // second moments (uncentred), then centred
     const int i = idx / na, j = idx - i * na;
     const int ri = D.active[i], rj = D.active[j];
-    const double ai = m[ri], aj = m[rj], vi = S[ri * nx + ri], vj = S[rj * nx + rj];
+    const double vi = S[ri * nx + ri], vj = S[rj * nx + rj];
     const double sij = 0.5 * (S[ri * nx + rj] + S[rj * nx + ri]);       // (Sxx + Sxx^T) / 2
     const double A = exp(-0.5 * (vi + vj) - sij), Bm = exp(-0.5 * (vi + vj) + sij);
-    const double Acos = A * cos(ai + aj), Bcos = Bm * cos(ai - aj);
+    const double cc = ca[i] * ca[j], ss = sa[i] * sa[j];
+    const double Acos = A * (cc - ss), Bcos = Bm * (cc + ss);           // cos(a_i + a_j), cos(a_i - a_j)
     const double s2 = 0.5 * (Bcos - Acos), c2 = 0.5 * (Bcos + Acos);
-    const double sc = 0.5 * (sin(ai) * cos(aj) * (Bm + A) - sin(aj) * cos(ai) * (Bm - A));   // E[sin a_i cos a_j]
+    const double sc = 0.5 * (sa[i] * ca[j] * (Bm + A) - sa[j] * ca[i] * (Bm - A));   // E[sin a_i cos a_j]
     Syy[i * n2 + j] = s2 - s1[i] * s1[j];
     Syy[(na + i) * n2 + na + j] = c2 - c1[i] * c1[j];
     Syy[i * n2 + na + j] = sc - s1[i] * c1[j];
@@ -217,13 +237,17 @@ __global__ __launch_bounds__(64) void k_compose_tail(MMComposeDims D, double dt,
   // in an ordinary rollout, consecutive tape slots in a taped one)
   extern __shared__ double csm[];
   const int b = blockIdx.x, lane = threadIdx.x;
+  MM_STAMP_INIT();
   mmc_step_body<T>(D, dt, Sxe_in, cpol, Sdd, df1, dSff, dcross, mx, Sxx, traj_mu, traj_S, b, lane);
   __syncthreads();
+  MM_STAMP(0);
   mmc_encode_body<T>(D, mx, Sxx, me, See, Sxe, b, lane);
+  MM_STAMP(1);
   if (cost) {
     __syncthreads();
     mm_expected_cost_body<T>(D.ne, me, See, target, precis, cost, b, lane, csm);
   }
+  MM_STAMP(2);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -259,7 +283,9 @@ __global__ __launch_bounds__(256) void k_policy_match_small(const double* __rest
     Sg[i * DP + j] = (double)(i >= j ? Sb[i * d + j] : Sb[j * d + i]);     // symmetrised from the lower triangle (k_prep)
   }
   if (tid < 4) okw[tid] = 1;
+  MM_STAMP_INIT();
   __syncthreads();
+  MM_STAMP(4);
   // wave 0: Sigma + Lambda; wave 1: Sigma + Lambda / 2 (V of the pair (a, a), kernel_expectation.py:119); waves 2, 3: identity
   for (int idx = lane; idx < d * d; idx += 64) {
     const int i = idx / d, j = idx - i * d;
@@ -271,6 +297,7 @@ __global__ __launch_bounds__(256) void k_policy_match_small(const double* __rest
   if (!ok && wv < 2) okw[wv] = 0;
   if (lane == 0) lds4[wv] = ldw;
   __syncthreads();
+  MM_STAMP(5);
   ok = okw[0] && okw[1];
   const double ldA = lds4[0], ldS = lds4[1];
   const double* Pm = Am[0];            // (Sigma + Lambda)^-1
@@ -304,6 +331,7 @@ __global__ __launch_bounds__(256) void k_policy_match_small(const double* __rest
   sl = lds4[2];
   const double lognorm = log(var[0]) + 0.5 * sl - 0.5 * ldA;
   const double cst = -0.5 * ldS - 0.5 * (sl + d * 0.6931471805599453) + ldA;
+  MM_STAMP(6);
   // ---- per centre -------------------------------------------------------------------------------------------------
   double wv_m = 0.0, acc[DK];
 #pragma unroll
@@ -337,6 +365,7 @@ __global__ __launch_bounds__(256) void k_policy_match_small(const double* __rest
     for (int k = 0; k < DK; ++k) acc[k] = wv_m * z[k];
   }
   __syncthreads();
+  MM_STAMP(7);
   // ---- the M x M sum: 256 / M threads share a column (rows interleaved); every partial goes into the workgroup sum ----
   double colsum = 0.0;
   {
@@ -356,6 +385,7 @@ __global__ __launch_bounds__(256) void k_policy_match_small(const double* __rest
       colsum *= ws[j];
     }
   }
+  MM_STAMP(8);
   // ---- the d + 2 workgroup sums (f1, sum w zeta, Sff) together -----------------------------------------------------
   {
     double v[DK + 2];
@@ -388,6 +418,7 @@ __global__ __launch_bounds__(256) void k_policy_match_small(const double* __rest
     atomicMax(status, (int)gridDim.x - b);                          // B - b: the host decodes the smallest failing b
     status[1] = 0;
   }
+  MM_STAMP(9);
 }
 
 // ---------------------------------------------------------------------------------------------

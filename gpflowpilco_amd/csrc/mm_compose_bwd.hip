@@ -16,6 +16,17 @@
 #include "mm_compose.h"
 #include "mm_adjoint.h"
 
+// stage profile (tools/profile_c1_stages.py; -DMM_STAGE_PROFILE builds only): cycles per stage of block 0
+#ifdef MM_STAGE_PROFILE
+__device__ long long* mmb_stage_prof = nullptr;
+extern "C" void mm_stage_profile_set_bwd(void* device_buffer) {
+  hipMemcpyToSymbol(HIP_SYMBOL(mmb_stage_prof), &device_buffer, sizeof(void*));
+}
+#define MMB_PROF_CTX(c_) long long mmb_last_ = clock64(); (c_).prof = mmb_stage_prof; (c_).last = &mmb_last_
+#else
+#define MMB_PROF_CTX(c_) do {} while (0)
+#endif
+
 #define MMB_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -111,6 +122,11 @@ extern "C" int mm_moment_match_backward(const void* packed, size_t packed_bytes,
   const double* col = (const double*)(bw + bl.sums);
   const double* row = col + (size_t)B * P * (3 + d) * Mp;
   const size_t shm = (size_t)mma_gp_item_scratch(d, 256) * sizeof(double);
+  if (shm > 160 * 1024) return MM_E_DIM;
+  if (shm > 64 * 1024) {                                   // d >= 20: more than the default dynamic LDS limit
+    hipError_t ea = hipFuncSetAttribute((const void*)k_gp_bwd_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    if (ea != hipSuccess) return (int)ea;
+  }
   hipLaunchKernelGGL(k_gp_bwd_items, dim3(L + P, B), dim3(256), shm, s, L, M, Mp, d, P, (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0,
                      (flags & MM_FULL_OUTPUT_COV) ? 1 : 0, (const double*)(pk + ml.Z64), (const double*)(pk + ml.ls2),
                      (const double*)mu, (const double*)Sigma, (const double*)(ws + wl.latmat), (const double*)(ws + wl.w64),
@@ -207,6 +223,7 @@ __global__ __launch_bounds__(256) void k_policy_head_bwd_small(int M, int ne, do
   extern __shared__ double sm[];
   const int b = blockIdx.x, nd = ne + 1;
   MMADevCtx c;
+  MMB_PROF_CTX(c);
   double* gme = sm; double* gSee = gme + ne; double* gpc = gSee + ne * ne; double* gmu = gpc + ne; double* gSig = gmu + ne;
   double* hw = gSig + ne * ne;             // head scratch: ne + 4
   double* wk = hw + ne + 4;
@@ -214,8 +231,10 @@ __global__ __launch_bounds__(256) void k_policy_head_bwd_small(int M, int ne, do
                cSdd + (size_t)b * nd * nd, ccp + (size_t)b * ne, gme, gSee, gpc, hw);
   const double gpf1 = hw[ne], gpSff = hw[ne + 1];
   bool ok = true;
-  mma_policy_small_bwd(c, M, ne, Z, beta, ls2, var[0], me + (size_t)b * ne, See + (size_t)b * ne * ne, gpf1, gpSff, gpc, gmu, gSig,
+  c.stamp(8);
+  mma_policy_small_bwd<MMADevCtx, 8>(c, M, ne, Z, beta, ls2, var[0], me + (size_t)b * ne, See + (size_t)b * ne * ne, gpf1, gpSff, gpc, gmu, gSig,
                        gpar + (size_t)b * ((size_t)M * ne + M + ne + 2), wk, &ok);
+  c.stamp(9);
   for (int k = threadIdx.x; k < ne; k += 256) cme[(size_t)b * ne + k] = gme[k] + gmu[k];
   for (int idx = threadIdx.x; idx < ne * ne; idx += 256) cSee[(size_t)b * ne * ne + idx] = gSee[idx] + gSig[idx];
   if (!ok && threadIdx.x == 0 && status) { atomicMax(status, (int)gridDim.x - b); status[1] = 0; }

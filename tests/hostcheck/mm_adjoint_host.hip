@@ -41,7 +41,7 @@ extern "C" int hc_policy_small_bwd(int M, int d, const double* Z, const double* 
                                    double* gpar) {
   std::vector<double> sm(mma_policy_small_bwd_scratch(M, d, 1) + 8);
   bool ok = true;
-  mma_policy_small_bwd(MMAHostCtx(), M, d, Z, beta, ls2, var, mu, Sigma, gf1, gSff, gcross, gmu, gSig, gpar, sm.data(), &ok);
+  mma_policy_small_bwd<MMAHostCtx, 8>(MMAHostCtx(), M, d, Z, beta, ls2, var, mu, Sigma, gf1, gSff, gcross, gmu, gSig, gpar, sm.data(), &ok);
   return ok ? 0 : 1;
 }
 

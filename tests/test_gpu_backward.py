@@ -275,8 +275,9 @@ def test_graphed_policy_loss_replays_eager_values_and_gradients(device):
 
 
 @pytest.mark.parametrize("case", [(3, 90, 4, 3, True, True), (2, 130, 6, 2, True, False), (3, 40, 3, 4, False, True),
-                                  (1, 200, 8, 2, True, True), (4, 100, 6, 1, True, True), (2, 70, 16, 2, True, True)],
-                         ids=["L3d4", "L2d6nounc", "L3diagcov", "L1d8", "c1drift", "d16"])
+                                  (1, 200, 8, 2, True, True), (4, 100, 6, 1, True, True), (2, 70, 16, 2, True, True),
+                                  (2, 50, 31, 1, True, True)],
+                         ids=["L3d4", "L2d6nounc", "L3diagcov", "L1d8", "c1drift", "d16", "d31"])
 def test_native_match_backward_equals_the_torch_chain_rule(case, device):
   """mm_moment_match_backward (M x M sweeps + k_gp_bwd_items + k_gp_bwd_sum: everything on the device) against
   autodiff.moment_match_backward (the same sums, chain rule in torch) -- which the tests above pin to finite differences
@@ -284,7 +285,7 @@ def test_native_match_backward_equals_the_torch_chain_rule(case, device):
   from gpflowpilco_amd import autodiff as ad, ops
   from gpflowpilco_amd.synthetic import make_inputs, make_svgp
   L, M, d, B, full, unc = case
-  syn = make_svgp(L, M, d, seed=60 + L + d, device=str(device), ls_bounds=(0.7, 3.0), mean_c=True)
+  syn = make_svgp(L, M, d, seed=60 + L + d, device=str(device), ls_bounds=(0.7, 3.0) if d <= 16 else (2.5, 5.0), mean_c=True)
   model = syn.to_model(device)
   pm = model.packed(torch.float64, True, device)
   pre = model._cache._pre
