@@ -75,3 +75,40 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     assert "no CPU" in str(e)
   else:
     raise AssertionError("expected MomentMatchingLibraryError")
+
+
+def test_argument_validation_of_the_gradient_entry_points_without_gpu():
+  """The reverse-sweep / tape entry points validate before any HIP call too."""
+  lib = _lib.lib()
+  buf = (ctypes.c_char * 64)()
+  p = ctypes.addressof(buf)
+  act = (ctypes.c_int32 * 1)(1)
+  F64, F32 = _lib.MM_F64, _lib.MM_F32
+  # sizes: cartpole wiring (nx 4, one angle), H = 30
+  tape = lib.mm_compose_tape_bytes(1, 30, 4, 1, F64)
+  assert tape > 31 * lib.mm_compose_workspace_bytes(1, 4, 1, F64) > 0
+  assert lib.mm_compose_tape_bytes(1, 30, 4, 5, F64) == 0                         # more angles than state dims
+  assert lib.mm_compose_backward_workspace_bytes(1, 4, 1, 100) > lib.mm_moment_match_backward_bytes(1, 4, 100, 6, 3) > 0
+  assert lib.mm_policy_grad_bytes(2, 30, 5) == 2 * (30 * 5 + 30 + 5 + 2) * 8
+  assert lib.mm_rollout_small_supported(4, 1, 100, 30) == 1
+  assert lib.mm_rollout_small_supported(4, 1, 100, 200) == 0 and lib.mm_rollout_small_supported(6, 2, 100, 30) == 0
+  # backward of the composed rollout: f64 only, pointers required, shapes must compose, small policy only
+  args = lambda dtype=F64, tapep=p, pol_M=30, drift_d=6: (
+      p, 64, 4, 100, drift_d, p, 64, pol_M, 5, dtype, 1, 30, 1.0, 4, 1, act, 2.0, -0.5, p, p, tapep, 64, p, p, None, None,
+      p, 64, p, 64, None, None)
+  assert lib.mm_rollout_composed_backward(*args(dtype=F32)) == -3                 # MM_E_DTYPE
+  assert lib.mm_rollout_composed_backward(*args(tapep=None)) == -1                # MM_E_ARG
+  assert lib.mm_rollout_composed_backward(*args(drift_d=7)) == -6                 # MM_E_STATE: shapes do not compose
+  assert lib.mm_rollout_composed_backward(*args(pol_M=200)) == -2                 # MM_E_DIM: not the one-launch policy shape
+  assert lib.mm_rollout_composed_backward(*args()) == -4                          # tape too small
+  # backward of one match
+  mb = lambda dtype=F64, mu=p, d=4: (p, 64, 2, 16, d, dtype, 2, mu, p, 3, p, p, p, p, p, 0, p, 64, p, 64, None, None)
+  assert lib.mm_moment_match_backward(*mb(dtype=F32)) == -3
+  assert lib.mm_moment_match_backward(*mb(mu=None)) == -1
+  assert lib.mm_moment_match_backward(*mb(d=40)) == -2
+  assert lib.mm_moment_match_backward(*mb()) == -4                                 # workspaces too small
+  # engine selector
+  eng = lambda e: (e, p, 64, 4, 100, 6, p, 64, 30, 5, F64, 1, 3, 1.0, 4, 1, act, 2.0, -0.5, p, p, p, p, None, None, None,
+                   p, 64, p, 64, p, 64, None, None)
+  assert lib.mm_rollout_composed_engine(*eng(3)) == -1
+  assert lib.mm_rollout_composed_engine(*eng(1)) == -4                             # compose workspace too small
