@@ -69,16 +69,26 @@ static inline int mm_compose_dims(int nx, int na, const int32_t* active_dims, MM
 struct MMTapeLayout {
   size_t slot_bytes;         // = mm_compose_layout(...).total
   size_t xm, xS;             // [H+1][B][nx], [H+1][B][nx][nx] T
+  size_t ws, ws_stride;      // [H][ws_stride]: the drift match's workspace of every step (ws_stride = 0: not kept)
   size_t total;
 };
 
-static inline MMTapeLayout mm_tape_layout(int B, int H, int nx, int na, int dtype) {
+// The reverse sweep needs the drift's q-stage workspace of every step (mm_backward_sums reads w, q and the streamed
+// operands).  Where H copies fit in MM_TAPE_WS_LIMIT the taped forward keeps them (its drift matches run IN the tape) and the
+// reverse sweep skips re-running the q stage: three launches less per reverse step at cartpole sizes (110 KB per step and
+// element).  Larger models re-run the q stage from the taped (md, Sdd).
+#define MM_TAPE_WS_LIMIT ((size_t)512 << 20)
+
+static inline MMTapeLayout mm_tape_layout(int B, int H, int nx, int na, int drift_M, int dtype) {
   MMTapeLayout o;
   const size_t es = mm_elem_size(dtype), A = 256;
   o.slot_bytes = mm_compose_layout(B, nx, na, dtype).total;
   size_t off = (size_t)(H + 1) * o.slot_bytes;
   o.xm = off; off = mm_align_up(off + (size_t)(H + 1) * B * nx * es, A);
   o.xS = off; off = mm_align_up(off + (size_t)(H + 1) * B * nx * nx * es, A);
+  const size_t wsb = mm_align_up(mm_workspace_layout(B, nx, drift_M, nx + na + 1, dtype, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY).total, A);
+  o.ws = off; o.ws_stride = 0;
+  if (wsb * (size_t)H <= MM_TAPE_WS_LIMIT) { o.ws_stride = wsb; off += wsb * (size_t)H; }
   o.total = off;
   return o;
 }

@@ -450,7 +450,7 @@ static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, 
   const int nx = D.nx, ne = D.ne, nd = D.nd;
   // taped: step h works in tape slot h and the tail writes the next encoding into slot h + 1; the states x_0 .. x_H
   // go to the tape's state block.  Untaped: every step reuses the one workspace.
-  const MMTapeLayout tl = mm_tape_layout(B, H, nx, D.na, dtype);
+  const MMTapeLayout tl = mm_tape_layout(B, H, nx, D.na, Md, dtype);
   auto slot = [&](int h) { return MMCSlot<T>(tape ? tape + (size_t)h * tl.slot_bytes : wsc, cl); };
   T* xm = tape ? (T*)(tape + tl.xm) : nullptr;
   T* xS = tape ? (T*)(tape + tl.xS) : nullptr;
@@ -486,8 +486,11 @@ static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, 
     hipLaunchKernelGGL((k_compose_policy<T>), dim3(B), dim3(64), 0, s, D, scale, shift, (const T*)c.me, (const T*)c.See,
                        (const T*)c.pf1, (const T*)c.pSff, (const T*)c.pcross, c.md, c.Sdd, c.cpol);
     MMC_CHECK();
+    // (taped, small enough: the match runs in the tape's own workspace slot of this step, which the reverse sweep reads)
+    void* wsd = (tape && tl.ws_stride) ? (void*)(tape + tl.ws + (size_t)h * tl.ws_stride) : ws_drift;
+    const size_t wsd_bytes = (tape && tl.ws_stride) ? tl.ws_stride : ws_drift_bytes;
     rc = mm_moment_match(drift, drift_bytes, nx, Md, nd, dtype, B, c.md, c.Sdd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY, 0.0,
-                         c.df1, c.dSff, c.dcross, ws_drift, ws_drift_bytes, status, (void*)s);
+                         c.df1, c.dSff, c.dcross, wsd, wsd_bytes, status, (void*)s);
     if (rc) return rc;
     // Euler update, the new state's encoding (the cost statistic of this step, pilco.py:199-205, and the next step's
     // policy input) and the expected cost: one launch
@@ -541,7 +544,7 @@ static int mm_rollout_composed_impl(int engine, const void* drift_packed, size_t
   if (drift_L != nx || drift_d != D.nd || policy_d != D.ne) return MM_E_STATE;
   const MMComposeLayout cl = mm_compose_layout(B, nx, na, dtype);
   if (engine != 2 && !tape && ws_compose_bytes < cl.total) return MM_E_WORKSPACE;
-  if (tape && tape_bytes < mm_tape_layout(B, H, nx, na, dtype).total) return MM_E_WORKSPACE;
+  if (tape && tape_bytes < mm_tape_layout(B, H, nx, na, drift_M, dtype).total) return MM_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const bool small_ok = !tape && mm_rollout_small_supported(nx, na, drift_M, policy_M) != 0;
   if (engine == 2 && !small_ok) return MM_E_DIM;
@@ -589,10 +592,10 @@ extern "C" int mm_rollout_composed_engine(int engine, const void* drift_packed, 
                                   ws_compose_bytes, nullptr, 0, status, stream);
 }
 
-extern "C" size_t mm_compose_tape_bytes(int B, int H, int nx, int na, int dtype) {
-  if (B <= 0 || H <= 0 || nx <= 0 || nx > MMC_NX || na <= 0 || na > MMC_NA || na > nx) return 0;
+extern "C" size_t mm_compose_tape_bytes(int B, int H, int nx, int na, int drift_M, int dtype) {
+  if (B <= 0 || H <= 0 || nx <= 0 || nx > MMC_NX || na <= 0 || na > MMC_NA || na > nx || drift_M <= 0) return 0;
   if (2 * na + (nx - na) + 1 > MMC_ND) return 0;
-  return mm_tape_layout(B, H, nx, na, dtype).total;
+  return mm_tape_layout(B, H, nx, na, drift_M, dtype).total;
 }
 
 // The same rollout, recorded: every per-step intermediate and the states x_0 .. x_H go to `tape`

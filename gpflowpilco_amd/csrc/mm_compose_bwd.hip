@@ -95,12 +95,14 @@ extern "C" size_t mm_moment_match_backward_bytes(int B, int L, int M, int d, int
 
 // (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> g_mu [B,d], g_Sigma [B,d,d] (symmetric; += if accumulate_Sigma).
 // f64 packs only.  Re-runs the q stage for (mu, Sigma) on `workspace`, then the M x M sweeps, the items and their sum.
-extern "C" int mm_moment_match_backward(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
-                                        const void* mu, const void* Sigma, int flags,
-                                        const void* g_f1, const void* g_Sff, const void* g_cross,
-                                        void* g_mu, void* g_Sigma, int accumulate_Sigma,
-                                        void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
-                                        int32_t* status, void* stream) {
+// workspace_is_current: `workspace` already holds the q stage of exactly this (mu, Sigma, flags) -- the reverse sweep of a
+// rollout whose tape kept the drift's workspace per step -- so the q stage is not run again
+static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                         const void* mu, const void* Sigma, int flags,
+                                         const void* g_f1, const void* g_Sff, const void* g_cross,
+                                         void* g_mu, void* g_Sigma, int accumulate_Sigma,
+                                         void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
+                                         int32_t* status, void* stream, bool workspace_is_current, bool skip_sum = false) {
   if (!packed || !mu || !Sigma || !g_f1 || !g_Sff || !g_cross || !g_mu || !g_Sigma || !workspace || !bwd_ws) return MM_E_ARG;
   if (L <= 0 || M <= 0 || d <= 0 || B <= 0) return MM_E_ARG;
   if (d > MM_DMAX) return MM_E_DIM;
@@ -112,9 +114,12 @@ extern "C" int mm_moment_match_backward(const void* packed, size_t packed_bytes,
   if (workspace_bytes < wl.total) return MM_E_WORKSPACE;
   char* bw = (char*)bwd_ws; const char* pk = (const char*)packed; const char* ws = (const char*)workspace;
   hipStream_t s = (hipStream_t)stream;
-  int rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, bw + bl.f1, bw + bl.cross, nullptr,
-                        workspace, workspace_bytes, status, stream);
-  if (rc) return rc;
+  int rc = 0;
+  if (!workspace_is_current) {
+    rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, bw + bl.f1, bw + bl.cross, nullptr,
+                      workspace, workspace_bytes, status, stream);
+    if (rc) return rc;
+  }
   rc = mm_backward_sums(packed, packed_bytes, L, M, d, dtype, B, mu, flags, workspace, workspace_bytes, bw + bl.sums,
                         mm_backward_bytes(B, L, M, d, flags), stream);
   if (rc) return rc;
@@ -133,10 +138,21 @@ extern "C" int mm_moment_match_backward(const void* packed, size_t packed_bytes,
                      (const double*)(ws + wl.q64), col, row, (const double*)g_f1, (const double*)g_Sff, (const double*)g_cross,
                      (double*)(bw + bl.items), (double*)(bw + bl.cbuf), status);
   MMB_CHECK();
+  if (skip_sum) return 0;                                   // the consumer sums the items itself (k_policy_head_bwd_small)
   hipLaunchKernelGGL(k_gp_bwd_sum, dim3(B), dim3(64), 0, s, L + P, d, (const double*)(bw + bl.items), (double*)g_mu,
                      (double*)g_Sigma, accumulate_Sigma);
   MMB_CHECK();
   return 0;
+}
+
+extern "C" int mm_moment_match_backward(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                        const void* mu, const void* Sigma, int flags,
+                                        const void* g_f1, const void* g_Sff, const void* g_cross,
+                                        void* g_mu, void* g_Sigma, int accumulate_Sigma,
+                                        void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
+                                        int32_t* status, void* stream) {
+  return mm_moment_match_backward_impl(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, g_f1, g_Sff, g_cross, g_mu, g_Sigma,
+                                       accumulate_Sigma, workspace, workspace_bytes, bwd_ws, bwd_ws_bytes, status, stream, false);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -219,16 +235,40 @@ __global__ __launch_bounds__(256) void k_policy_head_bwd_small(int M, int ne, do
                                                                const double* __restrict__ pcross, const double* __restrict__ cmd,
                                                                const double* __restrict__ cSdd, const double* __restrict__ ccp,
                                                                double* __restrict__ cme, double* __restrict__ cSee,
-                                                               double* __restrict__ gpar, int32_t* status) {
+                                                               double* __restrict__ gpar, int32_t* status,
+                                                               const double* __restrict__ items, int nitems) {
   extern __shared__ double sm[];
   const int b = blockIdx.x, nd = ne + 1;
   MMADevCtx c;
   MMB_PROF_CTX(c);
   double* gme = sm; double* gSee = gme + ne; double* gpc = gSee + ne * ne; double* gmu = gpc + ne; double* gSig = gmu + ne;
   double* hw = gSig + ne * ne;             // head scratch: ne + 4
-  double* wk = hw + ne + 4;
-  mma_head_bwd(c, ne, scale, shift, pf1[b], pSff[b], pcross + (size_t)b * ne, See + (size_t)b * ne * ne, cmd + (size_t)b * nd,
-               cSdd + (size_t)b * nd * nd, ccp + (size_t)b * ne, gme, gSee, gpc, hw);
+  double* dmd = hw + ne + 4;               // [nd], [nd][nd]: adjoint of the drift's input moments
+  double* dSd = dmd + nd;
+  double* wk = dSd + nd * nd;
+  if (items) {
+    // the drift match's (latent | pair) items are summed here (what k_gp_bwd_sum does as a launch of its own): g md = the
+    // sum, g Sdd = the bookkeeping's part (cSdd) + the symmetrised sum
+    const int st = nd * nd + nd;
+    const double* it = items + (size_t)b * nitems * st;
+    for (int idx = threadIdx.x; idx < nd * nd; idx += 256) {
+      const int i = idx / nd, j = idx - i * nd;
+      double sv = 0.0;
+      for (int t = 0; t < nitems; ++t) sv += 0.5 * (it[(size_t)t * st + i * nd + j] + it[(size_t)t * st + j * nd + i]);
+      dSd[idx] = cSdd[(size_t)b * nd * nd + idx] + sv;
+    }
+    for (int k = threadIdx.x; k < nd; k += 256) {
+      double sv = 0.0;
+      for (int t = 0; t < nitems; ++t) sv += it[(size_t)t * st + nd * nd + k];
+      dmd[k] = sv;
+    }
+  } else {
+    for (int idx = threadIdx.x; idx < nd * nd; idx += 256) dSd[idx] = cSdd[(size_t)b * nd * nd + idx];
+    for (int k = threadIdx.x; k < nd; k += 256) dmd[k] = cmd[(size_t)b * nd + k];
+  }
+  __syncthreads();
+  mma_head_bwd(c, ne, scale, shift, pf1[b], pSff[b], pcross + (size_t)b * ne, See + (size_t)b * ne * ne, dmd, dSd,
+               ccp + (size_t)b * ne, gme, gSee, gpc, hw);
   const double gpf1 = hw[ne], gpSff = hw[ne + 1];
   bool ok = true;
   c.stamp(8);
@@ -240,7 +280,8 @@ __global__ __launch_bounds__(256) void k_policy_head_bwd_small(int M, int ne, do
   if (!ok && threadIdx.x == 0 && status) { atomicMax(status, (int)gridDim.x - b); status[1] = 0; }
 }
 static inline size_t mm_policy_bwd_lds(int M, int ne) {
-  return (size_t)(4 * ne + 2 * ne * ne + 4 + mma_policy_small_bwd_scratch(M, ne, 256) + 8) * sizeof(double);
+  const int nd = ne + 1;
+  return (size_t)(4 * ne + 2 * ne * ne + 4 + nd + nd * nd + mma_policy_small_bwd_scratch(M, ne, 256) + 8) * sizeof(double);
 }
 
 // k_compose_encode_bwd0: grid B, 64 threads: the adjoint of the initial state.
@@ -315,7 +356,7 @@ extern "C" int mm_rollout_composed_backward(const void* drift_packed, size_t dri
   const int ne = D.ne, nd = D.nd;
   if (drift_L != nx || drift_d != nd || policy_d != ne) return MM_E_STATE;
   if (policy_M > 128 || ne > 8) return MM_E_DIM;
-  const MMTapeLayout tl = mm_tape_layout(B, H, nx, na, dtype);
+  const MMTapeLayout tl = mm_tape_layout(B, H, nx, na, drift_M, dtype);
   if (tape_bytes < tl.total) return MM_E_WORKSPACE;
   const MMComposeBwdLayout bl = mm_compose_bwd_layout(B, nx, na, drift_M);
   if (ws_bwd_bytes < bl.total) return MM_E_WORKSPACE;
@@ -337,7 +378,8 @@ extern "C" int mm_rollout_composed_backward(const void* drift_packed, size_t dri
     if (e != hipSuccess) return (int)e;
   }
   const int dflags = MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY;
-  const size_t gp_bytes = mm_gp_bwd_layout(B, nx, drift_M, nd, dflags).total;
+  const MMGpBwdLayout gbl = mm_gp_bwd_layout(B, nx, drift_M, nd, dflags);
+  const size_t gp_bytes = gbl.total;
   for (int h = H - 1; h >= 0; --h) {
     const char* sl = tp + (size_t)h * tl.slot_bytes; const char* sn = tp + (size_t)(h + 1) * tl.slot_bytes;
     hipLaunchKernelGGL(k_compose_tail_bwd, dim3(B), dim3(64), lds_tail, s, D, dt, h == H - 1 ? 1 : 0,
@@ -348,16 +390,18 @@ extern "C" int mm_rollout_composed_backward(const void* drift_packed, size_t dri
                        cr(kl.cSee), cr(kl.cSxe), cr(kl.ccp), cr(kl.cSdd), cr(kl.cdf1), cr(kl.cdSff), cr(kl.cdcross));
     MMB_CHECK();
     // the drift's match: (g df1, g dSff, g dcross) -> g md (assigned), g Sdd (accumulated onto the bookkeeping's part)
-    rc = mm_moment_match_backward(drift_packed, drift_bytes, nx, drift_M, nd, dtype, B, sl + cl.md, sl + cl.Sdd, dflags,
-                                  cr(kl.cdf1), cr(kl.cdSff), cr(kl.cdcross), cr(kl.cmd), cr(kl.cSdd), 1, ws_drift, ws_drift_bytes,
-                                  gw, gp_bytes, status, stream);
+    const bool kept = tl.ws_stride != 0;                   // the tape holds this step's q-stage workspace
+    void* wsd = kept ? (void*)(const_cast<char*>(tp) + tl.ws + (size_t)h * tl.ws_stride) : ws_drift;
+    rc = mm_moment_match_backward_impl(drift_packed, drift_bytes, nx, drift_M, nd, dtype, B, sl + cl.md, sl + cl.Sdd, dflags,
+                                       cr(kl.cdf1), cr(kl.cdSff), cr(kl.cdcross), cr(kl.cmd), cr(kl.cSdd), 1, wsd,
+                                       kept ? tl.ws_stride : ws_drift_bytes, gw, gp_bytes, status, stream, kept, true);
     if (rc) return rc;
     hipLaunchKernelGGL(k_policy_head_bwd_small, dim3(B), dim3(256), lds_pol, s, policy_M, ne, head_scale, head_shift,
                        (const double*)(pp + pl.Z64), (const double*)(pp + pl.beta64), (const double*)(pp + pl.ls2),
                        (const double*)(pp + pl.var), (const double*)(sl + cl.me), (const double*)(sl + cl.See),
                        (const double*)(sl + cl.pf1), (const double*)(sl + cl.pSff), (const double*)(sl + cl.pcross),
                        (const double*)cr(kl.cmd), (const double*)cr(kl.cSdd), (const double*)cr(kl.ccp), cr(kl.cme), cr(kl.cSee),
-                       (double*)g_policy, status);
+                       (double*)g_policy, status, (const double*)(gw + gbl.items), nx + nx * (nx + 1) / 2);
     MMB_CHECK();
   }
   if (g_mx0) {

@@ -385,7 +385,7 @@ class ComposedRollout:
       raise ValueError(f"expected {dt_} mx [B,{self.nx}], Sxx [B,{self.nx},{self.nx}]")
     mx, Sxx = mx.contiguous().clone(), Sxx.contiguous().clone()
     cost = torch.empty(H, B, dtype=dt_, device=mx.device)
-    n = lib().mm_compose_tape_bytes(B, H, self.nx, self.na, _dtype_code(dt_))
+    n = lib().mm_compose_tape_bytes(B, H, self.nx, self.na, self.drift.M, _dtype_code(dt_))
     tape = torch.empty(n, dtype=torch.uint8, device=mx.device)
     wd = self.drift.workspace(B, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY)
     wp = pol.workspace(B, MM_FULL_OUTPUT_COV)

@@ -185,8 +185,10 @@ int mm_rollout_composed_engine(int engine, const void* drift_packed, size_t drif
                                void* ws_compose, size_t ws_compose_bytes, int32_t* status, void* stream);
 
 /* The same rollout, RECORDED for differentiation: every per-step intermediate and the states x_0 .. x_H are written into
- * `tape` (mm_compose_tape_bytes) instead of a reused workspace; mx / Sxx / cost as above. */
-size_t mm_compose_tape_bytes(int B, int H, int nx, int na, int dtype);
+ * `tape` (mm_compose_tape_bytes) instead of a reused workspace; mx / Sxx / cost as above.  Where H copies of the drift's
+ * workspace fit in 512 MB the tape also keeps the drift match's q stage of every step (the reverse sweep then does not
+ * re-run it). */
+size_t mm_compose_tape_bytes(int B, int H, int nx, int na, int drift_M, int dtype);
 int mm_rollout_composed_taped(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
                               const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
                               int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,

@@ -85,9 +85,11 @@ def test_argument_validation_of_the_gradient_entry_points_without_gpu():
   act = (ctypes.c_int32 * 1)(1)
   F64, F32 = _lib.MM_F64, _lib.MM_F32
   # sizes: cartpole wiring (nx 4, one angle), H = 30
-  tape = lib.mm_compose_tape_bytes(1, 30, 4, 1, F64)
-  assert tape > 31 * lib.mm_compose_workspace_bytes(1, 4, 1, F64) > 0
-  assert lib.mm_compose_tape_bytes(1, 30, 4, 5, F64) == 0                         # more angles than state dims
+  tape = lib.mm_compose_tape_bytes(1, 30, 4, 1, 100, F64)
+  assert tape > 31 * lib.mm_compose_workspace_bytes(1, 4, 1, F64) + 30 * lib.mm_workspace_bytes(1, 4, 100, 6, F64, 3) > 0     # keeps the drift's q stage
+  big = lib.mm_compose_tape_bytes(64, 50, 4, 1, 4000, F64)
+  assert 0 < big < 51 * lib.mm_compose_workspace_bytes(64, 4, 1, F64) + (1 << 20)      # too large to keep: recomputed in the reverse sweep
+  assert lib.mm_compose_tape_bytes(1, 30, 4, 5, 100, F64) == 0                         # more angles than state dims
   assert lib.mm_compose_backward_workspace_bytes(1, 4, 1, 100) > lib.mm_moment_match_backward_bytes(1, 4, 100, 6, 3) > 0
   assert lib.mm_policy_grad_bytes(2, 30, 5) == 2 * (30 * 5 + 30 + 5 + 2) * 8
   assert lib.mm_rollout_small_supported(4, 1, 100, 30) == 1
