@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_compose.h"
+#include "mm_mono.h"
 
 #define MMA_FN template <class Ctx> __host__ __device__ inline
 
@@ -793,6 +794,120 @@ __host__ __device__ inline void mma_policy_small_bwd(Ctx c, int M, int d, const 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Off-diagonal pair aggregates of an f32 model (csrc/mm_bwd_f32.hip).  With Omega_ij = what_i what'_j e^{b_ij},
+// b_ij = zeta_i^T G zc'_j (zeta_i = z_i - mu, zc' = the column latent's inducing inputs centred at their centroid):
+//     T[alpha, beta] = sum_ij Omega_ij zeta_i^alpha zc'_j^beta,   |alpha| + |beta| <= 2,
+// stored as (N0 | r1 [d] | R2 [d, d] | k1' [d] | K2' [d, d] | XC' [d, d]) = mma_pair_agg_len(d) doubles.  The polynomial
+// part 1 + b + b^2/2 of e^b is exact from the moments of the two weight vectors (the forward's k_wmom_gemm tables, to
+// degree 4):   sum_ij what_i what'_j zeta_i^alpha zc'_j^beta b_ij^n = < M~_{|alpha|+n}[alpha, .], G^{(x)n} Q_{|beta|+n}[beta, .] >,
+// M~_k = sum_i what_i zeta_i^{(x)k} (binomial shift of the table's zc-moments by dmu = mu - zbar_a), Q_k = sum_j what'_j zc'_j^{(x)k};
+// the remainder r(b) = e^b - 1 - b - b^2/2 is reduced by the tile kernel.  mma_pair_convert then re-centres the column side
+// at mu (zeta'_j = zc'_j - dmu2, dmu2 = mu - zbar_a').
+//   mR, mC: packed moments (graded colex, mm_mono.h) of the row / column weight vector, degree <= 4.
+//   sm: mma_pair_poly_scratch(d) doubles.  T is ASSIGNED.
+// ---------------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline int mma_pair_agg_len(int d) { return 1 + 2 * d + 3 * d * d; }
+__host__ __device__ inline int mma_ipow(int b, int e) { int r = 1; for (int i = 0; i < e; ++i) r *= b; return r; }
+__host__ __device__ inline int mma_pair_poly_scratch(int d) {
+  int n = 0;
+  for (int k = 0; k <= 4; ++k) n += mma_ipow(d, k);
+  return n + mma_ipow(d, 4) + 8;
+}
+
+MMA_FN void mma_pair_poly(Ctx c, int d, const double* G, const double* dmu, const double* mR, const double* mC, double* T,
+                          double* sm) {
+  const int lane = c.lane(), nl = c.nl();
+  int moff[5], toff[6];
+  toff[0] = 0;
+  for (int k = 0; k <= 4; ++k) { moff[k] = mm_mono_off(k, d); toff[k + 1] = toff[k] + mma_ipow(d, k); }
+  double* Mt = sm;                 // M~_k, k = 0..4, full tensors (index 0 most significant)
+  double* Q = sm + toff[5];        // Q_t expanded, then G applied along its trailing indices
+  // ---- M~_k[i_1..i_k] = sum_{S subset [k]} (-1)^{k - |S|} m_{|S|}[i_S] prod_{t not in S} dmu[i_t] ------------------------------
+  for (int idx = lane; idx < toff[5]; idx += nl) {
+    int k = 0;
+    while (idx >= toff[k + 1]) ++k;
+    int rem = idx - toff[k], ix[4] = {0, 0, 0, 0};
+    for (int t = k - 1; t >= 0; --t) { ix[t] = rem % d; rem /= d; }
+    double acc = 0.0;
+    for (int S = 0; S < (1 << k); ++S) {
+      int sel[4] = {0, 0, 0, 0}, ns = 0;
+      double pr = 1.0;
+      for (int t = 0; t < k; ++t) {
+        if (S & (1 << t)) sel[ns++] = ix[t];
+        else pr *= -dmu[ix[t]];
+      }
+      const int r = ns ? mm_mono_rank_unsorted(sel[0], sel[1], sel[2], sel[3], ns) : 0;
+      acc = fma(pr, mR[moff[ns] + r], acc);
+    }
+    Mt[idx] = acc;
+  }
+  const int nT = mma_pair_agg_len(d);
+  for (int idx = lane; idx < nT; idx += nl) T[idx] = 0.0;
+  c.sync();
+  // ---- total column order t = s + n: Q_t expanded; n = 0, 1, 2: G applied to the last n indices; s = t - n <= 2 ----------------
+  const int oR1 = 1, oR2 = 1 + d, oK1 = 1 + d + d * d, oK2 = 1 + 2 * d + d * d, oXC = 1 + 2 * d + 2 * d * d;
+  for (int t = 0; t <= 4; ++t) {
+    const int dt = mma_ipow(d, t);
+    for (int idx = lane; idx < dt; idx += nl) {
+      int rem = idx, ix[4] = {0, 0, 0, 0};
+      for (int u = t - 1; u >= 0; --u) { ix[u] = rem % d; rem /= d; }
+      Q[idx] = mC[moff[t] + (t ? mm_mono_rank_unsorted(ix[0], ix[1], ix[2], ix[3], t) : 0)];
+    }
+    c.sync();
+    for (int n = 0; n <= 2 && n <= t; ++n) {
+      if (n > 0) {
+        // apply G along index (t - n) (0-based from the left): fibre stride d^(n - 1); one lane owns a whole fibre
+        const int st = mma_ipow(d, n - 1), nf = dt / d;
+        for (int f = lane; f < nf; f += nl) {
+          const int lo = f % st, hi = f / st, base = hi * st * d + lo;
+          double v[8], o[8];
+          for (int l = 0; l < d; ++l) v[l] = Q[base + l * st];
+          for (int k = 0; k < d; ++k) {
+            double a = 0.0;
+            for (int l = 0; l < d; ++l) a = fma(G[k * d + l], v[l], a);
+            o[k] = a;
+          }
+          for (int k = 0; k < d; ++k) Q[base + k * st] = o[k];
+        }
+        c.sync();
+      }
+      const int s = t - n;
+      if (s > 2) continue;
+      const double fac = n == 2 ? 0.5 : 1.0;
+      const int dn = mma_ipow(d, n), ds = mma_ipow(d, s);
+      // outputs (alpha, beta), |alpha| = ra <= 2 - s: += fac < M~_{ra + n}[alpha, .], Q[beta, .] >
+      for (int ra = 0; ra + s <= 2; ++ra) {
+        const int da = mma_ipow(d, ra), nout = da * ds;
+        const double* Mk = Mt + toff[ra + n];
+        const int obase = (ra == 0 && s == 0) ? 0 : (ra == 1 && s == 0) ? oR1 : (ra == 2) ? oR2 : (ra == 0 && s == 1) ? oK1
+                          : (ra == 0 && s == 2) ? oK2 : oXC;
+        for (int o = lane; o < nout; o += nl) {
+          const int al = o / ds, be = o - al * ds;
+          double a = 0.0;
+          for (int k = 0; k < dn; ++k) a = fma(Mk[al * dn + k], Q[be * dn + k], a);
+          T[obase + o] += fac * a;              // (alpha, beta) flat = alpha * d^s + beta: each output owned by one lane
+        }
+      }
+      c.sync();
+    }
+  }
+}
+
+// T (zeta, zc') -> aggregates (zeta, zeta'), zeta'_j = zc'_j - dmu2; in place.  One sync inside, none at the end.
+MMA_FN void mma_pair_convert(Ctx c, int d, const double* dmu2, double* T) {
+  const int lane = c.lane(), nl = c.nl();
+  const int oR1 = 1, oK1 = 1 + d + d * d, oK2 = 1 + 2 * d + d * d, oXC = 1 + 2 * d + 2 * d * d;
+  const double N0 = T[0];
+  for (int idx = lane; idx < d * d; idx += nl) {
+    const int k = idx / d, l = idx - k * d;
+    T[oK2 + idx] += -dmu2[k] * T[oK1 + l] - T[oK1 + k] * dmu2[l] + dmu2[k] * dmu2[l] * N0;
+    T[oXC + idx] -= T[oR1 + k] * dmu2[l];
+  }
+  c.sync();
+  for (int k = lane; k < d; k += nl) T[oK1 + k] -= dmu2[k] * N0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // mma_gp_item_bwd: one (latent | kernel pair) item of d(f1, Sff, cross)/d(mu, Sigma) of a frozen model, from the M-sized
 // sums of mm_backward_sums (csrc/mm_backward.hip).  Pair order: the L diagonal pairs, then a < a' row by row.
 //   col  [P][3 + d][Mp]: Ksum_j, csum_j, cC_j, Usum_j[d]  (columns: latent a' of the pair)
@@ -801,6 +916,9 @@ __host__ __device__ inline void mma_policy_small_bwd(Ctx c, int M, int d, const 
 // item < L: latent a = item;  item >= L: pair p = item - L.   out: gS_item [d, d], gmu_item [d] (ASSIGNED; the caller sums
 // the items and symmetrises).  The formulas are those of autodiff.moment_match_backward (moment form).
 // cbuf: M doubles private to the item (coefficient vector of a latent item);  sm: mma_gp_item_scratch(d, nl) doubles.
+// pagg != nullptr (f32 models, csrc/mm_bwd_f32.hip): the off-diagonal pairs come as AGGREGATES instead of M-sized vectors,
+//   pagg [Po][mma_pair_agg_len(d)] = sum_ij Omega_ij (1 | zeta_i | zeta_i zeta_i^T | zeta'_j | zeta'_j zeta'_j^T | zeta_i zeta'_j^T),
+//   zeta = z - mu; `col` then holds the L diagonal pairs only and `row` is not read; f1raw [L] = sum_i w_i per latent.
 // ---------------------------------------------------------------------------------------------------------------------
 __host__ __device__ inline int mma_gp_ncol(int d) { return 1 + d + d * d; }
 __host__ __device__ inline int mma_gp_nslice(int d, int nl) { const int n = nl / mma_gp_ncol(d); return n < 1 ? 1 : n; }
@@ -850,9 +968,10 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
                             const double* Z, const double* ls2, const double* mu, const double* Sigma, const double* latmat,
                             const double* w, const double* q, const double* col, const double* row,
                             const double* g_f1, const double* g_Sff, int full_cov, const double* g_cross,
-                            double* gS_item, double* gmu_item, double* cbuf, double* sm, bool* ok) {
+                            double* gS_item, double* gmu_item, double* cbuf, double* sm, bool* ok,
+                            const double* pagg = nullptr, const double* f1raw = nullptr) {
   const int lane = c.lane(), nl = c.nl(), dp = d + 1, msz = d * dp, nc = mma_gp_ncol(d), ns = mma_gp_nslice(d, nl);
-  const int Po = P - L, lat = 2 * d * d + 2;
+  const int Po = P - L, lat = 2 * d * d + 2, na = mma_pair_agg_len(d);
   double* part = sm;                        // [3][ns][nc]
   double* mom0 = part + 3 * ns * nc;        // [nc]
   double* mom1 = mom0 + nc;                 // [nc]
@@ -890,10 +1009,12 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
       double e = -pvmu;
       for (int k = 0; k < d; ++k) e = fma(Za[(size_t)m * d + k], v0[k], e);
       double pw = 2.0 * gdiag * col[((size_t)a * (3 + d) + 1) * Mp + m];         // diagonal pair: rsum = csum
-      for (int p = L; p < P; ++p) {
-        int r, s2; mma_decode_pair(p, L, r, s2);
-        if (r == a) pw = fma(gpair(p), row[((size_t)(p - L) * 2 + 1) * Mp + m], pw);
-        else if (s2 == a) pw = fma(gpair(p), col[((size_t)p * (3 + d) + 1) * Mp + m], pw);
+      if (!pagg) {
+        for (int p = L; p < P; ++p) {
+          int r, s2; mma_decode_pair(p, L, r, s2);
+          if (r == a) pw = fma(gpair(p), row[((size_t)(p - L) * 2 + 1) * Mp + m], pw);
+          else if (s2 == a) pw = fma(gpair(p), col[((size_t)p * (3 + d) + 1) * Mp + m], pw);
+        }
       }
       double cm = (gfa + e + pw) * wa[m];
       if (with_unc) cm = fma(2.0 * gdiag * col[((size_t)a * (3 + d) + 2) * Mp + m], qa[m], cm);
@@ -902,12 +1023,42 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
     c.sync();
     mma_raw_moments(c, M, d, Za, cbuf, part, mom0);       // cmom
     mma_raw_moments(c, M, d, Za, wa, part, mom1);         // wmom
-    const double c0 = mom0[0], w0 = mom1[0];
+    const double w0 = mom1[0];
+    // the off-diagonal pairs' share of the coefficient moments, from the aggregates: with E = e - 1,
+    //   sum_ij w_i w'_j E_ij phi(zeta_i) = sum_ij Omega_ij phi(zeta_i) - (sum_i w_i phi(zeta_i)) (sum_j w'_j)
+    // (mu-centred: dc0, dc1 [d] in v1, dC2 [d, d] in A4)
+    double dc0 = 0.0;
+    if (pagg) {
+      for (int idx = lane; idx < d * d + d; idx += nl) {
+        const bool isv = idx >= d * d;
+        const int i = isv ? idx - d * d : idx / d, j = isv ? 0 : idx - i * d;
+        double acc = 0.0;
+        for (int p = L; p < P; ++p) {
+          int r, s2; mma_decode_pair(p, L, r, s2);
+          if (r != a && s2 != a) continue;
+          const double* ag = pagg + (size_t)(p - L) * na;
+          const double Wo = f1raw[r == a ? s2 : r];                          // sum of the partner latent's weights
+          const double* v1p = r == a ? ag + 1 : ag + 1 + d + d * d;          // r1 | k1
+          const double* m2p = r == a ? ag + 1 + d : ag + 1 + 2 * d + d * d;  // R2 | K2
+          const double own = isv ? mom1[1 + i] - w0 * mu[i] : second(mom1, i, j);
+          acc = fma(gpair(p), (isv ? v1p[i] : m2p[i * d + j]) - own * Wo, acc);
+        }
+        if (isv) v1[i] = acc; else A4[i * dp + j] = acc;
+      }
+      for (int p = L; p < P; ++p) {
+        int r, s2; mma_decode_pair(p, L, r, s2);
+        if (r != a && s2 != a) continue;
+        dc0 = fma(gpair(p), pagg[(size_t)(p - L) * na] - w0 * f1raw[r == a ? s2 : r], dc0);
+      }
+      c.sync();
+    }
+    const double c0 = mom0[0] + dc0;
     for (int idx = lane; idx < d * d; idx += nl) {
       const int i = idx / d, j = idx - i * d;
       const double si = mom1[1 + i] - w0 * mu[i], sj = mom1[1 + j] - w0 * mu[j];       // s_det
       const double vi = g_cross[i * L + a], vj = g_cross[j * L + a];
-      A0[i * dp + j] = -0.5 * second(mom0, i, j) + 0.5 * (vi * sj + si * vj);           // Abar
+      const double c2 = second(mom0, i, j) + (pagg ? A4[i * dp + j] : 0.0);
+      A0[i * dp + j] = -0.5 * c2 + 0.5 * (vi * sj + si * vj);                           // Abar
       A1[i * dp + j] = Pa[i * d + j];
     }
     c.sync();
@@ -921,7 +1072,7 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
     }
     for (int k = lane; k < d; k += nl) {
       double s = 0.0;
-      for (int l = 0; l < d; ++l) s = fma(A1[k * dp + l], mom0[1 + l] - c0 * mu[l], s);
+      for (int l = 0; l < d; ++l) s = fma(A1[k * dp + l], mom0[1 + l] - mom0[0] * mu[l] + (pagg ? v1[l] : 0.0), s);
       gmu_item[k] = s - w0 * v0[k];
     }
     c.sync();
@@ -937,6 +1088,20 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
   const double* Ksum = colp;
   const double* Rsum = p < L ? colp : row + (size_t)(p - L) * 2 * Mp;
   (void)Po;
+  const bool agg = pagg != nullptr && p >= L;
+  // mu-centred aggregates of the pair: R0 = K0 = sum Omega;  r1 (v1), k1 (v2), u (v3) [d];  R2 (A5), K2 (A6), XC (mom2) [d, d]
+  if (agg) {
+    const double* ag = pagg + (size_t)(p - L) * na;
+    for (int idx = lane; idx < d * d; idx += nl) {
+      const int i = idx / d, j = idx - i * d;
+      A5[i * dp + j] = ag[1 + d + idx];
+      A6[i * dp + j] = ag[1 + 2 * d + d * d + idx];
+      mom2[idx] = ag[1 + 2 * d + 2 * d * d + idx];
+    }
+    for (int k = lane; k < d; k += nl) { v1[k] = ag[1 + k]; v2[k] = ag[1 + d + d * d + k]; v3[k] = ag[1 + k]; }
+    if (lane == 0) { mom0[0] = ag[0]; mom1[0] = ag[0]; }
+    c.sync();
+  } else {
   mma_raw_moments(c, M, d, Za, Rsum, part, mom0);        // Rmom
   mma_raw_moments(c, M, d, Zb, Ksum, part, mom1);        // Kmom
   // X [d, d] = sum_j U_j z'_j^T, u [d] = sum_j U_j  (into mom2: X at [0, d^2), u at [d^2, d^2 + d))
@@ -963,7 +1128,22 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
     }
     c.sync();
   }
-  const double* X = mom2; const double* u = mom2 + d * d;
+  // centre at mu: XC = X - u mu^T (in place; u is copied out first)
+  for (int k = lane; k < d; k += nl) {
+    v1[k] = mom0[1 + k] - mom0[0] * mu[k];
+    v2[k] = mom1[1 + k] - mom1[0] * mu[k];
+    v3[k] = mom2[d * d + k];
+  }
+  for (int idx = lane; idx < d * d; idx += nl) {
+    const int i = idx / d, j = idx - i * d;
+    A5[i * dp + j] = second(mom0, i, j);
+    A6[i * dp + j] = second(mom1, i, j);
+  }
+  c.sync();
+  for (int idx = lane; idx < d * d; idx += nl) mom2[idx] -= v3[idx / d] * mu[idx % d];
+  c.sync();
+  }
+  const double* XC = mom2; const double* u = v3;
   const double R0 = mom0[0], K0 = mom1[0];
   // Svi = (Sigma + V)^-1
   for (int idx = lane; idx < d * d; idx += nl) {
@@ -983,10 +1163,9 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
     A3[i * dp + j] = Wm;
     A4[i * dp + j] = T;
     const double iab = 1.0 / (La[i] * Lb[j]), iaa = 1.0 / (La[i] * La[j]), ibb = 1.0 / (Lb[i] * Lb[j]);
-    const double R2 = second(mom0, i, j), K2 = second(mom1, i, j);
-    A5[i * dp + j] = R2; A6[i * dp + j] = K2;
-    const double xg_ij = (X[i * d + j] - u[i] * mu[j]) * iab;
-    const double xg_ji = (X[j * d + i] - u[j] * mu[i]) / (La[j] * Lb[i]);
+    const double R2 = A5[i * dp + j], K2 = A6[i * dp + j];
+    const double xg_ij = XC[i * d + j] * iab;
+    const double xg_ji = XC[j * d + i] / (La[j] * Lb[i]);
     A7[i * dp + j] = 0.5 * (xg_ij + xg_ji) + 0.5 * R2 * iaa + 0.5 * K2 * ibb;     // Tbar
   }
   c.sync();
@@ -1018,11 +1197,11 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
       const double T = A4[i * dp + j];
       const double Dr = (i == j ? 1.0 / La[i] : 0.0) - A1[i * dp + j] - T / (La[i] * La[j]);
       const double Dc = (i == j ? 1.0 / Lb[i] : 0.0) - A2[i * dp + j] - T / (Lb[i] * Lb[j]);
-      const double r1 = mom0[1 + j] - R0 * mu[j], k1 = mom1[1 + j] - K0 * mu[j];
+      const double r1 = v1[j], k1 = v2[j];
       s += Dr * r1 + Dc * k1 - (A4[j * dp + i] / (La[j] * Lb[i])) * u[j] - (T / (La[i] * Lb[j])) * k1;
     }
     gmu_item[i] = gp * s;
   }
   c.sync();
-  (void)v1; (void)v2; (void)v3; (void)v4; (void)v5;
+  (void)v4; (void)v5; (void)R0;
 }

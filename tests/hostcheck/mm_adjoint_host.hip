@@ -62,6 +62,33 @@ extern "C" int hc_gp_bwd(int L, int M, int Mp, int d, int full_cov, int with_unc
   return ok ? 0 : 1;
 }
 
+// the same with the off-diagonal pairs given as aggregates (f32-model backward): col holds the L diagonal pairs only
+extern "C" int hc_gp_bwd_agg(int L, int M, int Mp, int d, int full_cov, int with_unc, const double* Z, const double* ls2, const double* mu,
+                             const double* Sigma, const double* latmat, const double* w, const double* q, const double* col,
+                             const double* pagg, const double* f1raw, const double* g_f1, const double* g_Sff, const double* g_cross,
+                             double* gmu, double* gS) {
+  const int P = full_cov ? L * (L + 1) / 2 : L;
+  std::vector<double> sm(mma_gp_item_scratch(d, 1) + 8), cbuf(M), gSi(d * d), gmi(d), accS(d * d, 0.0), accm(d, 0.0);
+  bool ok = true;
+  for (int item = 0; item < L + P; ++item) {
+    mma_gp_item_bwd(MMAHostCtx(), item, L, M, Mp, d, P, with_unc != 0, Z, ls2, mu, Sigma, latmat, w, q, col, nullptr, g_f1, g_Sff,
+                    full_cov, g_cross, gSi.data(), gmi.data(), cbuf.data(), sm.data(), &ok, pagg, f1raw);
+    for (int i = 0; i < d * d; ++i) accS[i] += gSi[i];
+    for (int i = 0; i < d; ++i) accm[i] += gmi[i];
+  }
+  for (int i = 0; i < d; ++i) { gmu[i] = accm[i]; for (int j = 0; j < d; ++j) gS[i * d + j] = 0.5 * (accS[i * d + j] + accS[j * d + i]); }
+  return ok ? 0 : 1;
+}
+
+// polynomial part of one off-diagonal pair's aggregates from the packed weight moments, then the re-centring
+extern "C" void hc_pair_poly(int d, const double* G, const double* dmu, const double* mR, const double* mC, double* T) {
+  std::vector<double> sm(mma_pair_poly_scratch(d));
+  mma_pair_poly(MMAHostCtx(), d, G, dmu, mR, mC, T, sm.data());
+}
+extern "C" void hc_pair_convert(int d, const double* dmu2, double* T) { mma_pair_convert(MMAHostCtx(), d, dmu2, T); }
+extern "C" int hc_mono_off(int n, int d) { return mm_mono_off(n, d); }
+extern "C" int hc_mono_rank(const int* k, int n) { return mm_mono_rank_unsorted(n > 0 ? k[0] : 0, n > 1 ? k[1] : 0, n > 2 ? k[2] : 0, n > 3 ? k[3] : 0, n); }
+
 // ---- forward stages of the one-workgroup rollout (csrc/mm_small.h), on one host thread -------------------------------------
 #include "../../gpflowpilco_amd/csrc/mm_small.h"
 

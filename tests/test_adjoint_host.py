@@ -243,6 +243,96 @@ def test_gp_match_adjoint_from_the_M_sized_sums(hc, L, M, d, full, unc):
   assert _rel(gmu, gmu_w.numpy()[0]) < 1e-10 and _rel(gS, _sym(gS_w.numpy()[0])) < 1e-10
 
 
+@pytest.mark.parametrize("L,M,d,unc", [(3, 20, 4, True), (2, 33, 6, False), (4, 15, 3, True)])
+def test_gp_match_adjoint_from_pair_aggregates(hc, L, M, d, unc):
+  """The f32-model backward hands the off-diagonal pairs to mma_gp_item_bwd as AGGREGATES
+  sum_ij Omega_ij (1 | zeta_i | zeta_i zeta_i^T | zeta'_j | zeta'_j zeta'_j^T | zeta_i zeta'_j^T) instead of M-sized sums
+  (csrc/mm_bwd_f32.hip): formed here from their definition, result against autograd of the materialised evaluation."""
+  rng = np.random.default_rng(100 * L + d)
+  Z = rng.uniform(size=(L, M, d)); ls = np.exp(rng.uniform(np.log(0.6), np.log(2.0), size=(L, d))); var = 0.7 + 0.3 * rng.uniform(size=L)
+  beta = rng.standard_normal((L, M)); Cm = _sym(0.2 * rng.standard_normal((L, M, M)))
+  mu = rng.uniform(0.2, 0.8, size=(1, d)); Sigma = generate_covariance(rng, d, (1,), 0.15)
+  Pn = L * (L + 1) // 2
+  g_f1 = rng.standard_normal((1, L)); g_Sff = rng.standard_normal((1, L, L)); g_cross = rng.standard_normal((1, d, L))
+  Zt, lst, vart, bt, Ct = _t(Z), _t(ls), _t(var), _t(beta), _t(Cm)
+  mut, St = _t(mu, True), _t(Sigma, True)
+  f1, Sff, cross = autodiff.moment_match_torch(mut, 0.5 * (St + St.transpose(1, 2)), Zt, lst, vart, bt, Ct if unc else None, None, True, unc)
+  val = (f1 * _t(g_f1)).sum() + (Sff * _t(g_Sff)).sum() + (cross * _t(g_cross)).sum()
+  gmu_w, gS_w = torch.autograd.grad(val, (mut, St))
+  with torch.no_grad():
+    ia, ib = autodiff.pair_indices(L, True)
+    Pa, lognorm, G, Dr, Dc, const = autodiff.small_algebra(St, lst * lst, vart, ia, ib)
+    zeta = Zt[None] - mut[:, None, None, :]
+    q = torch.exp(lognorm[..., None] - 0.5 * torch.einsum('blmi,blij,blmj->blm', zeta, Pa, zeta))
+    w = bt[None] * q
+    zr, zc = zeta[:, ia], zeta[:, ib]
+    delta = (const[..., None, None] - 0.5 * torch.einsum('bpmi,bpij,bpmj->bpm', zr, Dr, zr)[..., :, None]
+             - 0.5 * torch.einsum('bpmi,bpij,bpmj->bpm', zc, Dc, zc)[..., None, :] + torch.einsum('bpmi,bpij,bpnj->bpmn', zr, G, zc))
+    E = torch.expm1(delta); e = E + 1.0
+    Om = w[:, ia][..., :, None] * w[:, ib][..., None, :] * e
+    Cq = torch.zeros_like(e)
+    if unc:
+      Cq[:, :L] = Ct[None] * q[..., :, None] * e[:, :L]
+      Om[:, :L] = Om[:, :L] + Cq[:, :L] * q[..., None, :]
+    Mp = M + 5
+    col = np.zeros((L, 3 + d, Mp))                                   # the diagonal pairs only
+    col[:, 0, :M] = Om.sum(2)[0, :L].numpy(); col[:, 1, :M] = (w[:, ia][..., :, None] * E).sum(2)[0, :L].numpy()
+    col[:, 2, :M] = Cq.sum(2)[0, :L].numpy(); col[:, 3:, :M] = torch.einsum('bpij,bpid->bpdj', Om, zr)[0, :L].numpy()
+    Oo, zro, zco = Om[0, L:], zr[0, L:], zc[0, L:]
+    agg = torch.cat([Oo.sum((1, 2))[:, None], torch.einsum('pij,pik->pk', Oo, zro),
+                     torch.einsum('pij,pik,pil->pkl', Oo, zro, zro).reshape(Pn - L, -1), torch.einsum('pij,pjk->pk', Oo, zco),
+                     torch.einsum('pij,pjk,pjl->pkl', Oo, zco, zco).reshape(Pn - L, -1),
+                     torch.einsum('pij,pik,pjl->pkl', Oo, zro, zco).reshape(Pn - L, -1)], 1).numpy()
+    assert agg.shape[1] == 1 + 2 * d + 3 * d * d
+    latmat = np.zeros((L, 2 * d * d + 2)); latmat[:, :d * d] = Pa[0].reshape(L, d * d).numpy()
+    wp = np.zeros((L, Mp)); qp = np.zeros((L, Mp)); wp[:, :M] = w[0].numpy(); qp[:, :M] = q[0].numpy()
+    f1raw = w[0].sum(1).numpy()
+  gmu = np.zeros(d); gS = np.zeros((d, d))
+  rc = hc.hc_gp_bwd_agg(L, M, Mp, d, 1, int(unc), _p(_c(Z)), _p(_c(ls * ls)), _p(_c(mu[0])), _p(_c(Sigma[0])), _p(_c(latmat)),
+                        _p(_c(wp)), _p(_c(qp)), _p(_c(col)), _p(_c(agg)), _p(_c(f1raw)), _p(_c(g_f1[0])), _p(_c(g_Sff[0])),
+                        _p(_c(g_cross[0])), _p(gmu), _p(gS))
+  assert rc == 0
+  assert _rel(gmu, gmu_w.numpy()[0]) < 1e-10 and _rel(gS, _sym(gS_w.numpy()[0])) < 1e-10
+
+
+def _packed_moments(hc, wt, zc, deg=4):
+  """sum_m wt[m] zc[m]^alpha for every monomial of degree <= deg, graded colex (csrc/mm_mono.h)."""
+  import itertools
+  d = zc.shape[1]
+  out = np.zeros(hc.hc_mono_off(deg + 1, d))
+  for n in range(deg + 1):
+    for ks in itertools.combinations_with_replacement(range(d), n):
+      kk = np.array(ks, dtype=np.int32)
+      r = hc.hc_mono_rank(kk.ctypes.data_as(C.POINTER(C.c_int)), n) if n else 0
+      out[hc.hc_mono_off(n, d) + r] = (wt * np.prod(zc[:, list(ks)], axis=1)).sum() if n else wt.sum()
+  return out
+
+
+@pytest.mark.parametrize("d,M", [(3, 17), (8, 12), (5, 9)])
+def test_pair_polynomial_part_and_recentring_equal_brute_force(hc, d, M):
+  """mma_pair_poly: sum_ij what_i what'_j (1 + b + b^2/2) zeta_i^alpha zc'_j^beta, |alpha| + |beta| <= 2, from the packed
+  degree-4 moments of the two weight vectors (b = zeta_i^T G zc'_j, zeta = zc - dmu); mma_pair_convert: zc' -> zeta'."""
+  rng = np.random.default_rng(d * 31 + M)
+  zc = 0.6 * rng.standard_normal((M, d)); zc2 = 0.6 * rng.standard_normal((M + 3, d))
+  wr = rng.standard_normal(M); wc = rng.standard_normal(M + 3)
+  G = 0.4 * rng.standard_normal((d, d)); dmu = 0.3 * rng.standard_normal(d); dmu2 = 0.3 * rng.standard_normal(d)
+  mR = _packed_moments(hc, wr, zc); mC = _packed_moments(hc, wc, zc2)
+  nT = 1 + 2 * d + 3 * d * d
+  T = np.zeros(nT)
+  hc.hc_pair_poly(d, _p(_c(G)), _p(_c(dmu)), _p(_c(mR)), _p(_c(mC)), _p(T))
+  zeta = zc - dmu
+  b = zeta @ G @ zc2.T
+  Om = wr[:, None] * wc[None, :] * (1.0 + b + 0.5 * b * b)
+
+  def brute(colside):
+    return np.concatenate([[Om.sum()], np.einsum('ij,ik->k', Om, zeta), np.einsum('ij,ik,il->kl', Om, zeta, zeta).ravel(),
+                           np.einsum('ij,jk->k', Om, colside), np.einsum('ij,jk,jl->kl', Om, colside, colside).ravel(),
+                           np.einsum('ij,ik,jl->kl', Om, zeta, colside).ravel()])
+  assert _rel(T, brute(zc2)) < 1e-12
+  hc.hc_pair_convert(d, _p(_c(dmu2)), _p(T))
+  assert _rel(T, brute(zc2 - dmu2)) < 1e-12
+
+
 # ---- forward stages of the one-workgroup rollout (csrc/mm_small.h) on the host, against the oracle --------------------------
 def _packed(p):
   """beta = Kuu^-1 u and C of an oracle model (the precompute the product does in gpflowpilco_amd/models.py)."""
