@@ -90,6 +90,11 @@ SIGNATURES = {
                                                C.c_void_p, C.c_void_p, C.c_void_p,
                                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                                C.c_void_p, C.c_void_p]),
+    "mm_bwd_f32_supported": (C.c_int, [C.c_int]),
+    "mm_backward_pair_aggregates_bytes": (C.c_size_t, [C.c_int] * 5),
+    "mm_backward_pair_aggregates": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                              C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "mm_moment_match_backward_bytes": (C.c_size_t, [C.c_int] * 5),
     "mm_moment_match_backward": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_int,

@@ -272,9 +272,9 @@ def moment_match_backward_reference(pm: ops.PackedModel, pre, mu: torch.Tensor, 
 class MomentMatchFunction(torch.autograd.Function):
   """``ops.moment_match`` as a differentiable function of (mu, Sigma) for a frozen packed model.
 
-  ``pm`` runs the forward in the inputs' dtype; ``pm_bwd`` is the float64 pack of the same model the
-  backward sums are taken on (the same object for a float64 model: an f32 model's gradients are
-  computed in f64 from the f32 state and cast back)."""
+  ``pm`` runs the forward in the inputs' dtype; ``pm_bwd`` is the pack the backward runs on: ``pm`` itself for a
+  float64 model and for a float32 model with d <= 8 (``ops.backward_supported``: diagonal pairs in f64, off-diagonal
+  pairs as moment + bf16-MFMA aggregates), else a float64 pack of the same model (the f32 state cast up)."""
 
   @staticmethod
   def forward(ctx, mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty):
@@ -289,10 +289,10 @@ class MomentMatchFunction(torch.autograd.Function):
     mu, Sigma = ctx.saved_tensors
     full, unc = ctx.flags
     pmb = ctx.pm_bwd
-    mu64, S64 = mu.to(torch.float64), Sigma.to(torch.float64)
+    mub, Sb = mu.to(pmb.dtype), Sigma.to(pmb.dtype)
     # native: M x M sweeps, M-sized moments and the d x d chain rule all on the device (mm_moment_match_backward);
     # moment_match_backward / _reference above are the torch forms it is tested against
-    gmu, gS = ops.moment_match_backward(pmb, mu64.contiguous(), S64.contiguous(), g_f1, g_Sff, g_cross, full, unc)
+    gmu, gS = ops.moment_match_backward(pmb, mub.contiguous(), Sb.contiguous(), g_f1, g_Sff, g_cross, full, unc)
     return gmu.to(mu.dtype), gS.to(Sigma.dtype), None, None, None, None, None
 
 
@@ -300,7 +300,7 @@ def moment_match_differentiable(model, mu: torch.Tensor, Sigma: torch.Tensor, fu
                                 model_uncertainty: bool = True):
   """(mu, Sigma) -> (f1, Sff, cross_pre) with gradients flowing back to (mu, Sigma)."""
   pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
-  pm_bwd = pm if mu.dtype == torch.float64 else model.packed(dtype=torch.float64, with_C=bool(model_uncertainty),
+  pm_bwd = pm if ops.backward_supported(pm) else model.packed(dtype=torch.float64, with_C=bool(model_uncertainty),
                                                               device=mu.device)
   pre = model._cache._pre
   return MomentMatchFunction.apply(mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty)

@@ -8,12 +8,12 @@ mkdir -p "${obj}"
 common=(-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-result)
 objs=()
 pids=()
-for src in mm_kernels mm_mfma mm_f64 mm_moments mm_compose mm_compose_bwd mm_rollout_small mm_pathwise mm_backward; do
+for src in mm_kernels mm_mfma mm_f64 mm_moments mm_compose mm_compose_bwd mm_rollout_small mm_pathwise mm_backward mm_bwd_f32; do
   extra=()
   # mm_mfma.hip alone is built with -fno-honor-nans: its per-tile range check max(|x|) then folds
   # into one v_max3_f32 per two entries (no canonicalising v_max x, x); inputs are finite by the
   # time they reach that kernel (k_prep's status word rejects non-PD / non-finite states).
-  [[ "${src}" == mm_mfma ]] && extra=(-fno-honor-nans)
+  [[ "${src}" == mm_mfma || "${src}" == mm_bwd_f32 ]] && extra=(-fno-honor-nans)
   # mm_pathwise.hip without the SLP vectoriser: it pairs elements of different 16-byte loads into
   # v_pk_fma_f32 operands, and the shuffles it places on the loop back edge wait for the prefetched
   # (still in flight) weight blocks -- s_waitcnt vmcnt(0) per iteration instead of vmcnt(8)

@@ -427,39 +427,27 @@ extern "C" size_t mm_backward_bytes(int B, int L, int M, int d, int flags) {
   return ((size_t)B * P * (3 + d) * Mp + (size_t)B * Po * 2 * Mp) * sizeof(double);
 }
 
-// out: [B][P][3 + d][Mp] column sums followed by [B][Po][2][Mp] row sums (f64).
-extern "C" int mm_backward_sums(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
-                                const void* mu, int flags, const void* workspace, size_t workspace_bytes,
-                                void* out, size_t out_bytes, void* stream) {
-  if (!packed || !mu || !workspace || !out) return MM_E_ARG;
-  if (L <= 0 || M <= 0 || d <= 0 || B <= 0) return MM_E_ARG;
-  if (d > MM_DMAX) return MM_E_DIM;
-  if (dtype != MM_F64) return MM_E_DTYPE;              // f64 mode only (see file header)
-  const MMModelLayout ml = mm_model_layout(L, M, d, dtype, 1);
-  if (packed_bytes < ml.Cm) return MM_E_WORKSPACE;
-  const bool has_C = packed_bytes >= ml.total;
-  const bool with_unc = (flags & MM_MODEL_UNCERTAINTY) != 0;
-  if (with_unc && !has_C) return MM_E_NO_C;
-  const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
-  if (workspace_bytes < wl.total) return MM_E_WORKSPACE;
-  if (out_bytes < mm_backward_bytes(B, L, M, d, flags)) return MM_E_WORKSPACE;
-  const char* pk = (const char*)packed; const char* ws = (const char*)workspace;
-  hipStream_t s = (hipStream_t)stream;
+// The sweeps on an already validated layout.  diag_only: the L diagonal pairs alone, out [B][L][3 + d][Mp] (the f32-model
+// backward: its off-diagonal pairs are aggregated by mm_bwd_f32.hip; the diagonal operands rowD / colD / w64 / q64 and
+// Zc64 are f64 in both pack types).  mu: [B][d] f64.
+int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* ws, const MMWorkspaceLayout& wl, int L, int M, int d,
+                          int B, const double* mu, int flags, bool with_unc, bool diag_only, double* out, hipStream_t s) {
   const double* Cm = with_unc ? (const double*)(pk + ml.Cm) : nullptr;
-  double* out_col = (double*)out;
-  double* out_row = out_col + (size_t)B * wl.P * (3 + d) * wl.Mp;
+  const int Pk = diag_only ? L : wl.P, Pok = diag_only ? 0 : wl.Po;       // what the kernels see as P / Po
+  double* out_col = out;
+  double* out_row = out_col + (size_t)B * Pk * (3 + d) * wl.Mp;
   if (!(flags & MM_FORCE_GENERIC) && d <= 31) {
     const double* Zc = (const double*)(pk + ml.Zc64);
     const double* zb = (const double*)(pk + ml.zbar);
     const int ks4 = (d + 3) / 4, nu = (d + 16) / 16;          // (d + 1) <= 16 nu
-#define MMB_M_ARGS Zc, ml.Kz, zb, Cm, (const double*)mu, L, wl.Mp, d, wl.P, (const double*)(ws + wl.w64),          \
+#define MMB_M_ARGS Zc, ml.Kz, zb, Cm, mu, L, wl.Mp, d, Pk, (const double*)(ws + wl.w64),                              \
                    (const double*)(ws + wl.q64), (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD),       \
                    (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO)
 #define MMB_M_LAUNCH(KS_, NU_)                                                                                      \
     do {                                                                                                            \
-      hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, false>), dim3(wl.Mp / 64, wl.P, B), dim3(256), 0, s, MMB_M_ARGS, out_col); \
-      if (wl.Po > 0)                                                                                                \
-        hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, true>), dim3(wl.Mp / 64, wl.Po, B), dim3(256), 0, s, MMB_M_ARGS, out_row); \
+      hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, false>), dim3(wl.Mp / 64, Pk, B), dim3(256), 0, s, MMB_M_ARGS, out_col); \
+      if (Pok > 0)                                                                                                  \
+        hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, true>), dim3(wl.Mp / 64, Pok, B), dim3(256), 0, s, MMB_M_ARGS, out_row); \
     } while (0)
     if (ks4 <= 1) MMB_M_LAUNCH(1, 1);
     else if (ks4 == 2) MMB_M_LAUNCH(2, 1);
@@ -472,14 +460,14 @@ extern "C" int mm_backward_sums(const void* packed, size_t packed_bytes, int L, 
     hipError_t em = hipGetLastError();
     return em == hipSuccess ? 0 : (int)em;
   }
-#define MMB_ARGS (const double*)(pk + ml.Z64), (const double*)(pk + ml.Zc64), ml.Kz, Cm, (const double*)mu, L, M, wl.Mp, d, wl.P, \
+#define MMB_ARGS (const double*)(pk + ml.Z64), (const double*)(pk + ml.Zc64), ml.Kz, Cm, mu, L, M, wl.Mp, d, Pk,      \
                  (const double*)(ws + wl.w64), (const double*)(ws + wl.q64), (const double*)(ws + wl.rowD),                 \
                  (const double*)(ws + wl.colD), (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO)
 #define MMB_LAUNCH(DK_)                                                                                             \
   do {                                                                                                              \
-    hipLaunchKernelGGL((k_bwd_sums<DK_, false>), dim3((wl.Mp + 255) / 256, wl.P, B), dim3(256), 0, s, MMB_ARGS, out_col); \
-    if (wl.Po > 0)                                                                                                  \
-      hipLaunchKernelGGL((k_bwd_sums<DK_, true>), dim3((wl.Mp + 255) / 256, wl.Po, B), dim3(256), 0, s, MMB_ARGS, out_row); \
+    hipLaunchKernelGGL((k_bwd_sums<DK_, false>), dim3((wl.Mp + 255) / 256, Pk, B), dim3(256), 0, s, MMB_ARGS, out_col); \
+    if (Pok > 0)                                                                                                    \
+      hipLaunchKernelGGL((k_bwd_sums<DK_, true>), dim3((wl.Mp + 255) / 256, Pok, B), dim3(256), 0, s, MMB_ARGS, out_row); \
   } while (0)
   if (d <= 4) MMB_LAUNCH(4);
   else if (d <= 8) MMB_LAUNCH(8);
@@ -489,4 +477,24 @@ extern "C" int mm_backward_sums(const void* packed, size_t packed_bytes, int L, 
 #undef MMB_ARGS
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
+}
+
+// out: [B][P][3 + d][Mp] column sums followed by [B][Po][2][Mp] row sums (f64).
+extern "C" int mm_backward_sums(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                const void* mu, int flags, const void* workspace, size_t workspace_bytes,
+                                void* out, size_t out_bytes, void* stream) {
+  if (!packed || !mu || !workspace || !out) return MM_E_ARG;
+  if (L <= 0 || M <= 0 || d <= 0 || B <= 0) return MM_E_ARG;
+  if (d > MM_DMAX) return MM_E_DIM;
+  if (dtype != MM_F64) return MM_E_DTYPE;              // f64 packs (f32 packs: mm_moment_match_backward)
+  const MMModelLayout ml = mm_model_layout(L, M, d, dtype, 1);
+  if (packed_bytes < ml.Cm) return MM_E_WORKSPACE;
+  const bool has_C = packed_bytes >= ml.total;
+  const bool with_unc = (flags & MM_MODEL_UNCERTAINTY) != 0;
+  if (with_unc && !has_C) return MM_E_NO_C;
+  const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
+  if (workspace_bytes < wl.total) return MM_E_WORKSPACE;
+  if (out_bytes < mm_backward_bytes(B, L, M, d, flags)) return MM_E_WORKSPACE;
+  return mm_backward_sums_impl((const char*)packed, ml, (const char*)workspace, wl, L, M, d, B, (const double*)mu, flags, with_unc,
+                               false, (double*)out, (hipStream_t)stream);
 }

@@ -59,6 +59,10 @@ struct MMModelLayout {
   size_t rtab;    // int16: for k = 1..deg the rank (inside the degree-k block of the moment table) of every index tuple
                   // encoded base DK = 8 (d <= 8) or 32 in a flat position, -1 where a digit is >= d; blocks of DK^k
                   // entries one after another (k_spoly's lookups: no integer arithmetic per tensor entry)
+  size_t Zq2;     // [L][Mp/32][2 (s)][2 (nb)][2 (hi, lo)][64 lanes][8] bf16 (f32 mode, d <= 8): the monomials of zc up to degree 2
+                  // (slot 0: 1; 1..d: zc_l; then zc_l zc_l', l <= l', row-major; 64 slots, zero beyond) as the B operand of
+                  // v_mfma_f32_32x32x16_bf16 -- lane (slot & 31, h) of image (tile, s, nb = slot >> 5, part) holds K slots
+                  // t = 0..7 = columns 16 s + 8 (t >> 2) + 4 h + (t & 3) of the tile (mm_bwd_f32.hip); 8 KB per 32 columns
   size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
                   // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
@@ -88,6 +92,8 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   if (dtype != MM_F64) off = mm_align_up(off + (size_t)L * o.Mp * o.KMp * 8, A);
   o.zmax2 = off;  off = mm_align_up(off + (size_t)L * 8, A);
   o.rtab = off;   off = mm_align_up(off + mm_rank_table_entries(d) * 2, A);
+  o.Zq2 = off;
+  if (dtype != MM_F64 && d <= 8) off = mm_align_up(off + (size_t)L * (o.Mp / 32) * 8192, A);
   o.Cm = off;
   if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;

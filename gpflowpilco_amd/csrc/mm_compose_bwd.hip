@@ -16,6 +16,15 @@
 #include "mm_compose.h"
 #include "mm_adjoint.h"
 
+// mm_backward.hip / mm_bwd_f32.hip
+int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* ws, const MMWorkspaceLayout& wl, int L, int M, int d,
+                          int B, const double* mu, int flags, bool with_unc, bool diag_only, double* out, hipStream_t s);
+extern "C" int mm_bwd_f32_supported(int d);
+size_t mm_bwd_f32_slab_bytes(int B, int Po, int Mp, int d);
+int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
+                              int B, int L, int d, const float* mu, double* slab, double* pagg, hipStream_t stream);
+int mm_launch_cast_f32_f64(const float* x, double* y, size_t n, hipStream_t stream);
+
 // stage profile (tools/profile_c1_stages.py; -DMM_STAGE_PROFILE builds only): cycles per stage of block 0
 #ifdef MM_STAGE_PROFILE
 __device__ long long* mmb_stage_prof = nullptr;
@@ -33,12 +42,15 @@ extern "C" void mm_stage_profile_set_bwd(void* device_buffer) {
 // GP match backward: items and their sum
 // ---------------------------------------------------------------------------------------------------------------------
 // grid (L + P, B), 256 threads.  items [B][L + P][d^2 + d]; cbuf [B][L][Mp].
+// col [B][col_pairs][3 + d][Mp]: col_pairs = P, or L with pagg [B][Po][mma_pair_agg_len(d)] for the off-diagonal pairs.
 __global__ __launch_bounds__(256) void k_gp_bwd_items(int L, int M, int Mp, int d, int P, int with_unc, int full_cov,
                                                       const double* __restrict__ Z, const double* __restrict__ ls2,
                                                       const double* __restrict__ mu, const double* __restrict__ Sigma,
                                                       const double* __restrict__ latmat, const double* __restrict__ w,
                                                       const double* __restrict__ q, const double* __restrict__ col,
-                                                      const double* __restrict__ row, const double* __restrict__ g_f1,
+                                                      const double* __restrict__ row, int col_pairs,
+                                                      const double* __restrict__ pagg, const double* __restrict__ f1raw,
+                                                      const double* __restrict__ g_f1,
                                                       const double* __restrict__ g_Sff, const double* __restrict__ g_cross,
                                                       double* __restrict__ items, double* __restrict__ cbuf, int32_t* status) {
   extern __shared__ double sm[];
@@ -47,9 +59,10 @@ __global__ __launch_bounds__(256) void k_gp_bwd_items(int L, int M, int Mp, int 
   double* out = items + ((size_t)b * (L + P) + item) * (d * d + d);
   mma_gp_item_bwd(MMADevCtx(), item, L, M, Mp, d, P, with_unc != 0, Z, ls2, mu + (size_t)b * d, Sigma + (size_t)b * d * d,
                   latmat + (size_t)b * L * (2 * d * d + 2), w + (size_t)b * L * Mp, q + (size_t)b * L * Mp,
-                  col + (size_t)b * P * (3 + d) * Mp, row + (size_t)b * Po * 2 * Mp, g_f1 + (size_t)b * L,
+                  col + (size_t)b * col_pairs * (3 + d) * Mp, row + (size_t)b * Po * 2 * Mp, g_f1 + (size_t)b * L,
                   g_Sff + (size_t)b * nsff, full_cov, g_cross + (size_t)b * d * L, out, out + d * d,
-                  cbuf + ((size_t)b * L + (item < L ? item : 0)) * Mp, sm, &ok);
+                  cbuf + ((size_t)b * L + (item < L ? item : 0)) * Mp, sm, &ok,
+                  pagg ? pagg + (size_t)b * Po * mma_pair_agg_len(d) : nullptr, f1raw + (size_t)b * L);
   if (!ok && threadIdx.x == 0 && status) { atomicMax(status, (int)gridDim.y - b); status[1] = item; }
 }
 
@@ -72,29 +85,40 @@ __global__ __launch_bounds__(64) void k_gp_bwd_sum(int nitems, int d, const doub
 }
 
 struct MMGpBwdLayout {
-  size_t sums, items, cbuf, f1, cross, total;
+  size_t sums, items, cbuf, f1, cross, slab, pagg, mu64, S64, total;
 };
-static inline MMGpBwdLayout mm_gp_bwd_layout(int B, int L, int M, int d, int flags) {
+// dtype MM_F64: the sums of all P pairs; MM_F32 (d <= 8): the L diagonal pairs' sums, the off-diagonal pairs' remainder slabs
+// and aggregates (mm_bwd_f32.hip), and f64 copies of the f32 state
+static inline MMGpBwdLayout mm_gp_bwd_layout(int B, int L, int M, int d, int dtype, int flags) {
   MMGpBwdLayout o;
   const size_t A = 256;
-  const int Mp = mm_round_up_int(M, MM_M_ALIGN), P = mm_num_pairs(L, flags);
+  const int Mp = mm_round_up_int(M, MM_M_ALIGN), P = mm_num_pairs(L, flags), Po = P - L;
+  const bool f32 = dtype == MM_F32;
   size_t off = 0;
-  o.sums = off;  off = mm_align_up(off + mm_backward_bytes(B, L, M, d, flags), A);
+  o.sums = off;  off = mm_align_up(off + (f32 ? (size_t)B * L * (3 + d) * Mp * 8 : mm_backward_bytes(B, L, M, d, flags)), A);
   o.items = off; off = mm_align_up(off + (size_t)B * (L + P) * (d * d + d) * 8, A);
   o.cbuf = off;  off = mm_align_up(off + (size_t)B * L * Mp * 8, A);
   o.f1 = off;    off = mm_align_up(off + (size_t)B * L * 8, A);
   o.cross = off; off = mm_align_up(off + (size_t)B * d * L * 8, A);
+  o.slab = off;  off = mm_align_up(off + (f32 ? mm_bwd_f32_slab_bytes(B, Po, Mp, d) : 0), A);
+  o.pagg = off;  off = mm_align_up(off + (f32 ? (size_t)B * Po * mma_pair_agg_len(d) * 8 : 0), A);
+  o.mu64 = off;  off = mm_align_up(off + (f32 ? (size_t)B * d * 8 : 0), A);
+  o.S64 = off;   off = mm_align_up(off + (f32 ? (size_t)B * d * d * 8 : 0), A);
   o.total = off;
   return o;
 }
 
+// enough for either pack type of the model (an f32 pack with d <= 8 runs mm_bwd_f32.hip; anything else the f64 sweeps)
 extern "C" size_t mm_moment_match_backward_bytes(int B, int L, int M, int d, int flags) {
   if (B <= 0 || L <= 0 || M <= 0 || d <= 0 || d > MM_DMAX) return 0;
-  return mm_gp_bwd_layout(B, L, M, d, flags).total;
+  const size_t n64 = mm_gp_bwd_layout(B, L, M, d, MM_F64, flags).total;
+  const size_t n32 = mm_bwd_f32_supported(d) ? mm_gp_bwd_layout(B, L, M, d, MM_F32, flags).total : 0;
+  return n64 > n32 ? n64 : n32;
 }
 
-// (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> g_mu [B,d], g_Sigma [B,d,d] (symmetric; += if accumulate_Sigma).
-// f64 packs only.  Re-runs the q stage for (mu, Sigma) on `workspace`, then the M x M sweeps, the items and their sum.
+// (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> g_mu [B,d], g_Sigma [B,d,d] (symmetric; += if accumulate_Sigma);
+// gradients are f64 for either pack type, (mu, Sigma) have the pack's type.
+// Re-runs the q stage for (mu, Sigma) on `workspace`, then the M x M sweeps, the items and their sum.
 // workspace_is_current: `workspace` already holds the q stage of exactly this (mu, Sigma, flags) -- the reverse sweep of a
 // rollout whose tape kept the drift's workspace per step -- so the q stage is not run again
 static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
@@ -106,13 +130,18 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
   if (!packed || !mu || !Sigma || !g_f1 || !g_Sff || !g_cross || !g_mu || !g_Sigma || !workspace || !bwd_ws) return MM_E_ARG;
   if (L <= 0 || M <= 0 || d <= 0 || B <= 0) return MM_E_ARG;
   if (d > MM_DMAX) return MM_E_DIM;
-  if (dtype != MM_F64) return MM_E_DTYPE;
-  const MMGpBwdLayout bl = mm_gp_bwd_layout(B, L, M, d, flags);
+  if (dtype != MM_F64 && dtype != MM_F32) return MM_E_DTYPE;
+  const bool f32 = dtype == MM_F32;
+  if (f32 && !mm_bwd_f32_supported(d)) return MM_E_DTYPE;     // d > 8: differentiate through an f64 pack of the model
+  const MMGpBwdLayout bl = mm_gp_bwd_layout(B, L, M, d, dtype, flags);
   if (bwd_ws_bytes < bl.total) return MM_E_WORKSPACE;
   const MMModelLayout ml = mm_model_layout(L, M, d, dtype, 1);
+  if (packed_bytes < ml.Cm) return MM_E_WORKSPACE;
+  const bool with_unc = (flags & MM_MODEL_UNCERTAINTY) != 0;
+  if (with_unc && packed_bytes < ml.total) return MM_E_NO_C;
   const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
   if (workspace_bytes < wl.total) return MM_E_WORKSPACE;
-  char* bw = (char*)bwd_ws; const char* pk = (const char*)packed; const char* ws = (const char*)workspace;
+  char* bw = (char*)bwd_ws; const char* pk = (const char*)packed; char* ws = (char*)workspace;
   hipStream_t s = (hipStream_t)stream;
   int rc = 0;
   if (!workspace_is_current) {
@@ -120,22 +149,43 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
                       workspace, workspace_bytes, status, stream);
     if (rc) return rc;
   }
-  rc = mm_backward_sums(packed, packed_bytes, L, M, d, dtype, B, mu, flags, workspace, workspace_bytes, bw + bl.sums,
-                        mm_backward_bytes(B, L, M, d, flags), stream);
-  if (rc) return rc;
   const int P = wl.P, Mp = wl.Mp;
+  const double* mu64 = (const double*)mu;
+  const double* S64 = (const double*)Sigma;
+  const double* pagg = nullptr;
+  if (f32) {
+    rc = mm_launch_cast_f32_f64((const float*)mu, (double*)(bw + bl.mu64), (size_t)B * d, s);
+    if (rc) return rc;
+    rc = mm_launch_cast_f32_f64((const float*)Sigma, (double*)(bw + bl.S64), (size_t)B * d * d, s);
+    if (rc) return rc;
+    mu64 = (const double*)(bw + bl.mu64);
+    S64 = (const double*)(bw + bl.S64);
+    rc = mm_backward_sums_impl(pk, ml, ws, wl, L, M, d, B, mu64, flags, with_unc, true, (double*)(bw + bl.sums), s);
+    if (rc) return rc;
+    if (wl.Po > 0) {
+      rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, d, (const float*)mu, (double*)(bw + bl.slab), (double*)(bw + bl.pagg), s);
+      if (rc) return rc;
+      pagg = (const double*)(bw + bl.pagg);
+    }
+  } else {
+    rc = mm_backward_sums(packed, packed_bytes, L, M, d, dtype, B, mu, flags, workspace, workspace_bytes, bw + bl.sums,
+                          mm_backward_bytes(B, L, M, d, flags), stream);
+    if (rc) return rc;
+  }
+  const int col_pairs = f32 ? L : P;
   const double* col = (const double*)(bw + bl.sums);
-  const double* row = col + (size_t)B * P * (3 + d) * Mp;
+  const double* row = col + (size_t)B * P * (3 + d) * Mp;       // (f64 packs; not read with aggregates)
   const size_t shm = (size_t)mma_gp_item_scratch(d, 256) * sizeof(double);
   if (shm > 160 * 1024) return MM_E_DIM;
   if (shm > 64 * 1024) {                                   // d >= 20: more than the default dynamic LDS limit
     hipError_t ea = hipFuncSetAttribute((const void*)k_gp_bwd_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (ea != hipSuccess) return (int)ea;
   }
-  hipLaunchKernelGGL(k_gp_bwd_items, dim3(L + P, B), dim3(256), shm, s, L, M, Mp, d, P, (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0,
+  hipLaunchKernelGGL(k_gp_bwd_items, dim3(L + P, B), dim3(256), shm, s, L, M, Mp, d, P, with_unc ? 1 : 0,
                      (flags & MM_FULL_OUTPUT_COV) ? 1 : 0, (const double*)(pk + ml.Z64), (const double*)(pk + ml.ls2),
-                     (const double*)mu, (const double*)Sigma, (const double*)(ws + wl.latmat), (const double*)(ws + wl.w64),
-                     (const double*)(ws + wl.q64), col, row, (const double*)g_f1, (const double*)g_Sff, (const double*)g_cross,
+                     mu64, S64, (const double*)(ws + wl.latmat), (const double*)(ws + wl.w64),
+                     (const double*)(ws + wl.q64), col, row, col_pairs, pagg, (const double*)(ws + wl.f1raw),
+                     (const double*)g_f1, (const double*)g_Sff, (const double*)g_cross,
                      (double*)(bw + bl.items), (double*)(bw + bl.cbuf), status);
   MMB_CHECK();
   if (skip_sum) return 0;                                   // the consumer sums the items itself (k_policy_head_bwd_small)
@@ -316,7 +366,7 @@ static inline MMComposeBwdLayout mm_compose_bwd_layout(int B, int nx, int na, in
   const int nd = nx + na + 1;
   o.carry = 0;
   o.gp = mm_align_up(mm_carry_layout(B, nx, na).total, 256);
-  o.total = o.gp + mm_gp_bwd_layout(B, nx, Md, nd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY).total;
+  o.total = o.gp + mm_gp_bwd_layout(B, nx, Md, nd, MM_F64, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY).total;
   return o;
 }
 
@@ -378,7 +428,7 @@ extern "C" int mm_rollout_composed_backward(const void* drift_packed, size_t dri
     if (e != hipSuccess) return (int)e;
   }
   const int dflags = MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY;
-  const MMGpBwdLayout gbl = mm_gp_bwd_layout(B, nx, drift_M, nd, dflags);
+  const MMGpBwdLayout gbl = mm_gp_bwd_layout(B, nx, drift_M, nd, MM_F64, dflags);
   const size_t gp_bytes = gbl.total;
   for (int h = H - 1; h >= 0; --h) {
     const char* sl = tp + (size_t)h * tl.slot_bytes; const char* sn = tp + (size_t)(h + 1) * tl.slot_bytes;

@@ -181,6 +181,37 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
       o[32 * kw] = __builtin_bit_cast(unsigned short, mm);
       o[64 * kw] = __builtin_bit_cast(unsigned short, l);
     }
+    if (d <= 8) {
+      // degree-2 monomial images for the backward's aggregate product (MMModelLayout::Zq2)
+      unsigned short* Zq = (unsigned short*)(packed + lay.Zq2) + (size_t)a * (lay.Mp / 32) * 4096;
+      const int nslot = 1 + d + d * (d + 1) / 2;
+      for (int idx = tid; idx < (lay.Mp / 32) * 2048; idx += 256) {       // one (hi, lo) pair per index
+        int r = idx;
+        const int t = r & 7; r >>= 3;
+        const int ln = r & 63; r >>= 6;
+        const int nb = r & 1; r >>= 1;
+        const int s2 = r & 1; r >>= 1;
+        const int ct = r;
+        const int slot = 32 * nb + (ln & 31), hh = ln >> 5;
+        const int m = 32 * ct + 16 * s2 + 8 * (t >> 2) + 4 * hh + (t & 3);
+        float v = 0.0f;
+        if (m < M && slot < nslot) {
+          if (slot == 0) v = 1.0f;
+          else if (slot <= d) v = (float)(Z[((size_t)a * M + m) * d + slot - 1] - zb[slot - 1]);
+          else {
+            int qq = slot - 1 - d, l0 = 0;
+            while (qq >= d - l0) { qq -= d - l0; ++l0; }
+            const int l1 = l0 + qq;
+            v = (float)((Z[((size_t)a * M + m) * d + l0] - zb[l0]) * (Z[((size_t)a * M + m) * d + l1] - zb[l1]));
+          }
+        }
+        const __bf16 h = (__bf16)v;
+        const __bf16 lo = (__bf16)(v - (float)h);
+        unsigned short* o = Zq + ((((size_t)(ct * 2 + s2) * 2 + nb) * 2) * 64 + ln) * 8 + t;
+        o[0] = __builtin_bit_cast(unsigned short, h);
+        o[512] = __builtin_bit_cast(unsigned short, lo);
+      }
+    }
   }
 }
 

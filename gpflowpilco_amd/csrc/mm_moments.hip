@@ -307,6 +307,21 @@ __global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, i
 #undef MM_PADI
 }
 
+// the moment GEMM alone with EVERY column block for every (b, pair) (no early exit for the cubic / quartic blocks): the
+// backward's aggregates need the moments to degree 4 whether or not the forward collapsed the item (mm_bwd_f32.hip)
+int mm_launch_wmom_full(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
+                        int B, int L, int d, hipStream_t stream) {
+  const int nrb = ((L - 1) * B + MM_GEMM_RB - 1) / MM_GEMM_RB, ncb = (ml.KMp + MM_GEMM_NB - 1) / MM_GEMM_NB;
+  const long long nwork_ll = (long long)L * ncb * MM_MOM_SPLIT * nrb;
+  if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
+  hipLaunchKernelGGL(k_wmom_gemm, dim3((int)nwork_ll), dim3(256), 0, stream, (const double*)(ws + wl.whR),
+                     (const double*)(ws + wl.whC), (const double*)(packed + ml.Zm), ml.KMp, L, wl.Mp, B, wl.Po, nrb, ncb,
+                     (int)nwork_ll, 0x7fffffff /* no block is optional */, (const unsigned int*)nullptr, (const double*)(packed + ml.zmax2),
+                     (double*)(ws + wl.mom));
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+
 int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
                       int B, int L, int d, const void* mu_f32, int flags, hipStream_t stream) {
   const double* Zm = (const double*)(packed + ml.Zm);

@@ -480,12 +480,19 @@ def expected_cost(mean: torch.Tensor, cov: torch.Tensor, target: torch.Tensor, p
   return out.reshape(lead)
 
 
+def backward_supported(pm: PackedModel) -> bool:
+  """Whether ``moment_match_backward`` runs on this pack itself (else: on a float64 pack of the same model)."""
+  return pm.dtype == torch.float64 or bool(lib().mm_bwd_f32_supported(pm.d))
+
+
 def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor, g_f1: torch.Tensor, g_Sff: torch.Tensor,
                           g_cross: torch.Tensor, full_output_cov: bool = True, model_uncertainty: bool = True):
-  """``mm_moment_match_backward``: the vector-Jacobian product of one moment match of a frozen f64 pack,
-  (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> (g_mu [B,d], g_Sigma [B,d,d] symmetric)."""
-  if pm.dtype != torch.float64:
-    raise NotImplementedError("the backward runs on a float64 pack")
+  """``mm_moment_match_backward``: the vector-Jacobian product of one moment match of a frozen pack,
+  (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> (g_mu [B,d], g_Sigma [B,d,d] symmetric), gradients in float64.
+  float64 packs: f64 sweeps for every pair; float32 packs with d <= 8 (``backward_supported``): f64 for the diagonal
+  pairs, moment + bf16-MFMA aggregates for the off-diagonal pairs (csrc/mm_bwd_f32.hip)."""
+  if not backward_supported(pm):
+    raise NotImplementedError("float32 packs with d > 8 differentiate through a float64 pack of the model")
   B, mu, Sigma = _prep_state(pm, mu, Sigma)
   flags = make_flags(full_output_cov, model_uncertainty)
   f64 = torch.float64
@@ -499,7 +506,7 @@ def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor
     pm._workspaces[key] = wb
   g_mu = torch.empty(B, pm.d, dtype=f64, device=pm.device)
   g_S = torch.empty(B, pm.d, pm.d, dtype=f64, device=pm.device)
-  rc = lib().mm_moment_match_backward(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, MM_F64, B, mu.data_ptr(), Sigma.data_ptr(),
+  rc = lib().mm_moment_match_backward(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, mu.data_ptr(), Sigma.data_ptr(),
                                       flags, g_f1.data_ptr(), g_Sff.data_ptr(), g_cross.data_ptr(), g_mu.data_ptr(),
                                       g_S.data_ptr(), 0, ws.data_ptr(), ws.numel(), wb.data_ptr(), wb.numel(),
                                       pm.status().data_ptr(), _stream(pm.device))

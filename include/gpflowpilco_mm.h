@@ -229,12 +229,26 @@ int mm_backward_sums(const void* packed, size_t packed_bytes, int L, int M, int 
                      const void* mu, int flags, const void* workspace, size_t workspace_bytes,
                      void* out, size_t out_bytes, void* stream);
 
-/* ---- backward w.r.t. the input moments, complete (f64 packs): the vector-Jacobian product of one moment match
+/* ---- backward w.r.t. the input moments, complete: the vector-Jacobian product of one moment match
  *   (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> g_mu [B,d], g_Sigma [B,d,d] (symmetric; += if accumulate_Sigma)
- * for a frozen model: re-runs the q stage for (mu, Sigma) on `workspace`, the M x M sweeps of mm_backward_sums, then the
- * M-sized moments and the d x d chain rule per (latent | pair) item and their sum (csrc/mm_compose_bwd.hip, mm_adjoint.h).
- * bwd_ws: mm_moment_match_backward_bytes. */
+ * for a frozen model (the reference: tf.GradientTape through moment_matching/models.py:200-299).  Gradients are f64 in and
+ * out; (mu, Sigma) have the pack's type.  Re-runs the q stage for (mu, Sigma) on `workspace`, then
+ *   MM_F64 packs: the M x M sweeps of mm_backward_sums for every pair,
+ *   MM_F32 packs with d <= 8 (mm_bwd_f32_supported): the f64 sweep for the L diagonal pairs only; the off-diagonal pairs
+ *     are reduced to 1 + 2d + 3d^2 aggregates each -- polynomial part from the degree-4 weight moments in f64, remainder
+ *     by a bf16-MFMA tile sweep (csrc/mm_bwd_f32.hip); other f32 packs return MM_E_DTYPE (use an f64 pack of the model),
+ * then the M-sized moments and the d x d chain rule per (latent | pair) item and their sum (csrc/mm_compose_bwd.hip,
+ * mm_adjoint.h).  bwd_ws: mm_moment_match_backward_bytes (enough for either pack type). */
+int mm_bwd_f32_supported(int d);
 size_t mm_moment_match_backward_bytes(int B, int L, int M, int d, int flags);
+/* the off-diagonal aggregates of an MM_F32 pack alone (tests, diagnostics): runs the q stage of (mu, Sigma) on `workspace`;
+ * pagg [B][P-L][1 + 2d + 3d^2] f64 = sum_ij Omega_ij (1 | zeta_i | zeta_i zeta_i^T | zeta'_j | zeta'_j zeta'_j^T | zeta_i zeta'_j^T),
+ * zeta = z - mu, Omega_ij = w_i w'_j e^{delta_ij} (pairs a < a' row by row) */
+size_t mm_backward_pair_aggregates_bytes(int B, int L, int M, int d, int flags);
+int mm_backward_pair_aggregates(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                const void* mu, const void* Sigma, int flags, void* workspace, size_t workspace_bytes,
+                                void* scratch, size_t scratch_bytes, void* pagg, size_t pagg_bytes,
+                                int32_t* status, void* stream);
 int mm_moment_match_backward(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
                              const void* mu, const void* Sigma, int flags,
                              const void* g_f1, const void* g_Sff, const void* g_cross,

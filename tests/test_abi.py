@@ -105,7 +105,9 @@ def test_argument_validation_of_the_gradient_entry_points_without_gpu():
   assert lib.mm_rollout_composed_backward(*args()) == -4                          # tape too small
   # backward of one match
   mb = lambda dtype=F64, mu=p, d=4: (p, 64, 2, 16, d, dtype, 2, mu, p, 3, p, p, p, p, p, 0, p, 64, p, 64, None, None)
-  assert lib.mm_moment_match_backward(*mb(dtype=F32)) == -3
+  assert lib.mm_moment_match_backward(*mb(dtype=F32, d=12)) == -3                 # f32 packs: d <= 8 only
+  assert lib.mm_moment_match_backward(*mb(dtype=F32)) == -4                       # ... where they get as far as the size check
+  assert lib.mm_bwd_f32_supported(8) == 1 and lib.mm_bwd_f32_supported(9) == 0
   assert lib.mm_moment_match_backward(*mb(mu=None)) == -1
   assert lib.mm_moment_match_backward(*mb(d=40)) == -2
   assert lib.mm_moment_match_backward(*mb()) == -4                                 # workspaces too small

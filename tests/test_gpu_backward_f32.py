@@ -1,0 +1,114 @@
+"""Backward of one moment match on an f32 pack (row f-1; csrc/mm_bwd_f32.hip): the off-diagonal pairs' aggregates
+(f64 moments for 1 + b + b^2/2, bf16-MFMA tile sweep for the remainder) against their definition in torch float64, and the
+whole vector-Jacobian product against the f64 pack of the same model on the same (f32-rounded) state."""
+import numpy as np
+import pytest
+import torch
+
+from gpflowpilco_amd import _lib, autodiff, ops
+from gpflowpilco_amd.synthetic import make_inputs, make_svgp
+from tests.helpers import to_dev
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+
+def _aggregates_reference(Z, ls, var, beta, mu, S):
+  """sum_ij Omega_ij (1 | zeta_i | zeta_i zeta_i^T | zeta'_j | zeta'_j zeta'_j^T | zeta_i zeta'_j^T) per off-diagonal pair,
+  from the definitions (materialised [B, Po, M, M] blocks, float64)."""
+  L, M, d = Z.shape
+  ia, ib = autodiff.pair_indices(L, True, Z.device)
+  Pa, lognorm, G, Dr, Dc, const = autodiff.small_algebra(S, ls * ls, var, ia, ib)
+  zeta = Z[None] - mu[:, None, None, :]
+  q = torch.exp(lognorm[..., None] - 0.5 * torch.einsum('blmi,blij,blmj->blm', zeta, Pa, zeta))
+  w = beta[None] * q
+  io, jo = ia[L:], ib[L:]
+  zr, zc = zeta[:, io], zeta[:, jo]
+  delta = (const[:, L:, None, None] - 0.5 * torch.einsum('bpmi,bpij,bpmj->bpm', zr, Dr[:, L:], zr)[..., :, None]
+           - 0.5 * torch.einsum('bpmi,bpij,bpmj->bpm', zc, Dc[:, L:], zc)[..., None, :]
+           + torch.einsum('bpmi,bpij,bpnj->bpmn', zr, G[:, L:], zc))
+  Om = w[:, io][..., :, None] * w[:, jo][..., None, :] * torch.exp(delta)
+  B, Po = Om.shape[:2]
+  return torch.cat([Om.sum((2, 3))[..., None], torch.einsum('bpij,bpik->bpk', Om, zr),
+                    torch.einsum('bpij,bpik,bpil->bpkl', Om, zr, zr).reshape(B, Po, -1), torch.einsum('bpij,bpjk->bpk', Om, zc),
+                    torch.einsum('bpij,bpjk,bpjl->bpkl', Om, zc, zc).reshape(B, Po, -1),
+                    torch.einsum('bpij,bpik,bpjl->bpkl', Om, zr, zc).reshape(B, Po, -1)], -1)
+
+
+def _pair_aggregates(pm, mu, S, flags):
+  B = mu.shape[0]
+  Po = pm.L * (pm.L - 1) // 2
+  nT = 1 + 2 * pm.d + 3 * pm.d * pm.d
+  ws = pm.workspace(B, flags)
+  n = _lib.lib().mm_backward_pair_aggregates_bytes(B, pm.L, pm.M, pm.d, flags)
+  scratch = torch.empty(n, dtype=torch.uint8, device=mu.device)
+  out = torch.zeros(B, Po, nT, dtype=F64, device=mu.device)
+  rc = _lib.lib().mm_backward_pair_aggregates(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _lib.MM_F32, B, mu.data_ptr(),
+                                               S.data_ptr(), flags, ws.data_ptr(), ws.numel(), scratch.data_ptr(), n,
+                                               out.data_ptr(), out.numel() * 8, pm.status().data_ptr(), ops._stream(mu.device))
+  _lib.check(rc, "mm_backward_pair_aggregates")
+  return out
+
+
+@pytest.mark.parametrize("shape,scale", [((3, 200, 8, 3), 0.1), ((3, 300, 5, 2), 0.2), ((2, 520, 8, 2), 0.05), ((4, 130, 3, 2), 0.3)],
+                         ids=["L3d8", "L3d5", "L2M520", "L4d3wide"])
+def test_pair_aggregates_match_their_definition(shape, scale, device):
+  L, M, d, B = shape
+  syn = make_svgp(L, M, d, seed=50 + L + d, device=str(device), ls_bounds=(0.5, 2.5))
+  model = syn.to_model(device)
+  pm = model.packed(torch.float32, True, device)
+  mu, S = make_inputs(B, d, seed=3, scale=scale, lo=0.2, hi=0.8)
+  mu32, S32 = to_dev(mu, device, torch.float32), to_dev(S, device, torch.float32)
+  got = _pair_aggregates(pm, mu32, S32, ops.make_flags(True, True))
+  Z, ls, var, beta, _, _ = model.precompute(device)          # what mm_pack_model received (float64)
+  want = _aggregates_reference(Z, ls, var, beta, mu32.to(F64), S32.to(F64))
+  # blocks: N0 | r1 | R2 | k1 | K2 | XC -- each against its own scale (the sums cancel: |Omega| >> |sum Omega|)
+  o = np.cumsum([0, 1, d, d * d, d, d * d, d * d])
+  for k in range(6):
+    g, w_ = got[..., o[k]:o[k + 1]], want[..., o[k]:o[k + 1]]
+    sc = float(w_.abs().amax())
+    assert float((g - w_).abs().amax()) < 2e-5 * sc, (k, float((g - w_).abs().amax()), sc)
+
+
+@pytest.mark.parametrize("shape,full,unc", [((4, 300, 8, 3), True, True), ((3, 200, 5, 2), True, False), ((2, 140, 8, 2), False, True),
+                                            ((1, 260, 6, 2), True, True), ((5, 530, 7, 2), True, True)],
+                         ids=["L4d8", "L3d5nounc", "L2diagcov", "L1", "L5M530"])
+def test_f32_pack_backward_matches_f64_pack(shape, full, unc, device):
+  L, M, d, B = shape
+  syn = make_svgp(L, M, d, seed=60 + L + d, device=str(device), ls_bounds=(0.5, 2.5))
+  model = syn.to_model(device)
+  pm32, pm64 = model.packed(torch.float32, unc, device), model.packed(F64, unc, device)
+  assert ops.backward_supported(pm32)
+  mu, S = make_inputs(B, d, seed=4, scale=0.15, lo=0.2, hi=0.8)
+  mu32, S32 = to_dev(mu, device, torch.float32), to_dev(S, device, torch.float32)
+  rng = np.random.default_rng(5)
+  g_f1 = to_dev(rng.standard_normal((B, L)), device, F64)
+  g_Sff = to_dev(rng.standard_normal((B, L, L) if full else (B, L)), device, F64)
+  g_cross = to_dev(rng.standard_normal((B, d, L)), device, F64)
+  gmu32, gS32 = ops.moment_match_backward(pm32, mu32, S32, g_f1, g_Sff, g_cross, full, unc)
+  gmu64, gS64 = ops.moment_match_backward(pm64, mu32.to(F64), S32.to(F64), g_f1, g_Sff, g_cross, full, unc)
+  assert int(pm32.status()[0]) == 0
+  for a_, b_ in ((gmu32, gmu64), (gS32, gS64)):
+    sc = float(b_.abs().amax())
+    assert float((a_ - b_).abs().amax()) < 1e-4 * sc, (float((a_ - b_).abs().amax()), sc)
+
+
+def test_differentiable_match_of_an_f32_model_uses_its_own_pack(device):
+  """autodiff.moment_match_differentiable on float32 inputs: the gradient comes from the f32 pack (no f64 pack is built)
+  and agrees with the float64 evaluation of the same functional."""
+  L, M, d, B = 3, 260, 8, 2
+  syn = make_svgp(L, M, d, seed=71, device=str(device), ls_bounds=(0.6, 2.5))
+  model = syn.to_model(device)
+  mu, S = make_inputs(B, d, seed=8, scale=0.1, lo=0.3, hi=0.7)
+  rng = np.random.default_rng(9)
+  A1, A2, A3 = (to_dev(rng.standard_normal(s), device, F64) for s in ((B, L), (B, L, L), (B, d, L)))
+  grads = []
+  for dt in (torch.float32, F64):
+    mu_t = to_dev(mu, device, torch.float32).to(dt).requires_grad_(True)
+    S_t = to_dev(S, device, torch.float32).to(dt).requires_grad_(True)
+    f1, Sff, cr = autodiff.moment_match_differentiable(model, mu_t, S_t, True, True)
+    ((A1.to(dt) * f1).sum() + (A2.to(dt) * Sff).sum() + (A3.to(dt) * cr).sum()).backward()
+    grads.append((mu_t.grad.to(F64), S_t.grad.to(F64)))
+  for a_, b_ in zip(grads[0], grads[1]):
+    sc = float(b_.abs().amax())
+    assert float((a_ - b_).abs().amax()) < 2e-4 * sc, (float((a_ - b_).abs().amax()), sc)

@@ -5,7 +5,7 @@
        replayed from HIP graphs (loops.GraphedPolicyLoss), forward and forward+backward
   C4   one per-GPU shard of BASELINE configs[3] (B=32, d=16, L=32, N=4000, fp32): stage times of one match
 
-  python tools/bench_next_rows.py [--skip-c4]
+  python tools/bench_next_rows.py [--skip-c4] [--skip-composed]
 """
 import argparse, json, os, sys, time
 import numpy as np, torch
@@ -19,6 +19,7 @@ from gpflowpilco_amd.synthetic import make_inputs, make_svgp
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--skip-c4", action="store_true")
+ap.add_argument("--skip-composed", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 
@@ -66,7 +67,8 @@ system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=Trigonomet
                                   solver=dynamics.MomentMatchingEuler())
 objective = GaussianObjective(target=to_dev(target, dev, F64), precis=to_dev(precis, dev, F64))
 init = get_state_initializer(to_dev(mu[:1], dev, F64), to_dev(S[:1] * 0.04, dev, F64))
-for label, native in (("native (taped rollout + mm_rollout_composed_backward)", None), ("torch composition (native=False)", False)):
+for label, native in (() if args.skip_composed else (("native (taped rollout + mm_rollout_composed_backward)", None),
+                                                    ("torch composition (native=False)", False))):
   closure = policy_loss_closure(system, objective, init, H, native=native)
 
   def eager_fwd():
