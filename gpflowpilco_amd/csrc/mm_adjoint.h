@@ -814,33 +814,54 @@ __host__ __device__ inline int mma_pair_poly_scratch(int d) {
   return n + mma_ipow(d, 4) + 8;
 }
 
+//   rtab: the packed model's rank table for DK = 8 (MMModelLayout::rtab; nullptr: ranks are computed).
 MMA_FN void mma_pair_poly(Ctx c, int d, const double* G, const double* dmu, const double* mR, const double* mC, double* T,
-                          double* sm) {
+                          double* sm, const short* rtab = nullptr) {
   const int lane = c.lane(), nl = c.nl();
   int moff[5], toff[6];
   toff[0] = 0;
   for (int k = 0; k <= 4; ++k) { moff[k] = mm_mono_off(k, d); toff[k + 1] = toff[k] + mma_ipow(d, k); }
+  // rank of an (unsorted) index tuple of length k inside its degree block: table lookup (block k starts at (8^k - 8) / 7)
+  auto rank_of = [&](const int (&ix)[4], int k) -> int {
+    if (k == 0) return 0;
+    if (rtab) {
+      int pos = 0;
+      for (int t = 0; t < k; ++t) pos |= ix[t] << (3 * t);
+      return (int)rtab[(((1 << (3 * k)) - 8) / 7) + pos];
+    }
+    return mm_mono_rank_unsorted(ix[0], ix[1], ix[2], ix[3], k);
+  };
   double* Mt = sm;                 // M~_k, k = 0..4, full tensors (index 0 most significant)
   double* Q = sm + toff[5];        // Q_t expanded, then G applied along its trailing indices
   // ---- M~_k[i_1..i_k] = sum_{S subset [k]} (-1)^{k - |S|} m_{|S|}[i_S] prod_{t not in S} dmu[i_t] ------------------------------
-  for (int idx = lane; idx < toff[5]; idx += nl) {
+  // the tensors are symmetric: the shift is evaluated once per monomial (packed, into Q as scratch), then expanded
+  const int nmono = mm_mono_off(5, d);
+  for (int idx = lane; idx < nmono; idx += nl) {
     int k = 0;
-    while (idx >= toff[k + 1]) ++k;
-    int rem = idx - toff[k], ix[4] = {0, 0, 0, 0};
-    for (int t = k - 1; t >= 0; --t) { ix[t] = rem % d; rem /= d; }
+    while (idx >= mm_mono_off(k + 1, d)) ++k;
+    int ix[4] = {0, 0, 0, 0};
+    mm_mono_unrank(idx - moff[k], k, ix);
     double acc = 0.0;
     for (int S = 0; S < (1 << k); ++S) {
       int sel[4] = {0, 0, 0, 0}, ns = 0;
       double pr = 1.0;
       for (int t = 0; t < k; ++t) {
-        if (S & (1 << t)) sel[ns++] = ix[t];
+        if (S & (1 << t)) sel[ns++] = ix[t];               // ix is sorted, so is every sub-tuple
         else pr *= -dmu[ix[t]];
       }
-      const int r = ns ? mm_mono_rank_unsorted(sel[0], sel[1], sel[2], sel[3], ns) : 0;
-      acc = fma(pr, mR[moff[ns] + r], acc);
+      acc = fma(pr, mR[moff[ns] + rank_of(sel, ns)], acc);
     }
-    Mt[idx] = acc;
+    Q[idx] = acc;
   }
+  c.sync();
+  for (int idx = lane; idx < toff[5]; idx += nl) {
+    int k = 0;
+    while (idx >= toff[k + 1]) ++k;
+    int rem = idx - toff[k], ix[4] = {0, 0, 0, 0};
+    for (int t = k - 1; t >= 0; --t) { ix[t] = rem % d; rem /= d; }
+    Mt[idx] = Q[moff[k] + rank_of(ix, k)];
+  }
+  c.sync();
   const int nT = mma_pair_agg_len(d);
   for (int idx = lane; idx < nT; idx += nl) T[idx] = 0.0;
   c.sync();
@@ -851,7 +872,7 @@ MMA_FN void mma_pair_poly(Ctx c, int d, const double* G, const double* dmu, cons
     for (int idx = lane; idx < dt; idx += nl) {
       int rem = idx, ix[4] = {0, 0, 0, 0};
       for (int u = t - 1; u >= 0; --u) { ix[u] = rem % d; rem /= d; }
-      Q[idx] = mC[moff[t] + (t ? mm_mono_rank_unsorted(ix[0], ix[1], ix[2], ix[3], t) : 0)];
+      Q[idx] = mC[moff[t] + rank_of(ix, t)];
     }
     c.sync();
     for (int n = 0; n <= 2 && n <= t; ++n) {
@@ -964,12 +985,115 @@ MMA_FN void mma_raw_moments(Ctx c, int M, int d, const double* Z, const double* 
   c.sync();
 }
 
+// coefficient of centre m in the moment sums of latent item a: (g_f1 + e_m + sum_pairs g_p rsum/csum_m) w_m + 2 g_aa cC_m q_m
+// (with aggregates the off-diagonal pairs' share is added to the moments instead: mma_gp_item_bwd)
+template <class GP>
+__host__ __device__ inline double mma_gp_latent_coef(int a, int m, int L, int Mp, int d, int P, bool with_unc, bool have_pagg,
+                                                     const double* Za, const double* v0, double pvmu, double gfa, double gdiag,
+                                                     GP gpair, const double* wa, const double* qa, const double* col,
+                                                     const double* row) {
+  double e = -pvmu;
+  for (int k = 0; k < d; ++k) e = fma(Za[(size_t)m * d + k], v0[k], e);
+  double pw = 2.0 * gdiag * col[((size_t)a * (3 + d) + 1) * Mp + m];         // diagonal pair: rsum = csum
+  if (!have_pagg) {
+    for (int p = L; p < P; ++p) {
+      int r, s2; mma_decode_pair(p, L, r, s2);
+      if (r == a) pw = fma(gpair(p), row[((size_t)(p - L) * 2 + 1) * Mp + m], pw);
+      else if (s2 == a) pw = fma(gpair(p), col[((size_t)p * (3 + d) + 1) * Mp + m], pw);
+    }
+  }
+  double cm = (gfa + e + pw) * wa[m];
+  if (with_unc) cm = fma(2.0 * gdiag * col[((size_t)a * (3 + d) + 2) * Mp + m], qa[m], cm);
+  return cm;
+}
+
+// Partial moment sums of one (latent | pair) item over the centres [m0, m1): what mma_gp_item_bwd otherwise forms in loops
+// over all M centres (one workgroup per item: the slow part at M = 2000).  out [3 nc] (nc = 1 + d + d^2):
+//   latent item: cmom | wmom | unused;     pair item (not aggregated): Rmom | Kmom | X [d, d], u [d].
+// sm: mma_gp_moments_scratch(d, nl, m1 - m0) doubles.  Items that come as aggregates need no moments (not called).
+__host__ __device__ inline int mma_gp_moments_scratch(int d, int nl, int n) {
+  return (2 + d) * n + 2 * n * d + 3 * mma_gp_nslice(d, nl) * mma_gp_ncol(d) + d + 8;
+}
+
+MMA_FN void mma_gp_item_moments(Ctx c, int item, int m0, int m1, int L, int M, int Mp, int d, int P, bool with_unc,
+                                const double* Z, const double* mu, const double* latmat, const double* w, const double* q,
+                                const double* col, const double* row, const double* g_f1, const double* g_Sff, int full_cov,
+                                const double* g_cross, bool have_pagg, double* out, double* sm) {
+  const int lane = c.lane(), nl = c.nl(), nc = mma_gp_ncol(d), ns = mma_gp_nslice(d, nl), n = m1 - m0, lat = 2 * d * d + 2;
+  double* cA = sm;                 // [n]
+  double* cB = cA + n;             // [n]
+  double* Uc = cB + n;             // [d][n]
+  double* Zra = Uc + d * n;        // [n][d] the row side's inducing inputs
+  double* Zcb = Zra + n * d;       // [n][d] the column side's
+  double* part = Zcb + n * d;      // [3][ns][nc]
+  double* v0 = part + 3 * ns * nc; // [d]
+  auto gpair = [&](int p) -> double {
+    if (!full_cov) return g_Sff[p];
+    int a, a2; mma_decode_pair(p, L, a, a2);
+    return p < L ? g_Sff[a * L + a] : g_Sff[a * L + a2] + g_Sff[a2 * L + a];
+  };
+  const bool latent = item < L;
+  int a, b;
+  if (latent) { a = item; b = item; } else mma_decode_pair(item - L, L, a, b);
+  const double* Za = Z + (size_t)a * M * d; const double* Zb = Z + (size_t)b * M * d;
+  for (int idx = lane; idx < n * d; idx += nl) { Zra[idx] = Za[(size_t)m0 * d + idx]; Zcb[idx] = Zb[(size_t)m0 * d + idx]; }
+  if (latent) {
+    const double* Pa = latmat + (size_t)a * lat;
+    for (int k = lane; k < d; k += nl) {
+      double s = 0.0;
+      for (int l = 0; l < d; ++l) s = fma(Pa[k * d + l], g_cross[l * L + a], s);
+      v0[k] = s;
+    }
+    c.sync();
+    double pvmu = 0.0;
+    for (int k = 0; k < d; ++k) pvmu = fma(v0[k], mu[k], pvmu);
+    const double gfa = g_f1[a], gdiag = gpair(a);
+    for (int i = lane; i < n; i += nl) {
+      cA[i] = mma_gp_latent_coef(a, m0 + i, L, Mp, d, P, with_unc, have_pagg, Za, v0, pvmu, gfa, gdiag, gpair, w + (size_t)a * Mp,
+                                 q + (size_t)a * Mp, col, row);
+      cB[i] = w[(size_t)a * Mp + m0 + i];
+    }
+  } else {
+    const int p = item - L;
+    const double* colp = col + (size_t)p * (3 + d) * Mp;
+    const double* Rsum = p < L ? colp : row + (size_t)(p - L) * 2 * Mp;
+    for (int i = lane; i < n; i += nl) { cA[i] = Rsum[m0 + i]; cB[i] = colp[m0 + i]; }
+    for (int idx = lane; idx < d * n; idx += nl) { const int k = idx / n, i = idx - k * n; Uc[idx] = colp[(size_t)(3 + k) * Mp + m0 + i]; }
+  }
+  c.sync();
+  const int nq = d * d + d;
+  for (int idx = lane; idx < ns * nc; idx += nl) {
+    const int k = idx % nc, sl = idx / nc;
+    const int i = k <= d ? k - 1 : (k - 1 - d) / d, j = k <= d ? 0 : (k - 1 - d) % d;
+    // X / u column k < nq: X[i2][j2] = sum U_i2 z'_j2 (k < d^2), u[i2] = sum U_i2
+    const int i2 = k < d * d ? k / d : k - d * d, j2 = k < d * d ? k % d : 0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int m = sl; m < n; m += ns) {
+      const double fa = k == 0 ? 1.0 : k <= d ? Zra[m * d + i] : Zra[m * d + i] * Zra[m * d + j];
+      const double fb = k == 0 ? 1.0 : k <= d ? Zcb[m * d + i] : Zcb[m * d + i] * Zcb[m * d + j];
+      s0 = fma(cA[m], fa, s0);
+      s1 = fma(cB[m], fb, s1);
+      if (!latent && k < nq) s2 = fma(Uc[i2 * n + m], k < d * d ? Zcb[m * d + j2] : 1.0, s2);
+    }
+    part[idx] = s0; part[ns * nc + idx] = s1; part[2 * ns * nc + idx] = s2;
+  }
+  c.sync();
+  for (int k = lane; k < 3 * nc; k += nl) {
+    const int which = k / nc, kk = k - which * nc;
+    double s = 0.0;
+    for (int t = 0; t < ns; ++t) s += part[which * ns * nc + t * nc + kk];
+    out[k] = s;
+  }
+  c.sync();
+}
+
 MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P, bool with_unc,
                             const double* Z, const double* ls2, const double* mu, const double* Sigma, const double* latmat,
                             const double* w, const double* q, const double* col, const double* row,
                             const double* g_f1, const double* g_Sff, int full_cov, const double* g_cross,
                             double* gS_item, double* gmu_item, double* cbuf, double* sm, bool* ok,
-                            const double* pagg = nullptr, const double* f1raw = nullptr) {
+                            const double* pagg = nullptr, const double* f1raw = nullptr,
+                            const double* pre = nullptr, int nchunk = 0) {
   const int lane = c.lane(), nl = c.nl(), dp = d + 1, msz = d * dp, nc = mma_gp_ncol(d), ns = mma_gp_nslice(d, nl);
   const int Po = P - L, lat = 2 * d * d + 2, na = mma_pair_agg_len(d);
   double* part = sm;                        // [3][ns][nc]
@@ -989,6 +1113,15 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
   auto second = [&](const double* mm, int i, int j) -> double {
     return mm[1 + d + i * d + j] - mm[1 + i] * mu[j] - mu[i] * mm[1 + j] + mm[0] * mu[i] * mu[j];
   };
+  // pre != nullptr: the moment sums come as nchunk partials [nchunk][3 nc] of mma_gp_item_moments
+  auto from_partials = [&]() {
+    for (int k = lane; k < 3 * nc; k += nl) {
+      double sacc = 0.0;
+      for (int ch = 0; ch < nchunk; ++ch) sacc += pre[(size_t)ch * 3 * nc + k];
+      (k < nc ? mom0[k] : k < 2 * nc ? mom1[k - nc] : mom2[k - 2 * nc]) = sacc;
+    }
+    c.sync();
+  };
   if (item < L) {
     // ---- latent a: F_a = c0 lognorm - 1/2 <Pa, C2(mu)> + v^T Pa s - w0 (Pa v)^T mu --------------------------------------
     const int a = item;
@@ -1005,24 +1138,15 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
     double pvmu = 0.0;
     for (int k = 0; k < d; ++k) pvmu = fma(v0[k], mu[k], pvmu);
     const double gfa = g_f1[a], gdiag = gpair(a);
-    for (int m = lane; m < M; m += nl) {
-      double e = -pvmu;
-      for (int k = 0; k < d; ++k) e = fma(Za[(size_t)m * d + k], v0[k], e);
-      double pw = 2.0 * gdiag * col[((size_t)a * (3 + d) + 1) * Mp + m];         // diagonal pair: rsum = csum
-      if (!pagg) {
-        for (int p = L; p < P; ++p) {
-          int r, s2; mma_decode_pair(p, L, r, s2);
-          if (r == a) pw = fma(gpair(p), row[((size_t)(p - L) * 2 + 1) * Mp + m], pw);
-          else if (s2 == a) pw = fma(gpair(p), col[((size_t)p * (3 + d) + 1) * Mp + m], pw);
-        }
-      }
-      double cm = (gfa + e + pw) * wa[m];
-      if (with_unc) cm = fma(2.0 * gdiag * col[((size_t)a * (3 + d) + 2) * Mp + m], qa[m], cm);
-      cbuf[m] = cm;
+    if (pre) {
+      from_partials();
+    } else {
+      for (int m = lane; m < M; m += nl)
+        cbuf[m] = mma_gp_latent_coef(a, m, L, Mp, d, P, with_unc, pagg != nullptr, Za, v0, pvmu, gfa, gdiag, gpair, wa, qa, col, row);
+      c.sync();
+      mma_raw_moments(c, M, d, Za, cbuf, part, mom0);       // cmom
+      mma_raw_moments(c, M, d, Za, wa, part, mom1);         // wmom
     }
-    c.sync();
-    mma_raw_moments(c, M, d, Za, cbuf, part, mom0);       // cmom
-    mma_raw_moments(c, M, d, Za, wa, part, mom1);         // wmom
     const double w0 = mom1[0];
     // the off-diagonal pairs' share of the coefficient moments, from the aggregates: with E = e - 1,
     //   sum_ij w_i w'_j E_ij phi(zeta_i) = sum_ij Omega_ij phi(zeta_i) - (sum_i w_i phi(zeta_i)) (sum_j w'_j)
@@ -1102,6 +1226,8 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
     if (lane == 0) { mom0[0] = ag[0]; mom1[0] = ag[0]; }
     c.sync();
   } else {
+  if (pre) from_partials();
+  else {
   mma_raw_moments(c, M, d, Za, Rsum, part, mom0);        // Rmom
   mma_raw_moments(c, M, d, Zb, Ksum, part, mom1);        // Kmom
   // X [d, d] = sum_j U_j z'_j^T, u [d] = sum_j U_j  (into mom2: X at [0, d^2), u at [d^2, d^2 + d))
@@ -1127,6 +1253,7 @@ MMA_FN void mma_gp_item_bwd(Ctx c, int item, int L, int M, int Mp, int d, int P,
       mom2[k] = s;
     }
     c.sync();
+  }
   }
   // centre at mu: XC = X - u mu^T (in place; u is copied out first)
   for (int k = lane; k < d; k += nl) {

@@ -27,7 +27,7 @@
 #include "mm_f32_tile.h"
 #include "mm_adjoint.h"
 
-#define MMR_BS 65            // LDS row stride (floats) of the per-wave B_i[slot] image
+#define MMR_BS 33            // LDS row stride (floats) of the per-wave B_i[slot] image (32 slots at a time)
 
 __device__ __forceinline__ void mmr_decode_pair_o(int p, int L, int& a, int& a2) {
   int r = p - L, i = 0;
@@ -45,29 +45,26 @@ __device__ __forceinline__ f32x2 mmr_unpk_bf16(unsigned int u) {
   return (f32x2){__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
 }
 
-// v = w * x^3 * R_DEG(x) per entry (16 register pairs of a 64 x 32 wave tile; wq: the 8 column-weight pairs of a row tile)
+// v = w * x^3 * R_DEG(x) per entry of one 32 x 32 block (8 register pairs per lane; wq: the 8 column-weight pairs)
 template <int DEG>
-__device__ __forceinline__ void mmr_rem_entries(const f32x2 (&xx)[16], const f32x2 (&wq)[8], f32x2 (&v)[16]) {
+__device__ __forceinline__ void mmr_rem_entries(const f32x2 (&xx)[8], const f32x2 (&wq)[8], f32x2 (&v)[8]) {
+  f32x2 pp[8];
 #pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    f32x2 pp[8];
+  for (int r = 0; r < 8; ++r) pp[r] = mm_pkfma(MM_PK(MMRem<DEG>::c[DEG]), xx[r], MM_PK(MMRem<DEG>::c[DEG - 1]));
 #pragma unroll
-    for (int r = 0; r < 8; ++r) pp[r] = mm_pkfma(MM_PK(MMRem<DEG>::c[DEG]), xx[8 * hh + r], MM_PK(MMRem<DEG>::c[DEG - 1]));
+  for (int k = DEG - 2; k >= 0; --k)
 #pragma unroll
-    for (int k = DEG - 2; k >= 0; --k)
+    for (int r = 0; r < 8; ++r) pp[r] = mm_pkfma(pp[r], xx[r], MM_PK(MMRem<DEG>::c[k]));
 #pragma unroll
-      for (int r = 0; r < 8; ++r) pp[r] = mm_pkfma(pp[r], xx[8 * hh + r], MM_PK(MMRem<DEG>::c[k]));
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const f32x2 wx = wq[r] * xx[8 * hh + r];
-      const f32x2 tv = (xx[8 * hh + r] * xx[8 * hh + r]) * pp[r];
-      v[8 * hh + r] = tv * wx;
-    }
+  for (int r = 0; r < 8; ++r) {
+    const f32x2 wx = wq[r] * xx[r];
+    const f32x2 tv = (xx[r] * xx[r]) * pp[r];
+    v[r] = tv * wx;
   }
 }
 
 // grid: 1-D over (b, off-diagonal pair, 256-row panel), XCD-remapped.  slab [B][Po][npanel][nT] f64 (ASSIGNED).
-__global__ __launch_bounds__(256, 1) void k_bwd_rem_f32(const unsigned short* __restrict__ Zs3, const unsigned short* __restrict__ Zq2,
+__global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __restrict__ Zs3, const unsigned short* __restrict__ Zq2,
                                                         const double* __restrict__ Zc64, int Kz, const double* __restrict__ zbar,
                                                         const float* __restrict__ mu, int L, int Mp, int d, int Po, int npanel,
                                                         int nwork, const float* __restrict__ rowO, const float* __restrict__ colO,
@@ -130,140 +127,147 @@ __global__ __launch_bounds__(256, 1) void k_bwd_rem_f32(const unsigned short* __
     const unsigned int offA = (h ? 0u : 1u) * 512u + (unsigned int)l31 * 16u;
     const unsigned int offB = (h ? 0u : 2u) * 512u + (unsigned int)l31 * 16u;
     const int nct = Mp >> 5;
-    struct Tile { u32x4 zA, zB, psi[8]; float4 wc[4]; };
-    auto load_tile = [&](int ct, Tile& t) {
-      t.zA = *reinterpret_cast<const u32x4*>(zbase + (size_t)ct * 1536 + offA);
-      t.zB = *reinterpret_cast<const u32x4*>(zbase + (size_t)ct * 1536 + offB);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) t.psi[i] = *reinterpret_cast<const u32x4*>(qbase + (size_t)ct * 8192 + i * 1024 + lane * 16);
-#pragma unroll
-      for (int g = 0; g < 4; ++g) t.wc[g] = *reinterpret_cast<const float4*>(wcf + ct * 32 + 8 * g + 4 * h);
+    const bool two_nb = 1 + d + d * (d + 1) / 2 > 32;
+    // the split inputs of the next tile are prefetched (first thing a tile needs); the monomial images and the column
+    // weights of a tile are requested at its top and consumed after its bilinear product and polynomial
+    auto load_z = [&](int ct, u32x4& zA, u32x4& zB) {
+      zA = *reinterpret_cast<const u32x4*>(zbase + (size_t)ct * 1536 + offA);
+      zB = *reinterpret_cast<const u32x4*>(zbase + (size_t)ct * 1536 + offB);
     };
-    auto process = [&](const Tile& t) {
-      // b tile, TRANSPOSED: A slot = the streamed columns, B slot = the stationary rows -> lane = row, registers = columns
-      f32x16 acc[2];
+    auto process = [&](int ct, const u32x4& zA, const u32x4& zB) {
+      u32x4 psi[8];
+      float4 wc[4];
+#ifndef MMR_EXP
+#define MMR_EXP 0
+#endif
+#pragma unroll
+      for (int i = 0; i < 8; ++i) psi[i] = *reinterpret_cast<const u32x4*>(qbase + (size_t)(MMR_EXP == 1 ? 0 : ct) * 8192 + i * 1024 + lane * 16);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) wc[g] = *reinterpret_cast<const float4*>(wcf + ct * 32 + 8 * g + 4 * h);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
-        f32x16 c = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, t.zA), a3[rt], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, t.zA), a1[rt], c, 0, 0, 0);
-        acc[rt] = c;
-      }
-      float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // b block, TRANSPOSED: A slot = the streamed columns, B slot = the stationary rows -> lane = row, registers = columns
+        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, zA), a3[rt], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, zA), a1[rt], acc, 0, 0, 0);
+        float m4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        m4[r & 3] = fmaxf(fmaxf(m4[r & 3], fabsf(acc[r >> 3][2 * (r & 7)])), fabsf(acc[r >> 3][2 * (r & 7) + 1]));
-      const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-      if (__any(mx > 0.03125f)) {
+        for (int r = 0; r < 8; ++r) m4[r & 3] = fmaxf(fmaxf(m4[r & 3], fabsf(acc[2 * r])), fabsf(acc[2 * r + 1]));
+        const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        if (__any(mx > 0.03125f))
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, zB), a2v[rt], acc, 0, 0, 0);
+        f32x2 xx[8], v[8], wq[8];
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, t.zB), a2v[rt], acc[rt], 0, 0, 0);
-      }
-      f32x2 xx[16], v[16], wq[8];
+        for (int r = 0; r < 8; ++r) xx[r] = (f32x2){acc[2 * r], acc[2 * r + 1]};
 #pragma unroll
-      for (int r = 0; r < 16; ++r) xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
+        for (int g = 0; g < 4; ++g) { wq[2 * g] = (f32x2){wc[g].x, wc[g].y}; wq[2 * g + 1] = (f32x2){wc[g].z, wc[g].w}; }
+        // range tier of the 32 x 32 block (wave-uniform, ballots)
+        if (!__any(mx > MM_TIER1_MAX)) mmr_rem_entries<1>(xx, wq, v);
+        else if (!__any(mx > 0.25f)) mmr_rem_entries<3>(xx, wq, v);
+        else if (!__any(mx > 0.5f)) mmr_rem_entries<4>(xx, wq, v);
+        else if (!__any(mx > 1.0f)) mmr_rem_entries<5>(xx, wq, v);
+        else {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) { wq[2 * g] = (f32x2){t.wc[g].x, t.wc[g].y}; wq[2 * g + 1] = (f32x2){t.wc[g].z, t.wc[g].w}; }
-      if (!__any(mx > MM_TIER1_MAX)) mmr_rem_entries<1>(xx, wq, v);
-      else if (!__any(mx > 0.25f)) mmr_rem_entries<3>(xx, wq, v);
-      else if (!__any(mx > 0.5f)) mmr_rem_entries<4>(xx, wq, v);
-      else if (!__any(mx > 1.0f)) mmr_rem_entries<5>(xx, wq, v);
-      else {
+          for (int r = 0; r < 8; ++r)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-          for (int e2 = 0; e2 < 2; ++e2) {
-            const float x = xx[r][e2];
-            const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
-            const float big = (__builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f) - fmaf(0.5f * x, x, x);
-            v[r][e2] = wq[r & 7][e2] * ((fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big);
-          }
-      }
-      // bf16 (hi, lo) of V, packed as the A operand: K slot t of product s = register 8 s + t of the row tile
-      u32x4 vh[2][2], vl[2][2];
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
+            for (int e2 = 0; e2 < 2; ++e2) {
+              const float x = xx[r][e2];
+              const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
+              const float big = (__builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f) - fmaf(0.5f * x, x, x);
+              v[r][e2] = wq[r][e2] * ((fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big);
+            }
+        }
+        // bf16 (hi, lo) of V, packed as the A operand: K slot t of product s = register 8 s + t of the block
+        u32x4 vh[2], vl[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const f32x2 val = v[8 * rt + 4 * s + q];
+            const f32x2 val = v[4 * s + q];
             const unsigned int hi = mmr_pk_bf16(val);
-            vh[rt][s][q] = hi;
-            vl[rt][s][q] = mmr_pk_bf16(val - mmr_unpk_bf16(hi));
+            vh[s][q] = hi;
+            vl[s][q] = mmr_pk_bf16(val - mmr_unpk_bf16(hi));
           }
-      // B_i[slot] += V psi: hi.hi + lo.hi + hi.lo, four independent accumulator chains
+        // B_i[slot] += V psi: hi.hi + lo.hi + hi.lo, alternating between the two accumulator chains of the row tile
 #pragma unroll
-      for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int term = 0; term < 3; ++term)
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt)
+          for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-              const u32x4 av = term == 1 ? vl[rt][s] : vh[rt][s];
-              const u32x4 bv = t.psi[(s * 2 + nb) * 2 + (term == 2 ? 1 : 0)];
+              if (nb == 1 && !two_nb) continue;             // d <= 6: the monomials fit one 32-slot block
+              if (MMR_EXP == 2 && (s > 0 || term > 0)) continue;
+              if (MMR_EXP == 3 && term > 0) continue;
+              const u32x4 av = term == 1 ? vl[s] : vh[s];
+              const u32x4 bv = psi[(s * 2 + nb) * 2 + (term == 2 ? 1 : 0)];
               acc2[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
                                                                      acc2[rt][nb], 0, 0, 0);
             }
+      }
     };
-    Tile t0, t1;
-    load_tile(0, t0);
+    u32x4 zA0, zB0, zA1, zB1;
+    load_z(0, zA0, zB0);
     for (int ct = 0; ct < nct; ct += 2) {          // nct is even (Mp % 128 == 0)
-      load_tile(ct + 1, t1);
-      process(t0);
-      load_tile(ct + 2 < nct ? ct + 2 : ct, t0);   // clamped: the last pass re-reads its own tile
-      process(t1);
+      load_z(ct + 1, zA1, zB1);
+      process(ct, zA0, zB0);
+      load_z(ct + 2 < nct ? ct + 2 : ct, zA0, zB0);   // clamped: the last pass re-reads its own tile
+      process(ct + 1, zA1, zB1);
     }
   }
 
   // ---- epilogue: T_rem[alpha, slot] = sum_i what_i zeta_i^alpha B_i[slot] over the wave's rows, f64 ----------------------------
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r)
-        Bm[(32 * rt + 8 * (r >> 2) + 4 * h + (r & 3)) * MMR_BS + 32 * nb + l31] = acc2[rt][nb][r];
   {
     const int row = row0 + lane;
     for (int k = 0; k < d; ++k)
       zr[lane * (d + 1) + k] = live ? Zc64[((size_t)a * Mp + row) * Kz + k] - ((double)mu[(size_t)b * d + k] - zbar[a * d + k]) : 0.0;
     zr[lane * (d + 1) + d] = live ? whR[((size_t)b * Po + lp) * Mp + row] : 0.0;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   const int nslot = 1 + d + d * (d + 1) / 2, n1 = d * (d + 1), ncomb = nslot + n1 + d * d;
   const int oR1 = 1, oR2 = 1 + d, oK1 = 1 + d + d * d, oK2 = 1 + 2 * d + d * d, oXC = 1 + 2 * d + 2 * d * d;
-  for (int c = lane; c < ncomb; c += 64) {
-    int kind, k = 0, k2 = 0, slot;
-    if (c < nslot) { kind = 0; slot = c; }
-    else if (c < nslot + n1) { kind = 1; k = (c - nslot) / (d + 1); slot = (c - nslot) - k * (d + 1); }
-    else { kind = 2; k = (c - nslot - n1) / d; k2 = (c - nslot - n1) - k * d; slot = 0; }
-    double acc = 0.0;
-    for (int row = 0; row < 64; ++row) {
-      const double* zi = zr + row * (d + 1);
-      double wz = zi[d];
-      if (kind >= 1) wz *= zi[k];
-      if (kind == 2) wz *= zi[k2];
-      acc = fma(wz, (double)Bm[row * MMR_BS + slot], acc);
-    }
-    if (kind == 0) {
-      if (slot == 0) Tw[0] = acc;
-      else if (slot <= d) Tw[oK1 + slot - 1] = acc;
-      else {
-        int qq = slot - 1 - d, l0 = 0;
-        while (qq >= d - l0) { qq -= d - l0; ++l0; }
-        const int l1 = l0 + qq;
-        Tw[oK2 + l0 * d + l1] = acc;
-        Tw[oK2 + l1 * d + l0] = acc;
+  auto wave_sync = [] {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {              // 32 slots at a time through the wave's LDS image
+    if (nb == 1 && nslot <= 32) break;
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Bm[(32 * rt + 8 * (r >> 2) + 4 * h + (r & 3)) * MMR_BS + l31] = acc2[rt][nb][r];
+    wave_sync();
+    for (int c = lane; c < ncomb; c += 64) {
+      int kind, k = 0, k2 = 0, slot;
+      if (c < nslot) { kind = 0; slot = c; }
+      else if (c < nslot + n1) { kind = 1; k = (c - nslot) / (d + 1); slot = (c - nslot) - k * (d + 1); }
+      else { kind = 2; k = (c - nslot - n1) / d; k2 = (c - nslot - n1) - k * d; slot = 0; }
+      if ((slot >> 5) != nb) continue;
+      double acc = 0.0;
+      for (int row = 0; row < 64; ++row) {
+        const double* zi = zr + row * (d + 1);
+        double wz = zi[d];
+        if (kind >= 1) wz *= zi[k];
+        if (kind == 2) wz *= zi[k2];
+        acc = fma(wz, (double)Bm[row * MMR_BS + (slot & 31)], acc);
       }
-    } else if (kind == 1) {
-      if (slot == 0) Tw[oR1 + k] = acc; else Tw[oXC + k * d + slot - 1] = acc;
-    } else {
-      Tw[oR2 + k * d + k2] = acc;
+      if (kind == 0) {
+        if (slot == 0) Tw[0] = acc;
+        else if (slot <= d) Tw[oK1 + slot - 1] = acc;
+        else {
+          int qq = slot - 1 - d, l0 = 0;
+          while (qq >= d - l0) { qq -= d - l0; ++l0; }
+          const int l1 = l0 + qq;
+          Tw[oK2 + l0 * d + l1] = acc;
+          Tw[oK2 + l1 * d + l0] = acc;
+        }
+      } else if (kind == 1) {
+        if (slot == 0) Tw[oR1 + k] = acc; else Tw[oXC + k * d + slot - 1] = acc;
+      } else {
+        Tw[oR2 + k * d + k2] = acc;
+      }
     }
+    wave_sync();
   }
   __syncthreads();
   const double* Tall = reinterpret_cast<const double*>(smem + (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8);
@@ -275,10 +279,11 @@ static size_t mmr_rem_lds_bytes(int d) {
   return (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * mma_pair_agg_len(d) * 8;
 }
 
-// grid (Po, B), 256 threads: polynomial part + remainder slabs, re-centred at mu -> pagg [B][Po][nT]
-__global__ __launch_bounds__(256) void k_pair_agg(const double* __restrict__ mom, int KMp, const double* __restrict__ pairmat,
+// grid (Po, B), 512 threads: polynomial part + remainder slabs, re-centred at mu -> pagg [B][Po][nT]
+__global__ __launch_bounds__(512) void k_pair_agg(const double* __restrict__ mom, int KMp, const double* __restrict__ pairmat,
                                                   const double* __restrict__ zbar, const float* __restrict__ mu, int L, int d,
-                                                  int P, int npanel, const double* __restrict__ slab, double* __restrict__ pagg) {
+                                                  int P, int npanel, const double* __restrict__ slab,
+                                                  const short* __restrict__ rtab, double* __restrict__ pagg) {
   extern __shared__ double smd[];
   const int po = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, Po = P - L, p = L + po;
   int a, a2;
@@ -294,14 +299,14 @@ __global__ __launch_bounds__(256) void k_pair_agg(const double* __restrict__ mom
   {
     const double* nm = mom + (((size_t)b * Po + po) * 2 + 0) * MM_MOM_SPLIT * KMp;
     const double* qm = mom + (((size_t)b * Po + po) * 2 + 1) * MM_MOM_SPLIT * KMp;
-    for (int k = tid; k < KMp; k += 256) {
+    for (int k = tid; k < KMp; k += blockDim.x) {
       double sn = 0.0, sq = 0.0;
 #pragma unroll
       for (int t = 0; t < MM_MOM_SPLIT; ++t) { sn += nm[t * KMp + k]; sq += qm[t * KMp + k]; }
       nh[k] = sn; qh[k] = sq;
     }
     const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
-    for (int idx = tid; idx < d * d; idx += 256) G[idx] = pm[idx];
+    for (int idx = tid; idx < d * d; idx += blockDim.x) G[idx] = pm[idx];
     if (tid < d) {
       const double m = (double)mu[(size_t)b * d + tid];
       dmu[tid] = m - zbar[a * d + tid];
@@ -309,9 +314,9 @@ __global__ __launch_bounds__(256) void k_pair_agg(const double* __restrict__ mom
     }
   }
   __syncthreads();
-  mma_pair_poly(MMADevCtx(), d, G, dmu, nh, qh, T, scr);
+  mma_pair_poly(MMADevCtx(), d, G, dmu, nh, qh, T, scr, rtab);
   const double* sl = slab + ((size_t)b * Po + po) * npanel * nT;
-  for (int idx = tid; idx < nT; idx += 256) {
+  for (int idx = tid; idx < nT; idx += blockDim.x) {
     double s = 0.0;
     for (int pn = 0; pn < npanel; ++pn) s += sl[(size_t)pn * nT + idx];
     T[idx] += s;
@@ -320,7 +325,7 @@ __global__ __launch_bounds__(256) void k_pair_agg(const double* __restrict__ mom
   mma_pair_convert(MMADevCtx(), d, dmu2, T);
   __syncthreads();
   double* o = pagg + ((size_t)b * Po + po) * nT;
-  for (int idx = tid; idx < nT; idx += 256) o[idx] = T[idx];
+  for (int idx = tid; idx < nT; idx += blockDim.x) o[idx] = T[idx];
 }
 
 __global__ void k_cast_f32_f64(const float* __restrict__ x, double* __restrict__ y, size_t n) {
@@ -360,9 +365,9 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
   const size_t shm2 = (size_t)(2 * ml.KMp + d * d + 2 * d + nT + mma_pair_poly_scratch(d)) * sizeof(double);
   e = hipFuncSetAttribute((const void*)k_pair_agg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k_pair_agg, dim3(wl.Po, B), dim3(256), shm2, stream, (const double*)(ws + wl.mom), ml.KMp,
+  hipLaunchKernelGGL(k_pair_agg, dim3(wl.Po, B), dim3(512), shm2, stream, (const double*)(ws + wl.mom), ml.KMp,
                      (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), mu, L, d, wl.P, npanel,
-                     (const double*)slab, pagg);
+                     (const double*)slab, (const short*)(packed + ml.rtab), pagg);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

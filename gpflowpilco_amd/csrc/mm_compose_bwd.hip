@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void k_gp_bwd_items(int L, int M, int Mp, int 
                                                       const double* __restrict__ q, const double* __restrict__ col,
                                                       const double* __restrict__ row, int col_pairs,
                                                       const double* __restrict__ pagg, const double* __restrict__ f1raw,
+                                                      const double* __restrict__ pre, int nchunk, int nmom,
                                                       const double* __restrict__ g_f1,
                                                       const double* __restrict__ g_Sff, const double* __restrict__ g_cross,
                                                       double* __restrict__ items, double* __restrict__ cbuf, int32_t* status) {
@@ -62,8 +63,36 @@ __global__ __launch_bounds__(256) void k_gp_bwd_items(int L, int M, int Mp, int 
                   col + (size_t)b * col_pairs * (3 + d) * Mp, row + (size_t)b * Po * 2 * Mp, g_f1 + (size_t)b * L,
                   g_Sff + (size_t)b * nsff, full_cov, g_cross + (size_t)b * d * L, out, out + d * d,
                   cbuf + ((size_t)b * L + (item < L ? item : 0)) * Mp, sm, &ok,
-                  pagg ? pagg + (size_t)b * Po * mma_pair_agg_len(d) : nullptr, f1raw + (size_t)b * L);
+                  pagg ? pagg + (size_t)b * Po * mma_pair_agg_len(d) : nullptr, f1raw + (size_t)b * L,
+                  (pre && item < nmom) ? pre + ((size_t)b * nmom + item) * nchunk * 3 * mma_gp_ncol(d) : nullptr, nchunk);
   if (!ok && threadIdx.x == 0 && status) { atomicMax(status, (int)gridDim.y - b); status[1] = item; }
+}
+
+// Partial moment sums of the items over chunks of centres (mma_gp_item_moments): grid (nchunk, nmom, B), 256 threads;
+// nmom = L + (pagg ? L : P) items need moments (latents, then pairs -- with aggregates only the diagonal pairs).
+// pre [B][nmom][nchunk][3 nc].  For M >= 512 the items kernel's own loops over all centres (one workgroup per item) were
+// 0.6 ms at C3 shape; 8 chunks x 16 items x B workgroups do the same sums from LDS-staged tiles.
+__global__ __launch_bounds__(256) void k_gp_bwd_moments(int L, int M, int Mp, int d, int P, int with_unc, int full_cov, int chunk,
+                                                        const double* __restrict__ Z, const double* __restrict__ mu,
+                                                        const double* __restrict__ latmat, const double* __restrict__ w,
+                                                        const double* __restrict__ q, const double* __restrict__ col,
+                                                        const double* __restrict__ row, int col_pairs, int have_pagg,
+                                                        const double* __restrict__ g_f1, const double* __restrict__ g_Sff,
+                                                        const double* __restrict__ g_cross, double* __restrict__ pre) {
+  extern __shared__ double sm[];
+  const int ch = blockIdx.x, item = blockIdx.y, b = blockIdx.z, Po = P - L, nsff = full_cov ? L * L : L, nc = mma_gp_ncol(d);
+  const int m0 = ch * chunk, m1 = m0 + chunk < M ? m0 + chunk : M;
+  double* out = pre + (((size_t)b * gridDim.y + item) * gridDim.x + ch) * 3 * nc;
+  mma_gp_item_moments(MMADevCtx(), item, m0, m1, L, M, Mp, d, P, with_unc != 0, Z, mu + (size_t)b * d,
+                      latmat + (size_t)b * L * (2 * d * d + 2), w + (size_t)b * L * Mp, q + (size_t)b * L * Mp,
+                      col + (size_t)b * col_pairs * (3 + d) * Mp, row + (size_t)b * Po * 2 * Mp, g_f1 + (size_t)b * L,
+                      g_Sff + (size_t)b * nsff, full_cov, g_cross + (size_t)b * d * L, have_pagg != 0, out, sm);
+}
+
+// chunk of centres per workgroup of k_gp_bwd_moments (0: the items kernel sums over the centres itself)
+static inline int mm_gp_moment_chunk(int M, int d) {
+  if (M < 512 || d > 16) return 0;
+  return d <= 8 ? 256 : 128;
 }
 
 // grid B, 64 threads: gmu [B][d] = sum of the items; gS [B][d][d] (+)= the symmetrised sum.
@@ -85,7 +114,7 @@ __global__ __launch_bounds__(64) void k_gp_bwd_sum(int nitems, int d, const doub
 }
 
 struct MMGpBwdLayout {
-  size_t sums, items, cbuf, f1, cross, slab, pagg, mu64, S64, total;
+  size_t sums, items, cbuf, f1, cross, slab, pagg, mu64, S64, pre, total;
 };
 // dtype MM_F64: the sums of all P pairs; MM_F32 (d <= 8): the L diagonal pairs' sums, the off-diagonal pairs' remainder slabs
 // and aggregates (mm_bwd_f32.hip), and f64 copies of the f32 state
@@ -104,6 +133,8 @@ static inline MMGpBwdLayout mm_gp_bwd_layout(int B, int L, int M, int d, int dty
   o.pagg = off;  off = mm_align_up(off + (f32 ? (size_t)B * Po * mma_pair_agg_len(d) * 8 : 0), A);
   o.mu64 = off;  off = mm_align_up(off + (f32 ? (size_t)B * d * 8 : 0), A);
   o.S64 = off;   off = mm_align_up(off + (f32 ? (size_t)B * d * d * 8 : 0), A);
+  const int chunk = mm_gp_moment_chunk(M, d);
+  o.pre = off;   off = mm_align_up(off + (chunk ? (size_t)B * (L + P) * ((M + chunk - 1) / chunk) * 3 * mma_gp_ncol(d) * 8 : 0), A);
   o.total = off;
   return o;
 }
@@ -181,11 +212,24 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     hipError_t ea = hipFuncSetAttribute((const void*)k_gp_bwd_items, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     if (ea != hipSuccess) return (int)ea;
   }
+  const int chunk = mm_gp_moment_chunk(M, d), nchunk = chunk ? (M + chunk - 1) / chunk : 0;
+  const int nmom = L + (pagg ? L : P);
+  const double* pre = nullptr;
+  if (chunk) {
+    const size_t shm_m = (size_t)mma_gp_moments_scratch(d, 256, chunk) * sizeof(double);
+    hipLaunchKernelGGL(k_gp_bwd_moments, dim3(nchunk, nmom, B), dim3(256), shm_m, s, L, M, Mp, d, P, with_unc ? 1 : 0,
+                       (flags & MM_FULL_OUTPUT_COV) ? 1 : 0, chunk, (const double*)(pk + ml.Z64), mu64,
+                       (const double*)(ws + wl.latmat), (const double*)(ws + wl.w64), (const double*)(ws + wl.q64), col, row,
+                       col_pairs, pagg ? 1 : 0, (const double*)g_f1, (const double*)g_Sff, (const double*)g_cross,
+                       (double*)(bw + bl.pre));
+    MMB_CHECK();
+    pre = (const double*)(bw + bl.pre);
+  }
   hipLaunchKernelGGL(k_gp_bwd_items, dim3(L + P, B), dim3(256), shm, s, L, M, Mp, d, P, with_unc ? 1 : 0,
                      (flags & MM_FULL_OUTPUT_COV) ? 1 : 0, (const double*)(pk + ml.Z64), (const double*)(pk + ml.ls2),
                      mu64, S64, (const double*)(ws + wl.latmat), (const double*)(ws + wl.w64),
                      (const double*)(ws + wl.q64), col, row, col_pairs, pagg, (const double*)(ws + wl.f1raw),
-                     (const double*)g_f1, (const double*)g_Sff, (const double*)g_cross,
+                     pre, nchunk, nmom, (const double*)g_f1, (const double*)g_Sff, (const double*)g_cross,
                      (double*)(bw + bl.items), (double*)(bw + bl.cbuf), status);
   MMB_CHECK();
   if (skip_sum) return 0;                                   // the consumer sums the items itself (k_policy_head_bwd_small)

@@ -2,6 +2,7 @@
 // INFRASTRUCTURE ONLY.  tests/test_adjoint_host.py loads it to check the hand-derived adjoints against autograd and
 // finite differences without a GPU; nothing under gpflowpilco_amd/ loads or links it, and the product library holds
 // no host path.
+#include <algorithm>
 #include <vector>
 #include "../../gpflowpilco_amd/csrc/mm_adjoint.h"
 
@@ -45,16 +46,31 @@ extern "C" int hc_policy_small_bwd(int M, int d, const double* Z, const double* 
   return ok ? 0 : 1;
 }
 
-// all P + L items of one batch element, summed and symmetrised (what k_gp_bwd_items + k_gp_bwd_sum do on the device)
-extern "C" int hc_gp_bwd(int L, int M, int Mp, int d, int full_cov, int with_unc, const double* Z, const double* ls2, const double* mu,
-                         const double* Sigma, const double* latmat, const double* w, const double* q, const double* col,
-                         const double* row, const double* g_f1, const double* g_Sff, const double* g_cross, double* gmu, double* gS) {
-  const int P = full_cov ? L * (L + 1) / 2 : L;
+// all P + L items of one batch element, summed and symmetrised (what k_gp_bwd_items + k_gp_bwd_sum do on the device).
+// pagg != nullptr: the off-diagonal pairs as aggregates (col then holds the L diagonal pairs only).
+// chunk > 0: the moment sums of every item first as partials over chunks of that many centres (k_gp_bwd_moments).
+static int gp_bwd_all(int L, int M, int Mp, int d, int full_cov, int with_unc, const double* Z, const double* ls2, const double* mu,
+                      const double* Sigma, const double* latmat, const double* w, const double* q, const double* col,
+                      const double* row, const double* pagg, const double* f1raw, const double* g_f1, const double* g_Sff,
+                      const double* g_cross, int chunk, double* gmu, double* gS) {
+  const int P = full_cov ? L * (L + 1) / 2 : L, nc = mma_gp_ncol(d);
   std::vector<double> sm(mma_gp_item_scratch(d, 1) + 8), cbuf(M), gSi(d * d), gmi(d), accS(d * d, 0.0), accm(d, 0.0);
   bool ok = true;
   for (int item = 0; item < L + P; ++item) {
+    std::vector<double> pre;
+    int nchunk = 0;
+    const bool needs = item < L || !(pagg && item - L >= L);
+    if (chunk > 0 && needs) {
+      nchunk = (M + chunk - 1) / chunk;
+      pre.resize((size_t)nchunk * 3 * nc);
+      std::vector<double> ms(mma_gp_moments_scratch(d, 1, chunk) + 8);
+      for (int ch = 0; ch < nchunk; ++ch)
+        mma_gp_item_moments(MMAHostCtx(), item, ch * chunk, std::min(M, (ch + 1) * chunk), L, M, Mp, d, P, with_unc != 0, Z, mu, latmat,
+                            w, q, col, row, g_f1, g_Sff, full_cov, g_cross, pagg != nullptr, pre.data() + (size_t)ch * 3 * nc, ms.data());
+    }
     mma_gp_item_bwd(MMAHostCtx(), item, L, M, Mp, d, P, with_unc != 0, Z, ls2, mu, Sigma, latmat, w, q, col, row, g_f1, g_Sff,
-                    full_cov, g_cross, gSi.data(), gmi.data(), cbuf.data(), sm.data(), &ok);
+                    full_cov, g_cross, gSi.data(), gmi.data(), cbuf.data(), sm.data(), &ok, pagg, f1raw,
+                    nchunk ? pre.data() : nullptr, nchunk);
     for (int i = 0; i < d * d; ++i) accS[i] += gSi[i];
     for (int i = 0; i < d; ++i) accm[i] += gmi[i];
   }
@@ -62,22 +78,25 @@ extern "C" int hc_gp_bwd(int L, int M, int Mp, int d, int full_cov, int with_unc
   return ok ? 0 : 1;
 }
 
-// the same with the off-diagonal pairs given as aggregates (f32-model backward): col holds the L diagonal pairs only
+extern "C" int hc_gp_bwd(int L, int M, int Mp, int d, int full_cov, int with_unc, const double* Z, const double* ls2, const double* mu,
+                         const double* Sigma, const double* latmat, const double* w, const double* q, const double* col,
+                         const double* row, const double* g_f1, const double* g_Sff, const double* g_cross, double* gmu, double* gS) {
+  return gp_bwd_all(L, M, Mp, d, full_cov, with_unc, Z, ls2, mu, Sigma, latmat, w, q, col, row, nullptr, nullptr, g_f1, g_Sff, g_cross,
+                    0, gmu, gS);
+}
+extern "C" int hc_gp_bwd_chunked(int L, int M, int Mp, int d, int full_cov, int with_unc, const double* Z, const double* ls2,
+                                 const double* mu, const double* Sigma, const double* latmat, const double* w, const double* q,
+                                 const double* col, const double* row, const double* g_f1, const double* g_Sff,
+                                 const double* g_cross, int chunk, double* gmu, double* gS) {
+  return gp_bwd_all(L, M, Mp, d, full_cov, with_unc, Z, ls2, mu, Sigma, latmat, w, q, col, row, nullptr, nullptr, g_f1, g_Sff, g_cross,
+                    chunk, gmu, gS);
+}
 extern "C" int hc_gp_bwd_agg(int L, int M, int Mp, int d, int full_cov, int with_unc, const double* Z, const double* ls2, const double* mu,
                              const double* Sigma, const double* latmat, const double* w, const double* q, const double* col,
                              const double* pagg, const double* f1raw, const double* g_f1, const double* g_Sff, const double* g_cross,
-                             double* gmu, double* gS) {
-  const int P = full_cov ? L * (L + 1) / 2 : L;
-  std::vector<double> sm(mma_gp_item_scratch(d, 1) + 8), cbuf(M), gSi(d * d), gmi(d), accS(d * d, 0.0), accm(d, 0.0);
-  bool ok = true;
-  for (int item = 0; item < L + P; ++item) {
-    mma_gp_item_bwd(MMAHostCtx(), item, L, M, Mp, d, P, with_unc != 0, Z, ls2, mu, Sigma, latmat, w, q, col, nullptr, g_f1, g_Sff,
-                    full_cov, g_cross, gSi.data(), gmi.data(), cbuf.data(), sm.data(), &ok, pagg, f1raw);
-    for (int i = 0; i < d * d; ++i) accS[i] += gSi[i];
-    for (int i = 0; i < d; ++i) accm[i] += gmi[i];
-  }
-  for (int i = 0; i < d; ++i) { gmu[i] = accm[i]; for (int j = 0; j < d; ++j) gS[i * d + j] = 0.5 * (accS[i * d + j] + accS[j * d + i]); }
-  return ok ? 0 : 1;
+                             int chunk, double* gmu, double* gS) {
+  return gp_bwd_all(L, M, Mp, d, full_cov, with_unc, Z, ls2, mu, Sigma, latmat, w, q, col, nullptr, pagg, f1raw, g_f1, g_Sff, g_cross,
+                    chunk, gmu, gS);
 }
 
 // polynomial part of one off-diagonal pair's aggregates from the packed weight moments, then the re-centring

@@ -241,6 +241,12 @@ def test_gp_match_adjoint_from_the_M_sized_sums(hc, L, M, d, full, unc):
                     _p(gmu), _p(gS))
   assert rc == 0
   assert _rel(gmu, gmu_w.numpy()[0]) < 1e-10 and _rel(gS, _sym(gS_w.numpy()[0])) < 1e-10
+  # the same through partial moment sums over chunks of 7 centres (k_gp_bwd_moments on the device)
+  gmu2 = np.zeros(d); gS2 = np.zeros((d, d))
+  rc = hc.hc_gp_bwd_chunked(L, M, Mp, d, int(full), int(unc), _p(_c(Z)), _p(_c(ls * ls)), _p(_c(mu[0])), _p(_c(Sigma[0])), _p(_c(latmat)),
+                            _p(_c(wp)), _p(_c(qp)), _p(_c(col)), _p(_c(row)), _p(_c(g_f1[0])), _p(_c(g_Sff[0])), _p(_c(g_cross[0])),
+                            7, _p(gmu2), _p(gS2))
+  assert rc == 0 and _rel(gmu2, gmu) < 1e-12 and _rel(gS2, gS) < 1e-12
 
 
 @pytest.mark.parametrize("L,M,d,unc", [(3, 20, 4, True), (2, 33, 6, False), (4, 15, 3, True)])
@@ -287,12 +293,13 @@ def test_gp_match_adjoint_from_pair_aggregates(hc, L, M, d, unc):
     latmat = np.zeros((L, 2 * d * d + 2)); latmat[:, :d * d] = Pa[0].reshape(L, d * d).numpy()
     wp = np.zeros((L, Mp)); qp = np.zeros((L, Mp)); wp[:, :M] = w[0].numpy(); qp[:, :M] = q[0].numpy()
     f1raw = w[0].sum(1).numpy()
-  gmu = np.zeros(d); gS = np.zeros((d, d))
-  rc = hc.hc_gp_bwd_agg(L, M, Mp, d, 1, int(unc), _p(_c(Z)), _p(_c(ls * ls)), _p(_c(mu[0])), _p(_c(Sigma[0])), _p(_c(latmat)),
-                        _p(_c(wp)), _p(_c(qp)), _p(_c(col)), _p(_c(agg)), _p(_c(f1raw)), _p(_c(g_f1[0])), _p(_c(g_Sff[0])),
-                        _p(_c(g_cross[0])), _p(gmu), _p(gS))
-  assert rc == 0
-  assert _rel(gmu, gmu_w.numpy()[0]) < 1e-10 and _rel(gS, _sym(gS_w.numpy()[0])) < 1e-10
+  for chunk in (0, 6):                                               # 6: partial moment sums over chunks of centres
+    gmu = np.zeros(d); gS = np.zeros((d, d))
+    rc = hc.hc_gp_bwd_agg(L, M, Mp, d, 1, int(unc), _p(_c(Z)), _p(_c(ls * ls)), _p(_c(mu[0])), _p(_c(Sigma[0])), _p(_c(latmat)),
+                          _p(_c(wp)), _p(_c(qp)), _p(_c(col)), _p(_c(agg)), _p(_c(f1raw)), _p(_c(g_f1[0])), _p(_c(g_Sff[0])),
+                          _p(_c(g_cross[0])), chunk, _p(gmu), _p(gS))
+    assert rc == 0
+    assert _rel(gmu, gmu_w.numpy()[0]) < 1e-10 and _rel(gS, _sym(gS_w.numpy()[0])) < 1e-10
 
 
 def _packed_moments(hc, wt, zc, deg=4):

@@ -140,7 +140,7 @@ def test_moment_form_backward_equals_reference_surrogate(full, unc, device):
 
 
 def test_f32_model_gradients_track_f64(device):
-  """An f32 model's backward (taken on the f64 pack of the same model) agrees with the f64 model's."""
+  """An f32 model's backward (d <= 8: taken on the f32 pack itself, csrc/mm_bwd_f32.hip) agrees with the f64 model's."""
   L, M, d, B = 3, 40, 4, 3
   p = random_svgp_params(seed=21, L=L, M=M, d=d, whiten=True, ls_bounds=(0.5, 2.0), mean=False)
   rng = np.random.default_rng(2)
@@ -276,8 +276,8 @@ def test_graphed_policy_loss_replays_eager_values_and_gradients(device):
 
 @pytest.mark.parametrize("case", [(3, 90, 4, 3, True, True), (2, 130, 6, 2, True, False), (3, 40, 3, 4, False, True),
                                   (1, 200, 8, 2, True, True), (4, 100, 6, 1, True, True), (2, 70, 16, 2, True, True),
-                                  (2, 50, 31, 1, True, True)],
-                         ids=["L3d4", "L2d6nounc", "L3diagcov", "L1d8", "c1drift", "d16", "d31"])
+                                  (2, 50, 31, 1, True, True), (3, 600, 5, 2, True, True), (2, 520, 12, 1, True, False)],
+                         ids=["L3d4", "L2d6nounc", "L3diagcov", "L1d8", "c1drift", "d16", "d31", "M600chunks", "M520d12chunks"])
 def test_native_match_backward_equals_the_torch_chain_rule(case, device):
   """mm_moment_match_backward (M x M sweeps + k_gp_bwd_items + k_gp_bwd_sum: everything on the device) against
   autodiff.moment_match_backward (the same sums, chain rule in torch) -- which the tests above pin to finite differences
