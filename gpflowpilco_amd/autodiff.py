@@ -282,6 +282,10 @@ class MomentMatchFunction(torch.autograd.Function):
                                       model_uncertainty=model_uncertainty)
     ctx.save_for_backward(mu, Sigma)
     ctx.pm_bwd, ctx.pre, ctx.flags = pm_bwd, pre, (full_output_cov, model_uncertainty)
+    # the backward may reuse the q stage this forward left on the workspace, if it runs on the same pack and nothing else
+    # touches that workspace in between (ops.PackedModel.workspace_generation)
+    ctx.generation = (pm.workspace_generation(mu.shape[0], ops.make_flags(full_output_cov, model_uncertainty))
+                      if pm_bwd is pm else None)
     return f1, Sff, cross
 
   @staticmethod
@@ -292,7 +296,8 @@ class MomentMatchFunction(torch.autograd.Function):
     mub, Sb = mu.to(pmb.dtype), Sigma.to(pmb.dtype)
     # native: M x M sweeps, M-sized moments and the d x d chain rule all on the device (mm_moment_match_backward);
     # moment_match_backward / _reference above are the torch forms it is tested against
-    gmu, gS = ops.moment_match_backward(pmb, mub.contiguous(), Sb.contiguous(), g_f1, g_Sff, g_cross, full, unc)
+    gmu, gS = ops.moment_match_backward(pmb, mub.contiguous(), Sb.contiguous(), g_f1, g_Sff, g_cross, full, unc,
+                                        forward_generation=ctx.generation)
     return gmu.to(mu.dtype), gS.to(Sigma.dtype), None, None, None, None, None
 
 

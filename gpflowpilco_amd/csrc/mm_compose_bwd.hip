@@ -245,8 +245,9 @@ extern "C" int mm_moment_match_backward(const void* packed, size_t packed_bytes,
                                         void* g_mu, void* g_Sigma, int accumulate_Sigma,
                                         void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
                                         int32_t* status, void* stream) {
-  return mm_moment_match_backward_impl(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, g_f1, g_Sff, g_cross, g_mu, g_Sigma,
-                                       accumulate_Sigma, workspace, workspace_bytes, bwd_ws, bwd_ws_bytes, status, stream, false);
+  return mm_moment_match_backward_impl(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags & ~MM_WORKSPACE_CURRENT, g_f1, g_Sff,
+                                       g_cross, g_mu, g_Sigma, accumulate_Sigma, workspace, workspace_bytes, bwd_ws, bwd_ws_bytes,
+                                       status, stream, (flags & MM_WORKSPACE_CURRENT) != 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

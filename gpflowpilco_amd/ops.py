@@ -13,7 +13,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (MM_F32, MM_F64, MM_FORCE_GENERIC, MM_FULL_OUTPUT_COV,
+from ._lib import (MM_F32, MM_F64, MM_FORCE_GENERIC, MM_FULL_OUTPUT_COV, MM_WORKSPACE_CURRENT,
                    MM_MODEL_UNCERTAINTY, check, lib)
 
 _DTYPES = {torch.float32: MM_F32, torch.float64: MM_F64}
@@ -58,6 +58,7 @@ class PackedModel:
   with_C: bool
   buf: torch.Tensor                      # uint8 [packed_bytes]
   _workspaces: Dict[Tuple[int, int], torch.Tensor] = field(default_factory=dict, repr=False)
+  _ws_gen: Dict[Tuple[int, int], int] = field(default_factory=dict, repr=False)
   _status: Optional[torch.Tensor] = field(default=None, repr=False)
   _keep: Optional[tuple] = field(default=None, repr=False)
 
@@ -69,8 +70,12 @@ class PackedModel:
   def nbytes(self) -> int:
     return self.buf.numel()
 
-  def workspace(self, B: int, flags: int) -> torch.Tensor:
+  def workspace(self, B: int, flags: int, peek: bool = False) -> torch.Tensor:
+    """The per-(B, flags) scratch buffer of the kernels.  Every request counts as a use (``workspace_generation``):
+    whoever asks may overwrite it; ``peek`` looks without counting."""
     key = (B, flags & (MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY))
+    if not peek:
+      self._ws_gen[key] = self._ws_gen.get(key, 0) + 1
     ws = self._workspaces.get(key)
     if ws is None:
       n = lib().mm_workspace_bytes(B, self.L, self.M, self.d, _dtype_code(self.dtype), flags)
@@ -79,6 +84,10 @@ class PackedModel:
       ws = torch.empty(n, dtype=torch.uint8, device=self.device)
       self._workspaces[key] = ws
     return ws
+
+  def workspace_generation(self, B: int, flags: int) -> int:
+    """Counter of the requests for this workspace: unchanged since a forward <=> that forward's q stage is still on it."""
+    return self._ws_gen.get((B, flags & (MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY)), 0)
 
   def status(self) -> torch.Tensor:
     if self._status is None:
@@ -257,6 +266,7 @@ class GraphedRollout:
     self.tmu = torch.empty(num_steps, B, pm.d, **kw) if keep_trajectory else None
     self.tS = torch.empty(num_steps, B, pm.d, pm.d, **kw) if keep_trajectory else None
     flags = make_flags(True, model_uncertainty, False)
+    self._flags = flags
     ws = pm.workspace(B, flags)
     status = pm.status()
 
@@ -284,6 +294,7 @@ class GraphedRollout:
       raise ValueError(f"graph was captured for B={self.B}, d={self.pm.d}")
     _require_device(mu, Sigma)
     self.mu_in.copy_(mu); self.S_in.copy_(Sigma)
+    self.pm.workspace(self.B, self._flags)                 # the replay overwrites it: counts as a use (workspace_generation)
     self.graph.replay()
     return (self.mu, self.S, self.tmu, self.tS) if self.tmu is not None else (self.mu, self.S)
 
@@ -461,6 +472,7 @@ class GraphedComposedRollout:
     if tuple(mx.shape) != (self.B, self.roll.nx):
       raise ValueError(f"graph was captured for B={self.B}, nx={self.roll.nx}")
     self.mx_in.copy_(mx); self.S_in.copy_(Sxx)
+    self.roll.drift.workspace(self.B, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY)      # (see GraphedRollout.__call__)
     self.graph.replay()
     return self.out
 
@@ -486,7 +498,8 @@ def backward_supported(pm: PackedModel) -> bool:
 
 
 def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor, g_f1: torch.Tensor, g_Sff: torch.Tensor,
-                          g_cross: torch.Tensor, full_output_cov: bool = True, model_uncertainty: bool = True):
+                          g_cross: torch.Tensor, full_output_cov: bool = True, model_uncertainty: bool = True,
+                          forward_generation: Optional[int] = None):
   """``mm_moment_match_backward``: the vector-Jacobian product of one moment match of a frozen pack,
   (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> (g_mu [B,d], g_Sigma [B,d,d] symmetric), gradients in float64.
   float64 packs: f64 sweeps for every pair; float32 packs with d <= 8 (``backward_supported``): f64 for the diagonal
@@ -497,7 +510,10 @@ def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor
   flags = make_flags(full_output_cov, model_uncertainty)
   f64 = torch.float64
   g_f1, g_Sff, g_cross = (t.to(f64).contiguous() for t in (g_f1, g_Sff, g_cross))
-  ws = pm.workspace(B, flags)
+  # forward_generation: pm.workspace_generation(B, flags) right after the forward of THIS match (same mu, Sigma, flags): if
+  # nobody has asked for the workspace since, its q stage is still there and is not run again (MM_WORKSPACE_CURRENT)
+  current = forward_generation is not None and forward_generation == pm.workspace_generation(B, flags)
+  ws = pm.workspace(B, flags, peek=current)
   key = ("bwd", B, flags)
   wb = pm._workspaces.get(key)
   if wb is None:
@@ -507,7 +523,8 @@ def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor
   g_mu = torch.empty(B, pm.d, dtype=f64, device=pm.device)
   g_S = torch.empty(B, pm.d, pm.d, dtype=f64, device=pm.device)
   rc = lib().mm_moment_match_backward(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, mu.data_ptr(), Sigma.data_ptr(),
-                                      flags, g_f1.data_ptr(), g_Sff.data_ptr(), g_cross.data_ptr(), g_mu.data_ptr(),
+                                      flags | (MM_WORKSPACE_CURRENT if current else 0), g_f1.data_ptr(), g_Sff.data_ptr(),
+                                      g_cross.data_ptr(), g_mu.data_ptr(),
                                       g_S.data_ptr(), 0, ws.data_ptr(), ws.numel(), wb.data_ptr(), wb.numel(),
                                       pm.status().data_ptr(), _stream(pm.device))
   check(rc, "mm_moment_match_backward")

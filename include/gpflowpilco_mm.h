@@ -54,6 +54,9 @@ extern "C" {
  * split-product stages + the exp2 branch; f64 reduce: the k ln2 + r form) whatever the data.  The tiers are all
  * valid on the whole range, so results are unchanged up to rounding; bench.py --recipe worst times it. */
 #define MM_FORCE_WORST_TIER 64
+/* mm_moment_match_backward only: `workspace` still holds the q stage of exactly this (mu, Sigma, flags) -- the forward of the
+ * same match was the last call on it -- so the q stage is not run again */
+#define MM_WORKSPACE_CURRENT 128
 
 /* error codes */
 #define MM_E_ARG      (-1)  /* NULL pointer / non-positive size                  */

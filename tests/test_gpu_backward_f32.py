@@ -112,3 +112,29 @@ def test_differentiable_match_of_an_f32_model_uses_its_own_pack(device):
   for a_, b_ in zip(grads[0], grads[1]):
     sc = float(b_.abs().amax())
     assert float((a_ - b_).abs().amax()) < 2e-4 * sc, (float((a_ - b_).abs().amax()), sc)
+
+
+def test_backward_reuses_the_forward_q_stage_only_while_it_is_current(device):
+  """MomentMatchFunction saves the workspace generation of its forward; the backward skips the q stage
+  (MM_WORKSPACE_CURRENT) only if nothing asked for that workspace in between -- another match on the same pack with the same
+  batch size in between must not change the gradient."""
+  L, M, d, B = 3, 260, 6, 2
+  syn = make_svgp(L, M, d, seed=81, device=str(device), ls_bounds=(0.6, 2.5))
+  model = syn.to_model(device)
+  mu, S = make_inputs(B, d, seed=8, scale=0.1, lo=0.3, hi=0.7)
+  mu2, S2 = make_inputs(B, d, seed=9, scale=0.2, lo=0.1, hi=0.9)
+  grads = []
+  for disturb in (False, True):
+    for dt in (torch.float32, F64):
+      mu_t = to_dev(mu, device, dt).requires_grad_(True); S_t = to_dev(S, device, dt).requires_grad_(True)
+      f1, Sff, cr = autodiff.moment_match_differentiable(model, mu_t, S_t, True, True)
+      pm = model.packed(dt, True, device)
+      gen = pm.workspace_generation(B, ops.make_flags(True, True))
+      if disturb:
+        ops.moment_match(pm, to_dev(mu2, device, dt), to_dev(S2, device, dt))
+        assert pm.workspace_generation(B, ops.make_flags(True, True)) == gen + 1
+      (f1.sum() + Sff.sum() + cr.sum()).backward()
+      grads.append((mu_t.grad.to(F64).clone(), S_t.grad.to(F64).clone()))
+  for k in (0, 1):            # f32, f64: identical with and without the call in between
+    for a_, b_ in zip(grads[k], grads[k + 2]):
+      assert float((a_ - b_).abs().amax()) <= 1e-12 * float(b_.abs().amax())
