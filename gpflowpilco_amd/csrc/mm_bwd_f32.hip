@@ -26,7 +26,6 @@
 #include "mm_mono.h"
 #include "mm_f32_tile.h"
 #include "mm_adjoint.h"
-
 #define MMR_BS 33            // LDS row stride (floats) of the per-wave B_i[slot] image (32 slots at a time)
 
 __device__ __forceinline__ void mmr_decode_pair_o(int p, int L, int& a, int& a2) {
@@ -64,20 +63,26 @@ __device__ __forceinline__ void mmr_rem_entries(const f32x2 (&xx)[8], const f32x
 }
 
 // grid: 1-D over (b, off-diagonal pair, 256-row panel), XCD-remapped.  slab [B][Po][npanel][nT] f64 (ASSIGNED).
+template <bool TWO_NB>
 __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __restrict__ Zs3, const unsigned short* __restrict__ Zq2,
                                                         const double* __restrict__ Zc64, int Kz, const double* __restrict__ zbar,
-                                                        const float* __restrict__ mu, int L, int Mp, int d, int Po, int npanel,
+                                                        const float* __restrict__ mu, int B, int L, int Mp, int d, int Po, int npanel,
                                                         int nwork, const float* __restrict__ rowO, const float* __restrict__ colO,
                                                         const double* __restrict__ whR, double* __restrict__ slab) {
   const int orig = blockIdx.x;
   const int xcd = orig & 7, slotx = orig >> 3;
   const int qn = nwork >> 3, rn = nwork & 7;
   const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slotx;
+  // work order: the panels of one (b, pair), then the batch elements of one pair, then the pairs SORTED BY COLUMN LATENT a':
+  // the workgroups in flight on an XCD stream the same latent's split inputs and monomial images (0.6 MB), so they stay in
+  // its L2 (pair-major order had up to seven latents' images, 3.5 MB, in flight per XCD)
   const int panel = wi % npanel;
   const int tq = wi / npanel;
-  const int lp = tq % Po, b = tq / Po;
-  int a, a2;
-  mmr_decode_pair_o(L + lp, L, a, a2);
+  const int b = tq % B, si = tq / B;
+  int a2 = 1;
+  while (a2 * (a2 + 1) / 2 <= si) ++a2;
+  const int a = si - a2 * (a2 - 1) / 2;
+  const int lp = a * (L - 1) - a * (a - 1) / 2 + (a2 - a - 1);
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   const int row0 = panel * 256 + wv * 64;
   const int nT = mma_pair_agg_len(d);
@@ -86,6 +91,14 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
   float* Bm = reinterpret_cast<float*>(smem) + (size_t)wv * 64 * MMR_BS;                       // [64 rows][MMR_BS]
   double* zr = reinterpret_cast<double*>(smem + (size_t)4 * 64 * MMR_BS * 4) + (size_t)wv * 64 * (d + 1);   // zeta_i | what_i
   double* Tw = reinterpret_cast<double*>(smem + (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8) + (size_t)wv * nT;
+  // the pair's column weights what'_j, shared by the four waves (a tile needs its 32 right after its bilinear product: from
+  // global memory that was an exposed L2 latency per tile)
+  float* wlds = reinterpret_cast<float*>(smem + (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * nT * 8);
+  {
+    const float* wsrc = colO + ((size_t)b * Po + lp) * Mp;
+    for (int i = threadIdx.x * 4; i < Mp; i += 1024) *reinterpret_cast<float4*>(wlds + i) = *reinterpret_cast<const float4*>(wsrc + i);
+  }
+  __syncthreads();
 
   f32x16 acc2[2][2];
 #pragma unroll
@@ -98,7 +111,6 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
   const bool live = row0 < Mp;                     // Mp % 128 == 0: a wave's 64 rows are all inside or all outside
   if (live) {
     const float* ra = rowO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;      // [d + 1][Mp]: A_i, what_i
-    const float* wcf = colO + ((size_t)b * Po + lp) * Mp;                       // what'_j
     // ---- stationary side: the split A_i of the wave's 64 rows, as in the forward (here the B operand) --------------------
     bf16x8 a1[2], a2v[2], a3[2];
 #pragma unroll
@@ -127,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
     const unsigned int offA = (h ? 0u : 1u) * 512u + (unsigned int)l31 * 16u;
     const unsigned int offB = (h ? 0u : 2u) * 512u + (unsigned int)l31 * 16u;
     const int nct = Mp >> 5;
-    const bool two_nb = 1 + d + d * (d + 1) / 2 > 32;
+    constexpr bool two_nb = TWO_NB;                  // 1 + d + d (d + 1) / 2 > 32 monomials (d >= 7): two 32-slot blocks
     // the split inputs of the next tile are prefetched (first thing a tile needs); the monomial images and the column
     // weights of a tile are requested at its top and consumed after its bilinear product and polynomial
     auto load_z = [&](int ct, u32x4& zA, u32x4& zB) {
@@ -137,13 +149,10 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
     auto process = [&](int ct, const u32x4& zA, const u32x4& zB) {
       u32x4 psi[8];
       float4 wc[4];
-#ifndef MMR_EXP
-#define MMR_EXP 0
-#endif
 #pragma unroll
-      for (int i = 0; i < 8; ++i) psi[i] = *reinterpret_cast<const u32x4*>(qbase + (size_t)(MMR_EXP == 1 ? 0 : ct) * 8192 + i * 1024 + lane * 16);
+      for (int i = 0; i < 8; ++i) psi[i] = *reinterpret_cast<const u32x4*>(qbase + (size_t)ct * 8192 + i * 1024 + lane * 16);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) wc[g] = *reinterpret_cast<const float4*>(wcf + ct * 32 + 8 * g + 4 * h);
+      for (int g = 0; g < 4; ++g) wc[g] = *reinterpret_cast<const float4*>(wlds + ct * 32 + 8 * g + 4 * h);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         // b block, TRANSPOSED: A slot = the streamed columns, B slot = the stationary rows -> lane = row, registers = columns
@@ -195,9 +204,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
           for (int term = 0; term < 3; ++term)
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-              if (nb == 1 && !two_nb) continue;             // d <= 6: the monomials fit one 32-slot block
-              if (MMR_EXP == 2 && (s > 0 || term > 0)) continue;
-              if (MMR_EXP == 3 && term > 0) continue;
+              if constexpr (!two_nb) { if (nb == 1) continue; }   // d <= 6: the monomials fit one 32-slot block
               const u32x4 av = term == 1 ? vl[s] : vh[s];
               const u32x4 bv = psi[(s * 2 + nb) * 2 + (term == 2 ? 1 : 0)];
               acc2[rt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv),
@@ -275,8 +282,8 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
   for (int idx = threadIdx.x; idx < nT; idx += 256) o[idx] = (Tall[idx] + Tall[nT + idx]) + (Tall[2 * nT + idx] + Tall[3 * nT + idx]);
 }
 
-static size_t mmr_rem_lds_bytes(int d) {
-  return (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * mma_pair_agg_len(d) * 8;
+static size_t mmr_rem_lds_bytes(int d, int Mp) {
+  return (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * mma_pair_agg_len(d) * 8 + (size_t)Mp * 4;
 }
 
 // grid (Po, B), 512 threads: polynomial part + remainder slabs, re-centred at mu -> pagg [B][Po][nT]
@@ -352,13 +359,20 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
   const int npanel = (wl.Mp + 255) / 256;
   const long long nwork_ll = (long long)npanel * wl.Po * B;
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
-  const size_t shm = mmr_rem_lds_bytes(d);
-  hipError_t e = hipFuncSetAttribute((const void*)k_bwd_rem_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(k_bwd_rem_f32, dim3((int)nwork_ll), dim3(256), shm, stream, (const unsigned short*)(packed + ml.Zs3),
-                     (const unsigned short*)(packed + ml.Zq2), (const double*)(packed + ml.Zc64), ml.Kz,
-                     (const double*)(packed + ml.zbar), mu, L, wl.Mp, d, wl.Po, npanel, (int)nwork_ll,
-                     (const float*)(ws + wl.rowO), (const float*)(ws + wl.colO), (const double*)(ws + wl.whR), slab);
+  const size_t shm = mmr_rem_lds_bytes(d, wl.Mp);
+  if (shm > 160 * 1024) return MM_E_DIM;
+  hipError_t e = hipSuccess;
+#define MMR_LAUNCH(TWO_)                                                                                                       \
+  do {                                                                                                                        \
+    e = hipFuncSetAttribute((const void*)k_bwd_rem_f32<TWO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);          \
+    if (e != hipSuccess) return (int)e;                                                                                       \
+    hipLaunchKernelGGL(k_bwd_rem_f32<TWO_>, dim3((int)nwork_ll), dim3(256), shm, stream, (const unsigned short*)(packed + ml.Zs3), \
+                       (const unsigned short*)(packed + ml.Zq2), (const double*)(packed + ml.Zc64), ml.Kz,                    \
+                       (const double*)(packed + ml.zbar), mu, B, L, wl.Mp, d, wl.Po, npanel, (int)nwork_ll,                   \
+                       (const float*)(ws + wl.rowO), (const float*)(ws + wl.colO), (const double*)(ws + wl.whR), slab);       \
+  } while (0)
+  if (1 + d + d * (d + 1) / 2 > 32) MMR_LAUNCH(true); else MMR_LAUNCH(false);
+#undef MMR_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const int nT = mma_pair_agg_len(d);
