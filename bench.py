@@ -74,6 +74,12 @@ CONFIGS = {
 # BASELINE.json configs[4]: S = 65536 sample paths in total, N = 2000, K = 1024 bases, H = 50
 PATHWISE = dict(L=8, M=2000, d=8, K=1024, H=50, S=65536, dtype="f32", seed=1004, scaling="strong",
                 label="C5 (BASELINE configs[4]): pathwise sample rollout S=65536 total N=2000 K=1024 d=D=8 H=50 fp32")
+# SURVEY 8(f) row f-1 at C3 shape: one step = forward + backward (vector-Jacobian product w.r.t. mu, Sigma) of the C3 moment
+# match -- what one rollout step costs when the rollout is differentiated (the reference: tf.GradientTape through
+# moment_matching/models.py:200-299, utils/optimizers.py:51-56).  Not BASELINE.json's metric: a next-row line.
+GRAD = dict(L=8, M=2000, d=8, B=256, dtype="f32", seed=1002, scaling="weak", recipe="baseline",
+            label="C3-shaped forward + backward of one moment match (row f-1): N=2000 d=8 D=8 fp32 model, full output covariance, "
+                  "model uncertainty; gradient of a fixed linear functional of (f1, Sff, cross) w.r.t. (mu, Sigma)")
 RECIPES = {
     "pilco": dict(ls_bounds=(0.7, 3.0), stable=True, independent=False, worst=False,
                   text="lengthscales log-U[0.7,3], targets -0.5(z_a-0.5)+0.25*prior draw (state stays in the data's support)"),
@@ -84,7 +90,7 @@ RECIPES = {
 }
 # MI355X_MICROARCH.md: dense peaks and the peak clock; per-SIMD issue costs measured by tools/ubench_gap.hip /
 # tools/ubench_rates.hip on MI355X (profiles/r02_ubench_gap.txt): cycles per wave-instruction on one SIMD
-PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6}
+PEAK_TFLOPS = {"f32": 157.3, "f64": 78.6, "bf16": 2500.0}
 PEAK_HBM_GBS = 8000.0
 PEAK_CLOCK_HZ = 2.4e9
 N_SIMD = 1024
@@ -97,7 +103,7 @@ def parse():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=80)
   ap.add_argument("--warmup", type=int, default=8)
-  ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c5"])
+  ap.add_argument("--config", default="c3", choices=sorted(CONFIGS) + ["c1", "c5", "c3_grad"])
   ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                   help="weak: the config's B (or S) per GPU; strong: the config's B (or S) sharded over the ranks "
                        "(default: weak for c1..c3, strong for c4/c5 -- BASELINE.json shards those)")
@@ -306,6 +312,8 @@ def main():
     return pathwise_bench(args, rank, world, dev, dist)
   if args.config == "c1":
     return composed_bench(args, rank, world, dev, dist)
+  if args.config == "c3_grad":
+    return grad_bench(args, rank, world, dev, dist)
   cfg = dict(CONFIGS[args.config])
   scaling = args.scaling or cfg["scaling"]
   L, M, d, H = cfg["L"], cfg["M"], cfg["d"], cfg["H"]
@@ -818,6 +826,153 @@ def composed_bench(args, rank, world, dev, dist):
                                      "loss": float(np.abs(cost[:1].sum(1).cpu().numpy() - loss_o).max())},
                      "max_abs": {"mu_H": float(np.abs(traj_o[-1][0]).max()), "Sigma_H": float(np.abs(traj_o[-1][1]).max()),
                                  "loss": float(np.abs(loss_o).max())}}
+  if rank == 0:
+    print(json.dumps(out))
+  if world > 1:
+    dist.destroy_process_group()
+
+
+def grad_bench(args, rank, world, dev, dist):
+  """Row f-1 at C3 shape: one step = moment match forward + its backward on the f32 pack (csrc/mm_bwd_f32.hip for the
+  off-diagonal pairs, the f64 sweep of csrc/mm_backward.hip for the diagonal pairs), B elements per step; the batch shards
+  over the ranks with no collective on the data path (the gradients stay with their elements)."""
+  import numpy as np
+  import torch
+  from gpflowpilco_amd import _lib as F, ops
+  from gpflowpilco_amd.distributed import shard_range
+  from gpflowpilco_amd.synthetic import make_inputs, make_svgp
+  c = dict(GRAD)
+  scaling = args.scaling or c["scaling"]
+  L, M, d, dtype = c["L"], c["M"], c["d"], torch.float32
+  rec = RECIPES[args.recipe or c["recipe"]]
+  Bcfg = args.batch or c["B"]
+  if scaling == "strong":
+    B_total = Bcfg
+    lo, hi = shard_range(B_total, rank, world)
+    B = hi - lo
+  else:
+    B, B_total, lo = Bcfg, Bcfg * world, rank * Bcfg
+  steps, ndraw = args.steps, 8
+
+  def build_model():
+    syn_ = make_svgp(L, M, d, seed=c["seed"], device=str(dev), ls_bounds=rec["ls_bounds"], stable=rec["stable"])
+    model_ = syn_.to_model(dev)
+    return syn_, model_, model_.packed(dtype, True, dev)
+  syn, model, pm = one_rank_at_a_time(build_model, rank, world, dist, args.rehearse_gloo)
+  if not ops.backward_supported(pm):
+    raise SystemExit("the f32 pack's backward needs d <= 8")
+  lo_mu, hi_mu = (0.0, 1.0) if rec["independent"] else (0.3, 0.7)
+  mu_np, S_np = make_inputs(B_total * ndraw, d, seed=2000 + c["seed"], scale=0.1, lo=lo_mu, hi=hi_mu)
+  draws_mu = torch.tensor(np.ascontiguousarray(mu_np.reshape(ndraw, B_total, d)[:, lo:lo + B]), dtype=dtype, device=dev)
+  draws_S = torch.tensor(np.ascontiguousarray(S_np.reshape(ndraw, B_total, d, d)[:, lo:lo + B]), dtype=dtype, device=dev)
+  gen = torch.Generator(device="cpu").manual_seed(c["seed"])
+  g1 = torch.randn(B_total, L, generator=gen, dtype=torch.float64)[lo:lo + B].to(dev)
+  g2 = torch.randn(B_total, L, L, generator=gen, dtype=torch.float64)[lo:lo + B].to(dev)
+  g3 = torch.randn(B_total, d, L, generator=gen, dtype=torch.float64)[lo:lo + B].to(dev)
+  flags = ops.make_flags(True, True)
+  Ev = lambda: torch.cuda.Event(enable_timing=True)
+  seg = {"forward": 0.0, "bwd_diag_f64": 0.0, "bwd_offdiag_f32": 0.0, "bwd_rest": 0.0}
+  last = {}
+
+  def one_step(k, timed):
+    mu, S = draws_mu[k % ndraw], draws_S[k % ndraw]
+    e = [Ev() for _ in range(5)] if timed else None
+    if timed: e[0].record()
+    f1, Sff, cr = ops.moment_match(pm, mu, S)
+    g = pm.workspace_generation(B, flags)
+    if timed: e[1].record()
+    # the backward in its three stages (the same kernels as one call without stage flags, which the tests use):
+    # the forward's q stage is still on the workspace (forward_generation)
+    ops.moment_match_backward(pm, mu, S, g1, g2, g3, True, True, forward_generation=g, stages=F.MM_STAGE_DIAG)
+    if timed: e[2].record()
+    ops.moment_match_backward(pm, mu, S, g1, g2, g3, True, True, forward_generation=g, stages=F.MM_STAGE_OFFDIAG)
+    if timed: e[3].record()
+    gmu, gS = ops.moment_match_backward(pm, mu, S, g1, g2, g3, True, True, forward_generation=g, stages=F.MM_STAGE_FINALIZE)
+    if timed: e[4].record()
+    last["out"] = (f1, Sff, gmu, gS)
+    return e
+
+  def fence():
+    torch.cuda.synchronize()
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  for k in range(max(1, args.warmup)):
+    one_step(k, False)
+  fence()
+  pm.check_status(B)
+  t0 = time.perf_counter()
+  evs = [one_step(k, True) for k in range(steps)]
+  fence()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+  for e in evs:
+    for name, i in (("forward", 0), ("bwd_diag_f64", 1), ("bwd_offdiag_f32", 2), ("bwd_rest", 3)):
+      seg[name] += e[i].elapsed_time(e[i + 1]) / steps
+  f1, Sff, gmu, gS = last["out"]
+  if not all(bool(torch.isfinite(t).all()) for t in (f1, Sff, gmu, gS)):
+    raise SystemExit("non-finite outputs")
+  # one-call backward == staged backward (same kernels, same order)
+  mu, S = draws_mu[(steps - 1) % ndraw], draws_S[(steps - 1) % ndraw]
+  gmu1, gS1 = ops.moment_match_backward(pm, mu, S, g1, g2, g3, True, True)
+  same = float((gmu1 - gmu).abs().amax()) <= 1e-12 * float(gmu1.abs().amax()) and float((gS1 - gS).abs().amax()) <= 1e-12 * float(gS1.abs().amax())
+  Po, Mp = L * (L - 1) // 2, -(-M // 128) * 128
+  nmono = 1 + d + d * (d + 1) // 2
+  e_off = float(B) * Po * M * M
+  e_diag = float(B) * L * M * M                        # the backward sweeps every entry of a diagonal pair (no symmetry)
+  flops_off = e_off * (2 * d + 12 + 2 * nmono)
+  flops_diag = e_diag * (2 * d + 12 + 2 * (d + 1) + 6)
+  pmc, pmc_src = load_pmc("c3_grad_" + (args.recipe or c["recipe"]), fallback="c3_grad")
+  pscale, pmc_src = pmc_scale(pmc, pmc_src, B, c["B"])
+  why_off = ("E_o (2d + 12 + 2 n_mono): per entry the bilinear form (2d), the remainder of e^b (12, as SURVEY 8d prices the forward) and "
+             f"the aggregate product against the {nmono} monomials of degree <= 2 (2 n_mono); E_o = B Po M^2.  Executed: 30 "
+             "v_mfma_f32_32x32x16_bf16 per 64 x 32 wave tile (3-way split bilinear product 6, hi/lo split aggregate product 24) = 480 "
+             "bf16 flop per entry")
+  r_off = roofline_block("k_bwd_rem_f32", seg["bwd_offdiag_f32"], flops_off, PEAK_TFLOPS["bf16"], pmc, pmc_src, pscale, "bf16",
+                         "k_bwd_rem_f32", why_off)
+  r_off["executed_mfma_tflops"] = round(e_off * 480.0 / (seg["bwd_offdiag_f32"] * 1e-3) / 1e12, 1) if seg["bwd_offdiag_f32"] > 0 else None
+  r_off["executed_mfma_frac_of_bf16_peak"] = (round(r_off["executed_mfma_tflops"] / PEAK_TFLOPS["bf16"], 4)
+                                              if r_off["executed_mfma_tflops"] else None)
+  r_off.pop("frac_null_reason", None)
+  r_diag = roofline_block("k_bwd_mfma", seg["bwd_diag_f64"], flops_diag, PEAK_TFLOPS["f64"], pmc, pmc_src, pscale, "f64", "k_bwd_mfma",
+                          "E_d (2d + 12 + 2 (d + 1) + 6): bilinear form, expm1, the column product Omega^T (zc | 1), the C-weighted sums; "
+                          "E_d = B L M^2 (every entry: column sums use no symmetry)")
+  r_diag.pop("frac_null_reason", None)
+  ms = 1e3 * elapsed / steps
+  out = {"metric": "moment_match_forward_backward_steps_per_sec", "value": round(B_total * steps / elapsed, 2),
+         "unit": "step-elements/s (B per forward+backward step)", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f32",
+         "data": "synthetic",
+         "config": {"workload": c["label"], "recipe": rec["text"], "N": M, "d": d, "D": L, "B_total": B_total, "B_this_rank": B,
+                    "parallelism": f"dp{world} over B ({scaling}); no collective on the data path",
+                    "row": "SURVEY 8(f) f-1 -- not BASELINE.json's metric", "staged_equals_one_call": same,
+                    "forward_ms": round(seg["forward"], 4), "backward_ms": round(ms - seg["forward"], 4),
+                    "backward_over_forward": round((ms - seg["forward"]) / seg["forward"], 2)},
+         "segments_ms": {k: round(v, 4) for k, v in seg.items()},
+         "roofline": r_off, "roofline_other": r_diag}
+  if not same:
+    raise SystemExit("staged backward differs from the one-call backward")
+  if rank == 0 and not args.no_cpu_baseline and world == 1:
+    # the reference's way: autograd through the materialised [P, M, M] evaluation (autodiff.moment_match_torch, the torch
+    # transliteration of models.py:200-299) on the host cores, float64, ONE batch element of the same workload
+    from gpflowpilco_amd import autodiff
+    torch.set_num_threads(os.cpu_count() or 1)
+    Z, ls, var, beta, Cm, mc = (None if t is None else t.detach().cpu() for t in model.precompute(dev))
+    mu_c = draws_mu[0, :1].double().cpu().requires_grad_(True)
+    S_c = draws_S[0, :1].double().cpu().requires_grad_(True)
+    tc0 = time.perf_counter()
+    f1c, Sffc, crc = autodiff.moment_match_torch(mu_c, S_c, Z, ls, var, beta, Cm, mc, True, True)
+    ((g1[:1].cpu() * f1c).sum() + (g2[:1].cpu() * Sffc).sum() + (g3[:1].cpu() * crc).sum()).backward()
+    tc = time.perf_counter() - tc0
+    out["cpu_baseline"] = {"value": round(1.0 / tc, 4), "unit": out["unit"], "cores": os.cpu_count(), "kind": "port",
+                           "sample": f"ONE batch element of the same workload (forward + torch autograd backward of the materialised "
+                                     f"[36, {M}, {M}] float64 evaluation, {tc:.1f} s on {os.cpu_count()} threads)"}
+    gm = gmu[:0]  # (parity of the GPU gradient is the tests' job; here only the baseline's clock)
+    del gm
   if rank == 0:
     print(json.dumps(out))
   if world > 1:

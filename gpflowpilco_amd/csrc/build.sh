@@ -10,9 +10,9 @@ objs=()
 pids=()
 for src in mm_kernels mm_mfma mm_f64 mm_moments mm_compose mm_compose_bwd mm_rollout_small mm_pathwise mm_backward mm_bwd_f32; do
   extra=()
-  # mm_mfma.hip alone is built with -fno-honor-nans: its per-tile range check max(|x|) then folds
+  # mm_mfma.hip and mm_bwd_f32.hip are built with -fno-honor-nans: the per-tile range check max(|x|) then folds
   # into one v_max3_f32 per two entries (no canonicalising v_max x, x); inputs are finite by the
-  # time they reach that kernel (k_prep's status word rejects non-PD / non-finite states).
+  # time they reach those kernels (k_prep's status word rejects non-PD / non-finite states).
   [[ "${src}" == mm_mfma || "${src}" == mm_bwd_f32 ]] && extra=(-fno-honor-nans)
   # mm_pathwise.hip without the SLP vectoriser: it pairs elements of different 16-byte loads into
   # v_pk_fma_f32 operands, and the shuffles it places on the loop back edge wait for the prefetched

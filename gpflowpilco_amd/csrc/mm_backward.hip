@@ -162,9 +162,19 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
                                                      const double* __restrict__ w, const double* __restrict__ q,
                                                      const double* __restrict__ rowD, const double* __restrict__ colD,
                                                      const double* __restrict__ rowO, const double* __restrict__ colO,
-                                                     double* __restrict__ out) {
+                                                     double* __restrict__ out, int B, int nwork) {
   const int Po = P - L;
-  const int jt = blockIdx.x, lp = blockIdx.y, b = blockIdx.z;
+  // 1-D grid, XCD-aware (blocks i and i + 8 share an XCD: consecutive work items go to the same XCD), batch element fastest:
+  // the B workgroups of one (pair, column tile) sweep the same 64-column strip of C_a (Mp x 64 doubles) at the same pace and
+  // share it in that XCD's L2.  In (column tile, pair, b) launch order every workgroup streamed its strip from HBM --
+  // B L Mp^2 x 8 bytes = 8.6 GB at C3 shape with B = 32: the kernel ran at HBM speed, not at its arithmetic.
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, slotx = orig >> 3;
+  const int qn = nwork >> 3, rn = nwork & 7;
+  const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slotx;
+  const int b = wi % B, rest = wi / B;
+  const int ntc = Mp / 64;
+  const int jt = rest % ntc, lp = rest / ntc;
   const int p = SWAP ? L + lp : lp;
   int a, a2;
   mmb_decode_pair(p, L, a, a2);
@@ -440,14 +450,17 @@ int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* w
     const double* Zc = (const double*)(pk + ml.Zc64);
     const double* zb = (const double*)(pk + ml.zbar);
     const int ks4 = (d + 3) / 4, nu = (d + 16) / 16;          // (d + 1) <= 16 nu
+    const long long nwc = (long long)(wl.Mp / 64) * Pk * B, nwr = (long long)(wl.Mp / 64) * Pok * B;
+    if (nwc > 0x7fffffffLL || nwr > 0x7fffffffLL) return MM_E_DIM;
+    const int nw_col = (int)nwc, nw_row = (int)nwr;
 #define MMB_M_ARGS Zc, ml.Kz, zb, Cm, mu, L, wl.Mp, d, Pk, (const double*)(ws + wl.w64),                              \
                    (const double*)(ws + wl.q64), (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD),       \
                    (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO)
 #define MMB_M_LAUNCH(KS_, NU_)                                                                                      \
     do {                                                                                                            \
-      hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, false>), dim3(wl.Mp / 64, Pk, B), dim3(256), 0, s, MMB_M_ARGS, out_col); \
+      hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, false>), dim3(nw_col), dim3(256), 0, s, MMB_M_ARGS, out_col, B, nw_col); \
       if (Pok > 0)                                                                                                  \
-        hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, true>), dim3(wl.Mp / 64, Pok, B), dim3(256), 0, s, MMB_M_ARGS, out_row); \
+        hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, true>), dim3(nw_row), dim3(256), 0, s, MMB_M_ARGS, out_row, B, nw_row); \
     } while (0)
     if (ks4 <= 1) MMB_M_LAUNCH(1, 1);
     else if (ks4 == 2) MMB_M_LAUNCH(2, 1);

@@ -350,18 +350,20 @@ size_t mm_bwd_f32_slab_bytes(int B, int Po, int Mp, int d) {
 }
 
 // Off-diagonal aggregates of an f32 pack whose q stage is current on `ws` (mm_q_forward, MM_F32).  mu: [B][d] f32.
+// stages (bench.py times them apart): MM_STAGE_OFFDIAG = the remainder sweep k_bwd_rem_f32 alone; MM_STAGE_FINALIZE = the full
+// moment GEMM and k_pair_agg
 int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
-                              int B, int L, int d, const float* mu, double* slab, double* pagg, hipStream_t stream) {
+                              int B, int L, int d, const float* mu, double* slab, double* pagg, hipStream_t stream,
+                              int stages = MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE) {
   if (wl.Po <= 0) return 0;
   if (!mm_bwd_f32_supported(d)) return MM_E_DIM;
-  int rc = mm_launch_wmom_full(packed, ml, ws, wl, B, L, d, stream);
-  if (rc) return rc;
   const int npanel = (wl.Mp + 255) / 256;
+  hipError_t e = hipSuccess;
+  if (stages & MM_STAGE_OFFDIAG) {
   const long long nwork_ll = (long long)npanel * wl.Po * B;
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const size_t shm = mmr_rem_lds_bytes(d, wl.Mp);
   if (shm > 160 * 1024) return MM_E_DIM;
-  hipError_t e = hipSuccess;
 #define MMR_LAUNCH(TWO_)                                                                                                       \
   do {                                                                                                                        \
     e = hipFuncSetAttribute((const void*)k_bwd_rem_f32<TWO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);          \
@@ -375,6 +377,10 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
 #undef MMR_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  }
+  if (!(stages & MM_STAGE_FINALIZE)) return 0;
+  const int rc = mm_launch_wmom_full(packed, ml, ws, wl, B, L, d, stream);
+  if (rc) return rc;
   const int nT = mma_pair_agg_len(d);
   const size_t shm2 = (size_t)(2 * ml.KMp + d * d + 2 * d + nT + mma_pair_poly_scratch(d)) * sizeof(double);
   e = hipFuncSetAttribute((const void*)k_pair_agg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);

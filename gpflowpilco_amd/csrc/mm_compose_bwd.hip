@@ -22,7 +22,7 @@ int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* w
 extern "C" int mm_bwd_f32_supported(int d);
 size_t mm_bwd_f32_slab_bytes(int B, int Po, int Mp, int d);
 int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
-                              int B, int L, int d, const float* mu, double* slab, double* pagg, hipStream_t stream);
+                              int B, int L, int d, const float* mu, double* slab, double* pagg, hipStream_t stream, int stages);
 int mm_launch_cast_f32_f64(const float* x, double* y, size_t n, hipStream_t stream);
 
 // stage profile (tools/profile_c1_stages.py; -DMM_STAGE_PROFILE builds only): cycles per stage of block 0
@@ -163,6 +163,11 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
   if (d > MM_DMAX) return MM_E_DIM;
   if (dtype != MM_F64 && dtype != MM_F32) return MM_E_DTYPE;
   const bool f32 = dtype == MM_F32;
+  // MM_STAGE_* (measurement, as in mm_Q_reduce_forward): DIAG = the f64 sweep (f64 packs: of every pair), OFFDIAG = the f32
+  // remainder sweep, FINALIZE = everything M-sized and smaller (moment GEMM, aggregates, item moments, items, sum)
+  int stages = flags & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE);
+  if (!stages) stages = MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE;
+  flags &= ~(MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE);
   if (f32 && !mm_bwd_f32_supported(d)) return MM_E_DTYPE;     // d > 8: differentiate through an f64 pack of the model
   const MMGpBwdLayout bl = mm_gp_bwd_layout(B, L, M, d, dtype, flags);
   if (bwd_ws_bytes < bl.total) return MM_E_WORKSPACE;
@@ -191,18 +196,22 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     if (rc) return rc;
     mu64 = (const double*)(bw + bl.mu64);
     S64 = (const double*)(bw + bl.S64);
-    rc = mm_backward_sums_impl(pk, ml, ws, wl, L, M, d, B, mu64, flags, with_unc, true, (double*)(bw + bl.sums), s);
-    if (rc) return rc;
+    if (stages & MM_STAGE_DIAG) {
+      rc = mm_backward_sums_impl(pk, ml, ws, wl, L, M, d, B, mu64, flags, with_unc, true, (double*)(bw + bl.sums), s);
+      if (rc) return rc;
+    }
     if (wl.Po > 0) {
-      rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, d, (const float*)mu, (double*)(bw + bl.slab), (double*)(bw + bl.pagg), s);
+      rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, d, (const float*)mu, (double*)(bw + bl.slab), (double*)(bw + bl.pagg), s,
+                                     stages);
       if (rc) return rc;
       pagg = (const double*)(bw + bl.pagg);
     }
-  } else {
+  } else if (stages & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG)) {
     rc = mm_backward_sums(packed, packed_bytes, L, M, d, dtype, B, mu, flags, workspace, workspace_bytes, bw + bl.sums,
                           mm_backward_bytes(B, L, M, d, flags), stream);
     if (rc) return rc;
   }
+  if (!(stages & MM_STAGE_FINALIZE)) return 0;
   const int col_pairs = f32 ? L : P;
   const double* col = (const double*)(bw + bl.sums);
   const double* row = col + (size_t)B * P * (3 + d) * Mp;       // (f64 packs; not read with aggregates)

@@ -499,11 +499,12 @@ def backward_supported(pm: PackedModel) -> bool:
 
 def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor, g_f1: torch.Tensor, g_Sff: torch.Tensor,
                           g_cross: torch.Tensor, full_output_cov: bool = True, model_uncertainty: bool = True,
-                          forward_generation: Optional[int] = None):
+                          forward_generation: Optional[int] = None, stages: int = 0):
   """``mm_moment_match_backward``: the vector-Jacobian product of one moment match of a frozen pack,
   (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> (g_mu [B,d], g_Sigma [B,d,d] symmetric), gradients in float64.
   float64 packs: f64 sweeps for every pair; float32 packs with d <= 8 (``backward_supported``): f64 for the diagonal
-  pairs, moment + bf16-MFMA aggregates for the off-diagonal pairs (csrc/mm_bwd_f32.hip)."""
+  pairs, moment + bf16-MFMA aggregates for the off-diagonal pairs (csrc/mm_bwd_f32.hip).
+  ``stages`` (``MM_STAGE_*``, measurement only): run just those parts of the backward on what earlier calls left behind."""
   if not backward_supported(pm):
     raise NotImplementedError("float32 packs with d > 8 differentiate through a float64 pack of the model")
   B, mu, Sigma = _prep_state(pm, mu, Sigma)
@@ -523,7 +524,7 @@ def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor
   g_mu = torch.empty(B, pm.d, dtype=f64, device=pm.device)
   g_S = torch.empty(B, pm.d, pm.d, dtype=f64, device=pm.device)
   rc = lib().mm_moment_match_backward(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, mu.data_ptr(), Sigma.data_ptr(),
-                                      flags | (MM_WORKSPACE_CURRENT if current else 0), g_f1.data_ptr(), g_Sff.data_ptr(),
+                                      flags | (MM_WORKSPACE_CURRENT if current else 0) | stages, g_f1.data_ptr(), g_Sff.data_ptr(),
                                       g_cross.data_ptr(), g_mu.data_ptr(),
                                       g_S.data_ptr(), 0, ws.data_ptr(), ws.numel(), wb.data_ptr(), wb.numel(),
                                       pm.status().data_ptr(), _stream(pm.device))
