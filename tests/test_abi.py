@@ -108,6 +108,11 @@ def test_argument_validation_of_the_gradient_entry_points_without_gpu():
   assert lib.mm_moment_match_backward(*mb(dtype=F32, d=12)) == -3                 # f32 packs: d <= 8 only
   assert lib.mm_moment_match_backward(*mb(dtype=F32)) == -4                       # ... where they get as far as the size check
   assert lib.mm_bwd_f32_supported(8) == 1 and lib.mm_bwd_f32_supported(9) == 0
+  # the off-diagonal aggregates alone: f32 packs with d <= 8 only
+  pa = lambda dtype=F32, d=4, mu=p: (p, 64, 3, 16, d, dtype, 2, mu, p, 3, p, 64, p, 64, p, 64, None, None)
+  assert lib.mm_backward_pair_aggregates(*pa(dtype=F64)) == -3 and lib.mm_backward_pair_aggregates(*pa(d=9)) == -3
+  assert lib.mm_backward_pair_aggregates(*pa(mu=None)) == -1 and lib.mm_backward_pair_aggregates(*pa()) == -4
+  assert lib.mm_backward_pair_aggregates_bytes(2, 3, 16, 4, 3) > 0 and lib.mm_backward_pair_aggregates_bytes(2, 3, 16, 9, 3) == 0
   assert lib.mm_moment_match_backward(*mb(mu=None)) == -1
   assert lib.mm_moment_match_backward(*mb(d=40)) == -2
   assert lib.mm_moment_match_backward(*mb()) == -4                                 # workspaces too small

@@ -193,3 +193,31 @@ def test_c3_at_the_configs_own_batch_256(recipe, device):
   assert torch.equal(m1, m2) and torch.equal(S1, S2)
   Sxf = Sigma[sel] @ cro
   assert scale_err(S1[sel], Sigma[sel] + Sxf + np.swapaxes(Sxf, 1, 2) + Sffo) < 5e-5
+
+
+@pytest.mark.parametrize("recipe", ["baseline", "pilco"])
+def test_c3_backward_on_the_f32_pack_matches_the_f64_pack(recipe, device):
+  """Row f-1 at C3's own sizes (N = 2000, d = D = 8, f32 model): the vector-Jacobian product of one match taken on the f32
+  pack (csrc/mm_bwd_f32.hip: diagonal pairs f64, off-diagonal pairs as moment + bf16-MFMA aggregates) against the f64 pack
+  of the same model on the same f32-rounded state, plus shard invariance of the gradient (size-independent property)."""
+  L, M, d, B = 8, 2000, 8, 6
+  ls, lo, hi = ((0.3, 3.0), 0.0, 1.0) if recipe == "baseline" else ((0.7, 3.0), 0.3, 0.7)
+  syn = make_svgp(L, M, d, seed=1002, device=str(device), ls_bounds=ls, stable=recipe == "pilco")
+  model = syn.to_model(device)
+  pm32, pm64 = model.packed(torch.float32, True, device), model.packed(torch.float64, True, device)
+  mu, S = make_inputs(B, d, seed=3002, scale=0.1, lo=lo, hi=hi)
+  mu32, S32 = to_dev(mu, device, torch.float32), to_dev(S, device, torch.float32)
+  g = torch.Generator(device="cpu").manual_seed(5)
+  g1 = torch.randn(B, L, generator=g, dtype=torch.float64).to(device)
+  g2 = torch.randn(B, L, L, generator=g, dtype=torch.float64).to(device)
+  g3 = torch.randn(B, d, L, generator=g, dtype=torch.float64).to(device)
+  gm32, gS32 = ops.moment_match_backward(pm32, mu32, S32, g1, g2, g3)
+  gm64, gS64 = ops.moment_match_backward(pm64, mu32.double(), S32.double(), g1, g2, g3)
+  pm32.check_status(B)
+  for a_, b_ in ((gm32, gm64), (gS32, gS64)):
+    sc = float(b_.abs().amax())
+    assert float((a_ - b_).abs().amax()) < 1e-4 * sc, (recipe, float((a_ - b_).abs().amax()), sc)
+  # the gradient of element b does not depend on what else is in the batch
+  gm_a, gS_a = ops.moment_match_backward(pm32, mu32[2:5].contiguous(), S32[2:5].contiguous(), g1[2:5], g2[2:5], g3[2:5])
+  assert float((gm_a - gm32[2:5]).abs().amax()) <= 1e-12 * float(gm32.abs().amax())
+  assert float((gS_a - gS32[2:5]).abs().amax()) <= 1e-12 * float(gS32.abs().amax())
