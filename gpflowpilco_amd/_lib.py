@@ -97,6 +97,7 @@ SIGNATURES = {
                                               C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "mm_moment_match_backward_bytes": (C.c_size_t, [C.c_int] * 5),
+    "mm_moment_match_backward_bytes_dtype": (C.c_size_t, [C.c_int] * 6),
     "mm_moment_match_backward": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_void_p, C.c_void_p,

@@ -26,6 +26,7 @@
 #include "mm_mono.h"
 #include "mm_f32_tile.h"
 #include "mm_adjoint.h"
+#define MMR_WLDS_MAX 16384   // column weights of a pair are staged in LDS up to this many (padded) inducing points
 #define MMR_BS 33            // LDS row stride (floats) of the per-wave B_i[slot] image (32 slots at a time)
 
 __device__ __forceinline__ void mmr_decode_pair_o(int p, int L, int& a, int& a2) {
@@ -94,8 +95,9 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
   // the pair's column weights what'_j, shared by the four waves (a tile needs its 32 right after its bilinear product: from
   // global memory that was an exposed L2 latency per tile)
   float* wlds = reinterpret_cast<float*>(smem + (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * nT * 8);
-  {
-    const float* wsrc = colO + ((size_t)b * Po + lp) * Mp;
+  const float* wsrc = colO + ((size_t)b * Po + lp) * Mp;
+  const bool wl_ok = Mp <= MMR_WLDS_MAX;           // (beyond: read from global memory, tile by tile)
+  if (wl_ok) {
     for (int i = threadIdx.x * 4; i < Mp; i += 1024) *reinterpret_cast<float4*>(wlds + i) = *reinterpret_cast<const float4*>(wsrc + i);
   }
   __syncthreads();
@@ -152,7 +154,9 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
 #pragma unroll
       for (int i = 0; i < 8; ++i) psi[i] = *reinterpret_cast<const u32x4*>(qbase + (size_t)ct * 8192 + i * 1024 + lane * 16);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) wc[g] = *reinterpret_cast<const float4*>(wlds + ct * 32 + 8 * g + 4 * h);
+      for (int g = 0; g < 4; ++g)
+        wc[g] = wl_ok ? *reinterpret_cast<const float4*>(wlds + ct * 32 + 8 * g + 4 * h)
+                      : *reinterpret_cast<const float4*>(wsrc + ct * 32 + 8 * g + 4 * h);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         // b block, TRANSPOSED: A slot = the streamed columns, B slot = the stationary rows -> lane = row, registers = columns
@@ -283,7 +287,8 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
 }
 
 static size_t mmr_rem_lds_bytes(int d, int Mp) {
-  return (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * mma_pair_agg_len(d) * 8 + (size_t)Mp * 4;
+  return (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * mma_pair_agg_len(d) * 8 +
+         (size_t)(Mp <= MMR_WLDS_MAX ? Mp : 0) * 4;
 }
 
 // grid (Po, B), 512 threads: polynomial part + remainder slabs, re-centred at mu -> pagg [B][Po][nT]
@@ -364,10 +369,16 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const size_t shm = mmr_rem_lds_bytes(d, wl.Mp);
   if (shm > 160 * 1024) return MM_E_DIM;
+  // (the attribute is set once per variant, to the most the kernel may ask for: not inside a later stream capture)
 #define MMR_LAUNCH(TWO_)                                                                                                       \
   do {                                                                                                                        \
-    e = hipFuncSetAttribute((const void*)k_bwd_rem_f32<TWO_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);          \
-    if (e != hipSuccess) return (int)e;                                                                                       \
+    static bool attr_set = false;                                                                                             \
+    if (!attr_set) {                                                                                                          \
+      e = hipFuncSetAttribute((const void*)k_bwd_rem_f32<TWO_>, hipFuncAttributeMaxDynamicSharedMemorySize,                   \
+                              (int)mmr_rem_lds_bytes(8, MMR_WLDS_MAX));                                                       \
+      if (e != hipSuccess) return (int)e;                                                                                     \
+      attr_set = true;                                                                                                        \
+    }                                                                                                                         \
     hipLaunchKernelGGL(k_bwd_rem_f32<TWO_>, dim3((int)nwork_ll), dim3(256), shm, stream, (const unsigned short*)(packed + ml.Zs3), \
                        (const unsigned short*)(packed + ml.Zq2), (const double*)(packed + ml.Zc64), ml.Kz,                    \
                        (const double*)(packed + ml.zbar), mu, B, L, wl.Mp, d, wl.Po, npanel, (int)nwork_ll,                   \
@@ -383,8 +394,13 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
   if (rc) return rc;
   const int nT = mma_pair_agg_len(d);
   const size_t shm2 = (size_t)(2 * ml.KMp + d * d + 2 * d + nT + mma_pair_poly_scratch(d)) * sizeof(double);
-  e = hipFuncSetAttribute((const void*)k_pair_agg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm2);
-  if (e != hipSuccess) return (int)e;
+  static bool agg_attr_set = false;
+  if (!agg_attr_set) {
+    const size_t shm_max = (size_t)(2 * mm_moment_cols(8) + 64 + 16 + mma_pair_agg_len(8) + mma_pair_poly_scratch(8)) * sizeof(double);
+    e = hipFuncSetAttribute((const void*)k_pair_agg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max);
+    if (e != hipSuccess) return (int)e;
+    agg_attr_set = true;
+  }
   hipLaunchKernelGGL(k_pair_agg, dim3(wl.Po, B), dim3(512), shm2, stream, (const double*)(ws + wl.mom), ml.KMp,
                      (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), mu, L, d, wl.P, npanel,
                      (const double*)slab, (const short*)(packed + ml.rtab), pagg);

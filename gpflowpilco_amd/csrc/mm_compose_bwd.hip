@@ -147,6 +147,14 @@ extern "C" size_t mm_moment_match_backward_bytes(int B, int L, int M, int d, int
   return n64 > n32 ? n64 : n32;
 }
 
+// what one pack type needs (0: that pack type has no backward of its own)
+extern "C" size_t mm_moment_match_backward_bytes_dtype(int B, int L, int M, int d, int dtype, int flags) {
+  if (B <= 0 || L <= 0 || M <= 0 || d <= 0 || d > MM_DMAX) return 0;
+  if (dtype == MM_F64) return mm_gp_bwd_layout(B, L, M, d, MM_F64, flags).total;
+  if (dtype == MM_F32 && mm_bwd_f32_supported(d)) return mm_gp_bwd_layout(B, L, M, d, MM_F32, flags).total;
+  return 0;
+}
+
 // (g_f1 [B,L], g_Sff [B,L,L] | [B,L], g_cross [B,d,L]) -> g_mu [B,d], g_Sigma [B,d,d] (symmetric; += if accumulate_Sigma);
 // gradients are f64 for either pack type, (mu, Sigma) have the pack's type.
 // Re-runs the q stage for (mu, Sigma) on `workspace`, then the M x M sweeps, the items and their sum.

@@ -518,7 +518,7 @@ def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor
   key = ("bwd", B, flags)
   wb = pm._workspaces.get(key)
   if wb is None:
-    n = lib().mm_moment_match_backward_bytes(B, pm.L, pm.M, pm.d, flags)
+    n = lib().mm_moment_match_backward_bytes_dtype(B, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), flags)
     wb = torch.empty(n, dtype=torch.uint8, device=pm.device)
     pm._workspaces[key] = wb
   g_mu = torch.empty(B, pm.d, dtype=f64, device=pm.device)

@@ -244,6 +244,7 @@ int mm_backward_sums(const void* packed, size_t packed_bytes, int L, int M, int 
  * mm_adjoint.h).  bwd_ws: mm_moment_match_backward_bytes (enough for either pack type). */
 int mm_bwd_f32_supported(int d);
 size_t mm_moment_match_backward_bytes(int B, int L, int M, int d, int flags);
+size_t mm_moment_match_backward_bytes_dtype(int B, int L, int M, int d, int dtype, int flags);   /* exactly what that pack type needs */
 /* the off-diagonal aggregates of an MM_F32 pack alone (tests, diagnostics): runs the q stage of (mu, Sigma) on `workspace`;
  * pagg [B][P-L][1 + 2d + 3d^2] f64 = sum_ij Omega_ij (1 | zeta_i | zeta_i zeta_i^T | zeta'_j | zeta'_j zeta'_j^T | zeta_i zeta'_j^T),
  * zeta = z - mu, Omega_ij = w_i w'_j e^{delta_ij} (pairs a < a' row by row) */
