@@ -138,3 +138,33 @@ def test_backward_reuses_the_forward_q_stage_only_while_it_is_current(device):
   for k in (0, 1):            # f32, f64: identical with and without the call in between
     for a_, b_ in zip(grads[k], grads[k + 2]):
       assert float((a_ - b_).abs().amax()) <= 1e-12 * float(b_.abs().amax())
+
+
+def test_f32_pack_gradient_against_central_differences_of_the_oracle(device):
+  """The f32 pack's vector-Jacobian product checked directly against the fp64 CPU oracle (the literal restatement of
+  models.py:200-299): directional derivatives of a random linear functional of (f1, Sff, cross) by central differences."""
+  from oracle import mm_oracle as mo
+  from tests.helpers import gp_model_from_oracle, random_svgp_params
+  L, M, d, B = 3, 150, 8, 2
+  p = random_svgp_params(seed=91, L=L, M=M, d=d, whiten=True, ls_bounds=(0.8, 2.5), mean=False)
+  rng = np.random.default_rng(3)
+  mu = rng.uniform(0.3, 0.7, size=(B, d)).astype(np.float32).astype(np.float64)
+  S = make_inputs(B, d, seed=4, scale=0.15)[1].astype(np.float32).astype(np.float64)
+  A1, A2, A3 = rng.standard_normal((B, L)), rng.standard_normal((B, L, L)), rng.standard_normal((B, d, L))
+  A2 = 0.5 * (A2 + A2.transpose(0, 2, 1))
+
+  def loss(mu_, S_):
+    f1, Sff, cr = mo.mm_gauss_svgp_mo(mu_, S_, p, True, True, 0.0)
+    return (A1 * f1).sum() + (A2 * Sff).sum() + (A3 * cr).sum()
+  model = gp_model_from_oracle(p, device)
+  pm = model.packed(torch.float32, True, device)
+  gmu, gS = ops.moment_match_backward(pm, to_dev(mu, device, torch.float32), to_dev(S, device, torch.float32),
+                                      to_dev(A1, device, F64), to_dev(A2, device, F64), to_dev(A3, device, F64))
+  gmu, gS = gmu.cpu().numpy(), gS.cpu().numpy()
+  eps = 1e-4
+  scale = max(np.abs(gmu).max(), np.abs(gS).max())
+  for trial in range(4):
+    dm = rng.standard_normal((B, d)); dS = rng.standard_normal((B, d, d)); dS = 0.5 * (dS + dS.transpose(0, 2, 1))
+    fd = (loss(mu + eps * dm, S + eps * dS) - loss(mu - eps * dm, S - eps * dS)) / (2 * eps)
+    an = (gmu * dm).sum() + (gS * dS).sum()
+    assert abs(fd - an) < 2e-4 * scale * np.sqrt(dm.size + dS.size), (trial, fd, an, scale)
