@@ -102,9 +102,14 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 
 // k_wmom_gemm: slices of the m range (split-K) per output tile; k_spoly adds the partial moment vectors
 #define MM_MOM_SPLIT 2
-// a (b, pair) is collapsed (cubic + quartic term of the remainder taken from moments, tiles with max|b| <= 1/16
-// skipped) when max_i |A_i|^2 * max_j |zc_j|^2 <= MM_COLLAPSE_BOUND2, i.e. every |b_ij| <= 1 by Cauchy-Schwarz
-#define MM_COLLAPSE_BOUND2 1.0f
+// a (b, pair) is collapsed (cubic + quartic term of the remainder taken from moments, tiles with max|b| inside the first
+// tier skipped after a one-MFMA screening) when max_i |A_i|^2 * max_j |zc_j|^2 <= MM_COLLAPSE_BOUND2 (Cauchy-Schwarz bound on
+// |b_ij|).  0.15^2: below it the screening skips most tiles; above it almost none, and the degree-3/4 moment columns
+// (91 % of the moment GEMM) would be paid for nothing -- measured on the BASELINE recipe with the GEMM rows compacted
+// (k_wmom_perm): threshold 1 -> 0.0225: q stage 1.38 -> 1.05 ms, tile sweep 5.75 -> 5.84, step 10.8 -> 10.6 ms
+#ifndef MM_COLLAPSE_BOUND2
+#define MM_COLLAPSE_BOUND2 0.0225f
+#endif
 // First tier of the f32 remainder: near-minimax r(x) = expm1(x) - x - x^2/2 ~ x^3 (C0 + C1 x) on |x| <= MM_TIER1_MAX
 // (tools/minimax_remainder.py).  It is the polynomial the moment collapse takes from the f64 moments, so its
 // approximation error is SYSTEMATIC (it does not average out over the M^2 entries the way rounding does) and sets the
@@ -168,6 +173,8 @@ struct MMWorkspaceLayout {
   size_t mom;      // [B][Po][2][MM_MOM_SPLIT][KMp] f64  partial sums over m of what_m zc_m^alpha (all monomials of the
                    //                  table): row side, column side; MM_MOM_SPLIT slices of the m range
   size_t amax;     // [B][Po] u32  bits of max_i |A_i|^2 (f32, >= 0: ordered like the integer), zeroed by k_prep
+  size_t gperm;    // [L][(L-1) B] i32 + [L] i32 (f32 mode): per latent the rows of its moment GEMM with the COLLAPSED (b, pair) items
+                   //              first (stable), and their count -- the cubic / quartic column blocks are formed for those only
   size_t s12;      // [B][Po] f64  the polynomial part of the off-diagonal sums from the moments:
                    //              orders 0..2 always, orders 3 and 4 as well where the (b, pair) is collapsed
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
@@ -213,6 +220,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.whC = off;     off = mm_align_up(off + nwh * 8, A);
   o.mom = off;     off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * 2 * MM_MOM_SPLIT * mm_moment_cols(d) * 8), A);
   o.amax = off;    off = mm_align_up(off + (size_t)B * o.Po * 4, A);
+  o.gperm = off;   off = mm_align_up(off + (dtype == MM_F64 || L < 2 ? 0 : ((size_t)L * (L - 1) * B + L) * 4), A);
   o.s12 = off;     off = mm_align_up(off + (size_t)B * o.Po * 8, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
   o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);

@@ -46,10 +46,6 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
 #ifndef MM_F32_PPW_DIV
 #define MM_F32_PPW_DIV 4
 #endif
-// collapsed items with bound^2 above this sweep without screening (see the kernel)
-#ifndef MM_SCREEN_BOUND2
-#define MM_SCREEN_BOUND2 0.0225f
-#endif
 #ifndef MM_F32_WAVES
 #define MM_F32_WAVES 2
 #endif
@@ -389,14 +385,13 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
         process_tile(collc, collm, ct + 1, zA1, zB1, w1);
       }
     };
-    // a collapsed (b, pair) whose bound is well above 1/16 skips almost no tile (measured on the BASELINE recipe,
-    // scratch statistics in DESIGN.md: bound <= 0.12 -> < 12 % of the tiles exceed 1/16, bound >= 0.18 -> > 90 %):
-    // it takes the prefetching sweep -- no screening check, operands of the next tile always in flight -- with the
-    // collapsed coefficients
-    // (three instantiations: a non-collapsed item must not pay for the collapsed coefficients -- as a run-time flag
+    // A (b, pair) is collapsed only where its bound lets the screening skip most tiles (MM_COLLAPSE_BOUND2 = 0.15^2: measured
+    // on the BASELINE recipe, bound <= 0.12 -> < 12 % of the tiles exceed the first tier, bound >= 0.18 -> > 90 %); up to
+    // round 3 every item with bound <= 1 was collapsed and the ones above 0.15 took a third, unscreened sweep with the
+    // collapsed coefficients -- they paid the cubic / quartic moment columns for nothing.
+    // (Two instantiations, not a run-time flag: a non-collapsed item must not pay for the collapsed coefficients -- as a flag
     // they cost the exp2 branch 4 more ops per entry: forced-worst C3 12.5 -> 16.8 ms)
-    if (coll && bound2 <= MM_SCREEN_BOUND2) sweep(mm_true{}, mm_true{});
-    else if (coll) sweep(mm_false{}, mm_true{});
+    if (coll) sweep(mm_true{}, mm_true{});
     else sweep(mm_false{}, mm_false{});
   }
   // workgroup reduction -> slab
