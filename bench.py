@@ -256,7 +256,7 @@ def roofline_block(kernel, k_ms, flops, peak, pmc, pmc_src, pscale, kind, prefix
       r["frac"] = round(ach / peak, 4)
     else:
       r["frac_null_reason"] = ("algorithmic rate exceeds the dense peak: the launch does not execute SURVEY 8d's per-entry work "
-                               "(cubic + quartic remainder from f64 moments, tiles with max|b| <= 1/16 skipped; config.offdiag_items)")
+                               "(cubic + quartic remainder from f64 moments, tiles with max|b| <= 1/20 skipped; config.offdiag_items)")
   got = pmc_kernel(pmc, prefix)
   if got is None:
     r["pmc"] = pmc_src
@@ -616,8 +616,8 @@ def main():
                  "diag_pairs": "f64", "offdiag_pairs": cfg["dtype"],
                  "offdiag_items_one_rollout": dict(pr["offdiag_items_one_rollout"],
                                                    meaning="(b, off-diagonal pair, step) items of one rollout; collapsed: cubic + quartic "
-                                                           "remainder terms from f64 moments, tiles with max|b| <= 1/16 skipped after a "
-                                                           "screening MFMA; wholly_inside: the Cauchy-Schwarz bound alone puts every |b| <= 1/16, "
+                                                           "remainder terms from f64 moments (items with Cauchy-Schwarz bound <= 0.15), tiles with max|b| <= 1/20 skipped after a "
+                                                           "screening MFMA; wholly_inside: the Cauchy-Schwarz bound alone puts every |b| <= 1/20, "
                                                            "no tile work (csrc/mm_moments.hip, mm_mfma.hip)")},
       "segments_ms": pr["segments_ms"],
       "roofline": pr["roofline"],
