@@ -1062,6 +1062,8 @@ MMA_FN void mma_gp_item_moments(Ctx c, int item, int m0, int m1, int L, int M, i
   }
   c.sync();
   const int nq = d * d + d;
+  const bool same_tab = a == b;                 // latent item or diagonal pair: one monomial per centre serves both sums
+  const bool same_coef = !latent && a == b;     // diagonal pair: Rsum = Ksum (the pair is symmetric), Rmom = Kmom
   for (int idx = lane; idx < ns * nc; idx += nl) {
     const int k = idx % nc, sl = idx / nc;
     const int i = k <= d ? k - 1 : (k - 1 - d) / d, j = k <= d ? 0 : (k - 1 - d) % d;
@@ -1070,12 +1072,14 @@ MMA_FN void mma_gp_item_moments(Ctx c, int item, int m0, int m1, int L, int M, i
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
     for (int m = sl; m < n; m += ns) {
       const double fa = k == 0 ? 1.0 : k <= d ? Zra[m * d + i] : Zra[m * d + i] * Zra[m * d + j];
-      const double fb = k == 0 ? 1.0 : k <= d ? Zcb[m * d + i] : Zcb[m * d + i] * Zcb[m * d + j];
       s0 = fma(cA[m], fa, s0);
-      s1 = fma(cB[m], fb, s1);
+      if (!same_coef) {
+        const double fb = same_tab ? fa : (k == 0 ? 1.0 : k <= d ? Zcb[m * d + i] : Zcb[m * d + i] * Zcb[m * d + j]);
+        s1 = fma(cB[m], fb, s1);
+      }
       if (!latent && k < nq) s2 = fma(Uc[i2 * n + m], k < d * d ? Zcb[m * d + j2] : 1.0, s2);
     }
-    part[idx] = s0; part[ns * nc + idx] = s1; part[2 * ns * nc + idx] = s2;
+    part[idx] = s0; part[ns * nc + idx] = same_coef ? s0 : s1; part[2 * ns * nc + idx] = s2;
   }
   c.sync();
   for (int k = lane; k < 3 * nc; k += nl) {

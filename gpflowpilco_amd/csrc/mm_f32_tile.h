@@ -40,10 +40,10 @@ __device__ __forceinline__ void mm_split3(float x, unsigned int& h, unsigned int
 // (tools/error_budget.py: 2.5e-3 -> 1e-8 of max|Sff| at C3).
 //
 // Near-minimax R(x) ~ r(x) / x^3 by range tier, |x^3 R(x) - r(x)| <= 5e-8 |x| with fused f32 Horner
-// steps (tools/minimax_remainder.py):  |x| <= 1/16: degree 1,  <= 1/4: 3,  <= 1/2: 4,  <= 1: 5.
+// steps (tools/minimax_remainder.py):  |x| <= 1/20 (MM_TIER1_MAX): degree 1,  <= 1/4: 3,  <= 1/2: 4,  <= 1: 5.
 // Along the C3 rollout 90-100 % of the 64 x 32 wave tiles are in the first tier (tools/tier_stats.py) -- which is why,
 // for d <= 8, that tier's own approximant c0 x^3 + c1 x^4 is taken from degree-3/4 moments as well (the collapse,
-// mm_moments.hip): a collapsed (b, pair) only visits tiles with max|b| > 1/16 and reduces r(x) - c0 x^3 - c1 x^4 there.
+// mm_moments.hip): a collapsed (b, pair) only visits tiles with max|b| > 1/20 and reduces r(x) - c0 x^3 - c1 x^4 there.
 template <int DEG> struct MMRem;
 template <> struct MMRem<1> {
   static constexpr float c[2] = {MM_REM1_C0, MM_REM1_C1};      // mm_common.h: shared with the moment collapse

@@ -5,12 +5,12 @@
 //     S = sum_ij w_i expm1(delta_ij) w'_j,   delta_ij = rho'_i + gamma_j + b_ij
 //       = sum_ij what_i what'_j (1 + b_ij + b_ij^2/2)  - (sum w)(sum w')        exact, f64 moments (O(M d^2))
 //       + sum_ij what_i what'_j r(b_ij),   r(x) = expm1(x) - x - x^2/2            THIS kernel, f32, O(M^2)
-// Where the model's input dimension allows a degree-4 moment table (d <= 8) and a (b, pair)'s Cauchy-Schwarz bound
-// guarantees |b_ij| <= 1, the (b, pair) is COLLAPSED (mm_moments.hip): the cubic and quartic terms of r -- this
-// kernel's own first-tier approximant c0 x^3 + c1 x^4, exact to 5e-8 |x| on |x| <= 1/16 -- are taken from f64
-// moments as well, every wave tile whose max|b| is <= 1/16 (known after ONE screening MFMA per 32 x 32 block,
-// the (h, h + m) part of the split product) contributes nothing and is skipped, and the other tiles reduce the
-// correction r(x) - c0 x^3 - c1 x^4 with the same range tiers.
+// Where the model's input dimension allows a degree-4 moment table (d <= 8) and a (b, pair)'s Cauchy-Schwarz bound on
+// |b_ij| is <= 0.15 (MM_COLLAPSE_BOUND2: most of its tiles are then inside the first tier), the (b, pair) is COLLAPSED
+// (mm_moments.hip): the cubic and quartic terms of r -- this kernel's own first-tier approximant c0 x^3 + c1 x^4, exact to
+// 9e-9 |x| on |x| <= 1/20 (MM_TIER1_MAX) -- are taken from f64 moments as well, every wave tile whose max|b| is inside that
+// tier (known after ONE screening MFMA per 32 x 32 block, the (h, h + m) part of the split product) contributes nothing
+// and is skipped, and the other tiles reduce the correction r(x) - c0 x^3 - c1 x^4 with the same range tiers.
 // The bilinear part runs on the bf16 matrix pipe as a 3-way split product with f32 accuracy
 // (v_mfma_f32_32x32x16_bf16), the remainder polynomial + weighted reduction on the VALU in packed
 // f32 (v_pk_fma_f32); MFMA and f32 FMA-class VALU time add on a gfx950 SIMD (tools/ubench_overlap.hip).
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   if constexpr (ND8 == 1) {
-    // Cauchy-Schwarz already bounds every |b_ij| of this (b, pair) by 1/16: the remainder is the first tier's
+    // Cauchy-Schwarz already bounds every |b_ij| of this (b, pair) by MM_TIER1_MAX: the remainder is the first tier's
     // c0 x^3 + c1 x^4 everywhere, which the moments carry (k_spoly) -- every tile would be skipped: no sweep at all
     if (!force_worst && zmax2 && mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) <= MM_INSIDE_BOUND2) {
       for (int panel = pgrp * ppw + (int)threadIdx.x; panel < npanel && panel < (pgrp + 1) * ppw; panel += 256)

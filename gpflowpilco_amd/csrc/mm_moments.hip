@@ -9,11 +9,13 @@
 //     Q_n = sum_j what'_j zc'_j^{(x)n},   M_n = sum_i what_i (zc_i - dmu)^{(x)n}.
 // Orders 0..2 (1 + b + b^2/2) are ALWAYS taken this way: in f32 it is the rounding of the linear term that
 // costs the digits of S (DESIGN.md "fp32 error budget").  For d <= 8 the tables go to degree 4, and a (b, pair)
-// whose Cauchy-Schwarz bound max_i |A_i| max_j |zc'_j| is <= 1 is COLLAPSED: the cubic and quartic terms
-// c0 x^3 + c1 x^4 -- the tile kernel's own first-tier approximant of the remainder, valid to 5e-8 |x| on
-// |x| <= 1/16 -- come from the moments too, the tile kernel skips every tile with max|b| <= 1/16 after a one-MFMA
+// whose Cauchy-Schwarz bound max_i |A_i| max_j |zc'_j| is <= 0.15 (MM_COLLAPSE_BOUND2) is COLLAPSED: the cubic and quartic
+// terms c0 x^3 + c1 x^4 -- the tile kernel's own first-tier approximant of the remainder, valid to 9e-9 |x| on
+// |x| <= 1/20 -- come from the moments too, the tile kernel skips every tile inside that tier after a one-MFMA
 // screening product and reduces only the correction r(x) - c0 x^3 - c1 x^4 on the others.
 //
+//   k_wmom_perm : per latent the rows of its GEMM with the collapsed (b, pair) items first (the cubic / quartic column
+//                 blocks are formed for those rows only);
 //   k_wmom_gemm : mom[(b, pair, side)][:] = sum_m what_m Zm[latent(side)][m][:]   -- an f64 GEMM
 //                 [rows = B per (pair, side)] x [K = Mp] x [N = KMp columns] on v_mfma_f64_16x16x4_f64:
 //                 64 x 128 output tile per workgroup (4 waves x 64 x 32), K-blocks of 32 staged through LDS
