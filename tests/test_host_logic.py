@@ -229,3 +229,19 @@ def test_blocked_cholesky_equals_lapack_and_reports_the_failing_minor():
   _, info = _blocked_cholesky_ex(B, nb=32)
   ref = torch.linalg.cholesky_ex(B)[1]
   assert info.tolist() == ref.tolist() == [0, 71]
+
+
+def test_workspace_generation_counts_every_request():
+  """ops.PackedModel.workspace_generation: the match backward reuses the forward's q stage only while nobody has asked for
+  that workspace since (no GPU needed: the size query and the bookkeeping are host code)."""
+  from gpflowpilco_amd import ops
+  pm = ops.PackedModel(L=2, M=16, d=3, dtype=torch.float64, with_C=True, buf=torch.zeros(8, dtype=torch.uint8))
+  fl = ops.make_flags(True, True)
+  assert pm.workspace_generation(4, fl) == 0
+  ws = pm.workspace(4, fl)
+  assert pm.workspace_generation(4, fl) == 1 and ws.numel() > 0
+  assert pm.workspace(4, fl, peek=True) is ws and pm.workspace_generation(4, fl) == 1          # looking does not count
+  assert pm.workspace(4, fl | 4) is ws and pm.workspace_generation(4, fl) == 2                  # FORCE_GENERIC: same workspace
+  pm.workspace(5, fl)
+  assert pm.workspace_generation(4, fl) == 2 and pm.workspace_generation(5, fl) == 1            # per batch size
+  assert pm.workspace_generation(4, ops.make_flags(False, True)) == 0                           # per pair layout
