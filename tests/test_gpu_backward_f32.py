@@ -168,3 +168,22 @@ def test_f32_pack_gradient_against_central_differences_of_the_oracle(device):
     fd = (loss(mu + eps * dm, S + eps * dS) - loss(mu - eps * dm, S - eps * dS)) / (2 * eps)
     an = (gmu * dm).sum() + (gS * dS).sum()
     assert abs(fd - an) < 2e-4 * scale * np.sqrt(dm.size + dS.size), (trial, fd, an, scale)
+
+
+def test_f32_pack_backward_beyond_the_lds_weight_cache(device):
+  """M > 16384: k_bwd_rem_f32 reads the pair's column weights from global memory instead of its LDS copy."""
+  L, M, d, B = 2, 16500, 4, 1
+  rng = np.random.default_rng(7)
+  t = lambda a: torch.as_tensor(a, dtype=F64, device=device)
+  Z = rng.uniform(size=(L, M, d)); ls = np.exp(rng.uniform(np.log(0.6), np.log(1.5), size=(L, d)))
+  beta = rng.standard_normal((L, M)) / np.sqrt(M)
+  pm32 = ops.pack_model(t(Z), t(ls), t(np.ones(L)), t(beta), None, None, dtype=torch.float32)
+  pm64 = ops.pack_model(t(Z), t(ls), t(np.ones(L)), t(beta), None, None, dtype=F64)
+  mu, S = make_inputs(B, d, seed=4, scale=0.1, lo=0.3, hi=0.7)
+  mu32, S32 = to_dev(mu, device, torch.float32), to_dev(S, device, torch.float32)
+  g1, g2, g3 = t(rng.standard_normal((B, L))), t(rng.standard_normal((B, L, L))), t(rng.standard_normal((B, d, L)))
+  a = ops.moment_match_backward(pm32, mu32, S32, g1, g2, g3, True, False)
+  b = ops.moment_match_backward(pm64, mu32.double(), S32.double(), g1, g2, g3, True, False)
+  for x, y in zip(a, b):
+    sc = float(y.abs().amax())
+    assert float((x - y).abs().amax()) < 1e-4 * sc, (float((x - y).abs().amax()), sc)
