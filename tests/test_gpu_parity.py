@@ -370,6 +370,12 @@ def test_empty_batch_returns_empty_outputs(device):
     ops.moment_match(model.packed(torch.float64, False, device), mu, S, model_uncertainty=True)
   with pytest.raises(ValueError):
     ops.moment_match(pm, torch.empty(0, 4, dtype=torch.float64, device=device), torch.empty(0, 4, 4, dtype=torch.float64, device=device))
+  # ... and so does the backward: an empty gradient, for either pack type
+  z = lambda *s_: torch.empty(*s_, dtype=torch.float64, device=device)
+  gmu, gS = ops.moment_match_backward(pm, mu, S, z(0, 2), z(0, 2, 2), z(0, 3, 2))
+  assert gmu.shape == (0, 3) and gS.shape == (0, 3, 3)
+  gmu, gS = ops.moment_match_backward(model.packed(torch.float32, True, device), mu.float(), S.float(), z(0, 2), z(0, 2, 2), z(0, 3, 2))
+  assert gmu.shape == (0, 3) and gS.shape == (0, 3, 3)
 
 
 def test_latents_with_different_active_dims_match_quadrature(device):
