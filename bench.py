@@ -678,6 +678,33 @@ def main():
                           "max_abs_err": {"f1": err(f1, first[0]), "Sff": err(Sff, first[1]), "cross_pre": err(cross, first[2])},
                           "max_abs": {"f1": float(np.abs(first[0]).max()), "Sff": float(np.abs(first[1]).max()),
                                       "cross_pre": float(np.abs(first[2]).max())}}, **pr.get("parity", {}))
+  # next row f-1, in the same driver-timed line (the full bench of that row: --config c3_grad): a short forward + backward of
+  # the primary regime's first step on the f32 pack
+  # (ctx: the primary regime's model, pack and first-step inputs, taken above)
+  if (ctx is not None and world == 1 and not args.pmc_run and args.recipe is None and f32_mode and not args.force_generic
+      and ops.backward_supported(ctx["pm"])):
+    pm_, mu_, S_ = ctx["pm"], ctx["mu0"], ctx["S0"]
+    gg = torch.Generator(device="cpu").manual_seed(cfg["seed"])
+    g1, g2, g3 = (torch.randn(s_, generator=gg, dtype=torch.float64).to(dev) for s_ in ((B, L), (B, L, L), (B, d, L)))
+    fl = ops.make_flags(True, True)
+
+    def fwd_bwd(with_bwd):
+      ops.moment_match(pm_, mu_, S_)
+      if with_bwd:
+        ops.moment_match_backward(pm_, mu_, S_, g1, g2, g3, True, True, forward_generation=pm_.workspace_generation(B, fl))
+    t_ms = {}
+    for name_, wb in (("forward_ms", False), ("forward_backward_ms", True)):
+      fwd_bwd(wb)
+      e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      e0.record()
+      for _ in range(5):
+        fwd_bwd(wb)
+      e1.record(); torch.cuda.synchronize()
+      t_ms[name_] = round(e0.elapsed_time(e1) / 5, 4)
+    out["next_rows"] = {"f-1": dict(t_ms, what="moment match forward / forward + backward (vector-Jacobian product w.r.t. mu, Sigma) on the f32 "
+                                         "pack, first step's inputs of the primary regime, B elements; stage times and roofline: "
+                                         "bench.py --config c3_grad", B=B,
+                                    forward_backward_over_forward=round(t_ms["forward_backward_ms"] / t_ms["forward_ms"], 2))}
   for r in results.values():
     r.pop("_fused", None); r.pop("_ctx", None)
   if len(results) > 1 or args.regimes:
