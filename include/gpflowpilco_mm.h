@@ -241,7 +241,10 @@ int mm_backward_sums(const void* packed, size_t packed_bytes, int L, int M, int 
  *     are reduced to 1 + 2d + 3d^2 aggregates each -- polynomial part from the degree-4 weight moments in f64, remainder
  *     by a bf16-MFMA tile sweep (csrc/mm_bwd_f32.hip); other f32 packs return MM_E_DTYPE (use an f64 pack of the model),
  * then the M-sized moments and the d x d chain rule per (latent | pair) item and their sum (csrc/mm_compose_bwd.hip,
- * mm_adjoint.h).  bwd_ws: mm_moment_match_backward_bytes (enough for either pack type). */
+ * mm_adjoint.h).  bwd_ws: mm_moment_match_backward_bytes (enough for either pack type).
+ * flags: the forward's, optionally | MM_WORKSPACE_CURRENT, optionally | MM_STAGE_* to run only part of the backward on what
+ * earlier calls left in `workspace` / `bwd_ws` (measurement): MM_STAGE_DIAG = the f64 sweep (f64 packs: of every pair),
+ * MM_STAGE_OFFDIAG = the f32 remainder sweep, MM_STAGE_FINALIZE = moment GEMM, aggregates, item moments, items and their sum. */
 int mm_bwd_f32_supported(int d);
 size_t mm_moment_match_backward_bytes(int B, int L, int M, int d, int flags);
 size_t mm_moment_match_backward_bytes_dtype(int B, int L, int M, int d, int dtype, int flags);   /* exactly what that pack type needs */
