@@ -515,7 +515,8 @@ def moment_match_backward(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor
   # nobody has asked for the workspace since, its q stage is still there and is not run again (MM_WORKSPACE_CURRENT)
   if B == 0:                        # an empty batch has an empty gradient (as the forward returns empty outputs); no launch
     return (torch.empty(0, pm.d, dtype=f64, device=pm.device), torch.empty(0, pm.d, pm.d, dtype=f64, device=pm.device))
-  current = forward_generation is not None and forward_generation == pm.workspace_generation(B, flags)
+  current = (forward_generation is not None and forward_generation > 0
+             and forward_generation == pm.workspace_generation(B, flags))
   ws = pm.workspace(B, flags, peek=current)
   key = ("bwd", B, flags)
   wb = pm._workspaces.get(key)
