@@ -226,8 +226,8 @@ def test_random_shapes_f32_pack_backward_matches_f64_pack(c, device):
   assert int(pm32.status()[0]) == 0
   # f32 models are specified for states narrower than the lengthscales (|b| < 1).  Beyond that the remainder of
   # e^b is no longer a small correction to the f64 polynomial part: the f32 FORWARD's off-diagonal covariances are then at
-  # ~1e-2 of their scale themselves (measured on draw 13: std 0.25 at lengthscales 0.5-1.4), and the backward -- which
-  # accumulates a whole column sweep in the f32 MFMA accumulators -- at a few 1e-2 of the gradient's
+  # ~1e-2 of their scale themselves (measured on draw 13: std 0.25 at lengthscales 0.5-1.4), and the backward at a few 1e-2
+  # of the gradient's (the f32 operands' rounding under e^b at |b| ~ 3: DESIGN.md section 8)
   tol = 2e-4 if c["scale"] <= 0.25 * lo else 5e-2
   for x, y in zip(a, b):
     sc = float(y.abs().amax())
