@@ -46,7 +46,7 @@ static int run(int L, int M, int d, int B, int dtype, int flags, const std::vect
   HIP_OK(hipMalloc(&ws, wbytes));
   HIP_OK(hipMalloc(&f1, (size_t)B * L * sizeof(T))); HIP_OK(hipMalloc(&Sff, (size_t)B * L * L * sizeof(T)));
   HIP_OK(hipMalloc(&cross, (size_t)B * d * L * sizeof(T)));
-  HIP_OK(hipMalloc((void**)&status, 2 * sizeof(int32_t))); HIP_OK(hipMemset(status, 0, 2 * sizeof(int32_t)));
+  HIP_OK(hipMalloc((void**)&status, 4 * sizeof(int32_t))); HIP_OK(hipMemset(status, 0, 4 * sizeof(int32_t)));
   rc = mm_moment_match(packed, pbytes, L, M, d, dtype, B, dmu, dS, flags, 0.0, f1, Sff, cross, ws, wbytes, status, nullptr);
   if (rc) { fprintf(stderr, "mm_moment_match: %d\n", rc); return 3; }
   HIP_OK(hipDeviceSynchronize());
@@ -57,7 +57,7 @@ static int run(int L, int M, int d, int B, int dtype, int flags, const std::vect
     return fwrite(o.data(), 8, n, fo) == n ? 0 : 1;
   };
   if (down(f1, (size_t)B * L) || down(Sff, (size_t)B * L * L) || down(cross, (size_t)B * d * L)) return 2;
-  int32_t st[2]; HIP_OK(hipMemcpy(st, status, sizeof(st), hipMemcpyDeviceToHost));
+  int32_t st[4]; HIP_OK(hipMemcpy(st, status, sizeof(st), hipMemcpyDeviceToHost));
   fwrite(st, sizeof(int32_t), 1, fo);
   printf("abi %d: L=%d M=%d d=%d B=%d dtype=%d packed %zu B workspace %zu B status %d\n", mm_abi_version(), L, M, d, B, dtype,
          pbytes, wbytes, st[0]);

@@ -25,6 +25,8 @@ MM_STAGE_OFFDIAG = 16
 MM_STAGE_FINALIZE = 32
 MM_FORCE_WORST_TIER = 64
 MM_WORKSPACE_CURRENT = 128
+MM_FORCE_ROUTE = 256
+MM_NO_ROUTE = 512
 
 ERRORS = {
     -1: "MM_E_ARG: NULL pointer or non-positive size",

@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
                                                         const double* __restrict__ Zc64, int Kz, const double* __restrict__ zbar,
                                                         const float* __restrict__ mu, int B, int L, int Mp, int d, int Po, int npanel,
                                                         int nwork, const float* __restrict__ rowO, const float* __restrict__ colO,
-                                                        const double* __restrict__ whR, double* __restrict__ slab) {
+                                                        const double* __restrict__ whR, double* __restrict__ slab,
+                                                        float* __restrict__ estO, int* __restrict__ rcount) {
   const int orig = blockIdx.x;
+  if (orig == 0 && threadIdx.x == 0 && rcount) { rcount[0] = 0; rcount[2] = 0; }   // this pass's route list (k_route_decide follows)
   const int xcd = orig & 7, slotx = orig >> 3;
   const int qn = nwork >> 3, rn = nwork & 7;
   const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slotx;
@@ -97,10 +99,26 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
   float* wlds = reinterpret_cast<float*>(smem + (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * nT * 8);
   const float* wsrc = colO + ((size_t)b * Po + lp) * Mp;
   const bool wl_ok = Mp <= MMR_WLDS_MAX;           // (beyond: read from global memory, tile by tile)
+  // csq[2 ct + h]: sum of what'_j^2 over the 16 columns a lane of half h holds of tile ct (the error estimate of mm_route.hip)
+  float* csq = wlds + (wl_ok ? Mp : 0);
   if (wl_ok) {
     for (int i = threadIdx.x * 4; i < Mp; i += 1024) *reinterpret_cast<float4*>(wlds + i) = *reinterpret_cast<const float4*>(wsrc + i);
+    __syncthreads();
+    for (int e = threadIdx.x; e < (Mp >> 4); e += 256) {
+      const int ct = e >> 1, hh = e & 1;
+      float s2 = 0.0f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 v = *reinterpret_cast<const float4*>(wlds + ct * 32 + 8 * g + 4 * hh);
+        s2 += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      csq[e] = s2;
+    }
   }
   __syncthreads();
+  // running estimate of the sweep's rounding error (mm_common.h: MM_ROUTE_TOL): per lane -- its two rows, 16 columns of each
+  // tile -- sum over the tiles of (max|b|^3)^2 sum what'_j^2; rows' squares and the (1 + X + X^2) factor once per sweep
+  float est = 0.0f, xall = 0.0f;
 
   f32x16 acc2[2][2];
 #pragma unroll
@@ -151,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
     auto process = [&](int ct, const u32x4& zA, const u32x4& zB) {
       u32x4 psi[8];
       float4 wc[4];
+      float mxs[2];
 #pragma unroll
       for (int i = 0; i < 8; ++i) psi[i] = *reinterpret_cast<const u32x4*>(qbase + (size_t)ct * 8192 + i * 1024 + lane * 16);
 #pragma unroll
@@ -167,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
 #pragma unroll
         for (int r = 0; r < 8; ++r) m4[r & 3] = fmaxf(fmaxf(m4[r & 3], fabsf(acc[2 * r])), fabsf(acc[2 * r + 1]));
         const float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        mxs[rt] = mx;
         if (__any(mx > 0.03125f))
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, zB), a2v[rt], acc, 0, 0, 0);
         f32x2 xx[8], v[8], wq[8];
@@ -215,6 +235,19 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
                                                                      acc2[rt][nb], 0, 0, 0);
             }
       }
+      {
+        float cs;
+        if (wl_ok) cs = csq[2 * ct + h];
+        else {
+          cs = 0.0f;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) cs += (wc[g].x * wc[g].x + wc[g].y * wc[g].y) + (wc[g].z * wc[g].z + wc[g].w * wc[g].w);
+        }
+        const float mt = fmaxf(mxs[0], mxs[1]);
+        const float x3 = (mt * mt) * mt;
+        est = fmaf(x3 * x3, cs, est);
+        xall = fmaxf(xall, mt);
+      }
     };
     u32x4 zA0, zB0, zA1, zB1;
     load_z(0, zA0, zB0);
@@ -224,6 +257,21 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
       load_z(ct + 2 < nct ? ct + 2 : ct, zA0, zB0);   // clamped: the last pass re-reads its own tile
       process(ct + 1, zA1, zB1);
     }
+    {
+      const float w0 = ra[(size_t)d * Mp + row0 + l31], w1 = ra[(size_t)d * Mp + row0 + 32 + l31];     // the lane's two rows
+      const float xf = fminf(xall, 8.0f);
+      const float pf = fmaf(xf, xf, xf) + 1.0f;
+      est = (est * fmaf(w0, w0, w1 * w1)) * (pf * pf);
+    }
+  }
+  if (estO) {
+    float e = est;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+    __shared__ float redf[4];
+    if (lane == 0) redf[wv] = e;
+    __syncthreads();
+    if (threadIdx.x == 0) estO[((size_t)b * Po + lp) * npanel + panel] = (redf[0] + redf[1]) + (redf[2] + redf[3]);
   }
 
   // ---- epilogue: T_rem[alpha, slot] = sum_i what_i zeta_i^alpha B_i[slot] over the wave's rows, f64 ----------------------------
@@ -288,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
 
 static size_t mmr_rem_lds_bytes(int d, int Mp) {
   return (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * mma_pair_agg_len(d) * 8 +
-         (size_t)(Mp <= MMR_WLDS_MAX ? Mp : 0) * 4;
+         (size_t)(Mp <= MMR_WLDS_MAX ? Mp + (Mp >> 4) : 0) * 4;
 }
 
 // grid (Po, B), 512 threads: polynomial part + remainder slabs, re-centred at mu -> pagg [B][Po][nT]
@@ -357,9 +405,12 @@ size_t mm_bwd_f32_slab_bytes(int B, int Po, int Mp, int d) {
 // Off-diagonal aggregates of an f32 pack whose q stage is current on `ws` (mm_q_forward, MM_F32).  mu: [B][d] f32.
 // stages (bench.py times them apart): MM_STAGE_OFFDIAG = the remainder sweep k_bwd_rem_f32 alone; MM_STAGE_FINALIZE = the full
 // moment GEMM and k_pair_agg
+int mm_launch_route(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl, int B, int L, int M,
+                    int d, int flags, int agg, double* out, int32_t* status, hipStream_t stream);
+
 int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
-                              int B, int L, int d, const float* mu, double* slab, double* pagg, hipStream_t stream,
-                              int stages = MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE) {
+                              int B, int L, int M, int d, int flags, const float* mu, double* slab, double* pagg, int32_t* status,
+                              hipStream_t stream, int stages = MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE) {
   if (wl.Po <= 0) return 0;
   if (!mm_bwd_f32_supported(d)) return MM_E_DIM;
   const int npanel = (wl.Mp + 255) / 256;
@@ -382,12 +433,16 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
     hipLaunchKernelGGL(k_bwd_rem_f32<TWO_>, dim3((int)nwork_ll), dim3(256), shm, stream, (const unsigned short*)(packed + ml.Zs3), \
                        (const unsigned short*)(packed + ml.Zq2), (const double*)(packed + ml.Zc64), ml.Kz,                    \
                        (const double*)(packed + ml.zbar), mu, B, L, wl.Mp, d, wl.Po, npanel, (int)nwork_ll,                   \
-                       (const float*)(ws + wl.rowO), (const float*)(ws + wl.colO), (const double*)(ws + wl.whR), slab);       \
+                       (const float*)(ws + wl.rowO), (const float*)(ws + wl.colO), (const double*)(ws + wl.whR), slab,        \
+                       (float*)(ws + wl.estO), (int*)(ws + wl.rcount));                                                       \
   } while (0)
   if (1 + d + d * (d + 1) / 2 > 32) MMR_LAUNCH(true); else MMR_LAUNCH(false);
 #undef MMR_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  // items whose estimated f32 / bf16 rounding error is beyond MM_ROUTE_TOL of the block's scale: remainder aggregates in f64
+  const int rcr = mm_launch_route(packed, ml, ws, wl, B, L, M, d, flags, 1, slab, status, stream);
+  if (rcr) return rcr;
   }
   if (!(stages & MM_STAGE_FINALIZE)) return 0;
   const int rc = mm_launch_wmom_full(packed, ml, ws, wl, B, L, d, stream);
@@ -439,6 +494,6 @@ extern "C" int mm_backward_pair_aggregates(const void* packed, size_t packed_byt
   int rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, ws + wl.f1s, ws + wl.crs, nullptr,
                         workspace, workspace_bytes, status, stream);
   if (rc) return rc;
-  return mm_launch_bwd_offdiag_f32((const char*)packed, ml, ws, wl, B, L, d, (const float*)mu, (double*)scratch, (double*)pagg,
-                                   (hipStream_t)stream);
+  return mm_launch_bwd_offdiag_f32((const char*)packed, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)scratch,
+                                   (double*)pagg, status, (hipStream_t)stream);
 }

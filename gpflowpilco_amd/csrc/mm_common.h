@@ -142,6 +142,16 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 // ... and when the bound itself says every |b_ij| <= MM_TIER1_MAX, the whole remainder of the (b, pair) is inside the
 // collapsed range: the tile kernel's workgroup writes zero partials and leaves
 #define MM_INSIDE_BOUND2 (0.998f * MM_TIER1_MAX * MM_TIER1_MAX)
+// Accuracy contract of the f32 off-diagonal reduce.  The f32 tile kernels carry, beside their sums, an
+// estimate of the rounding error of each (b, pair)'s remainder sum under an independent-rounding model,
+//     est = 2^-24 * (2/3) * sqrt( sum over lane blocks of (sum_rows what_i^2) what'_j^2 (max|b|^3 (1 + X + X^2))^2 )
+// (rho(x) = |r(x)| + |x| |r'(x)| <= (2/3) |x|^3 e^|x| bounds what a relative error 2^-24 in what_i, what'_j, b_ij does to
+// what_i what'_j r(b_ij)); measured 7-50 x above the actual error (tools/route_study.py).  An item whose estimate exceeds
+// MM_ROUTE_TOL x (the largest |off-diagonal covariance| of its batch element, taken from the f64 moments: s12 - f1 f1') is
+// re-reduced in f64 (mm_route.hip) and its slab overwritten: what stays in f32 is within ~1e-5 of the block's own scale.
+#ifndef MM_ROUTE_TOL
+#define MM_ROUTE_TOL 1.0e-4
+#endif
 // Rows per workgroup of the generic reduce kernel / columns per workgroup.
 #define MM_GEN_ROWS 64
 #define MM_GEN_COLS 256
@@ -179,6 +189,11 @@ struct MMWorkspaceLayout {
                    //              orders 0..2 always, orders 3 and 4 as well where the (b, pair) is collapsed
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
   size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i expm1(delta_ij) q_j  (+ q^T C q)
+  size_t mu64;     // [B][d] f64    the state mean as the q stage read it (mm_route.hip re-derives A_i = G^T (z_i - mu) in f64)
+  size_t estO;     // [B][Po][ceil(Mp/256)] f32 (f32 mode): per row panel the tile kernel's running estimate of its own rounding error,
+                   //              sum over lane blocks of (sum_rows what_i^2) what'_j^2 (max|b|^3)^2 (1 + X + X^2)^2 (mm_route.hip)
+  size_t rlist;    // [B Po] i32   the (b, off-diagonal pair) items k_route_decide hands to the f64 re-reduce
+  size_t rcount;   // [4] i32      {entries of rlist (current pass), items routed by the last forward, by the last backward, 0}
   size_t f1s;      // [B][L] T      rollout scratch outputs
   size_t Sffs;     // [B][L][L] T
   size_t crs;      // [B][d][L] T
@@ -224,6 +239,11 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.s12 = off;     off = mm_align_up(off + (size_t)B * o.Po * 8, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
   o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);
+  const size_t nro = dtype == MM_F64 ? 0 : (size_t)B * o.Po;
+  o.mu64 = off;    off = mm_align_up(off + (size_t)B * d * 8, A);
+  o.estO = off;    off = mm_align_up(off + nro * ((o.Mp + MM_PANEL_ROWS - 1) / MM_PANEL_ROWS) * 4, A);
+  o.rlist = off;   off = mm_align_up(off + nro * 4, A);
+  o.rcount = off;  off = mm_align_up(off + 16, A);
   o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);
   o.Sffs = off;    off = mm_align_up(off + (size_t)B * L * L * es, A);
   o.crs = off;     off = mm_align_up(off + (size_t)B * d * L * es, A);

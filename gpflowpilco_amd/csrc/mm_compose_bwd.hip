@@ -22,7 +22,8 @@ int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* w
 extern "C" int mm_bwd_f32_supported(int d);
 size_t mm_bwd_f32_slab_bytes(int B, int Po, int Mp, int d);
 int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
-                              int B, int L, int d, const float* mu, double* slab, double* pagg, hipStream_t stream, int stages);
+                              int B, int L, int M, int d, int flags, const float* mu, double* slab, double* pagg, int32_t* status,
+                              hipStream_t stream, int stages);
 int mm_launch_cast_f32_f64(const float* x, double* y, size_t n, hipStream_t stream);
 
 // stage profile (tools/profile_c1_stages.py; -DMM_STAGE_PROFILE builds only): cycles per stage of block 0
@@ -209,8 +210,8 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
       if (rc) return rc;
     }
     if (wl.Po > 0) {
-      rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, d, (const float*)mu, (double*)(bw + bl.slab), (double*)(bw + bl.pagg), s,
-                                     stages);
+      rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)(bw + bl.slab),
+                                     (double*)(bw + bl.pagg), status, s, stages);
       if (rc) return rc;
       pagg = (const double*)(bw + bl.pagg);
     }

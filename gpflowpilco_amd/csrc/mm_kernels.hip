@@ -30,7 +30,7 @@
 #include "mm_dev.h"
 #include "mm_mono.h"
 
-#define MM_ABI_VERSION 1
+#define MM_ABI_VERSION 2
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -372,7 +372,8 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
                                               const T* __restrict__ mu, const double* __restrict__ latmat,
                                               double* __restrict__ w64, double* __restrict__ q64, T* __restrict__ w,
                                               double* __restrict__ f1raw, double* __restrict__ rho1,
-                                              T* __restrict__ f1, T* __restrict__ cross, T* __restrict__ q_out) {
+                                              T* __restrict__ f1, T* __restrict__ cross, T* __restrict__ q_out,
+                                              double* __restrict__ mu64) {
   const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   // P_a = (Sigma + Lambda_a)^-1 and E_a, zero padded to DK x DK: compile-time LDS offsets (wide broadcast reads)
   __shared__ double Pa[DK * DK], Ea[DK * DK];
@@ -387,6 +388,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
     Pa[idx] = in ? pv : 0.0; Ea[idx] = in ? ev : 0.0;
   }
   if (tid < DK) mub[tid] = tid < d ? (double)mu[(size_t)b * d + tid] : 0.0;
+  if (a == 0 && tid < d) mu64[(size_t)b * d + tid] = (double)mu[(size_t)b * d + tid];   // for mm_route.hip (the Q stage gets no mu)
   __syncthreads();
   const double lognorm = lm[d * d];
   // d <= 8: the two SYMMETRIC matrices live in registers as their upper triangles (2 x 36 doubles at d = 8), broadcast
@@ -1077,6 +1079,9 @@ int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double*
                        double* partB, double* partC, hipStream_t stream);
 int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
                         int B, int L, int d, int flags, hipStream_t stream);
+// f32 mode: estimate-driven f64 re-reduce of the (b, pair) items the f32 sweep is not good for (mm_route.hip)
+int mm_launch_route(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl, int B, int L, int M,
+                    int d, int flags, int agg, double* out, int32_t* status, hipStream_t stream);
 // f32 mode: weight moments against the monomial tables + their per-(b, pair) contraction (mm_moments.hip): fills s12
 int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
                       int B, int L, int d, const void* mu_f32, int flags, hipStream_t stream);
@@ -1157,7 +1162,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
                      (const double*)(packed + ml.Zt64), (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
                      L, M, wl.Mp, d, mu, latmat, (double*)(ws + wl.w64), (double*)(ws + wl.q64), (T*)(ws + wl.w),
-                     (double*)(ws + wl.f1raw), (double*)(ws + wl.rho1), f1, cross, q_out);
+                     (double*)(ws + wl.f1raw), (double*)(ws + wl.rho1), f1, cross, q_out, (double*)(ws + wl.mu64));
   MM_CHECK_LAUNCH();
   {
     const int nblk = (wl.Mp + 255) / 256;                  // 256-row chunks = wsum slots per (b, pair)
@@ -1189,7 +1194,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
 
 template <typename T, int DK>
 static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C, char* ws, const MMWorkspaceLayout& wl,
-                         int L, int M, int d, int B, int flags, double jitter, T* Sff, hipStream_t s) {
+                         int L, int M, int d, int B, int flags, double jitter, T* Sff, int32_t* status, hipStream_t s) {
   const int with_unc = (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0;
   const int full = (flags & MM_FULL_OUTPUT_COV) ? 1 : 0;
   if (with_unc && !has_C) return MM_E_NO_C;
@@ -1227,8 +1232,14 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
   // (2) off-diagonal pairs in T
   if (wl.Po > 0 && (stages & MM_STAGE_OFFDIAG)) {
     if (use_mfma32) {
-      const int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, flags, s);
+      int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, flags, s);
       if (rc) return rc;
+      // the sweep left its own error estimate per (b, pair): items beyond MM_ROUTE_TOL are re-reduced in f64 (mm_route.hip).
+      // (Not with the forced worst tier: its tile ranges are fake.)
+      if (!(flags & MM_FORCE_WORST_TIER)) {
+        rc = mm_launch_route(packed, ml, ws, wl, B, L, M, d, flags, 0, partB, status, s);
+        if (rc) return rc;
+      }
     } else if (sizeof(T) == 8 && !generic) {
       const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, nullptr,
                                         (const double*)(packed + ml.beta64), M, L, wl.Mp, d, wl.P, wl.NS,
@@ -1275,7 +1286,7 @@ static int mm_moment_match_t(const char* packed, size_t packed_bytes, int L, int
     rc = mm_q_forward_t<T, DK>(packed, ml, ws, wl, L, M, d, B, mu, Sigma, flags, f1, cross, q_out, status, s);
     if (rc) return rc;
   }
-  if (do_Q) rc = mm_Q_reduce_t<T, DK>(packed, ml, has_C, ws, wl, L, M, d, B, flags, jitter, Sff, s);
+  if (do_Q) rc = mm_Q_reduce_t<T, DK>(packed, ml, has_C, ws, wl, L, M, d, B, flags, jitter, Sff, status, s);
   return rc;
 }
 

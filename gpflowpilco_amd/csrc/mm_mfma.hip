@@ -121,10 +121,12 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
                                                           const double* __restrict__ zmax2,
                                                           const float* __restrict__ rowO,
                                                           const float* __restrict__ colO,
-                                                          double* __restrict__ partB) {
+                                                          double* __restrict__ partB, float* __restrict__ estO,
+                                                          int* __restrict__ rcount) {
   // XCD-aware remap of the 1-D grid (blocks b and b+8 share an XCD): consecutive work items
   // go to the same XCD.  Bijective for any nwork (cdna guide T1).
   const int orig = blockIdx.x;
+  if (orig == 0 && threadIdx.x == 0 && rcount) { rcount[0] = 0; rcount[1] = 0; }   // this pass's route list (k_route_decide follows)
   const int xcd = orig & 7, slot = orig >> 3;
   const int qn = nwork >> 3, rn = nwork & 7;
   const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
@@ -143,8 +145,10 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // Cauchy-Schwarz already bounds every |b_ij| of this (b, pair) by MM_TIER1_MAX: the remainder is the first tier's
     // c0 x^3 + c1 x^4 everywhere, which the moments carry (k_spoly) -- every tile would be skipped: no sweep at all
     if (!force_worst && zmax2 && mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) <= MM_INSIDE_BOUND2) {
-      for (int panel = pgrp * ppw + (int)threadIdx.x; panel < npanel && panel < (pgrp + 1) * ppw; panel += 256)
+      for (int panel = pgrp * ppw + (int)threadIdx.x; panel < npanel && panel < (pgrp + 1) * ppw; panel += 256) {
         partB[((size_t)b * P + p) * NS + panel] = 0.0;
+        if (estO) estO[((size_t)b * Po + lp) * npanel + panel] = 0.0f;        // exact (f64 moments): nothing to estimate
+      }
       return;
     }
   }
@@ -174,9 +178,14 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     __syncthreads();
   }
   __shared__ double red[4];
+  __shared__ float redf[4];
   for (int panel = pgrp * ppw; panel < npanel && panel < (pgrp + 1) * ppw; ++panel) {
   const int row0 = panel * MM_PANEL_ROWS + wv * 64;
   double sum = 0.0;
+  // running estimate of the sweep's own rounding error (mm_common.h: MM_ROUTE_TOL; mm_route.hip): per lane -- one column,
+  // the lane's 32 rows -- sum over the reduced tiles of (max|b|^3 what'_j)^2; the rows' sum of squares and the (1 + X + X^2)
+  // factor of rho (X = the lane's largest |b|) are applied once per sweep
+  float est = 0.0f, xall = 0.0f, rowsq = 0.0f;
   if (row0 < Mp) {   // Mp % 128 == 0, so a wave's 64 rows are all inside or all outside
     const float* ra = rowO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;   // [d+1][Mp]: A_i, what_i
     const float* wcf = colO + ((size_t)b * Po + lp) * Mp;                    // what'_j
@@ -230,6 +239,14 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
           }
         }
       }
+    }
+    {
+      f32x2 rs = {0.0f, 0.0f};
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) rs = mm_pkfma(wrow[rt][r], wrow[rt][r], rs);
+      rowsq = rs[0] + rs[1];
     }
 
     // ---- streaming operands: lane half 0 reads parts (m, l), half 1 reads (h, h) ------------
@@ -358,6 +375,11 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
         if (!__any(mx > MM_TIER1_MAX)) return;                        // first tier of a collapsed pair: all in the moments
       }
       if constexpr (CM) wc = wcf[ct * 32 + l31];
+      {
+        const float u = (mx * mx) * (mx * wc);
+        est = fmaf(u, u, est);
+        xall = fmaxf(xall, mx);
+      }
       if (__any(mx > MM_TWO_WAY_MAX)) {
         if constexpr (CM) load_zB(ct, zB);
         mfma_tile_l(zB, acc);
@@ -395,12 +417,21 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     else sweep(mm_false{}, mm_false{});
   }
   // workgroup reduction -> slab
+  float estl;
+  {
+    const float xf = fminf(xall, 8.0f);                     // (beyond |b| = 8 the estimate is astronomically large anyway)
+    const float pf = fmaf(xf, xf, xf) + 1.0f;
+    estl = (est * rowsq) * (pf * pf);
+  }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+  for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off, 64); estl += __shfl_down(estl, off, 64); }
   __syncthreads();                               // (the previous panel's red[] has been read)
-  if (lane == 0) red[wv] = sum;
+  if (lane == 0) { red[wv] = sum; redf[wv] = estl; }
   __syncthreads();
-  if (threadIdx.x == 0) partB[((size_t)b * P + p) * NS + panel] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) {
+    partB[((size_t)b * P + p) * NS + panel] = red[0] + red[1] + red[2] + red[3];
+    if (estO) estO[((size_t)b * Po + lp) * npanel + panel] = (redf[0] + redf[1]) + (redf[2] + redf[3]);
+  }
   }
 }
 
@@ -428,9 +459,10 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
   const float* rowO = (const float*)(ws + wl.rowO);
   const float* colO = (const float*)(ws + wl.colO);
   double* partB = (double*)(ws + wl.partB);
+  float* estO = (float*)(ws + wl.estO);
 #define MM_LAUNCH_ND(ND_, LZ_, SH_)                                                                          \
   hipLaunchKernelGGL((k_qred_f32_mfma<ND_, LZ_>), dim3(nwork), dim3(256), SH_, stream, Zs3, L, wl.Mp, d,    \
-                     wl.P, wl.Po, wl.NS, npanel, ppw, nwork, force_worst, amax, zmax2, rowO, colO, partB)
+                     wl.P, wl.Po, wl.NS, npanel, ppw, nwork, force_worst, amax, zmax2, rowO, colO, partB, estO, (int*)(ws + wl.rcount))
   switch (ml.nd8) {
     case 1: if (ldsz) MM_LAUNCH_ND(1, true, zbytes); else MM_LAUNCH_ND(1, false, 0); break;
     case 2: MM_LAUNCH_ND(2, false, 0); break;

@@ -448,6 +448,10 @@ extern "C" int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, 
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(int32_t), s);
   if (e != hipSuccess) return (int)e;
+  if (dtype == MM_F32 && wl.Po > 0) {       // out[3]: items the last forward on this workspace re-reduced in f64 (mm_route.hip)
+    e = hipMemcpyAsync(out + 3, (const char*)workspace + wl.rcount + 4, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+  }
   if (dtype != MM_F32 || wl.Po == 0 || mm_moment_deg(d) < 4 || (flags & MM_FORCE_WORST_TIER)) return 0;   // nothing collapses
   const int n = B * wl.Po;
   hipLaunchKernelGGL(k_offdiag_stats, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned int*)((const char*)workspace + wl.amax),

@@ -91,8 +91,15 @@ class PackedModel:
 
   def status(self) -> torch.Tensor:
     if self._status is None:
-      self._status = torch.zeros(2, dtype=torch.int32, device=self.device)
+      self._status = torch.zeros(4, dtype=torch.int32, device=self.device)
     return self._status
+
+  def routed(self) -> Tuple[int, int]:
+    """(forward, backward) counts of (batch element, off-diagonal pair) items a float32 pack re-reduced in float64 since the
+    status word was last zeroed (csrc/mm_route.hip: items whose estimated f32 rounding error exceeded MM_ROUTE_TOL of the
+    covariance block's scale).  Synchronises."""
+    st = self.status().tolist()
+    return st[2], st[3]
 
   def check_status(self, B: int):
     """Synchronising check of the non-PD flag (the reference raises at this point)."""
@@ -147,10 +154,11 @@ def _prep_state(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor):
 
 def moment_match(pm: PackedModel, mu: torch.Tensor, Sigma: torch.Tensor,
                  full_output_cov: bool = True, model_uncertainty: bool = True,
-                 jitter: float = 0.0, force_generic: bool = False):
-  """(mu [B,d], Sigma [B,d,d]) -> f1 [B,L], Sff [B,L,L] | [B,L], Sigma^-1 Cov(x,f) [B,d,L]."""
+                 jitter: float = 0.0, force_generic: bool = False, extra_flags: int = 0):
+  """(mu [B,d], Sigma [B,d,d]) -> f1 [B,L], Sff [B,L,L] | [B,L], Sigma^-1 Cov(x,f) [B,d,L].
+  ``extra_flags``: test / measurement bits of the C ABI (``MM_FORCE_ROUTE``, ``MM_NO_ROUTE``, ``MM_FORCE_WORST_TIER``)."""
   B, mu, Sigma = _prep_state(pm, mu, Sigma)
-  flags = make_flags(full_output_cov, model_uncertainty, force_generic)
+  flags = make_flags(full_output_cov, model_uncertainty, force_generic) | int(extra_flags)
   f1 = torch.empty(B, pm.L, dtype=pm.dtype, device=pm.device)
   Sff = torch.empty((B, pm.L, pm.L) if full_output_cov else (B, pm.L), dtype=pm.dtype, device=pm.device)
   cross = torch.empty(B, pm.d, pm.L, dtype=pm.dtype, device=pm.device)
@@ -198,13 +206,26 @@ def offdiag_stats(pm: PackedModel, B: int, flags: int):
   this B and flags (f32 models with d <= 8; zeros otherwise): items whose cubic + quartic remainder terms come from
   the f64 moments, all items, and collapsed items whose Cauchy-Schwarz bound puts every |b| <= 1/16 (the tile kernel
   does nothing for them).  Synchronises."""
-  ws = pm.workspace(B, flags)
+  ws = pm.workspace(B, flags, peek=True)
   out = torch.zeros(4, dtype=torch.int32, device=pm.device)
   rc = lib().mm_offdiag_stats(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, flags,
                               ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(pm.device))
   check(rc, "mm_offdiag_stats")
   c, n, inside, _ = out.tolist()
   return c, n, inside
+
+
+def offdiag_routed(pm: PackedModel, B: int, flags: int) -> int:
+  """Items of the last ``moment_match`` / ``Q_reduce_forward`` with this B and flags that were re-reduced in float64
+  (``mm_offdiag_stats`` out[3]; float32 models, else 0).  Synchronises."""
+  if pm.dtype != torch.float32 or pm.L < 2 or not (flags & MM_FULL_OUTPUT_COV):
+    return 0
+  ws = pm.workspace(B, flags, peek=True)
+  out = torch.zeros(4, dtype=torch.int32, device=pm.device)
+  rc = lib().mm_offdiag_stats(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, flags,
+                              ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(pm.device))
+  check(rc, "mm_offdiag_stats")
+  return int(out[3])
 
 
 def euler_update(mu, Sigma, f1, Sff, cross_pre, dt: float = 1.0):

@@ -14,10 +14,15 @@
  *   - calls only enqueue work on `stream` (a hipStream_t passed as void*); no allocation,
  *     no synchronisation, no global state (re-entrant across streams, graph-capturable);
  *   - return value: 0 ok, <0 bad argument (MM_E_*), >0 a hipError_t;
- *   - `status` (device int32[2], zeroed by the caller, may be NULL): [0] = B - b for the smallest
+ *   - `status` (device int32[4], zeroed by the caller, may be NULL): [0] = B - b for the smallest
  *     batch index b whose (Sigma + V) Cholesky was not positive definite (0 = all fine; outputs
  *     of that b are NaN), [1] = an item code.  The reference raises InvalidArgumentError there
- *     (kernel_expectation.py:125-126, models.py:271).
+ *     (kernel_expectation.py:125-126, models.py:271).  [2] / [3] (MM_F32 packs; ABI version 2): running counts of the
+ *     (batch element, off-diagonal pair) items the forward / the backward re-reduced in f64 because the f32 sweep's own
+ *     rounding-error estimate exceeded MM_ROUTE_TOL (1e-4) of the batch element's off-diagonal covariance scale
+ *     (csrc/mm_route.hip): the f32 pack's accuracy contract -- what stays in f32 is within ~1e-5 of
+ *     that scale, the rest has f64 accuracy.  The reference computes these terms in float64 throughout
+ *     (kernel_expectation.py:158-165).
  *   - `packed` / `packed_bytes`: the buffer filled by mm_pack_model and its size (whether C is
  *     present is inferred from the size).
  *
@@ -57,6 +62,11 @@ extern "C" {
 /* mm_moment_match_backward only: `workspace` still holds the q stage of exactly this (mu, Sigma, flags) -- the forward of the
  * same match was the last call on it -- so the q stage is not run again */
 #define MM_WORKSPACE_CURRENT 128
+/* MM_F32 packs, test / measurement aids of the accuracy contract (csrc/mm_route.hip): MM_FORCE_ROUTE sends EVERY off-diagonal
+ * (b, pair) item through the f64 re-reduce whatever its error estimate says (forward and backward); MM_NO_ROUTE none (the f32
+ * sweep's result as it is: what rounds 1-3 returned). */
+#define MM_FORCE_ROUTE 256
+#define MM_NO_ROUTE 512
 
 /* error codes */
 #define MM_E_ARG      (-1)  /* NULL pointer / non-positive size                  */
@@ -139,8 +149,10 @@ int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
 
 /* Diagnostic: after mm_q_forward (f32 model, d <= 8), how many (batch element, off-diagonal pair) items take the
  * moment collapse of csrc/mm_moments.hip (cubic + quartic term of the remainder from f64 moments, tiles with
- * max |b| <= 1/16 skipped), and for how many of those the Cauchy-Schwarz bound alone puts every |b| <= 1/16 (no tile
- * work at all).  out: device int32[4] = {collapsed, total, wholly inside, 0}; zeros where the collapse does not apply. */
+ * max |b| <= 1/20 skipped: bound <= 0.15), and for how many of those the Cauchy-Schwarz bound alone puts every |b| <= 1/20
+ * (no tile work at all).  out: device int32[4] = {collapsed, total, wholly inside, routed}; the first three are zeros where
+ * the collapse does not apply; routed = the items the last mm_moment_match / mm_Q_reduce_forward on this workspace
+ * re-reduced in f64 (csrc/mm_route.hip; meaningful only after such a call on an MM_F32 pack). */
 int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
                      const void* workspace, size_t workspace_bytes, int32_t* out, void* stream);
 

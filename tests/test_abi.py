@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
   for name in names:
     assert hasattr(lib, name), f"{name} declared in the header but not exported"
   assert set(_lib.SIGNATURES) == set(names), "ctypes signatures out of sync with the header"
-  assert lib.mm_abi_version() == 1
+  assert lib.mm_abi_version() == 2
 
 
 def test_header_constants_match_python():

@@ -224,11 +224,10 @@ def test_random_shapes_f32_pack_backward_matches_f64_pack(c, device):
   a = ops.moment_match_backward(pm32, mu32, S32, g1, g2, g3, c["full"], c["unc"])
   b = ops.moment_match_backward(pm64, mu32.double(), S32.double(), g1, g2, g3, c["full"], c["unc"])
   assert int(pm32.status()[0]) == 0
-  # f32 models are specified for states narrower than the lengthscales (|b| < 1).  Beyond that the remainder of
-  # e^b is no longer a small correction to the f64 polynomial part: the f32 FORWARD's off-diagonal covariances are then at
-  # ~1e-2 of their scale themselves (measured on draw 13: std 0.25 at lengthscales 0.5-1.4), and the backward at a few 1e-2
-  # of the gradient's (the f32 operands' rounding under e^b at |b| ~ 3: DESIGN.md section 8)
-  tol = 2e-4 if c["scale"] <= 0.25 * lo else 5e-2
+  # one tolerance for every draw: where the f32 / bf16 sweep's own error estimate leaves the contract (draws 13 and 15: state std
+  # 0.25 at lengthscales 0.5-1.4 with beta ~ 1e4 -- rounds 1-3 accepted 5e-2 there) those items' aggregates are re-reduced in
+  # f64 (csrc/mm_route.hip)
+  tol = 2e-4
   for x, y in zip(a, b):
     sc = float(y.abs().amax())
     assert float((x - y).abs().amax()) < tol * sc, (c, float((x - y).abs().amax()), sc)
