@@ -115,6 +115,8 @@ def parse():
   ap.add_argument("--batch", type=int, default=None, help="override B (or S): per GPU if weak, total if strong")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--force-generic", action="store_true")
+  ap.add_argument("--extra-flags", type=int, default=0,
+                  help="C-ABI flag bits OR-ed into every moment match (measurement: 512 = MM_NO_ROUTE, 256 = MM_FORCE_ROUTE)")
   ap.add_argument("--pmc-run", action="store_true", help="set by tools/collect_pmc.sh: exact --steps, no rounding to rollouts")
   ap.add_argument("--rehearse-gloo", action="store_true",
                   help="multi-process rehearsal on ONE GPU: gloo backend, every rank on cuda:0, costs gathered via host")
@@ -383,7 +385,7 @@ def main():
     dc = d if cfg["closed"] else L                           # dimension of the per-step cost statistic's argument
     target = torch.full((dc,), 0.5 if cfg["closed"] else 0.0, dtype=dtype, device=dev)
     precis = torch.eye(dc, dtype=dtype, device=dev) * 4.0
-    base = ops.make_flags(True, True, args.force_generic) | (F.MM_FORCE_WORST_TIER if rec["worst"] else 0)
+    base = ops.make_flags(True, True, args.force_generic) | (F.MM_FORCE_WORST_TIER if rec["worst"] else 0) | args.extra_flags
     traj_mu = torch.empty(H, B, dc, dtype=dtype, device=dev)
     traj_S = torch.empty(H, B, dc, dc, dtype=dtype, device=dev)
     Bmax = -(-B_total // world)
@@ -475,11 +477,13 @@ def main():
     rollouts_timed, collectives_timed = state["rollouts"], state["collectives"]
     # regime of the off-diagonal reduce over one (untimed) rollout: its kernels' time depends on it
     collapsed = [0, 0, 0]
+    routed = 0
     if f32_mode and not args.pmc_run:
       state["h"] = 0
       for _ in range(H):
         one_step(False)
         collapsed = [x + y for x, y in zip(collapsed, ops.offdiag_stats(pm, B, base))]
+        routed += ops.offdiag_routed(pm, B, base)               # items the accuracy contract re-reduced in f64 (csrc/mm_route.hip)
     if cfg["closed"] and not torch.isfinite(state["S"]).all():
       raise SystemExit(f"non-finite state in the timed rollout (recipe {recipe_name})")
     if not args.pmc_run:
@@ -537,7 +541,8 @@ def main():
         "value": round(B_total * steps / elapsed, 2), "ms_per_step": round(step_ms, 4), "steps": steps,
         "rollouts_timed": rollouts_timed, "collectives_timed": collectives_timed if world > 1 else 0,
         "segments_ms": {k: round(v, 4) for k, v in seg.items()},
-        "offdiag_items_one_rollout": {"collapsed": collapsed[0], "wholly_inside": collapsed[2], "total": collapsed[1]},
+        "offdiag_items_one_rollout": {"collapsed": collapsed[0], "wholly_inside": collapsed[2], "total": collapsed[1],
+                                      "routed_to_f64": routed},
         "roofline": roofs[dominant], "roofline_other": roofs["diag" if dominant == "offdiag" else "offdiag"],
         "roofline_step": roof_step, "roofline_q_stage": qroof,
     }
@@ -618,7 +623,9 @@ def main():
                                                    meaning="(b, off-diagonal pair, step) items of one rollout; collapsed: cubic + quartic "
                                                            "remainder terms from f64 moments (items with Cauchy-Schwarz bound <= 0.15), tiles with max|b| <= 1/20 skipped after a "
                                                            "screening MFMA; wholly_inside: the Cauchy-Schwarz bound alone puts every |b| <= 1/20, "
-                                                           "no tile work (csrc/mm_moments.hip, mm_mfma.hip)")},
+                                                           "no tile work (csrc/mm_moments.hip, mm_mfma.hip); routed_to_f64: items whose f32 "
+                                                           "rounding-error estimate exceeded MM_ROUTE_TOL = 1e-4 of the covariance block's scale and "
+                                                           "were re-reduced in f64 inside the timed off-diagonal segment (csrc/mm_route.hip)")},
       "segments_ms": pr["segments_ms"],
       "roofline": pr["roofline"],
       "roofline_other": pr["roofline_other"],

@@ -59,6 +59,8 @@ SIGNATURES = {
     "mm_expected_cost": (C.c_int, [C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6),
     "mm_offdiag_stats": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "mm_route_estimates": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "mm_compose_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
     "mm_rollout_composed": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                       C.c_void_p, C.c_size_t, C.c_int, C.c_int,

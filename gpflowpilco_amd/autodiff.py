@@ -19,7 +19,7 @@ sweep is a plain VALU kernel (correctness first).
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional,  Tuple
 
 import torch
 
@@ -274,7 +274,15 @@ class MomentMatchFunction(torch.autograd.Function):
 
   ``pm`` runs the forward in the inputs' dtype; ``pm_bwd`` is the pack the backward runs on: ``pm`` itself for a
   float64 model and for a float32 model with d <= 8 (``ops.backward_supported``: diagonal pairs in f64, off-diagonal
-  pairs as moment + bf16-MFMA aggregates), else a float64 pack of the same model (the f32 state cast up)."""
+  pairs as moment + bf16-MFMA aggregates), else a float64 pack of the same model (the f32 state cast up).
+
+  Accuracy contract of the float32 pack (csrc/mm_route.hip): the diagonal pairs, the first moments,
+  the cross term and the polynomial part 1 + b + b^2/2 of every off-diagonal pair are float64 in both directions; the
+  off-diagonal remainder runs in f32 (forward) / bf16-split MFMA (backward) and carries its own rounding-error estimate --
+  a (batch element, pair) whose estimate exceeds 3e-4 of the batch element's off-diagonal covariance scale is re-reduced
+  in float64, forward sum and backward aggregates alike, and counted (``PackedModel.routed()``).  Measured: gradients
+  within 2e-4 of the float64 pack's on every draw of tests/test_gpu_backward_f32.py (1e-6 .. 3e-5 typical).
+  ``moment_match_differentiable(..., backward_dtype=torch.float64)`` keeps the float64-pack backward reachable."""
 
   @staticmethod
   def forward(ctx, mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty):
@@ -302,11 +310,19 @@ class MomentMatchFunction(torch.autograd.Function):
 
 
 def moment_match_differentiable(model, mu: torch.Tensor, Sigma: torch.Tensor, full_output_cov: bool = True,
-                                model_uncertainty: bool = True):
-  """(mu, Sigma) -> (f1, Sff, cross_pre) with gradients flowing back to (mu, Sigma)."""
+                                model_uncertainty: bool = True, backward_dtype: Optional[torch.dtype] = None):
+  """(mu, Sigma) -> (f1, Sff, cross_pre) with gradients flowing back to (mu, Sigma).
+
+  ``backward_dtype``: None = the forward's own pack where it has a backward (float64 models; float32 models with d <= 8,
+  under the accuracy contract stated on ``MomentMatchFunction``), else a float64 pack of the model; ``torch.float64`` =
+  always differentiate through the float64 pack (every pair swept in f64: 2.3 x the time at C3 shape)."""
+  if backward_dtype not in (None, torch.float64, mu.dtype):
+    raise ValueError(f"backward_dtype must be None, torch.float64 or the state's dtype, got {backward_dtype}")
   pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
-  pm_bwd = pm if ops.backward_supported(pm) else model.packed(dtype=torch.float64, with_C=bool(model_uncertainty),
-                                                              device=mu.device)
+  own = ops.backward_supported(pm) and backward_dtype in (None, mu.dtype)
+  if backward_dtype == mu.dtype and not own:
+    raise NotImplementedError("this pack has no backward of its own (float32 with d > 8): use backward_dtype=torch.float64")
+  pm_bwd = pm if own else model.packed(dtype=torch.float64, with_C=bool(model_uncertainty), device=mu.device)
   pre = model._cache._pre
   return MomentMatchFunction.apply(mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty)
 

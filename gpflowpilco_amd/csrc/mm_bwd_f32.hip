@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
   }
   __syncthreads();
   // running estimate of the sweep's rounding error (mm_common.h: MM_ROUTE_TOL): per lane -- its two rows, 16 columns of each
-  // tile -- sum over the tiles of (max|b|^3)^2 sum what'_j^2; rows' squares and the (1 + X + X^2) factor once per sweep
+  // tile -- sum over the tiles of (max|b|^3)^2 sum what'_j^2; rows' squares and the (1 + X + X^2) factor of rho (X = the lane's
+  // largest |b|) once per sweep
   float est = 0.0f, xall = 0.0f;
 
   f32x16 acc2[2][2];

@@ -148,10 +148,17 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 // (rho(x) = |r(x)| + |x| |r'(x)| <= (2/3) |x|^3 e^|x| bounds what a relative error 2^-24 in what_i, what'_j, b_ij does to
 // what_i what'_j r(b_ij)); measured 7-50 x above the actual error (tools/route_study.py).  An item whose estimate exceeds
 // MM_ROUTE_TOL x (the largest |off-diagonal covariance| of its batch element, taken from the f64 moments: s12 - f1 f1') is
-// re-reduced in f64 (mm_route.hip) and its slab overwritten: what stays in f32 is within ~1e-5 of the block's own scale.
+// re-reduced in f64 (mm_route.hip) and its slab overwritten: the ROUNDING error of what stays in f32 is then within ~4e-5 of
+// the block's own scale (est / 7).  3e-4: on the BASELINE recipe at C3 (7168 items per step) 4-7 items per step exceed it
+// (65 at 1e-4, none at 1e-3), every item of the ill-conditioned wide draws does (their est / scale is 5e-3 .. 0.2).
 #ifndef MM_ROUTE_TOL
-#define MM_ROUTE_TOL 1.0e-4
+#define MM_ROUTE_TOL 3.0e-4
 #endif
+// the f64 re-reduce of the forward splits an item's columns over this many work units per row panel (latency of a routed
+// item: 256 rows x M / MM_ROUTE_CSPLIT columns of f64 VALU work per workgroup); their partial sums take slots
+// [0, npanel * ncc) of the item's slab, ncc = min(MM_ROUTE_CSPLIT, NS / npanel)
+#define MM_ROUTE_CSPLIT 8
+static inline int mm_route_ncc(int NS, int npanel) { int n = NS / npanel; return n < 1 ? 1 : (n > MM_ROUTE_CSPLIT ? MM_ROUTE_CSPLIT : n); }
 // Rows per workgroup of the generic reduce kernel / columns per workgroup.
 #define MM_GEN_ROWS 64
 #define MM_GEN_COLS 256
@@ -194,6 +201,7 @@ struct MMWorkspaceLayout {
                    //              sum over lane blocks of (sum_rows what_i^2) what'_j^2 (max|b|^3)^2 (1 + X + X^2)^2 (mm_route.hip)
   size_t rlist;    // [B Po] i32   the (b, off-diagonal pair) items k_route_decide hands to the f64 re-reduce
   size_t rcount;   // [4] i32      {entries of rlist (current pass), items routed by the last forward, by the last backward, 0}
+  size_t rflag;    // [B Po] i32   1 where the last forward routed the item (k_finalize then sums the route kernel's slots)
   size_t f1s;      // [B][L] T      rollout scratch outputs
   size_t Sffs;     // [B][L][L] T
   size_t crs;      // [B][d][L] T
@@ -244,6 +252,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.estO = off;    off = mm_align_up(off + nro * ((o.Mp + MM_PANEL_ROWS - 1) / MM_PANEL_ROWS) * 4, A);
   o.rlist = off;   off = mm_align_up(off + nro * 4, A);
   o.rcount = off;  off = mm_align_up(off + 16, A);
+  o.rflag = off;   off = mm_align_up(off + nro * 4, A);
   o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);
   o.Sffs = off;    off = mm_align_up(off + (size_t)B * L * L * es, A);
   o.crs = off;     off = mm_align_up(off + (size_t)B * d * L * es, A);

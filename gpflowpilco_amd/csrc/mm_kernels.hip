@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
                                                   int nsB_diag, int nsB_off, int nsC, int full, int with_unc,
                                                   double jitter, const double* __restrict__ f1raw,
                                                   const double* __restrict__ s12, int diag_factored,
-                                                  T* __restrict__ Sff) {
+                                                  const int* __restrict__ rflag, int ns_routed, T* __restrict__ Sff) {
   // one wave per (b, pair): lanes stride over the slab (coalesced), fixed butterfly => reproducible
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (idx >= B * P) return;
@@ -988,7 +988,9 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
   int a, a2;
   mm_decode_pair(p, L, a, a2);
   const double* pb = partB + ((size_t)b * P + p) * NS;
-  const int ns = (a == a2) ? nsB_diag : nsB_off;
+  int ns = (a == a2) ? nsB_diag : nsB_off;
+  // an item the accuracy contract re-reduced in f64 (mm_route.hip): its slab holds the route kernel's npanel x ncc partial sums
+  if (a != a2 && rflag != nullptr && rflag[(size_t)b * (P - L) + (p - L)]) ns = ns_routed;
   double s = 0.0;
   for (int k = lane; k < ns; k += 64) s += pb[k];
   if (a == a2 && with_unc) {
@@ -1210,6 +1212,10 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
                                                          : mm_f64_num_slots(wl.Mp, 0));
   int stages = flags & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE);
   if (!stages) stages = MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE;
+  // the f32 sweep leaves its own error estimate per (b, pair); items beyond MM_ROUTE_TOL are re-reduced in f64 (mm_route.hip).
+  // A function of the flags alone: the stage calls of one match (bench.py) agree on it.  Not with the forced worst tier (its
+  // tile ranges are fake)
+  const bool routes = use_mfma32 && wl.Po > 0 && !(flags & (MM_FORCE_WORST_TIER | MM_NO_ROUTE));
   // (1) diagonal pairs: always f64
   if (stages & MM_STAGE_DIAG) {
     if (generic) {
@@ -1234,9 +1240,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
     if (use_mfma32) {
       int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, flags, s);
       if (rc) return rc;
-      // the sweep left its own error estimate per (b, pair): items beyond MM_ROUTE_TOL are re-reduced in f64 (mm_route.hip).
-      // (Not with the forced worst tier: its tile ranges are fake.)
-      if (!(flags & MM_FORCE_WORST_TIER)) {
+      if (routes) {
         rc = mm_launch_route(packed, ml, ws, wl, B, L, M, d, flags, 0, partB, status, s);
         if (rc) return rc;
       }
@@ -1262,7 +1266,9 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
     hipLaunchKernelGGL((k_finalize<T>), dim3((n + 3) / 4), dim3(256), 0, s,
                        partB, partC, (const double*)(packed + ml.var), B, L, wl.P, wl.NS,
                        nsB_diag, nsB_off, nsC, full, with_unc, jitter, (const double*)(ws + wl.f1raw),
-                       sizeof(T) == 4 ? (const double*)(ws + wl.s12) : (const double*)nullptr, generic ? 0 : 1, Sff);
+                       sizeof(T) == 4 ? (const double*)(ws + wl.s12) : (const double*)nullptr, generic ? 0 : 1,
+                       routes ? (const int*)(ws + wl.rflag) : (const int*)nullptr,
+                       mm_mfma_num_slots(wl.Mp) * mm_route_ncc(wl.NS, mm_mfma_num_slots(wl.Mp)), Sff);
     MM_CHECK_LAUNCH();
   }
   return 0;

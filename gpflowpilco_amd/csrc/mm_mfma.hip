@@ -46,6 +46,10 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
 #ifndef MM_F32_PPW_DIV
 #define MM_F32_PPW_DIV 4
 #endif
+// 0: the sweep without its rounding-error estimate (A/B measurement of what the accuracy contract costs: nothing is ever routed)
+#ifndef MM_ROUTE_EST
+#define MM_ROUTE_EST 1
+#endif
 #ifndef MM_F32_WAVES
 #define MM_F32_WAVES 2
 #endif
@@ -183,9 +187,10 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
   const int row0 = panel * MM_PANEL_ROWS + wv * 64;
   double sum = 0.0;
   // running estimate of the sweep's own rounding error (mm_common.h: MM_ROUTE_TOL; mm_route.hip): per lane -- one column,
-  // the lane's 32 rows -- sum over the reduced tiles of (max|b|^3 what'_j)^2; the rows' sum of squares and the (1 + X + X^2)
-  // factor of rho (X = the lane's largest |b|) are applied once per sweep
-  float est = 0.0f, xall = 0.0f, rowsq = 0.0f;
+  // the lane's 32 rows -- sum over the reduced tiles of (max|b|^3 what'_j)^2, two tiles per packed instruction; the rows' sum
+  // of squares and the (1 + X + X^2) factor of rho (X = the lane's largest |b|: one v_max3 per tile pair) once per sweep
+  f32x2 est2 = {0.0f, 0.0f};
+  float rowsq = 0.0f, xall = 0.0f;
   if (row0 < Mp) {   // Mp % 128 == 0, so a wave's 64 rows are all inside or all outside
     const float* ra = rowO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;   // [d+1][Mp]: A_i, what_i
     const float* wcf = colO + ((size_t)b * Po + lp) * Mp;                    // what'_j
@@ -361,9 +366,12 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // collc (compile time): SCREENED sweep -- the screening check, and neither the column weight nor the (l | h) parts
     // prefetched (few tiles of such an item need them, and a prefetched global load would put its latency on every tile
     // of a sweep that is otherwise 2 MFMAs long); collm: collapsed coefficients (reduce_tile)
-    auto process_tile = [&](auto collc, auto collm, int ct, const u32x4 (&zA)[ND8], u32x4 (&zB)[ND8], float wc) __attribute__((always_inline)) {
+    // (emx, ewc): what the error estimate takes from this tile -- its max|b| of the lane and the column weight; zeros for a
+    // tile that contributes exact moments only
+    auto process_tile = [&](auto collc, auto collm, int ct, const u32x4 (&zA)[ND8], u32x4 (&zB)[ND8], float wc, float& emx, float& ewc) __attribute__((always_inline)) {
       constexpr bool CM = decltype(collc)::value;
       f32x16 acc[2];
+      emx = 0.0f; ewc = 0.0f;
       mfma_tile_screen(zA, acc);
       if constexpr (CM) {
         const float ms = tile_max(acc);
@@ -375,11 +383,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
         if (!__any(mx > MM_TIER1_MAX)) return;                        // first tier of a collapsed pair: all in the moments
       }
       if constexpr (CM) wc = wcf[ct * 32 + l31];
-      {
-        const float u = (mx * mx) * (mx * wc);
-        est = fmaf(u, u, est);
-        xall = fmaxf(xall, mx);
-      }
+      emx = mx; ewc = wc;
       if (__any(mx > MM_TWO_WAY_MAX)) {
         if constexpr (CM) load_zB(ct, zB);
         mfma_tile_l(zB, acc);
@@ -400,11 +404,20 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
       for (int ct = 0; ct < nct; ct += 2) {
         load_zA(ct + 1, zA1);
         if constexpr (!CM) { load_zB(ct + 1, zB1); w1 = wcf[(ct + 1) * 32 + l31]; }
-        process_tile(collc, collm, ct, zA0, zB0, w0);
+        float emx0, ewc0, emx1, ewc1;
+        process_tile(collc, collm, ct, zA0, zB0, w0, emx0, ewc0);
         const int cn = ct + 2 < nct ? ct + 2 : ct;               // clamped: the last pass re-reads its own tile
         load_zA(cn, zA0);
         if constexpr (!CM) { load_zB(cn, zB0); w0 = wcf[cn * 32 + l31]; }
-        process_tile(collc, collm, ct + 1, zA1, zB1, w1);
+        process_tile(collc, collm, ct + 1, zA1, zB1, w1, emx1, ewc1);
+#if MM_ROUTE_EST
+        {
+          const f32x2 emx = {emx0, emx1}, ewc = {ewc0, ewc1};
+          const f32x2 u = (emx * emx) * (emx * ewc);             // both tiles at once: 4 packed instructions per tile pair
+          est2 = mm_pkfma(u, u, est2);
+          xall = fmaxf(fmaxf(xall, emx0), emx1);
+        }
+#endif
       }
     };
     // A (b, pair) is collapsed only where its bound lets the screening skip most tiles (MM_COLLAPSE_BOUND2 = 0.15^2: measured
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
   {
     const float xf = fminf(xall, 8.0f);                     // (beyond |b| = 8 the estimate is astronomically large anyway)
     const float pf = fmaf(xf, xf, xf) + 1.0f;
-    estl = (est * rowsq) * (pf * pf);
+    estl = ((est2[0] + est2[1]) * rowsq) * (pf * pf);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { sum += __shfl_down(sum, off, 64); estl += __shfl_down(estl, off, 64); }

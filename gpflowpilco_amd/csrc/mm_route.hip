@@ -16,7 +16,7 @@
 //                    max over the batch element's off-diagonal pairs of |s12 - f1 f1'| (the covariance up to the remainder,
 //                    already exact in f64 from the q stage); routed items go to a compact list, their count to the
 //                    workspace (mm_offdiag_stats) and to status[2] (forward) / status[3] (backward);
-//   k_route_f64    : persistent workgroups over (listed item, 256-row panel): the same sum from f64 operands -- A_i = G^T zeta_i
+//   k_route_f64    : persistent workgroups over (listed item, 256-row panel, column chunk): the same sum from f64 operands -- A_i = G^T zeta_i
 //                    re-derived from the pair matrix, the unrounded f64 weights whR / whC of k_pairvec, the f64 centred
 //                    inducing inputs -- thread = row, columns streamed through scalar loads (wave-uniform); it OVERWRITES the
 //                    f32 kernel's slab entries.  AGG: the backward's 1 + 2d + 3d^2 remainder aggregates instead of the sum.
@@ -35,13 +35,20 @@ __device__ __forceinline__ void mmx_decode_pair_o(int lp, int L, int& a, int& a2
   a = i; a2 = i + 1 + r;
 }
 
+// est = 2^-24 (2/3) sqrt(E2): E2 from the sweep (rho at every block's max|b|, its e^|x| <= 1 + X + X^2 part at the lane's max)
+__device__ __forceinline__ double mmx_est(double e2, unsigned int, double) {
+  return 5.9604644775390625e-8 * (2.0 / 3.0) * sqrt(e2);
+}
+
 // grid B, 64 threads.  slot: 1 = forward, 2 = backward (rcount[slot] and status[1 + slot] receive the number of routed items;
 // rcount[0] and rcount[slot] were zeroed by the tile kernel of this pass)
 __global__ __launch_bounds__(64) void k_route_decide(const float* __restrict__ estO, int npanel, const double* __restrict__ s12,
-                                                     const double* __restrict__ f1raw, int L, int Po, double tol, int force,
-                                                     int* __restrict__ rlist, int* __restrict__ rcount, int slot,
-                                                     int32_t* __restrict__ status) {
+                                                     const double* __restrict__ f1raw, const unsigned int* __restrict__ amax,
+                                                     const double* __restrict__ zmax2, int L, int Po, double tol, int force,
+                                                     int* __restrict__ rlist, int* __restrict__ rcount, int* __restrict__ rflag,
+                                                     int slot, int32_t* __restrict__ status) {
   const int b = blockIdx.x, lane = threadIdx.x;
+  auto zmax2a2 = [&](int po) { int a, a2; mmx_decode_pair_o(po, L, a, a2); return zmax2[a2]; };
   double sc = 0.0;
   for (int po = lane; po < Po; po += 64) {
     int a, a2;
@@ -59,8 +66,9 @@ __global__ __launch_bounds__(64) void k_route_decide(const float* __restrict__ e
       const float* e = estO + ((size_t)b * Po + po) * npanel;
       double e2 = 0.0;
       for (int pn = 0; pn < npanel; ++pn) e2 += (double)e[pn];
-      const double est = 5.9604644775390625e-8 * (2.0 / 3.0) * sqrt(e2);
+      const double est = mmx_est(e2, amax[(size_t)b * Po + po], zmax2a2(po));
       r = force || est > tol * sc;
+      if (rflag) rflag[(size_t)b * Po + po] = r ? 1 : 0;
     }
     const unsigned long long bal = __ballot(r);
     const int n = __popcll(bal);
@@ -76,6 +84,46 @@ __global__ __launch_bounds__(64) void k_route_decide(const float* __restrict__ e
     atomicAdd(rcount + slot, total);
     if (status) atomicAdd(status + 1 + slot, total);
   }
+}
+
+// Diagnostic: per (b, off-diagonal pair) {est, scale_b} as k_route_decide sees them (after a forward / backward sweep).
+__global__ __launch_bounds__(64) void k_route_report(const float* __restrict__ estO, int npanel, const double* __restrict__ s12,
+                                                     const double* __restrict__ f1raw, const unsigned int* __restrict__ amax,
+                                                     const double* __restrict__ zmax2, int L, int Po, double* __restrict__ out) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  auto zmax2a2 = [&](int po) { int a, a2; mmx_decode_pair_o(po, L, a, a2); return zmax2[a2]; };
+  double sc = 0.0;
+  for (int po = lane; po < Po; po += 64) {
+    int a, a2;
+    mmx_decode_pair_o(po, L, a, a2);
+    const double v = fabs(s12[(size_t)b * Po + po] - f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a2]);
+    sc = v > sc ? v : sc;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { const double o = __shfl_xor(sc, off, 64); sc = o > sc ? o : sc; }
+  for (int po = lane; po < Po; po += 64) {
+    const float* e = estO + ((size_t)b * Po + po) * npanel;
+    double e2 = 0.0;
+    for (int pn = 0; pn < npanel; ++pn) e2 += (double)e[pn];
+    out[((size_t)b * Po + po) * 2 + 0] = mmx_est(e2, amax[(size_t)b * Po + po], zmax2a2(po));
+    out[((size_t)b * Po + po) * 2 + 1] = sc;
+  }
+}
+
+extern "C" int mm_route_estimates(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
+                                  const void* workspace, size_t workspace_bytes, double* out, void* stream) {
+  if (!packed || !workspace || !out || L <= 0 || M <= 0 || d <= 0 || d > MM_DMAX || B <= 0) return MM_E_ARG;
+  if (dtype != MM_F32) return MM_E_DTYPE;
+  const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
+  const MMModelLayout ml = mm_model_layout(L, M, d, dtype, 1);
+  if (workspace_bytes < wl.total || packed_bytes < ml.Cm) return MM_E_WORKSPACE;
+  if (wl.Po <= 0) return 0;
+  const char* ws = (const char*)workspace;
+  hipLaunchKernelGGL(k_route_report, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)(ws + wl.estO),
+                     (wl.Mp + MM_PANEL_ROWS - 1) / MM_PANEL_ROWS, (const double*)(ws + wl.s12), (const double*)(ws + wl.f1raw),
+                     (const unsigned int*)(ws + wl.amax), (const double*)((const char*)packed + ml.zmax2), L, wl.Po, out);
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 // r(x) = e^x - 1 - x - x^2/2 in f64 for any x: Taylor to x^16 on |x| < 1/2 (truncation 0.5^14 / 17! x^3: 2e-19), else
@@ -116,15 +164,20 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
                                                    const double* __restrict__ whR, const double* __restrict__ whC,
                                                    const unsigned int* __restrict__ amax, const double* __restrict__ zmax2,
                                                    int allow_collapse, int L, int M, int Mp, int d, int P, int Po, int npanel,
-                                                   int NS, double* __restrict__ out) {
+                                                   int ncc, int NS, double* __restrict__ out) {
   constexpr int NB2 = AGG ? DK * (DK + 1) / 2 : 1;
+  constexpr int CS = DK + 2;                                // LDS row stride of a staged column (16-byte aligned rows)
   __shared__ double Gs[DK * DK];
+  __shared__ __align__(16) double colbuf[64 * CS];
   __shared__ double red[4];
   __shared__ double Tw[AGG ? 4 * (1 + 2 * DK + 3 * DK * DK) : 1];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  const int nwork = __builtin_amdgcn_readfirstlane(rcount[0]) * npanel;
+  // work unit = (listed item, row panel, column chunk cc of ncc): columns [cc Mc, (cc + 1) Mc) (AGG: ncc == 1)
+  const int upi = npanel * ncc, Mc = (M + ncc - 1) / ncc;
+  const int nwork = __builtin_amdgcn_readfirstlane(rcount[0]) * upi;
   for (int w = blockIdx.x; w < nwork; w += gridDim.x) {
-    const int item = __builtin_amdgcn_readfirstlane(rlist[w / npanel]), panel = w % npanel;
+    const int item = __builtin_amdgcn_readfirstlane(rlist[w / upi]), wu = w % upi, panel = wu / ncc, cc = wu - panel * ncc;
+    const int j0 = cc * Mc, j1 = (j0 + Mc < M) ? j0 + Mc : M;
     const int b = item / Po, lp = item - b * Po;
     int a, a2;
     mmx_decode_pair_o(lp, L, a, a2);
@@ -161,22 +214,24 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
     for (int k = 0; k < (AGG ? DK : 1); ++k) B1[k] = 0.0;
 #pragma unroll
     for (int k = 0; k < NB2; ++k) B2[k] = 0.0;
-    // column j: DK contiguous doubles of the [Mp][Kz] block (beyond Kz they belong to the next row -- or, after the last row
-    // of the last latent, to the section that follows Zc64 in an f32 pack -- and are masked), one scalar load; column j + 1 is
-    // requested before column j is used
-    double zn[DK], wn;
-    auto load_col = [&](int j) {
-#pragma unroll
-      for (int k = 0; k < DK; ++k) zn[k] = zc[(size_t)j * Kz + k];
-      wn = wc[j];
-    };
-    load_col(0);
-    for (int j = 0; j < M; ++j) {
+    // columns in chunks of 64 through LDS: coalesced loads of (zc'_j [d], what'_j), then every lane reads the same address per
+    // column (broadcast).  (Wave-uniform scalar loads straight from memory were tried first: one s_load per column, a fresh
+    // cache line every time -- 0.5 us per column, 130 us for a 250-column unit against 17 us of arithmetic.)
+    for (int jc = j0; jc < j1; jc += 64) {
+    __syncthreads();                                        // (the previous chunk has been consumed)
+    for (int idx = tid; idx < 64 * (DK + 1); idx += 256) {
+      const int c = idx / (DK + 1), k = idx - c * (DK + 1), jj = jc + c;
+      double v = 0.0;
+      if (jj < j1) v = k == DK ? wc[jj] : (k < d ? zc[(size_t)jj * Kz + k] : 0.0);
+      colbuf[c * CS + k] = v;                               // columns past the chunk's end: zero weight, zero inputs
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int c = 0; c < 64; ++c) {
       double z[DK];
 #pragma unroll
-      for (int k = 0; k < DK; ++k) z[k] = k < d ? zn[k] : 0.0;
-      const double wj = wn;
-      load_col(j + 1 < M ? j + 1 : j);
+      for (int k = 0; k < DK; ++k) z[k] = colbuf[c * CS + k];
+      const double wj = colbuf[c * CS + DK];
       double x = 0.0;
 #pragma unroll
       for (int k = 0; k < DK; ++k) x = fma(A[k], z[k], x);
@@ -195,11 +250,12 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
         }
       }
     }
+    }
     if constexpr (!AGG) {
       const double s = mmx_wave_sum(wr * B0);
       if (lane == 0) red[wv] = s;
       __syncthreads();
-      if (tid == 0) out[((size_t)b * P + (L + lp)) * NS + panel] = (red[0] + red[1]) + (red[2] + red[3]);
+      if (tid == 0) out[((size_t)b * P + (L + lp)) * NS + wu] = (red[0] + red[1]) + (red[2] + red[3]);
     } else {
       const int nT = mma_pair_agg_len(d);
       const int oR1 = 1, oR2 = 1 + d, oK1 = 1 + d + d * d, oK2 = 1 + 2 * d + d * d, oXC = 1 + 2 * d + 2 * d * d;
@@ -249,18 +305,20 @@ int mm_launch_route(const char* packed, const MMModelLayout& ml, char* ws, const
   int* rlist = (int*)(ws + wl.rlist);
   int* rcount = (int*)(ws + wl.rcount);
   hipLaunchKernelGGL(k_route_decide, dim3(B), dim3(64), 0, stream, (const float*)(ws + wl.estO), npanel,
-                     (const double*)(ws + wl.s12), (const double*)(ws + wl.f1raw), L, wl.Po, (double)MM_ROUTE_TOL,
-                     (flags & MM_FORCE_ROUTE) ? 1 : 0, rlist, rcount, agg ? 2 : 1, status);
+                     (const double*)(ws + wl.s12), (const double*)(ws + wl.f1raw), (const unsigned int*)(ws + wl.amax),
+                     (const double*)(packed + ml.zmax2), L, wl.Po, (double)MM_ROUTE_TOL,
+                     (flags & MM_FORCE_ROUTE) ? 1 : 0, rlist, rcount, agg ? (int*)nullptr : (int*)(ws + wl.rflag), agg ? 2 : 1, status);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  long long nw = (long long)B * wl.Po * npanel;
-  const int grid = (int)(nw < 1024 ? nw : 1024);
+  const int ncc = agg ? 1 : mm_route_ncc(wl.NS, npanel);
+  long long nw = (long long)B * wl.Po * npanel * ncc;
+  const int grid = (int)(nw < 2048 ? nw : 2048);
   const double* zmax2 = mm_moment_deg(d) >= 4 ? (const double*)(packed + ml.zmax2) : nullptr;
   const int allow = (flags & MM_FORCE_WORST_TIER) ? 0 : 1;
 #define MMX_ARGS                                                                                                             \
   (const int*)rlist, (const int*)rcount, (const double*)(packed + ml.Zt64), (const double*)(packed + ml.Zc64), ml.Kz,       \
   (const double*)(ws + wl.mu64), (const double*)(ws + wl.pairmat), (const double*)(ws + wl.whR), (const double*)(ws + wl.whC), \
-  (const unsigned int*)(ws + wl.amax), zmax2, allow, L, M, wl.Mp, d, wl.P, wl.Po, npanel, wl.NS, out
+  (const unsigned int*)(ws + wl.amax), zmax2, allow, L, M, wl.Mp, d, wl.P, wl.Po, npanel, ncc, wl.NS, out
   if (agg) {
     if (d > 8) return MM_E_DIM;
     if (d <= 4) hipLaunchKernelGGL((k_route_f64<4, true>), dim3(grid), dim3(256), 0, stream, MMX_ARGS);

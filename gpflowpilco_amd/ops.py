@@ -228,6 +228,19 @@ def offdiag_routed(pm: PackedModel, B: int, flags: int) -> int:
   return int(out[3])
 
 
+def route_estimates(pm: PackedModel, B: int, flags: int) -> torch.Tensor:
+  """[B, P - L, 2] float64: per (batch element, off-diagonal pair) the last sweep's estimate of its own f32 rounding error and the
+  scale it is compared with (``mm_route_estimates``; float32 packs)."""
+  Po = pm.L * (pm.L - 1) // 2 if (flags & MM_FULL_OUTPUT_COV) else 0
+  out = torch.zeros(B, Po, 2, dtype=torch.float64, device=pm.device)
+  if Po:
+    ws = pm.workspace(B, flags, peek=True)
+    rc = lib().mm_route_estimates(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, flags,
+                                  ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(pm.device))
+    check(rc, "mm_route_estimates")
+  return out
+
+
 def euler_update(mu, Sigma, f1, Sff, cross_pre, dt: float = 1.0):
   """MomentMatchingEuler.step on the GPU (d == L)."""
   _require_device(mu, Sigma, f1, Sff, cross_pre)

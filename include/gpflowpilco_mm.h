@@ -156,6 +156,12 @@ int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
 int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
                      const void* workspace, size_t workspace_bytes, int32_t* out, void* stream);
 
+/* Diagnostic of the f32 pack's accuracy contract (csrc/mm_route.hip): after mm_moment_match / mm_Q_reduce_forward (or the
+ * backward) on an MM_F32 pack, out [B][P-L][2] f64 = per (batch element, off-diagonal pair) {the sweep's estimate of its own
+ * rounding error, the scale it is compared with}: an item is re-reduced in f64 when est > 1e-4 scale. */
+int mm_route_estimates(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
+                       const void* workspace, size_t workspace_bytes, double* out, void* stream);
+
 /* ---- composed policy rollout: SURVEY.md row f-2 -------------------------------------------------------
  * The rollout harness of MomentMatchingPILCO (gpflow_pilco/loops/pilco.py:192-220) for the cartpole-shaped system
  *   x (nx) -> TrigonometricEncoder on `active_dims` (components.py:73-75, moment_matching/components.py:19-57,
