@@ -12,7 +12,7 @@ import torch
 def expected_gaussian_cost(mean: torch.Tensor, cov: torch.Tensor, target: torch.Tensor,
                            precis: torch.Tensor) -> torch.Tensor:
   """E_{x~N(mean,cov)}[-exp(-0.5 (x-x*)^T W (x-x*))]  (components.py:29-37) -> mean.shape[:-1]."""
-  needs_grad = torch.is_grad_enabled() and (mean.requires_grad or cov.requires_grad)
+  needs_grad = torch.is_grad_enabled() and any(t.requires_grad for t in (mean, cov, target, precis))
   if mean.is_cuda and not needs_grad:     # the HIP kernel has no backward: differentiable calls use torch ops
     from . import ops
     return ops.expected_cost(mean, cov, target, precis)

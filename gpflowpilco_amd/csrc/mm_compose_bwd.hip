@@ -450,7 +450,8 @@ extern "C" size_t mm_policy_grad_bytes(int B, int policy_M, int policy_d) {
 //            beta [M], ls2 = lengthscales^2 [d], variance, mean_c; the chain to (q_mu, Z, lengthscales, ...) through
 //            beta = Kuu^-1 u is the caller's (gpflowpilco_amd/autodiff.py does it with autograd on the 30 x 30 precompute)
 //   g_mx0 [B][nx], g_Sxx0 [B][nx][nx] (out, optional): gradient w.r.t. the initial state (symmetric)
-// The policy must be the one-launch shape (M <= 128, ne <= 8); else MM_E_DIM.
+// The policy: M <= 256 centres on ne <= 8 encoded dims (k_policy_head_bwd_small: one workgroup per element, the M x M block
+// and the M-sized vectors in LDS -- mm_policy_bwd_lds: 120 KB at M = 256, ne = 8); else MM_E_DIM.
 extern "C" int mm_rollout_composed_backward(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
                                             const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
                                             int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
@@ -468,7 +469,7 @@ extern "C" int mm_rollout_composed_backward(const void* drift_packed, size_t dri
   if (rc) return rc;
   const int ne = D.ne, nd = D.nd;
   if (drift_L != nx || drift_d != nd || policy_d != ne) return MM_E_STATE;
-  if (policy_M > 128 || ne > 8) return MM_E_DIM;
+  if (policy_M > 256 || ne > 8) return MM_E_DIM;
   const MMTapeLayout tl = mm_tape_layout(B, H, nx, na, drift_M, dtype);
   if (tape_bytes < tl.total) return MM_E_WORKSPACE;
   const MMComposeBwdLayout bl = mm_compose_bwd_layout(B, nx, na, drift_M);

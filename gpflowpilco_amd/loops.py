@@ -6,6 +6,8 @@ from __future__ import annotations
 
 from typing import Callable, Optional, Sequence
 
+import warnings
+
 import numpy as np
 import torch
 
@@ -20,41 +22,52 @@ def get_state_initializer(mean: torch.Tensor, covariance: torch.Tensor) -> Calla
   return lambda: (mx, Sxx)
 
 
-def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: int, dt: float = 1.0):
+def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: int, dt: float = 1.0,
+                       why: Optional[list] = None):
   """``f(mx, Sxx) -> loss [B]`` running the whole rollout in ``mm_rollout_composed`` (csrc/mm_compose.hip), or None
   when the system is not the shape that entry point implements: TrigonometricEncoder, policy =
   InverseLinkWrapper(KernelRegressor(SVGP with one latent), Chain[Scale, Shift, NormalCDF]) with scalar scale and
   shift, SVGP drift, no diffusion, MomentMatchingEuler, GaussianObjective -- the cartpole wiring of
   ``examples/cartpole_swingup/swingup_loops.py:41-91``.  ``f.with_grad(mx, Sxx)`` is the same loss as a differentiable op
-  (native reverse sweep, csrc/mm_compose_bwd.hip) where ``f.supports_grad(mx)``."""
+  (native reverse sweep, csrc/mm_compose_bwd.hip) where ``f.supports_grad(mx)``.  ``why``: a list that receives the reason
+  when None is returned."""
   from . import bijectors as tfb
   from . import ops
   from .components import TrigonometricEncoder
   from .cost import GaussianObjective
   from .models import SVGP, InverseLinkWrapper, KernelRegressor, LinearCoregionalization
   enc, pol, drift = system.encoder, system.policy, system.drift
+
+  def no(reason):
+    if why is not None:
+      why.append(reason)
+    return None
   if system.diffusion is not None or not isinstance(system.solver, MomentMatchingEuler):
-    return None
-  if not isinstance(enc, TrigonometricEncoder) or not isinstance(objective, GaussianObjective):
-    return None
+    return no("a diffusion term or a solver other than MomentMatchingEuler")
+  if not isinstance(enc, TrigonometricEncoder):
+    return no(f"encoder {type(enc).__name__} (the native rollout implements TrigonometricEncoder)")
+  if not isinstance(objective, GaussianObjective):
+    return no(f"objective {type(objective).__name__} (the native rollout implements GaussianObjective)")
   if not isinstance(pol, InverseLinkWrapper) or not isinstance(pol.model, KernelRegressor):
-    return None
+    return no("the policy is not InverseLinkWrapper(KernelRegressor(SVGP))")
   pm_, head = pol.model.model, pol.invlink
   if not isinstance(pm_, SVGP) or not isinstance(drift, SVGP) or pm_.num_latent_gps != 1:
-    return None
+    return no("the policy is not a one-latent SVGP or the drift is not an SVGP")
   if isinstance(pm_.kernel, LinearCoregionalization) or isinstance(drift.kernel, LinearCoregionalization):
-    return None
+    return no("a LinearCoregionalization kernel (its mixing stays on the host)")
   if any(k.active_dims is not None for k in pm_.latent_kernels + drift.latent_kernels):
-    return None
+    return no("a kernel with active_dims")
   bj = head.bijectors if isinstance(head, tfb.Chain) else None
   if not (bj and len(bj) == 3 and isinstance(bj[0], tfb.Scale) and isinstance(bj[1], tfb.Shift) and isinstance(bj[2], tfb.NormalCDF)):
-    return None
+    return no("the policy head is not Chain[Scale, Shift, NormalCDF]")
   def head_constants():
-    return float(bj[0].scale), float(bj[1].shift)
+    sc, sh = bj[0].scale, bj[1].shift
+    return (float(sc.detach()) if isinstance(sc, torch.Tensor) else float(sc),
+            float(sh.detach()) if isinstance(sh, torch.Tensor) else float(sh))
   try:
     head_constants()
-  except (TypeError, ValueError):
-    return None
+  except (TypeError, ValueError, RuntimeError):
+    return no("the policy head's scale / shift are not scalars (n-D action: Genz BVN, out of scope)")
   cache = {}
 
   def current_roll(mx: torch.Tensor, fresh_policy: bool = True):
@@ -87,14 +100,18 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
   def run_with_grad(mx: torch.Tensor, Sxx: torch.Tensor):
     """The same loss as a differentiable function of the policy's parameters (and of the initial state): forward =
     the taped native rollout, backward = the native reverse sweep (autodiff.ComposedRolloutFunction); the policy enters
-    in packed coordinates computed from its parameters by differentiable torch ops (a 30 x 30 precompute)."""
+    in packed coordinates computed from its parameters by differentiable torch ops (a 30 x 30 precompute).  The tape and
+    the reverse sweep are float64; a float32 state is cast up on the way in and the loss back down (autograd carries both)."""
     from .autodiff import ComposedRolloutFunction
+    out_dtype = mx.dtype
+    if mx.dtype != torch.float64:
+      mx, Sxx = mx.double(), Sxx.double()
     roll = current_roll(mx, fresh_policy=False)
     Zp, lsp, varp, betap, _, mcp = pm_.precompute(mx.device)
     if mcp is None:
       mcp = torch.zeros(1, dtype=Zp.dtype, device=mx.device)
     cost = ComposedRolloutFunction.apply(mx, Sxx, Zp, lsp, varp, betap, mcp, roll, num_steps, dt)
-    return cost.sum(1)
+    return cost.sum(1).to(out_dtype)
 
   def run_from_parameters(mx: torch.Tensor, Sxx: torch.Tensor):
     """Forward only, the policy packed from its parameters on the stream (no snapshot from outside): what a HIP-graph
@@ -107,10 +124,31 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
     return cost.sum(1)
   run.from_parameters = run_from_parameters
 
+  def grad_obstacle(mx: torch.Tensor) -> Optional[str]:
+    """None when ``with_grad`` covers everything that asks for a gradient here, else the reason it does not."""
+    if mx.dtype not in (torch.float32, torch.float64):
+      return f"state dtype {mx.dtype}"
+    # the native reverse sweep returns gradients for the policy SVGP's parameters and the initial state only: the head's
+    # Scale / Shift and the objective's target / precision enter as constants (float() / raw pointers)
+    outside = {"the policy head's Scale.scale": bj[0].scale, "the policy head's Shift.shift": bj[1].shift,
+               "objective.target": objective.target, "objective.precis": objective.precis}
+    for name, t in outside.items():
+      if isinstance(t, torch.Tensor) and t.requires_grad:
+        return f"{name} requires a gradient (the native reverse sweep covers the policy SVGP's parameters and the initial state)"
+    if any(t.requires_grad for t in drift._parameters()):
+      return "the drift is being trained (the native reverse sweep takes a frozen drift)"
+    mx64 = mx if mx.dtype == torch.float64 else torch.empty(mx.shape, dtype=torch.float64, device=mx.device)
+    roll = current_roll(mx64, fresh_policy=False)
+    if not roll.supports_backward():
+      return (f"the policy has M = {roll.policy.M} centres on {roll.ne} encoded dims (the native reverse sweep takes "
+              f"M <= {ops.ComposedRollout.BACKWARD_MAX_POLICY_M}, encoded dim <= 8)")
+    return None
+
   def supports_grad(mx: torch.Tensor) -> bool:
-    return mx.dtype == torch.float64 and current_roll(mx, fresh_policy=False).supports_backward()
+    return grad_obstacle(mx) is None
   run.with_grad = run_with_grad
   run.supports_grad = supports_grad
+  run.grad_obstacle = grad_obstacle
   return run
 
 
@@ -132,8 +170,17 @@ def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_init
     solution_times = np.arange(1, 1 + num_steps, dtype=np.float64)     # pilco.py:186
   encoder = system.encoder
   fast = None
-  if native is not False and uniform and float(initial_time) == 0.0 and not kwargs:
-    fast = native_policy_loss(system, objective, num_steps, dt=1.0)
+  shape_reason = None
+  if native is not False:
+    if not uniform or float(initial_time) != 0.0:
+      shape_reason = "non-uniform solution times (the native rollout takes unit steps from t = 0)"
+    elif kwargs:
+      shape_reason = f"solver options {sorted(kwargs)}"
+    else:
+      why_not = []
+      fast = native_policy_loss(system, objective, num_steps, dt=1.0, why=why_not)
+      if fast is None:
+        shape_reason = why_not[0] if why_not else "the system is not the shape mm_rollout_composed implements"
   if native is True and fast is None:
     raise ValueError("native=True: the system is not the shape mm_rollout_composed implements")
 
@@ -143,7 +190,18 @@ def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_init
       x = moment_matching(x, encoder).y
     return loss + objective(x=x, t=t)
 
+  warned = []
+
+  def _fallback(reason):
+    """The torch composition is about to run on GPU tensors (60 x slower than the native path at cartpole sizes): say so, once."""
+    if native is not False and not warned:
+      warned.append(reason)
+      warnings.warn(f"policy_loss_closure: falling back to the torch composition of the rollout ({reason})", RuntimeWarning,
+                    stacklevel=3)
+
   def _use_native(mx, Sxx):
+    if fast is None and mx.is_cuda:
+      _fallback(shape_reason or "the system is not the shape mm_rollout_composed implements")
     if fast is None or not mx.is_cuda or mx.ndim != 2:
       return False
     models = [system.drift, getattr(getattr(system.policy, "model", None), "model", None)]
@@ -158,12 +216,20 @@ def policy_loss_closure(system: DynamicalSystem, objective: Callable, state_init
 
   def _use_native_grad(mx, Sxx):
     """Someone differentiates, and what is differentiated is what the native reverse sweep covers: the policy's
-    parameters and / or the initial state, with a frozen drift, in float64."""
-    if native is False or fast is None or not mx.is_cuda or mx.ndim != 2 or not torch.is_grad_enabled():
+    parameters and / or the initial state, with a frozen drift (the tape is float64; a float32 state is cast up)."""
+    if native is False or not mx.is_cuda or not torch.is_grad_enabled():
       return False
-    if any(t.requires_grad for t in system.drift._parameters()):
+    if fast is None:
+      _fallback(shape_reason or "the system is not the shape mm_rollout_composed implements")
       return False
-    return fast.supports_grad(mx)
+    if mx.ndim != 2:
+      _fallback(f"state of rank {mx.ndim} (the native path takes mx [B, nx])")
+      return False
+    why = fast.grad_obstacle(mx)
+    if why is not None:
+      _fallback(why)
+      return False
+    return True
 
   def _closure():                                                      # pilco.py:207-217
     mx, Sxx = state_initializer()

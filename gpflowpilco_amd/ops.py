@@ -415,9 +415,12 @@ class ComposedRollout:
 
 
   # ---- differentiable form: tape + reverse sweep (csrc/mm_compose_bwd.hip) -------------------------------------------
+  BACKWARD_MAX_POLICY_M = 256
+
   def supports_backward(self) -> bool:
-    """The native reverse sweep exists for f64 rollouts whose policy is the one-launch shape (M <= 128, ne <= 8)."""
-    return self.drift.dtype == torch.float64 and self.policy.M <= 128 and self.ne <= 8
+    """The native reverse sweep exists for f64 rollouts whose policy has M <= 256 centres on ne <= 8 encoded dims (one
+    workgroup per batch element sweeps the policy's M x M block from LDS: 120 KB at M = 256, ne = 8)."""
+    return self.drift.dtype == torch.float64 and self.policy.M <= self.BACKWARD_MAX_POLICY_M and self.ne <= 8
 
   def taped(self, mx: torch.Tensor, Sxx: torch.Tensor, num_steps: int, dt: float = 1.0, policy: Optional[PackedModel] = None):
     """``mm_rollout_composed_taped``: -> (mx_H, Sxx_H, cost [H, B], tape).  ``policy``: another pack of the same shape

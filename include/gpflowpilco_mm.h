@@ -221,8 +221,8 @@ int mm_rollout_composed_taped(const void* drift_packed, size_t drift_bytes, int 
 /* ---- gradient of the composed rollout: SURVEY.md rows f-1 x f-2 -----------------------------------------------
  * What the only real caller needs: update_policy differentiates the whole closure with tf.GradientTape
  * (gpflow_pilco/utils/optimizers.py:51-56, examples/cartpole_swingup/train_utils.py:91-105, loops/pilco.py:192-220).
- * mm_rollout_composed_backward is the reverse sweep over the tape (f64 only; the policy must be the one-launch shape,
- * M <= 128 and ne <= 8, else MM_E_DIM):
+ * mm_rollout_composed_backward is the reverse sweep over the tape (f64 only; policy M <= 256 centres on ne <= 8 encoded dims,
+ * else MM_E_DIM; B >= 1):
  *   g_cost   [H][B]  (in)  d loss / d cost[h][b]  (all ones for the loss of pilco.py:199-205)
  *   g_policy [B][M d + M + d + 2] (out, overwritten): per batch element the gradient w.r.t. the PACKED policy --
  *            Z [M][d], beta = Kuu^-1 u [M], ls2 = lengthscales^2 [d], variance, mean_c; sum over B and chain through

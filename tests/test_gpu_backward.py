@@ -409,3 +409,88 @@ def test_policy_update_with_native_gradients_lowers_the_loss(device):
     runs[mode] = np.array(losses)
   assert runs["graph"][-1] < runs["graph"][0] - 1e-3, runs["graph"][[0, -1]]
   assert np.abs(runs["graph"] - runs["eager"]).max() < 1e-9 * max(1.0, np.abs(runs["eager"]).max())
+
+
+def _cartpole_like(device, M_pol, seed=21):
+  """(system, objective, params, m0, S0) of the cartpole wiring with a trainable policy of M_pol centres."""
+  from gpflowpilco_amd import bijectors as tfb, dynamics, models as gp
+  from gpflowpilco_amd.components import GaussianObjective, TrigonometricEncoder
+  from gpflowpilco_amd.synthetic import make_svgp
+  from tests.helpers import oracle_params
+  F64 = torch.float64
+  drift_o = oracle_params(make_svgp(4, 60, 6, seed=seed, ls_bounds=(0.8, 3.0)))
+  drift_o.Z = drift_o.Z * np.array([1, 1, 1, 1, 1, 4.0]) - np.array([0, 0, 0, 0, 0, 2.0])
+  pol_o = random_svgp_params(seed=seed + 1, L=1, M=M_pol, d=5, whiten=True, ls_bounds=(0.9, 2.0), mean=False)
+  pol_o.q_mu = 0.05 * pol_o.q_mu
+  drift, pol_model = gp_model_from_oracle(drift_o, device), gp_model_from_oracle(pol_o, device)
+  kern = pol_model.kernel.kernels[0]
+  params = {"q_mu": pol_model.q_mu, "Z": pol_model.inducing_variable.inducing_variables[0].Z, "lengthscales": kern.lengthscales}
+  for t in params.values():
+    t.requires_grad_(True)
+  scale_t = torch.tensor(2.0, dtype=F64, device=device)
+  policy = gp.InverseLinkWrapper(gp.KernelRegressor(pol_model),
+                                 invlink=tfb.Chain([tfb.Scale(scale_t), tfb.Shift(-0.5), tfb.NormalCDF()]))
+  system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=TrigonometricEncoder(active_dims=(1,)),
+                                    solver=dynamics.MomentMatchingEuler())
+  target = to_dev(np.array([0.0, 1.0, 0, 0, 0]), device, F64)
+  objective = GaussianObjective(target=target, precis=4.0 * torch.eye(5, dtype=F64, device=device))
+  rng = np.random.default_rng(seed + 2)
+  m0 = to_dev(np.array([[0.4, 0.2, 0.5, 0.3], [0.6, -0.1, 0.4, 0.5]]), device, F64)
+  S0 = to_dev(generate_covariance(rng, 4, (2,), 0.05), device, F64)
+  return system, objective, params, m0, S0, scale_t
+
+
+def _closure_grads(system, objective, params, m0, S0, H, native, extra=()):
+  from gpflowpilco_amd.loops import get_state_initializer, policy_loss_closure
+  leaves = list(params.values()) + list(extra)
+  for t in leaves:
+    t.grad = None
+  loss = policy_loss_closure(system, objective, get_state_initializer(m0, S0), H, native=native)()
+  loss.sum().backward()
+  return loss.detach(), [t.grad.detach().clone() for t in leaves]
+
+
+def test_policy_with_200_centres_takes_the_native_reverse_sweep(device):
+  """The native gradient's limits that cost nothing are lifted (policy M up to 256; loops.policy_loss_closure): a policy with
+  M = 200 differentiates through mm_rollout_composed_backward -- no fallback warning -- and agrees with the torch composition."""
+  import warnings
+  system, objective, params, m0, S0, _ = _cartpole_like(device, 200)
+  with warnings.catch_warnings():
+    warnings.simplefilter("error", RuntimeWarning)           # a fallback would raise here
+    loss_n, gn = _closure_grads(system, objective, params, m0, S0, 4, None)
+  loss_t, gt = _closure_grads(system, objective, params, m0, S0, 4, False)
+  assert float((loss_n - loss_t).abs().max()) < 1e-9
+  for a_, b_ in zip(gn, gt):
+    assert float((a_ - b_).abs().max()) < 1e-7 * max(1e-12, float(b_.abs().max()))
+
+
+def test_float32_state_takes_the_native_reverse_sweep(device):
+  """A float32 initial state: cast up into the float64 tape, the loss cast back (no fallback)."""
+  import warnings
+  system, objective, params, m0, S0, _ = _cartpole_like(device, 30)
+  loss64, g64 = _closure_grads(system, objective, params, m0, S0, 5, None)
+  with warnings.catch_warnings():
+    warnings.simplefilter("error", RuntimeWarning)
+    loss32, g32 = _closure_grads(system, objective, params, m0.float(), S0.float(), 5, None)
+  assert loss32.dtype == torch.float32
+  assert float((loss32.double() - loss64).abs().max()) < 1e-5
+  for a_, b_ in zip(g32, g64):
+    assert float((a_ - b_).abs().max()) < 1e-4 * max(1e-12, float(b_.abs().max()))
+
+
+def test_a_gradient_outside_the_native_sweep_warns_and_is_carried_by_the_torch_path(device):
+  """ADVICE (round 3): the native op returns gradients for the policy SVGP and the initial state only; if the head's scale or
+  the objective's target requires a gradient the closure must take the torch composition -- saying so once -- and carry it."""
+  system, objective, params, m0, S0, scale_t = _cartpole_like(device, 30)
+  objective.target.requires_grad_(True)
+  with pytest.warns(RuntimeWarning, match="objective.target requires a gradient"):
+    loss_a, ga = _closure_grads(system, objective, params, m0, S0, 3, None, extra=(objective.target,))
+  assert ga[-1] is not None and float(ga[-1].abs().max()) > 0.0
+  loss_t, gt = _closure_grads(system, objective, params, m0, S0, 3, False, extra=(objective.target,))
+  for a_, b_ in zip(ga, gt):
+    assert float((a_ - b_).abs().max()) < 1e-12 + 1e-10 * float(b_.abs().max())
+  objective.target.requires_grad_(False)
+  scale_t.requires_grad_(True)
+  with pytest.warns(RuntimeWarning, match="Scale.scale requires a gradient"):
+    _, gs = _closure_grads(system, objective, params, m0, S0, 3, None, extra=(scale_t,))
+  assert gs[-1] is not None and float(gs[-1].abs()) > 0.0
