@@ -22,6 +22,7 @@
 // The L diagonal pairs (the only ones with the C term) stay on the f64 column sweep of mm_backward.hip in both modes.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <atomic>
 #include "mm_common.h"
 #include "mm_mono.h"
 #include "mm_f32_tile.h"
@@ -335,6 +336,19 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
   for (int idx = threadIdx.x; idx < nT; idx += 256) o[idx] = (Tall[idx] + Tall[nT + idx]) + (Tall[2 * nT + idx] + Tall[3 * nT + idx]);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device): `done` is a bitmap over the device ordinals (thread
+// safe; devices >= 64 set it on every call)
+static hipError_t mmr_set_max_lds_once(const void* fn, int bytes, std::atomic<unsigned long long>& done) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+  if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+  return e;
+}
+
 static size_t mmr_rem_lds_bytes(int d, int Mp) {
   return (size_t)4 * 64 * MMR_BS * 4 + (size_t)4 * 64 * (d + 1) * 8 + (size_t)4 * mma_pair_agg_len(d) * 8 +
          (size_t)(Mp <= MMR_WLDS_MAX ? Mp + (Mp >> 4) : 0) * 4;
@@ -421,16 +435,13 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const size_t shm = mmr_rem_lds_bytes(d, wl.Mp);
   if (shm > 160 * 1024) return MM_E_DIM;
-  // (the attribute is set once per variant, to the most the kernel may ask for: not inside a later stream capture)
+  // (the attribute is set once per variant AND DEVICE -- HIP applies it per device --, to the most the kernel may ask for:
+  // not inside a later stream capture)
 #define MMR_LAUNCH(TWO_)                                                                                                       \
   do {                                                                                                                        \
-    static bool attr_set = false;                                                                                             \
-    if (!attr_set) {                                                                                                          \
-      e = hipFuncSetAttribute((const void*)k_bwd_rem_f32<TWO_>, hipFuncAttributeMaxDynamicSharedMemorySize,                   \
-                              (int)mmr_rem_lds_bytes(8, MMR_WLDS_MAX));                                                       \
-      if (e != hipSuccess) return (int)e;                                                                                     \
-      attr_set = true;                                                                                                        \
-    }                                                                                                                         \
+    static std::atomic<unsigned long long> attr_set{0ull};                                                                    \
+    e = mmr_set_max_lds_once((const void*)k_bwd_rem_f32<TWO_>, (int)mmr_rem_lds_bytes(8, MMR_WLDS_MAX), attr_set);            \
+    if (e != hipSuccess) return (int)e;                                                                                       \
     hipLaunchKernelGGL(k_bwd_rem_f32<TWO_>, dim3((int)nwork_ll), dim3(256), shm, stream, (const unsigned short*)(packed + ml.Zs3), \
                        (const unsigned short*)(packed + ml.Zq2), (const double*)(packed + ml.Zc64), ml.Kz,                    \
                        (const double*)(packed + ml.zbar), mu, B, L, wl.Mp, d, wl.Po, npanel, (int)nwork_ll,                   \
@@ -450,12 +461,11 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
   if (rc) return rc;
   const int nT = mma_pair_agg_len(d);
   const size_t shm2 = (size_t)(2 * ml.KMp + d * d + 2 * d + nT + mma_pair_poly_scratch(d)) * sizeof(double);
-  static bool agg_attr_set = false;
-  if (!agg_attr_set) {
+  {
+    static std::atomic<unsigned long long> agg_attr_set{0ull};
     const size_t shm_max = (size_t)(2 * mm_moment_cols(8) + 64 + 16 + mma_pair_agg_len(8) + mma_pair_poly_scratch(8)) * sizeof(double);
-    e = hipFuncSetAttribute((const void*)k_pair_agg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm_max);
+    e = mmr_set_max_lds_once((const void*)k_pair_agg, (int)shm_max, agg_attr_set);
     if (e != hipSuccess) return (int)e;
-    agg_attr_set = true;
   }
   hipLaunchKernelGGL(k_pair_agg, dim3(wl.Po, B), dim3(512), shm2, stream, (const double*)(ws + wl.mom), ml.KMp,
                      (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), mu, L, d, wl.P, npanel,

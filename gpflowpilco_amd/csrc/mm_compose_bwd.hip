@@ -114,6 +114,16 @@ __global__ __launch_bounds__(64) void k_gp_bwd_sum(int nitems, int d, const doub
   }
 }
 
+// MM_WORKSPACE_CURRENT is a promise of the caller ("the q stage of exactly this state is still on the workspace"): verify the part
+// of it the device can see -- the q stage stamped the mean it read into the workspace (MMWorkspaceLayout::mu64) -- and flag a stale
+// workspace through the status word ([0] = B - b, [1] = -1) instead of differentiating another state's q stage silently
+template <typename T>
+__global__ void k_check_workspace_current(const T* __restrict__ mu, const double* __restrict__ mu64, int B, int d, int32_t* status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * d) return;
+  if ((double)mu[i] != mu64[i]) { atomicMax(status, B - i / d); status[1] = -1; }
+}
+
 struct MMGpBwdLayout {
   size_t sums, items, cbuf, f1, cross, slab, pagg, mu64, S64, pre, total;
 };
@@ -193,6 +203,13 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, bw + bl.f1, bw + bl.cross, nullptr,
                       workspace, workspace_bytes, status, stream);
     if (rc) return rc;
+  } else if (status) {
+    const int n = B * d;
+    if (f32) hipLaunchKernelGGL((k_check_workspace_current<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)mu,
+                                (const double*)(ws + wl.mu64), B, d, status);
+    else hipLaunchKernelGGL((k_check_workspace_current<double>), dim3((n + 255) / 256), dim3(256), 0, s, (const double*)mu,
+                            (const double*)(ws + wl.mu64), B, d, status);
+    MMB_CHECK();
   }
   const int P = wl.P, Mp = wl.Mp;
   const double* mu64 = (const double*)mu;

@@ -104,6 +104,12 @@ class PackedModel:
   def check_status(self, B: int):
     """Synchronising check of the non-PD flag (the reference raises at this point)."""
     st = self.status().tolist()
+    if st[0] != 0 and st[1] == -1:
+      self._status.zero_()
+      raise RuntimeError(
+          f"moment_match_backward was told the workspace still holds the forward's q stage (MM_WORKSPACE_CURRENT), but batch "
+          f"element {B - st[0]} of it belongs to another state: something wrote the workspace in between without going "
+          "through PackedModel.workspace() (a graph replay, another stream, an external ABI caller)")
     if st[0] != 0:
       self._status.zero_()
       raise FloatingPointError(
@@ -374,6 +380,24 @@ class ComposedRollout:
 
   ENGINES = {"auto": 0, "multi": 1, "small": 2}
 
+  def _policy_pack(self, policy: Optional[PackedModel]) -> PackedModel:
+    """``policy`` (another pack of the same shape: the current parameters of a trainable policy) or ``self.policy``; a pack
+    of another (L, M, d, dtype) would be read through the wrong layout -- the C side only sees a byte count."""
+    pol = self.policy if policy is None else policy
+    if (pol.L, pol.M, pol.d, pol.dtype) != (self.policy.L, self.policy.M, self.policy.d, self.policy.dtype):
+      raise ValueError("the policy pack does not have the shape this rollout was built for")
+    return pol
+
+  def _check_state(self, mx: torch.Tensor, Sxx: torch.Tensor) -> int:
+    _require_device(mx, Sxx)
+    dt_ = self.drift.dtype
+    if mx.dtype != dt_ or Sxx.dtype != dt_:
+      raise TypeError(f"state dtype {mx.dtype} / {Sxx.dtype} does not match the packed models ({dt_})")
+    B = mx.shape[0]
+    if mx.shape != (B, self.nx) or Sxx.shape != (B, self.nx, self.nx):
+      raise ValueError(f"expected mx [B,{self.nx}], Sxx [B,{self.nx},{self.nx}]")
+    return B
+
   def small_supported(self) -> bool:
     """Whether the one-launch kernel (csrc/mm_rollout_small.hip) takes these shapes."""
     return bool(lib().mm_rollout_small_supported(self.nx, self.na, self.drift.M, self.policy.M))
@@ -384,16 +408,9 @@ class ComposedRollout:
     trainable policy, packed by the caller).  ``engine``: "auto" = "multi" (the multi-launch path), or "small": the
     one-launch kernel of csrc/mm_rollout_small.hip (an error where the shapes do not fit) -- measured slower at cartpole
     sizes, kept as the cross-check and the record of that experiment."""
-    pol = self.policy if policy is None else policy
-    if (pol.L, pol.M, pol.d, pol.dtype) != (self.policy.L, self.policy.M, self.policy.d, self.policy.dtype):
-      raise ValueError("the policy pack does not have the shape this rollout was built for")
-    _require_device(mx, Sxx)
+    pol = self._policy_pack(policy)
+    B = self._check_state(mx, Sxx)
     dt_ = self.drift.dtype
-    if mx.dtype != dt_ or Sxx.dtype != dt_:
-      raise TypeError(f"state dtype {mx.dtype} does not match the packed models ({dt_})")
-    B = mx.shape[0]
-    if mx.shape != (B, self.nx) or Sxx.shape != (B, self.nx, self.nx):
-      raise ValueError(f"expected mx [B,{self.nx}], Sxx [B,{self.nx},{self.nx}]")
     mx, Sxx = mx.contiguous().clone(), Sxx.contiguous().clone()
     H = int(num_steps)
     cost = torch.empty(H, B, dtype=dt_, device=mx.device)
@@ -425,12 +442,9 @@ class ComposedRollout:
   def taped(self, mx: torch.Tensor, Sxx: torch.Tensor, num_steps: int, dt: float = 1.0, policy: Optional[PackedModel] = None):
     """``mm_rollout_composed_taped``: -> (mx_H, Sxx_H, cost [H, B], tape).  ``policy``: another pack of the same shape
     (the current parameters of a trainable policy)."""
-    pol = self.policy if policy is None else policy
-    _require_device(mx, Sxx)
+    pol = self._policy_pack(policy)
     dt_ = self.drift.dtype
-    B, H = mx.shape[0], int(num_steps)
-    if mx.dtype != dt_ or mx.shape != (B, self.nx) or Sxx.shape != (B, self.nx, self.nx):
-      raise ValueError(f"expected {dt_} mx [B,{self.nx}], Sxx [B,{self.nx},{self.nx}]")
+    B, H = self._check_state(mx, Sxx), int(num_steps)
     mx, Sxx = mx.contiguous().clone(), Sxx.contiguous().clone()
     cost = torch.empty(H, B, dtype=dt_, device=mx.device)
     n = lib().mm_compose_tape_bytes(B, H, self.nx, self.na, self.drift.M, _dtype_code(dt_))
@@ -450,8 +464,8 @@ class ComposedRollout:
                policy: Optional[PackedModel] = None, want_state_grad: bool = True):
     """``mm_rollout_composed_backward``: g_cost [H, B] -> (g_policy [B, M d + M + d + 2], g_mx0 [B,nx] | None,
     g_Sxx0 [B,nx,nx] | None): the gradient w.r.t. the packed policy (Z, beta, lengthscales^2, variance, mean) per batch
-    element and w.r.t. the initial state."""
-    pol = self.policy if policy is None else policy
+    element and w.r.t. the initial state.  ``policy`` must be the pack the tape was recorded with (``taped(policy=...)``)."""
+    pol = self._policy_pack(policy)
     dev = tape.device
     H = int(num_steps)
     f64 = torch.float64

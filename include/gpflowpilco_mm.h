@@ -60,7 +60,9 @@ extern "C" {
  * valid on the whole range, so results are unchanged up to rounding; bench.py --recipe worst times it. */
 #define MM_FORCE_WORST_TIER 64
 /* mm_moment_match_backward only: `workspace` still holds the q stage of exactly this (mu, Sigma, flags) -- the forward of the
- * same match was the last call on it -- so the q stage is not run again */
+ * same match was the last call on it, on the same stream -- so the q stage is not run again.  The caller's promise; the
+ * device checks the part it can see (the q stage stamps the mean it read into the workspace) and reports a stale workspace
+ * as status = {B - b, -1}. */
 #define MM_WORKSPACE_CURRENT 128
 /* MM_F32 packs, test / measurement aids of the accuracy contract (csrc/mm_route.hip): MM_FORCE_ROUTE sends EVERY off-diagonal
  * (b, pair) item through the f64 re-reduce whatever its error estimate says (forward and backward); MM_NO_ROUTE none (the f32

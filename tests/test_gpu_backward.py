@@ -4,8 +4,9 @@ import numpy as np
 import pytest
 import torch
 
+from gpflowpilco_amd import _lib, ops
 from gpflowpilco_amd.autodiff import moment_match_differentiable
-from gpflowpilco_amd.synthetic import generate_covariance
+from gpflowpilco_amd.synthetic import generate_covariance, make_inputs
 from oracle import mm_oracle as mo
 from tests.helpers import gp_model_from_oracle, random_svgp_params, to_dev
 
@@ -494,3 +495,34 @@ def test_a_gradient_outside_the_native_sweep_warns_and_is_carried_by_the_torch_p
   with pytest.warns(RuntimeWarning, match="Scale.scale requires a gradient"):
     _, gs = _closure_grads(system, objective, params, m0, S0, 3, None, extra=(scale_t,))
   assert gs[-1] is not None and float(gs[-1].abs()) > 0.0
+
+
+def test_a_stale_workspace_under_MM_WORKSPACE_CURRENT_is_reported(device):
+  """ADVICE (round 3): the reuse of the forward's q stage is decided by a host-side counter; the device now checks the promise
+  (the q stage stamps the mean it read) and flags a workspace that belongs to another state instead of differentiating it."""
+  from gpflowpilco_amd.synthetic import make_svgp
+  model = make_svgp(3, 96, 4, seed=41).to_model(device)
+  pm = model.packed(torch.float64, True, device)
+  mu, S = make_inputs(3, 4, seed=42, scale=0.1, lo=0.3, hi=0.7)
+  mu, S = to_dev(mu, device, torch.float64), to_dev(S, device, torch.float64)
+  g1, g2, g3 = (torch.ones(s, dtype=torch.float64, device=device) for s in ((3, 3), (3, 3, 3), (3, 4, 3)))
+  fl = ops.make_flags(True, True)
+  ops.moment_match(pm, mu, S)
+  gen = pm.workspace_generation(3, fl)
+  good = ops.moment_match_backward(pm, mu, S, g1, g2, g3, forward_generation=gen)
+  pm.check_status(3)
+  # someone overwrites the workspace behind the counter's back (another state's q stage through the raw C ABI)
+  ws = pm.workspace(3, fl, peek=True)
+  f1 = torch.empty(3, 3, dtype=torch.float64, device=device); cr = torch.empty(3, 4, 3, dtype=torch.float64, device=device)
+  mu2 = (mu + 0.05).contiguous()
+  rc = _lib.lib().mm_q_forward(pm.buf.data_ptr(), pm.nbytes, 3, 96, 4, _lib.MM_F64, 3, mu2.data_ptr(), S.data_ptr(), fl,
+                               f1.data_ptr(), cr.data_ptr(), None, ws.data_ptr(), ws.numel(), pm.status().data_ptr(),
+                               ops._stream(device))
+  assert rc == 0
+  ops.moment_match_backward(pm, mu, S, g1, g2, g3, forward_generation=gen)
+  with pytest.raises(RuntimeError, match="belongs to another state"):
+    pm.check_status(3)
+  again = ops.moment_match_backward(pm, mu, S, g1, g2, g3)          # without the promise: the q stage is re-run
+  pm.check_status(3)
+  for a_, b_ in zip(again, good):
+    assert torch.equal(a_, b_)
