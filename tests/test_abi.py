@@ -101,7 +101,7 @@ def test_argument_validation_of_the_gradient_entry_points_without_gpu():
   assert lib.mm_rollout_composed_backward(*args(dtype=F32)) == -3                 # MM_E_DTYPE
   assert lib.mm_rollout_composed_backward(*args(tapep=None)) == -1                # MM_E_ARG
   assert lib.mm_rollout_composed_backward(*args(drift_d=7)) == -6                 # MM_E_STATE: shapes do not compose
-  assert lib.mm_rollout_composed_backward(*args(pol_M=200)) == -2                 # MM_E_DIM: not the one-launch policy shape
+  assert lib.mm_rollout_composed_backward(*args(pol_M=300)) == -2                 # MM_E_DIM: more than 256 policy centres
   assert lib.mm_rollout_composed_backward(*args()) == -4                          # tape too small
   # backward of one match
   mb = lambda dtype=F64, mu=p, d=4: (p, 64, 2, 16, d, dtype, 2, mu, p, 3, p, p, p, p, p, 0, p, 64, p, 64, None, None)
