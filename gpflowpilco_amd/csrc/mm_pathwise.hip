@@ -17,6 +17,7 @@
 // NS * BT contiguous elements (4 KB) and consecutive passes are consecutive in memory.
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <atomic>
 #include "mm_common.h"
 
 #define MM_PW_NS 4      // samples per workgroup (and per block of the weight stream)
@@ -40,6 +41,12 @@ __device__ __forceinline__ float pw_cos(float x) { return __builtin_amdgcn_cosf(
 __device__ __forceinline__ double pw_cos(double x) { return cospi(2.0 * x); }
 __device__ __forceinline__ float pw_exp(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ double pw_exp(double x) { return exp2(x); }
+// (cos, sin)(2 pi x) of one argument (the Jacobian pass needs both): one range reduction, two v_*_f32
+__device__ __forceinline__ void pw_sincos(float x, float& c, float& s) {
+  const float r = x - floorf(x);
+  c = __builtin_amdgcn_cosf(r); s = __builtin_amdgcn_sinf(r);
+}
+__device__ __forceinline__ void pw_sincos(double x, double& c, double& s) { sincospi(2.0 * x, &s, &c); }
 
 template <typename T>
 __device__ __forceinline__ void pw_unpack(const float4& v, T (&o)[4]) { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
@@ -66,12 +73,36 @@ __device__ __forceinline__ double pw_wave_sum63(double v) {
   return v;
 }
 
+// the same reduction in f32 (the Jacobian entries of an f32 path: 1 + d values per (latent, sample) -- in f64 the reductions
+// alone would cost a third of the stream pass)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float pw_dpp_addf(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false);
+  return v + __builtin_bit_cast(float, o);
+}
+__device__ __forceinline__ float pw_wave_sum63(float v) {
+  v = pw_dpp_addf<0xB1, 0xf>(v);
+  v = pw_dpp_addf<0x4E, 0xf>(v);
+  v = pw_dpp_addf<0x141, 0xf>(v);
+  v = pw_dpp_addf<0x140, 0xf>(v);
+  v = pw_dpp_addf<0x142, 0xa>(v);
+  v = pw_dpp_addf<0x143, 0xc>(v);
+  return v;
+}
+
+// JAC (both kernels): the same pass also emits the per-sample Jacobian d f_{s,a} / d x_s [S][L][d] -- what the reverse sweep of
+// a differentiated sample rollout needs (the reference differentiates the pathwise loss with a gradient tape:
+// examples/cartpole_swingup/train_utils.py:108-135 through loops/pilco.py:263-298):
+//   prior  : d/dx_k w cos(2 pi arg) = -2 pi omega_k w sin(2 pi arg)       -> accJ_k += (w sin) omega_k, factor -2 pi scale
+//   update : d/dx_k v 2^arg = ln2 v 2^arg (c_k - xscale_k^2 x_k), c = z xscale^2  -> accJ_k += (v 2^arg) c_k, then
+//            ln2 var (accJ_k - xscale_k^2 x_k accu)
+// d more FMAs and (prior blocks) one more transcendental per term and sample; 1 + d wave sums per (latent, sample).
 // grid: ceil(S / NS) workgroups of 256 threads = 4 waves.  Wave wv of a workgroup owns the latents
 // wv, wv + 4, ... of the workgroup's NS samples and streams their K + M weights alone: the only
 // cross-lane step is one shuffle reduction per (latent, sample) -- no LDS, no barriers.  The weight
 // loads are software-pipelined two passes ahead (PMC: 71 % of wave cycles were s_waitcnt with one
 // pass in flight).  EULER != 0: x_out = x + dt f (needs d == L), else f_out = f.
-template <typename T, int DK>
+template <typename T, int DK, bool JAC>
 __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, int d,
                                                   const T* __restrict__ x,        // [S,d]
                                                   const T* __restrict__ omega,    // [L,d,K] revolutions
@@ -85,9 +116,11 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
                                                   const T* __restrict__ wb,       // blocked weights
                                                   T* __restrict__ out,            // [S,L] (f or x_next)
                                                   T* __restrict__ traj,           // optional [S,L]
+                                                  T* __restrict__ jac,            // JAC: [S,L,d]
                                                   int euler, double dt) {
   typedef typename PwVec<T>::type VT;
   constexpr int W = PwVec<T>::W, NS = MM_PW_NS, BT = 64 * W;     // BT terms per pass of a wave
+  constexpr int NJ = JAC ? DK : 1;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int g = blockIdx.x, s0 = g * NS;
   const int nbK = K / BT, nbM = M / BT, NB = nbK + nbM;
@@ -104,9 +137,13 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
   }
 
   for (int a = wv; a < L; a += 4) {
-    T accp[NS], accu[NS];
+    T accp[NS], accu[NS], accJ[NS][NJ];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) { accp[s] = (T)0; accu[s] = (T)0; }
+    for (int s = 0; s < NS; ++s) {
+      accp[s] = (T)0; accu[s] = (T)0;
+#pragma unroll
+      for (int k = 0; k < NJ; ++k) accJ[s][k] = (T)0;
+    }
 
     // ---- prior part: random Fourier features ------------------------------------------------
     {
@@ -144,10 +181,31 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
             T arg = bv[j];
 #pragma unroll
             for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
-            accp[s] += wv4[s][j] * PW_COS(arg);
+            if constexpr (JAC) {
+              T cs, sn;
+              pw_sincos(arg, cs, sn);
+              accp[s] += wv4[s][j] * cs;
+              const T t = wv4[s][j] * sn;
+#pragma unroll
+              for (int k = 0; k < DK; ++k) accJ[s][k] += t * cv[k][j];
+            } else {
+              accp[s] += wv4[s][j] * PW_COS(arg);
+            }
           }
 #pragma unroll
         for (int s = 0; s < NS; ++s) { wq[0][s] = wq[1][s]; wq[1][s] = wq[2][s]; }
+      }
+      if constexpr (JAC) {
+        // ONE accumulator set for both halves: the prior sums are rescaled so that the update half's final factor
+        // ln2 var xscale_k applies to the total (no second [NS][DK] register set)
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+          const double scv = xscale[a * d + (k < d ? k : 0)];
+          const double den = 0.6931471805599453 * var[a] * scv;
+          const T fj = (k < d && den != 0.0) ? (T)(-6.283185307179586 * pscale[a] / den) : (T)0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s) accJ[s][k] *= fj;
+        }
       }
     }
     // ---- update part: kernel basis at the inducing points -----------------------------------
@@ -198,10 +256,27 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
             T arg = -hv[j] - hx[s];
 #pragma unroll
             for (int k = 0; k < DK; ++k) arg += cv[k][j] * xsc[s][k];
-            accu[s] += vv[s][j] * PW_EXP(arg);
+            const T t = vv[s][j] * PW_EXP(arg);
+            accu[s] += t;
+            if constexpr (JAC) {
+#pragma unroll
+              for (int k = 0; k < DK; ++k) accJ[s][k] += t * cv[k][j];
+            }
           }
 #pragma unroll
         for (int s = 0; s < NS; ++s) { vq[0][s] = vq[1][s]; vq[1][s] = vq[2][s]; }
+      }
+      if constexpr (JAC) {
+        // arg = zs . xs - hz - hx with xs = x xscale: d arg / d x_k = xscale_k (zs_k - xs_k)
+        const T fj = (T)(0.6931471805599453 * var[a]);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+          for (int k = 0; k < DK; ++k) {
+            const T scv = (T)xscale[a * d + (k < d ? k : 0)];
+            const T sc = (k < d) ? scv : (T)0;
+            accJ[s][k] = fj * sc * (accJ[s][k] - xsc[s][k] * accu[s]);
+          }
       }
     }
     // ---- wave reduction (f64), one value per sample -----------------------------------------
@@ -215,6 +290,13 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
         out[(size_t)(s0 + s) * L + a] = (T)f;
         if (traj) traj[(size_t)(s0 + s) * L + a] = (T)f;
       }
+      if constexpr (JAC) {
+#pragma unroll
+        for (int k = 0; k < DK; ++k) {
+          const T jv = pw_wave_sum63(accJ[s][k]);
+          if (lane == 63 && s0 + s < S && k < d) jac[((size_t)(s0 + s) * L + a) * d + k] = jv;
+        }
+      }
     }
   }
 }
@@ -224,16 +306,18 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
 // and then streams many sample groups through it, so the only global traffic in the loop is the
 // weight stream itself (operand re-reads through L2 cost 39 % of the plain kernel's time).
 // grid = L * nW workgroups; wave w of workgroup (a, i) handles sample groups i*8 + w, + nW*8, ...
-template <typename T, int DK>
+template <typename T, int DK, bool JAC>
 __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L, int M, int K, int d, int nW,
                                                       const T* __restrict__ x, const T* __restrict__ omega,
                                                       const T* __restrict__ phase, const T* __restrict__ zs,
                                                       const T* __restrict__ hz, const double* __restrict__ xscale,
                                                       const double* __restrict__ pscale, const double* __restrict__ var,
                                                       const double* __restrict__ meanc, const T* __restrict__ wb,
-                                                      T* __restrict__ out, T* __restrict__ traj, int euler, double dt) {
+                                                      T* __restrict__ out, T* __restrict__ traj, T* __restrict__ jac,
+                                                      int euler, double dt) {
   typedef typename PwVec<T>::type VT;
   constexpr int W = PwVec<T>::W, NS = MM_PW_NS, BT = 64 * W, NWAVE = PW_LDS_WAVES;
+  constexpr int NJ = JAC ? DK : 1;
   extern __shared__ __attribute__((aligned(16))) char pw_smem[];
   // [DK + 1][K + M]: rows 0..d-1 vectors (rows d..DK-1 zero: the k loops below are unconditional),
   // row DK the scalars (phase | hz)
@@ -289,7 +373,7 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
     else if (ld_g + g_stride < ngroups) { ld_g += g_stride; ld_tb = 0; }
   };
   int cg = g_first, ctb = 0;                            // block being consumed
-  T xr[NS][DK], hx[NS], accp[NS], accu[NS];
+  T xr[NS][DK], hx[NS], accp[NS], accu[NS], accJ[NS][NJ];
   auto consume = [&](const VT (&q)[NS]) {
     const int s0 = cg * NS;
     if (ctb == 0) {                                     // new group: its NS states (wave-uniform loads)
@@ -306,6 +390,8 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
         }
         hx[s] = (T)0.5 * h;
         accp[s] = (T)0; accu[s] = (T)0;
+#pragma unroll
+        for (int k = 0; k < NJ; ++k) accJ[s][k] = (T)0;
       }
     }
     T wv4[NS][W], cv[DK][W], sv[W];
@@ -323,8 +409,29 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
           T arg = sv[j];
 #pragma unroll
           for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
-          accp[s] += wv4[s][j] * PW_COS(arg);
+          if constexpr (JAC) {
+            T cs, sn;
+            pw_sincos(arg, cs, sn);
+            accp[s] += wv4[s][j] * cs;
+            const T t = wv4[s][j] * sn;
+#pragma unroll
+            for (int k = 0; k < DK; ++k) accJ[s][k] += t * cv[k][j];
+          } else {
+            accp[s] += wv4[s][j] * PW_COS(arg);
+          }
         }
+      if constexpr (JAC) {
+        if (ctb == nbK - 1) {
+          // last prior block: d/dx of w cos(2 pi arg) = -2 pi omega w sin.  ONE accumulator set for both halves: the prior sums
+          // are rescaled so that the update half's final factor ln2 var applies to the total
+          const double den = 0.6931471805599453 * vr;
+          const T fj = den != 0.0 ? (T)(-6.283185307179586 * ps / den) : (T)0;
+#pragma unroll
+          for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int k = 0; k < DK; ++k) accJ[s][k] *= fj;
+        }
+      }
     } else {                                            // update block
 #pragma unroll
       for (int j = 0; j < W; ++j)
@@ -333,7 +440,12 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
           T arg = -sv[j] - hx[s];
 #pragma unroll
           for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
-          accu[s] += wv4[s][j] * PW_EXP(arg);
+          const T t = wv4[s][j] * PW_EXP(arg);
+          accu[s] += t;
+          if constexpr (JAC) {
+#pragma unroll
+            for (int k = 0; k < DK; ++k) accJ[s][k] += t * cv[k][j];
+          }
         }
     }
     if (ctb == NB - 1) {                                // group done: reduce, Euler update, store
@@ -347,6 +459,15 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
           if (euler) f = (double)x[(size_t)(s0 + s) * d + a] + dt * f;
           out[(size_t)(s0 + s) * L + a] = (T)f;
           if (traj) traj[(size_t)(s0 + s) * L + a] = (T)f;
+        }
+        if constexpr (JAC) {
+          // update rows carry c = z xscale^2 and arg = c . x - hz - hx: d arg / d x_k = c_k - xscale_k^2 x_k
+          const T fj = (T)(0.6931471805599453 * vr);
+#pragma unroll
+          for (int k = 0; k < DK; ++k) {
+            const T jv = pw_wave_sum63(fj * (accJ[s][k] - sc[k] * sc[k] * xr[s][k] * accu[s]));
+            if (lane == 63 && s0 + s < S && k < d) jac[((size_t)(s0 + s) * L + a) * d + k] = jv;
+          }
         }
       }
       ctb = 0; cg += g_stride;
@@ -369,7 +490,9 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
 template <typename T>
 static int pw_launch(int S, int L, int M, int K, int d, const T* x, const T* omega, const T* phase, const T* zs,
                      const T* hz, const double* xscale, const double* pscale, const double* var,
-                     const double* meanc, const T* wb, T* out, T* traj, int euler, double dt, hipStream_t s) {
+                     const double* meanc, const T* wb, T* out, T* traj, int euler, double dt, hipStream_t s,
+                     T* jac = nullptr) {
+  if (jac && d > 8) return MM_E_DIM;               // the Jacobian pass keeps (1 + d) accumulators per sample: d <= 8
   // LDS-resident operands when one latent's (d + 1) x (K + M) block fits (<= 144 KB)
   const int dk = d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : 32;
   const size_t lds_bytes = (size_t)(dk + 1) * (K + M) * sizeof(T);      // rows d..dk-1 are zero padding
@@ -377,35 +500,42 @@ static int pw_launch(int S, int L, int M, int K, int d, const T* x, const T* ome
     const int ngroups = (S + MM_PW_NS - 1) / MM_PW_NS;
     int nW = 256 / L; if (nW < 1) nW = 1;                           // ~ one workgroup per CU
     while (nW > 1 && (nW - 1) * PW_LDS_WAVES >= ngroups) --nW;                 // no idle workgroups on small S
-#define PW_LAUNCH_LDS(DK_)                                                                          \
+#define PW_LAUNCH_LDS_(DK_, JAC_)                                                                   \
     do {                                                                                            \
-      /* raise the dynamic-LDS limit once per instantiation (the call is slow: not per launch) */  \
-      static int lds_limit = 0;                                                                     \
-      if ((int)lds_bytes > lds_limit) {                                                             \
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pathwise_lds<T, DK_>), \
+      /* raise the dynamic-LDS limit once per instantiation and device (the call is slow: not per launch) */ \
+      static std::atomic<unsigned long long> lds_set{0ull};                                         \
+      int dev_ = 0;                                                                                 \
+      if (hipGetDevice(&dev_) != hipSuccess) dev_ = 64;                                             \
+      const unsigned long long bit_ = (dev_ >= 0 && dev_ < 64) ? (1ull << dev_) : 0ull;             \
+      if (!bit_ || !(lds_set.load() & bit_)) {                                                      \
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pathwise_lds<T, DK_, JAC_>), \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
         if (ea != hipSuccess) return (int)ea;                                                       \
-        lds_limit = 144 * 1024;                                                                     \
+        lds_set.fetch_or(bit_);                                                                     \
       }                                                                                             \
-      hipLaunchKernelGGL((k_pathwise_lds<T, DK_>), dim3(L * nW), dim3(64 * PW_LDS_WAVES), lds_bytes, s, S, L, M, K, d, nW, \
-                         x, omega, phase, zs, hz, xscale, pscale, var, meanc, wb, out, traj, euler, dt); \
+      hipLaunchKernelGGL((k_pathwise_lds<T, DK_, JAC_>), dim3(L * nW), dim3(64 * PW_LDS_WAVES), lds_bytes, s, S, L, M, K, d, nW, \
+                         x, omega, phase, zs, hz, xscale, pscale, var, meanc, wb, out, traj, jac, euler, dt); \
     } while (0)
+#define PW_LAUNCH_LDS(DK_) do { if (jac) PW_LAUNCH_LDS_(DK_, true); else PW_LAUNCH_LDS_(DK_, false); } while (0)
     if (d <= 4) PW_LAUNCH_LDS(4);
     else if (d <= 8) PW_LAUNCH_LDS(8);
-    else if (d <= 16) PW_LAUNCH_LDS(16);
-    else PW_LAUNCH_LDS(32);
+    else if (d <= 16) PW_LAUNCH_LDS_(16, false);
+    else PW_LAUNCH_LDS_(32, false);
 #undef PW_LAUNCH_LDS
+#undef PW_LAUNCH_LDS_
     hipError_t el = hipGetLastError();
     return el == hipSuccess ? 0 : (int)el;
   }
   dim3 grid((S + MM_PW_NS - 1) / MM_PW_NS);
-#define PW_LAUNCH(DK_) hipLaunchKernelGGL((k_pathwise<T, DK_>), grid, dim3(256), 0, s, S, L, M, K, d, x, omega, phase, \
-                                          zs, hz, xscale, pscale, var, meanc, wb, out, traj, euler, dt)
+#define PW_LAUNCH_(DK_, JAC_) hipLaunchKernelGGL((k_pathwise<T, DK_, JAC_>), grid, dim3(256), 0, s, S, L, M, K, d, x, omega, phase, \
+                                                zs, hz, xscale, pscale, var, meanc, wb, out, traj, jac, euler, dt)
+#define PW_LAUNCH(DK_) do { if (jac) PW_LAUNCH_(DK_, true); else PW_LAUNCH_(DK_, false); } while (0)
   if (d <= 4) PW_LAUNCH(4);
   else if (d <= 8) PW_LAUNCH(8);
-  else if (d <= 16) PW_LAUNCH(16);
-  else PW_LAUNCH(32);
+  else if (d <= 16) PW_LAUNCH_(16, false);
+  else PW_LAUNCH_(32, false);
 #undef PW_LAUNCH
+#undef PW_LAUNCH_
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -436,6 +566,32 @@ extern "C" int mm_pathwise_eval(int S, int L, int M, int K, int d, int dtype,
   return pw_launch<float>(S, L, M, K, d, (const float*)x, (const float*)omega_t, (const float*)phase,
                           (const float*)zs_t, (const float*)hz, x_scale, prior_scale, variance, mean_c,
                           (const float*)wb, (float*)f_out, nullptr, 0, 0.0, s);
+}
+
+// one evaluation f [S,L] (and, jac != NULL, d f / d x [S,L,d]) for the other translation units (mm_pathwise_policy.hip)
+int mm_pathwise_launch(int S, int L, int M, int K, int d, int dtype, const void* x, const void* omega_t, const void* phase,
+                       const void* zs_t, const void* hz, const double* x_scale, const double* prior_scale, const double* variance,
+                       const double* mean_c, const void* wb, void* f_out, void* jac, hipStream_t s) {
+  int rc = pw_check(S, L, M, K, d, dtype);
+  if (rc) return rc;
+  if (dtype == MM_F64)
+    return pw_launch<double>(S, L, M, K, d, (const double*)x, (const double*)omega_t, (const double*)phase,
+                             (const double*)zs_t, (const double*)hz, x_scale, prior_scale, variance, mean_c,
+                             (const double*)wb, (double*)f_out, nullptr, 0, 0.0, s, (double*)jac);
+  return pw_launch<float>(S, L, M, K, d, (const float*)x, (const float*)omega_t, (const float*)phase,
+                          (const float*)zs_t, (const float*)hz, x_scale, prior_scale, variance, mean_c,
+                          (const float*)wb, (float*)f_out, nullptr, 0, 0.0, s, (float*)jac);
+}
+
+extern "C" int mm_pathwise_eval_jac(int S, int L, int M, int K, int d, int dtype,
+                                    const void* x, const void* omega_t, const void* phase, const void* zs_t,
+                                    const void* hz, const double* x_scale, const double* prior_scale,
+                                    const double* variance, const double* mean_c, const void* wb, void* f_out,
+                                    void* jac_out, void* stream) {
+  if (!x || !omega_t || !phase || !zs_t || !hz || !x_scale || !prior_scale || !variance || !wb || !f_out || !jac_out)
+    return MM_E_ARG;
+  return mm_pathwise_launch(S, L, M, K, d, dtype, x, omega_t, phase, zs_t, hz, x_scale, prior_scale, variance, mean_c, wb,
+                            f_out, jac_out, (hipStream_t)stream);
 }
 
 extern "C" int mm_pathwise_rollout(int S, int L, int M, int K, int d, int dtype, int H, double dt,

@@ -69,6 +69,23 @@ class Paths:
     check(rc, "mm_pathwise_eval")
     return out
 
+  def eval_jac(self, x: torch.Tensor):
+    """f_s(x_s) and its Jacobian: x [S, d] -> (f [S, L], d f / d x [S, L, d]) from ONE pass over the weight stream (d <= 8)."""
+    _require_device(x, self.wb)
+    S, L, Mp, Kp, d = self._dims()
+    if x.shape != (S, d) or x.dtype != self.dtype:
+      raise ValueError(f"expected x [{S},{d}] of {self.dtype}, got {tuple(x.shape)} {x.dtype}")
+    x = x.contiguous()
+    out = torch.empty(S, L, dtype=self.dtype, device=x.device)
+    jac = torch.empty(S, L, d, dtype=self.dtype, device=x.device)
+    rc = _lib.lib().mm_pathwise_eval_jac(S, L, Mp, Kp, d, _dtype_code(self.dtype), x.data_ptr(), self.omega.data_ptr(),
+                                         self.phase.data_ptr(), self.zs.data_ptr(), self.hz.data_ptr(),
+                                         self.lengthscales.data_ptr(), self.prior_scale.data_ptr(),
+                                         self.variance.data_ptr(), _ptr(self.mean_c), self.wb.data_ptr(),
+                                         out.data_ptr(), jac.data_ptr(), _stream(x.device))
+    check(rc, "mm_pathwise_eval_jac")
+    return out, jac
+
   def rollout(self, x0: torch.Tensor, num_steps: int, dt: float = 1.0, keep_trajectory: bool = False):
     """Drift-only Euler rollout of all S paths (d == L): x <- x + dt f(x), H steps in one ABI call."""
     _require_device(x0, self.wb)
@@ -173,3 +190,122 @@ class PathwiseSVGP(SVGP):
 
   def __call__(self, x, **kwargs):
     return self.predict_f_samples(x, **kwargs)
+
+
+class PolicyRollout:
+  """The pathwise policy rollout on the device (``mm_pathwise_policy_rollout``, csrc/mm_pathwise_policy.hip): per sample path
+  encoder -> policy mean through Chain[Scale, Shift, NormalCDF] -> drift sample -> Euler -> cost -- the body of
+  ``PathwisePILCO._policy_loss_closure`` (gpflow_pilco/loops/pilco.py:263-298).
+
+  ``paths``: the drift's sample paths (nx latents on nd = nx + na + 1 inputs, nd <= 8); ``policy``: a one-latent
+  ``ops.PackedModel`` on ne = nx + na inputs (any dtype: only its float64 blocks are read).  ``__call__(x0, H)`` ->
+  ``(cost [H, S], tape)``; ``backward(tape, g_cost)`` -> ``(g_policy [M ne + M + ne + 2], g_x0 [S, nx] | None)``."""
+
+  def __init__(self, paths: Paths, policy, nx: int, active_dims, head_scale: float, head_shift: float,
+               target: torch.Tensor, precis: torch.Tensor):
+    S, L, Mp, Kp, d = paths._dims()
+    self.paths, self.policy = paths, policy
+    self.nx, self.active = int(nx), tuple(int(i) for i in active_dims)
+    self.na = len(self.active)
+    self.ne, self.nd = self.nx + self.na, self.nx + self.na + 1
+    if L != self.nx or d != self.nd or policy.L != 1 or policy.d != self.ne:
+      raise ValueError(f"shapes do not compose: paths L={L} d={d} (want {self.nx}, {self.nd}), policy L={policy.L} d={policy.d} "
+                       f"(want 1, {self.ne})")
+    if self.nd > 8 or policy.M > 256:
+      raise ValueError("the pathwise policy rollout takes drift inputs of dimension <= 8 and policies of <= 256 centres")
+    self.scale, self.shift = float(head_scale), float(head_shift)
+    self.target = target.to(dtype=paths.dtype, device=paths.wb.device).contiguous()
+    self.precis = precis.to(dtype=paths.dtype, device=paths.wb.device).contiguous()
+    self._act = (_lib.C.c_int32 * self.na)(*self.active)
+
+  def _policy(self, policy):
+    pol = self.policy if policy is None else policy
+    if (pol.L, pol.M, pol.d) != (self.policy.L, self.policy.M, self.policy.d):
+      raise ValueError("the policy pack does not have the shape this rollout was built for")
+    return pol
+
+  def __call__(self, x0: torch.Tensor, num_steps: int, dt: float = 1.0, with_jacobians: bool = False, policy=None):
+    pol = self._policy(policy)
+    P = self.paths
+    S, L, Mp, Kp, d = P._dims()
+    _require_device(x0, P.wb)
+    if x0.shape != (S, self.nx) or x0.dtype != P.dtype:
+      raise ValueError(f"expected x0 [{S},{self.nx}] of {P.dtype}, got {tuple(x0.shape)} {x0.dtype}")
+    H, code = int(num_steps), _dtype_code(P.dtype)
+    n = _lib.lib().mm_pathwise_tape_bytes(S, H, self.nx, self.na, code, int(with_jacobians))
+    if n == 0:
+      raise ValueError("mm_pathwise_tape_bytes rejected the shape")
+    tape = torch.empty(n, dtype=torch.uint8, device=x0.device)
+    cost = torch.empty(H, S, dtype=P.dtype, device=x0.device)
+    x0 = x0.contiguous()
+    rc = _lib.lib().mm_pathwise_policy_rollout(S, Mp, Kp, code, H, float(dt), self.nx, self.na, self._act,
+                                               P.omega.data_ptr(), P.phase.data_ptr(), P.zs.data_ptr(), P.hz.data_ptr(),
+                                               P.lengthscales.data_ptr(), P.prior_scale.data_ptr(), P.variance.data_ptr(),
+                                               _ptr(P.mean_c), P.wb.data_ptr(), pol.buf.data_ptr(), pol.nbytes, pol.M,
+                                               self.scale, self.shift, self.target.data_ptr(), self.precis.data_ptr(),
+                                               x0.data_ptr(), cost.data_ptr(), tape.data_ptr(), tape.numel(),
+                                               int(with_jacobians), _stream(x0.device))
+    check(rc, "mm_pathwise_policy_rollout")
+    return cost, tape
+
+  def states(self, tape: torch.Tensor, num_steps: int) -> torch.Tensor:
+    """x_0 .. x_H [H + 1, S, nx] (a view of the tape)."""
+    S = self.paths.num_samples
+    es = 8 if self.paths.dtype == torch.float64 else 4
+    n = (num_steps + 1) * S * self.nx
+    return tape[:n * es].view(self.paths.dtype).view(num_steps + 1, S, self.nx)
+
+  def backward(self, tape: torch.Tensor, g_cost: torch.Tensor, num_steps: int, dt: float = 1.0, policy=None,
+               want_state_grad: bool = False):
+    pol = self._policy(policy)
+    S, H, code = self.paths.num_samples, int(num_steps), _dtype_code(self.paths.dtype)
+    dev = tape.device
+    g_cost = g_cost.to(torch.float64).contiguous()
+    if g_cost.shape != (H, S):
+      raise ValueError(f"g_cost must be [H={H}, S={S}]")
+    npar = pol.M * self.ne + pol.M + self.ne + 2
+    g_pol = torch.empty(npar, dtype=torch.float64, device=dev)
+    g_x0 = torch.empty(S, self.nx, dtype=torch.float64, device=dev) if want_state_grad else None
+    ns = _lib.lib().mm_pathwise_backward_scratch_bytes(S, pol.M, self.ne)
+    scratch = torch.empty(ns, dtype=torch.uint8, device=dev)
+    rc = _lib.lib().mm_pathwise_policy_rollout_backward(S, code, H, float(dt), self.nx, self.na, self._act, pol.buf.data_ptr(),
+                                                        pol.nbytes, pol.M, self.scale, self.shift, self.target.data_ptr(),
+                                                        self.precis.data_ptr(), tape.data_ptr(), tape.numel(),
+                                                        g_cost.data_ptr(), g_pol.data_ptr(), _ptr(g_x0), scratch.data_ptr(),
+                                                        scratch.numel(), _stream(dev))
+    check(rc, "mm_pathwise_policy_rollout_backward")
+    return g_pol, g_x0
+
+
+class PolicyRolloutFunction(torch.autograd.Function):
+  """The pathwise policy loss as ONE differentiable op: forward = ``mm_pathwise_policy_rollout`` with the Jacobian tape,
+  backward = ``mm_pathwise_policy_rollout_backward``.  The policy enters in packed coordinates (Z [1,M,ne], lengthscales
+  [1,ne], variance [1], beta [1,M], mean_c [1]) computed from its parameters by differentiable torch ops, as in
+  ``autodiff.ComposedRolloutFunction``.  Output: cost [S, H]."""
+
+  @staticmethod
+  def forward(ctx, x0, Z, ls, var, beta, mean_c, roll, num_steps, dt):
+    from . import ops
+    f64 = torch.float64
+    det = lambda t: t.detach().to(f64)
+    pol = ops.pack_model(det(Z), det(ls), det(var), det(beta), None, det(mean_c), dtype=f64, sync=False)
+    cost, tape = roll(x0.detach(), num_steps, dt=dt, with_jacobians=True, policy=pol)
+    ctx.roll, ctx.pol, ctx.tape, ctx.H, ctx.dt = roll, pol, tape, int(num_steps), float(dt)
+    ctx.save_for_backward(ls)
+    ctx.need_state = x0.requires_grad
+    ctx.shapes = (Z.shape, ls.shape, var.shape, beta.shape, mean_c.shape)
+    ctx.x_dtype = x0.dtype
+    return cost.T.contiguous()
+
+  @staticmethod
+  def backward(ctx, g_cost):
+    (ls,) = ctx.saved_tensors
+    g, g_x0 = ctx.roll.backward(ctx.tape, g_cost.T.contiguous(), ctx.H, dt=ctx.dt, policy=ctx.pol, want_state_grad=ctx.need_state)
+    M, d = ctx.pol.M, ctx.pol.d
+    zs, lss, vs, bs, ms = ctx.shapes
+    gZ = g[:M * d].reshape(zs)
+    gbeta = g[M * d:M * d + M].reshape(bs)
+    gls = (2.0 * ls.detach().reshape(-1) * g[M * d + M:M * d + M + d]).reshape(lss)        # d/d ls = 2 ls d/d ls^2
+    gvar = g[M * d + M + d].reshape(vs)
+    gmean = g[M * d + M + d + 1].reshape(ms)
+    return (None if g_x0 is None else g_x0.to(ctx.x_dtype)), gZ, gls, gvar, gbeta, gmean, None, None, None

@@ -309,6 +309,41 @@ int mm_pathwise_rollout(int S, int L, int M, int K, int d, int dtype, int H, dou
                         const double* variance, const double* mean_c, const void* wb,
                         void* traj, void* stream);
 
+/* The same evaluation that also emits the per-sample Jacobian d f[s,a] / d x[s,:]  (jac_out [S,L,d] T; d <= 8): in the SAME pass
+ * over the weight stream (d more FMAs and, in the prior blocks, one more transcendental per term and sample). */
+int mm_pathwise_eval_jac(int S, int L, int M, int K, int d, int dtype,
+                         const void* x, const void* omega_t, const void* phase, const void* zs_t, const void* hz,
+                         const double* x_scale, const double* prior_scale, const double* variance,
+                         const double* mean_c, const void* wb, void* f_out, void* jac_out, void* stream);
+
+/* ---- pathwise POLICY rollout and its gradient: row f-3 completed ---------------------------------------------------
+ * PathwisePILCO._policy_loss_closure (gpflow_pilco/loops/pilco.py:263-298) for the cartpole-shaped system, per sample path s:
+ *   e = TrigonometricEncoder(x) (components.py:44-75) -> u = scale (Phi(f_pol(e)) + shift), f_pol = the policy SVGP's predictive
+ *   mean (models/core.py:60-71) -> x' = x + dt f_s([e, u]) (tensor branch of forward_sde, dynamics/forward_sde.py:23-31; Euler.step,
+ *   solvers.py:50-65) -> cost[h][s] = -exp(-(enc(x') - target)^T precis (enc(x') - target) / 2) (components.py:39-41).
+ * The drift paths are the operands of mm_pathwise_eval with L = nx latents on nd = nx + na + 1 inputs (nd <= 8); the policy is a
+ * one-latent pack (mm_pack_model, M <= 256 centres on ne = nx + na inputs; only its f64 blocks are read).  x0 [S,nx], target [ne],
+ * precis [ne,ne], cost [H,S]: T.  tape (mm_pathwise_tape_bytes): states x_0..x_H, the drift inputs of every step and, with
+ * with_jacobians != 0, d f_s / d (e, u) of every step -- what mm_pathwise_policy_rollout_backward reads (the reference
+ * differentiates the mean sample loss with a gradient tape: examples/cartpole_swingup/train_utils.py:108-135):
+ *   g_cost [H][S] f64 (in; 1/S everywhere for the mean loss) -> g_policy [M ne + M + ne + 2] f64 (out: dZ, dbeta, d ls^2, dvar,
+ *   dmean of the PACKED policy, summed over the samples; chain through beta(q_mu, Z, ls, var) on the host), g_x0 [S][nx] f64
+ *   (optional).  The reverse sweep is ONE kernel (samples are independent) and does not touch the weight stream again. */
+size_t mm_pathwise_tape_bytes(int S, int H, int nx, int na, int dtype, int with_jacobians);
+int mm_pathwise_policy_rollout(int S, int M, int K, int dtype, int H, double dt, int nx, int na, const int32_t* active_dims,
+                               const void* omega_t, const void* phase, const void* zs_t, const void* hz,
+                               const double* x_scale, const double* prior_scale, const double* variance,
+                               const double* mean_c, const void* wb,
+                               const void* policy_packed, size_t policy_bytes, int policy_M, double head_scale, double head_shift,
+                               const void* target, const void* precis, const void* x0, void* cost,
+                               void* tape, size_t tape_bytes, int with_jacobians, void* stream);
+size_t mm_pathwise_backward_scratch_bytes(int S, int policy_M, int ne);
+int mm_pathwise_policy_rollout_backward(int S, int dtype, int H, double dt, int nx, int na, const int32_t* active_dims,
+                                        const void* policy_packed, size_t policy_bytes, int policy_M,
+                                        double head_scale, double head_shift, const void* target, const void* precis,
+                                        const void* tape, size_t tape_bytes, const void* g_cost, void* g_policy, void* g_x0,
+                                        void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,3 +94,45 @@ def tensor_cost(x, target, precis):
   """GaussianObjective on samples (components.py:39-41)."""
   err = x - target
   return -np.exp(-0.5 * np.einsum('...i,ij,...j->...', err, precis, err))
+
+
+# ---- the pathwise POLICY rollout (PathwisePILCO._policy_loss_closure) ------------------------------------------------
+def encode(x, active_dims):
+  """TrigonometricEncoder on tensors (gpflow_pilco/components.py:44-75): [sin a, cos a, x_inactive (ascending)]."""
+  nx = x.shape[-1]
+  active = list(active_dims)
+  inactive = [i for i in range(nx) if i not in set(active)]
+  a = x[..., active]
+  return np.concatenate([np.sin(a), np.cos(a), x[..., inactive]], axis=-1)
+
+
+def policy_mean(policy: mo.SVGPParams, e):
+  """KernelRegressor.__call__ = predict_f(x)[0] (gpflow_pilco/models/core.py:60-62) of a one-latent SVGP: e [n, ne] -> [n]."""
+  M = policy.Z.shape[1]
+  Kuu = mo.se_kernel(policy.Z[0], None, policy.lengthscales[0], policy.variance[0]) + policy.kuu_jitter * np.eye(M)
+  Lu = cholesky(Kuu, lower=True)
+  u = policy.q_mu[:, 0]
+  if policy.whiten:
+    u = Lu @ u
+  beta = cho_solve((Lu, True), u)
+  f = mo.se_kernel(e, policy.Z[0], policy.lengthscales[0], policy.variance[0]) @ beta
+  if policy.mean_c is not None:
+    f = f + np.asarray(policy.mean_c).reshape(-1)[0]
+  return f
+
+
+def policy_rollout_costs(paths: Paths, drift: mo.SVGPParams, policy: mo.SVGPParams, head_scale, head_shift, active_dims,
+                         target, precis, x0, num_steps, dt=1.0, keep=False):
+  """loops/pilco.py:263-298 for one batch of sample paths: per step e = encoder(x); u = scale (Phi(policy(e)) + shift)
+  (InverseLinkWrapper with Chain[Scale, Shift, NormalCDF]: applied NormalCDF -> Shift -> Scale); x <- x + dt f_s([e, u])
+  (forward_sde.py:23-31, solvers.py:50-65); cost[h] = objective(encoder(x)) (pilco.py:272-275).  -> cost [H, S]."""
+  from scipy.special import ndtr
+  x = np.array(x0, dtype=np.float64, copy=True)
+  costs, states = [], [x.copy()]
+  for _ in range(num_steps):
+    e = encode(x, active_dims)
+    u = head_scale * (ndtr(policy_mean(policy, e)) + head_shift)
+    x = x + dt * eval_paths(paths, drift, np.concatenate([e, u[:, None]], axis=-1))
+    costs.append(tensor_cost(encode(x, active_dims), target, precis))
+    states.append(x.copy())
+  return (np.stack(costs), np.stack(states)) if keep else np.stack(costs)

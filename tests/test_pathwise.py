@@ -116,3 +116,153 @@ def test_c5_shard_shape_against_oracle_on_a_slice_of_samples(device):
   f64 = gp64(torch.tensor(x[:256], dtype=torch.float64, device=device))
   assert scale_err(f64[:24], pw.eval_paths(pw.Paths(omega=paths.omega, phase=paths.phase, w=paths.w[:24], v=paths.v[:24]),
                                            po, x[:24])) < 1e-9
+
+
+# ---- the pathwise POLICY rollout and its gradient (row f-3 completed) ------------------------------------------------
+def _policy_case(device, dtype, S=37, K=130, M=50, Mp=12, seed=3):
+  """Cartpole wiring at small sizes: nx = 4 (one angle) -> ne = 5 -> nd = 6; drift paths of 4 latents; policy of Mp centres."""
+  from gpflowpilco_amd.pathwise import PolicyRollout, paths_from_arrays
+  rng = np.random.default_rng(seed)
+  drift = oracle_params(make_svgp(4, M, 6, seed=seed + 1, ls_bounds=(0.8, 3.0)))
+  drift.Z = drift.Z * np.array([1, 1, 1, 1, 1, 4.0]) - np.array([0, 0, 0, 0, 0, 2.0])
+  pol = random_svgp_params(seed=seed + 2, L=1, M=Mp, d=5, whiten=True, ls_bounds=(0.8, 2.0), mean=True)
+  pol.q_mu = 0.3 * pol.q_mu
+  paths = pw.draw_paths(rng, drift, S, K)
+  paths.w *= 0.3; paths.v *= 0.3                                  # (keeps 6-step sample rollouts inside the data's support)
+  x0 = rng.uniform(0.2, 0.8, size=(S, 4))
+  target = np.array([0.0, 1.0, 0.2, 0.0, 0.1])
+  A = rng.standard_normal((5, 5))
+  precis = 0.5 * (A @ A.T) / 5 + 0.5 * np.eye(5)
+  scale, shift, active = 2.0, -0.5, (1,)
+  gp_paths = paths_from_arrays(paths.omega, paths.phase, paths.w, paths.v, drift.Z, drift.lengthscales, drift.variance,
+                               drift.mean_c, dtype=dtype, device=device)
+  pol_model = gp_model_from_oracle(pol, device)
+  roll = PolicyRollout(gp_paths, pol_model.packed(torch.float64, False, device), nx=4, active_dims=active, head_scale=scale,
+                       head_shift=shift, target=torch.tensor(target), precis=torch.tensor(precis))
+  return dict(paths=paths, drift=drift, pol=pol, x0=x0, target=target, precis=precis, scale=scale, shift=shift, active=active,
+              gp_paths=gp_paths, pol_model=pol_model, roll=roll)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_gpu_jacobian_of_the_paths_matches_finite_differences_of_the_oracle(dtype, device):
+  c = _policy_case(device, dtype)
+  rng = np.random.default_rng(9)
+  x = rng.uniform(0.2, 0.8, size=(37, 6))
+  xt = torch.tensor(x, dtype=dtype, device=device)
+  f, J = c["gp_paths"].eval_jac(xt)
+  fo = pw.eval_paths(c["paths"], c["drift"], x)
+  assert scale_err(f, fo) < (1e-11 if dtype == torch.float64 else 2e-3)
+  assert torch.equal(f, c["gp_paths"](xt))                        # the Jacobian pass returns the plain pass's values
+  Jo = np.empty((37, 4, 6))
+  h = 1e-6
+  for k in range(6):
+    dx = np.zeros(6); dx[k] = h
+    Jo[:, :, k] = (pw.eval_paths(c["paths"], c["drift"], x + dx) - pw.eval_paths(c["paths"], c["drift"], x - dx)) / (2 * h)
+  assert scale_err(J, Jo) < (1e-7 if dtype == torch.float64 else 3e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_gpu_policy_rollout_costs_match_the_oracle(dtype, device):
+  c = _policy_case(device, dtype)
+  H = 6
+  co, so = pw.policy_rollout_costs(c["paths"], c["drift"], c["pol"], c["scale"], c["shift"], c["active"], c["target"],
+                                   c["precis"], c["x0"], H, dt=0.5, keep=True)
+  x0 = torch.tensor(c["x0"], dtype=dtype, device=device)
+  for jac in (False, True):
+    cost, tape = c["roll"](x0, H, dt=0.5, with_jacobians=jac)
+    tol = 1e-10 if dtype == torch.float64 else 5e-3
+    assert scale_err(cost, co) < tol
+    assert scale_err(c["roll"].states(tape, H), so) < tol
+
+
+@pytest.mark.gpu
+def test_gpu_policy_gradient_of_the_mean_sample_loss(device):
+  """The gradient the reference takes with a tape (train_utils.py:108-135: mean over samples of the summed costs) w.r.t. every
+  policy parameter and the initial states: native reverse sweep vs (i) central differences of the numpy oracle on sampled
+  coordinates (1e-6) and (ii) torch autograd of a torch mirror of the same composition."""
+  from gpflowpilco_amd.pathwise import PolicyRolloutFunction
+  F64 = torch.float64
+  c = _policy_case(device, F64)
+  H, dt, S = 5, 0.5, 37
+  pm = c["pol_model"]
+  kern = pm.kernel.kernels[0]
+  params = {"q_mu": pm.q_mu, "Z": pm.inducing_variable.inducing_variables[0].Z, "lengthscales": kern.lengthscales,
+            "variance": kern.variance}
+  for t in params.values():
+    t.requires_grad_(True)
+  x0 = torch.tensor(c["x0"], dtype=F64, device=device, requires_grad=True)
+
+  def native_loss():
+    Zp, lsp, varp, betap, _, mcp = pm.precompute(device)
+    cost = PolicyRolloutFunction.apply(x0, Zp, lsp, varp, betap, mcp, c["roll"], H, dt)       # [S, H]
+    return cost.sum(1).mean()
+  loss = native_loss()
+  loss.backward()
+  g_native = {k: t.grad.detach().clone() for k, t in params.items()}
+  g_native["x0"] = x0.grad.detach().clone()
+  co = pw.policy_rollout_costs(c["paths"], c["drift"], c["pol"], c["scale"], c["shift"], c["active"], c["target"], c["precis"],
+                               c["x0"], H, dt=dt)
+  assert abs(float(loss) - co.sum(0).mean()) < 1e-10
+
+  # (ii) torch mirror: the same composition in differentiable torch ops on the path arrays
+  P = c["paths"]; dr = c["drift"]
+  tt = lambda a: torch.tensor(np.asarray(a), dtype=F64, device=device)
+  om, ph, w, v = tt(P.omega), tt(P.phase), tt(P.w), tt(P.v)
+  Zd, lsd, vard = tt(dr.Z), tt(dr.lengthscales), tt(dr.variance)
+  target, precis = tt(c["target"]), tt(c["precis"])
+
+  def mirror_loss():
+    Zp, lsp, varp, betap, _, mcp = pm.precompute(device)
+    x = x0
+    tot = 0.0
+    enc = lambda y: torch.cat([torch.sin(y[:, 1:2]), torch.cos(y[:, 1:2]), y[:, [0, 2, 3]]], dim=-1)
+    for _ in range(H):
+      e = enc(x)
+      r2 = (((e[:, None, :] - Zp[0][None]) / lsp[0]) ** 2).sum(-1)
+      fp = (varp[0] * torch.exp(-0.5 * r2)) @ betap[0] + mcp[0]
+      u = c["scale"] * (0.5 * torch.erfc(-fp / np.sqrt(2.0)) + c["shift"])
+      dd = torch.cat([e, u[:, None]], dim=-1)
+      f = []
+      for a in range(4):
+        phi = torch.sqrt(2.0 * vard[a] / om.shape[1]) * torch.cos(dd @ om[a].T + ph[a][None])
+        kk = vard[a] * torch.exp(-0.5 * (((dd[:, None, :] - Zd[a][None]) / lsd[a]) ** 2).sum(-1))
+        f.append((w[:, a] * phi).sum(-1) + (v[:, a] * kk).sum(-1) + (0.0 if dr.mean_c is None else float(dr.mean_c[a])))
+      x = x + dt * torch.stack(f, dim=-1)
+      err = enc(x) - target
+      tot = tot - torch.exp(-0.5 * ((err @ precis) * err).sum(-1))
+    return tot.mean()
+  for t in list(params.values()) + [x0]:
+    t.grad = None
+  lm = mirror_loss()
+  lm.backward()
+  assert abs(float(lm) - float(loss)) < 1e-10
+  for k, t in list(params.items()) + [("x0", x0)]:
+    ref = t.grad.detach()
+    err = float((g_native[k] - ref).abs().max()) / max(1e-14, float(ref.abs().max()))
+    assert err < 1e-8, (k, err)
+
+  # (i) central differences of the numpy oracle along random directions of every parameter group
+  import copy
+  rng = np.random.default_rng(5)
+
+  def oracle_loss(pol, x_init):
+    return pw.policy_rollout_costs(c["paths"], c["drift"], pol, c["scale"], c["shift"], c["active"], c["target"], c["precis"],
+                                   x_init, H, dt=dt).sum(0).mean()
+  h = 1e-6
+  for name, field in (("q_mu", "q_mu"), ("Z", "Z"), ("lengthscales", "lengthscales"), ("variance", "variance")):
+    base = np.asarray(getattr(c["pol"], field), dtype=np.float64)
+    dirn = rng.standard_normal(base.shape)
+    lp, lm_ = [], []
+    for sgn, out in ((1.0, lp), (-1.0, lm_)):
+      pol2 = copy.deepcopy(c["pol"])
+      setattr(pol2, field, base + sgn * h * dirn)
+      out.append(oracle_loss(pol2, c["x0"]))
+    fd = (lp[0] - lm_[0]) / (2 * h)
+    an = float((g_native[name].cpu().numpy().reshape(base.shape) * dirn).sum())
+    assert abs(fd - an) < 1e-6 * max(1.0, abs(fd)), (name, fd, an)
+  dirx = rng.standard_normal(c["x0"].shape)
+  fd = (oracle_loss(c["pol"], c["x0"] + h * dirx) - oracle_loss(c["pol"], c["x0"] - h * dirx)) / (2 * h)
+  an = float((g_native["x0"].cpu().numpy() * dirx).sum())
+  assert abs(fd - an) < 1e-6 * max(1.0, abs(fd)), ("x0", fd, an)
