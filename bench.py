@@ -1100,11 +1100,106 @@ def pathwise_bench(args, rank, world, dev, dist):
                       "kernel_ms": round(k_ms, 4), "bytes_per_launch": bytes_per_launch,
                       "note": "achieved = algorithmic bytes S*L*(K+M)*4 per step / step time (the step time includes the small cost kernels "
                               "between launches)"}}
+  if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    out.update(pathwise_extras(args, dev, c, paths, x0, dtype))
   if rank == 0:
     print(json.dumps(out))
   if world > 1:
     dist.destroy_process_group()
 
 
+def pathwise_extras(args, dev, c, paths, x0, dtype):
+  """N == 1, rank 0: parity and the CPU baseline of the C5 line (the oracle on a slice of sample paths drawn on the host), the
+  f64-mode figure of the same rollout, and row f-3's policy rollout: forward, taped forward (Jacobians emitted in the same
+  stream pass) and the one-kernel reverse sweep."""
+  import numpy as np
+  import torch
+  from gpflowpilco_amd import models as gp, ops
+  from gpflowpilco_amd.pathwise import PathwiseSVGP, PolicyRollout, paths_from_arrays
+  from gpflowpilco_amd.synthetic import make_policy, make_svgp
+  from oracle import pathwise_oracle as pw
+  from oracle.mm_oracle import SVGPParams
+  L, M, d, K, H = c["L"], c["M"], c["d"], c["K"], c["H"]
+  res = {}
+  ev = lambda: torch.cuda.Event(enable_timing=True)
+
+  def timed(fn, reps=2):
+    fn()
+    e0, e1 = ev(), ev()
+    e0.record()
+    for _ in range(reps):
+      fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+  # ---- parity + CPU baseline: the numpy oracle on Sc sample paths of the same model, same kernels on the same path tensors
+  syn = make_svgp(L, M, d, seed=c["seed"], device=str(dev), ls_bounds=(0.7, 3.0))
+  po = SVGPParams(Z=np.broadcast_to(syn.Z, (L, M, d)).copy(), lengthscales=syn.lengthscales, variance=syn.variance,
+                  q_mu=syn.q_mu, q_sqrt=syn.q_sqrt, whiten=True)
+  rng = np.random.default_rng(c["seed"])
+  Sc, Hc = 64, 3                  # (an un-stabilised drift-only sample rollout leaves the data's support after a few unit steps)
+  pths = pw.draw_paths(rng, po, Sc, K)
+  xc = rng.uniform(0.3, 0.7, size=(Sc, d))
+  t0 = time.perf_counter()
+  xo, trajo = pw.rollout(pths, po, xc, Hc, dt=1.0, keep=True)
+  tc = time.perf_counter() - t0
+  res["cpu_baseline"] = {"value": round(Sc * Hc / tc, 1), "unit": "sample step-elements/s", "cores": os.cpu_count(), "kind": "port",
+                         "sample": f"oracle/pathwise_oracle.py (fp64 numpy: the published decoupled-sampling evaluation; parity unpinned), "
+                                   f"{Sc} sample paths x {Hc} Euler steps of the same model (N={M}, K={K}, d=D={d}), {tc:.2f}s"}
+  par = {"vs": "fp64 numpy oracle on identical path tensors", "S": Sc, "H": Hc}
+  for nm, dt_ in (("f32", torch.float32), ("f64", torch.float64)):
+    gpp = paths_from_arrays(pths.omega, pths.phase, pths.w, pths.v, po.Z, po.lengthscales, po.variance, None, dtype=dt_, device=dev)
+    xg, tg = gpp.rollout(torch.tensor(xc, dtype=dt_, device=dev), Hc, dt=1.0, keep_trajectory=True)
+    f1 = gpp(torch.tensor(xc, dtype=dt_, device=dev)).double().cpu().numpy()
+    fo = pw.eval_paths(pths, po, xc)
+    par[nm] = {"one_evaluation_max_abs_err": float(np.abs(f1 - fo).max()), "one_evaluation_max_abs": float(np.abs(fo).max()),
+               "rollout_max_abs_err": float(np.abs(tg.double().cpu().numpy() - trajo).max()), "rollout_max_abs": float(np.abs(trajo).max())}
+  res["parity"] = par
+  # ---- f64 mode of the headline rollout (the accurate mode: 2 x the bytes per weight)
+  S = paths.num_samples
+  S64 = min(S, 16384)
+  base = syn.to_model(dev)
+  pmodel = PathwiseSVGP(kernel=base.kernel, inducing_variable=base.inducing_variable, q_mu=base.q_mu, q_sqrt=base.q_sqrt, whiten=True,
+                        num_latent_gps=L)
+  g = torch.Generator(device=dev).manual_seed(c["seed"] + 7)
+  p64 = pmodel.generate_paths(S64, K, dtype=torch.float64, device=dev, generator=g)
+  x64 = x0[:S64].double().contiguous()
+  ms64 = timed(lambda: p64.rollout(x64, 10, dt=1.0)) / 10
+  res["f64_mode"] = {"S": S64, "ms_per_step": round(ms64, 4), "GBps": round(S64 * L * (K + M) * 8 / (ms64 * 1e-3) / 1e9, 1),
+                     "frac_of_hbm_peak": round(S64 * L * (K + M) * 8 / (ms64 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+  del p64
+  # ---- row f-3: the pathwise POLICY rollout (encoder -> policy -> drift sample -> Euler -> cost) and its gradient.
+  # nx = 6 states, one angle: ne = 7, nd = 8 drift inputs (the stream kernel's d of the headline), L = 6 latents
+  nx, na, Hp = 6, 1, 10
+  nd = nx + na + 1
+  synd = make_svgp(nx, M, nd, seed=c["seed"] + 1, device=str(dev), ls_bounds=(0.7, 3.0))
+  based = synd.to_model(dev)
+  pdrift = PathwiseSVGP(kernel=based.kernel, inducing_variable=based.inducing_variable, q_mu=based.q_mu, q_sqrt=based.q_sqrt,
+                        whiten=True, num_latent_gps=nx)
+  pp = pdrift.generate_paths(S, K, dtype=dtype, device=dev, generator=g)
+  pol = make_policy(30, nx + na, seed=c["seed"] + 2).to_model(dev)
+  roll = PolicyRollout(pp, pol.packed(torch.float64, False, dev), nx=nx, active_dims=(1,), head_scale=2.0, head_shift=-0.5,
+                       target=torch.full((nx + na,), 0.5), precis=torch.eye(nx + na) * 4.0)
+  xp = 0.3 + 0.4 * torch.rand(S, nx, dtype=dtype, device=dev, generator=g)
+  gcost = torch.full((Hp, S), 1.0 / S, dtype=torch.float64, device=dev)
+  fwd = timed(lambda: roll(xp, Hp)) / Hp
+  holder = {}
+
+  def taped():
+    holder["t"] = roll(xp, Hp, with_jacobians=True)[1]
+  tap = timed(taped) / Hp
+  bwd = timed(lambda: roll.backward(holder["t"], gcost, Hp)) / Hp
+  bytes_step = float(S) * nx * (K + M) * 4
+  res["next_rows"] = {"f-3": {
+      "what": "pathwise policy rollout (TrigonometricEncoder -> policy mean M=30 through Chain[Scale,Shift,NormalCDF] -> drift sample -> "
+              "Euler -> cost) of S sample paths, per step; taped = the stream pass also emits d f / d (e, u) [S,nx,nd]; backward = ONE "
+              "kernel over the tape (no second pass over the weight stream)",
+      "S": S, "nx": nx, "nd": nd, "H": Hp, "forward_ms": round(fwd, 4), "taped_forward_ms": round(tap, 4), "backward_ms": round(bwd, 4),
+      "forward_backward_over_forward": round((tap + bwd) / fwd, 3),
+      "forward_frac_of_hbm_peak": round(bytes_step / (fwd * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+      "taped_forward_frac_of_hbm_peak": round(bytes_step / (tap * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}}
+  return res
+
+
 if __name__ == "__main__":
   main()
+

@@ -96,7 +96,9 @@ __device__ __forceinline__ float pw_wave_sum63(float v) {
 //   prior  : d/dx_k w cos(2 pi arg) = -2 pi omega_k w sin(2 pi arg)       -> accJ_k += (w sin) omega_k, factor -2 pi scale
 //   update : d/dx_k v 2^arg = ln2 v 2^arg (c_k - xscale_k^2 x_k), c = z xscale^2  -> accJ_k += (v 2^arg) c_k, then
 //            ln2 var (accJ_k - xscale_k^2 x_k accu)
-// d more FMAs and (prior blocks) one more transcendental per term and sample; 1 + d wave sums per (latent, sample).
+// d more FMAs and (prior blocks) one more transcendental per term and sample; 1 + d wave sums per (latent, sample).  The pass
+// is then VALU-bound, not HBM-bound: 1.41 x the plain pass at the C5 shape (0.50 of the HBM peak against 0.70); the same pass in
+// packed f32 over term pairs (parity-split accumulators, 256 VGPRs + scratch, 1300 register moves) ran 1.9 x: not kept.
 // grid: ceil(S / NS) workgroups of 256 threads = 4 waves.  Wave wv of a workgroup owns the latents
 // wv, wv + 4, ... of the workgroup's NS samples and streams their K + M weights alone: the only
 // cross-lane step is one shuffle reduction per (latent, sample) -- no LDS, no barriers.  The weight

@@ -11,7 +11,7 @@ import warnings
 import numpy as np
 import torch
 
-from .dynamics import DynamicalSystem, MomentMatchingEuler
+from .dynamics import DynamicalSystem, Euler, MomentMatchingEuler
 from .moment_matching import GaussianMoments, moment_matching
 
 
@@ -22,17 +22,11 @@ def get_state_initializer(mean: torch.Tensor, covariance: torch.Tensor) -> Calla
   return lambda: (mx, Sxx)
 
 
-def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: int, dt: float = 1.0,
-                       why: Optional[list] = None):
-  """``f(mx, Sxx) -> loss [B]`` running the whole rollout in ``mm_rollout_composed`` (csrc/mm_compose.hip), or None
-  when the system is not the shape that entry point implements: TrigonometricEncoder, policy =
-  InverseLinkWrapper(KernelRegressor(SVGP with one latent), Chain[Scale, Shift, NormalCDF]) with scalar scale and
-  shift, SVGP drift, no diffusion, MomentMatchingEuler, GaussianObjective -- the cartpole wiring of
-  ``examples/cartpole_swingup/swingup_loops.py:41-91``.  ``f.with_grad(mx, Sxx)`` is the same loss as a differentiable op
-  (native reverse sweep, csrc/mm_compose_bwd.hip) where ``f.supports_grad(mx)``.  ``why``: a list that receives the reason
-  when None is returned."""
+def _native_parts(system: DynamicalSystem, objective: Callable, why: Optional[list], moment_solver: bool):
+  """The pieces the native rollouts are written for -- TrigonometricEncoder, policy = InverseLinkWrapper(KernelRegressor(SVGP with
+  one latent), Chain[Scale, Shift, NormalCDF]) with scalar scale and shift, SVGP drift, no diffusion, GaussianObjective (the
+  cartpole wiring of ``examples/cartpole_swingup/swingup_loops.py:41-91``) -- or None, with the reason appended to ``why``."""
   from . import bijectors as tfb
-  from . import ops
   from .components import TrigonometricEncoder
   from .cost import GaussianObjective
   from .models import SVGP, InverseLinkWrapper, KernelRegressor, LinearCoregionalization
@@ -42,8 +36,10 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
     if why is not None:
       why.append(reason)
     return None
-  if system.diffusion is not None or not isinstance(system.solver, MomentMatchingEuler):
-    return no("a diffusion term or a solver other than MomentMatchingEuler")
+  if system.diffusion is not None:
+    return no("a diffusion term")
+  if moment_solver and not isinstance(system.solver, MomentMatchingEuler):
+    return no("a solver other than MomentMatchingEuler")
   if not isinstance(enc, TrigonometricEncoder):
     return no(f"encoder {type(enc).__name__} (the native rollout implements TrigonometricEncoder)")
   if not isinstance(objective, GaussianObjective):
@@ -60,6 +56,7 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
   bj = head.bijectors if isinstance(head, tfb.Chain) else None
   if not (bj and len(bj) == 3 and isinstance(bj[0], tfb.Scale) and isinstance(bj[1], tfb.Shift) and isinstance(bj[2], tfb.NormalCDF)):
     return no("the policy head is not Chain[Scale, Shift, NormalCDF]")
+
   def head_constants():
     sc, sh = bj[0].scale, bj[1].shift
     return (float(sc.detach()) if isinstance(sc, torch.Tensor) else float(sc),
@@ -68,6 +65,23 @@ def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: 
     head_constants()
   except (TypeError, ValueError, RuntimeError):
     return no("the policy head's scale / shift are not scalars (n-D action: Genz BVN, out of scope)")
+  return enc, pm_, drift, bj, head_constants
+
+
+def native_policy_loss(system: DynamicalSystem, objective: Callable, num_steps: int, dt: float = 1.0,
+                       why: Optional[list] = None):
+  """``f(mx, Sxx) -> loss [B]`` running the whole rollout in ``mm_rollout_composed`` (csrc/mm_compose.hip), or None
+  when the system is not the shape that entry point implements: TrigonometricEncoder, policy =
+  InverseLinkWrapper(KernelRegressor(SVGP with one latent), Chain[Scale, Shift, NormalCDF]) with scalar scale and
+  shift, SVGP drift, no diffusion, MomentMatchingEuler, GaussianObjective -- the cartpole wiring of
+  ``examples/cartpole_swingup/swingup_loops.py:41-91``.  ``f.with_grad(mx, Sxx)`` is the same loss as a differentiable op
+  (native reverse sweep, csrc/mm_compose_bwd.hip) where ``f.supports_grad(mx)``.  ``why``: a list that receives the reason
+  when None is returned."""
+  from . import ops
+  parts = _native_parts(system, objective, why, moment_solver=True)
+  if parts is None:
+    return None
+  enc, pm_, drift, bj, head_constants = parts
   cache = {}
 
   def current_roll(mx: torch.Tensor, fresh_policy: bool = True):
@@ -318,3 +332,89 @@ class GraphedPolicyLoss:
     for p, g in zip(self.parameters, self._grads):
       p.grad = g
     return self._loss_bwd, self._grads
+
+
+def pathwise_policy_loss_closure(system: DynamicalSystem, objective: Callable, state_initializer: Callable, num_steps: int,
+                                 dt: float = 1.0, num_bases: int = 1024, paths=None, native: Optional[bool] = None,
+                                 generator: Optional[torch.Generator] = None) -> Callable:
+  """``PathwisePILCO._policy_loss_closure`` (gpflow_pilco/loops/pilco.py:263-298).  Returns ``closure() -> loss [S]``: the cost
+  accumulated along one sample rollout per initial state -- per step encoder -> policy -> drift sample path -> Euler -> objective
+  of the encoded state (tensor branch of ``forward_sde``, dynamics/forward_sde.py:23-31; ``Euler.step``, solvers.py:50-65).  The
+  caller takes the mean and differentiates it w.r.t. the policy (examples/cartpole_swingup/train_utils.py:108-135).
+
+  ``system.drift``: a ``pathwise.PathwiseSVGP``; ``state_initializer() -> x0 [S, nx]`` (pilco.py:300-303: ``p.sample([batch_size])``);
+  ``paths``: None = new sample paths on every call (pilco.py:281-284), else a ``pathwise.Paths`` to reuse.  Unit-spaced solution
+  times ``dt, 2 dt, ...`` (pilco.py:257: ``arange(1, 1 + num_steps)``).
+
+  On the GPU, for the cartpole wiring (``_native_parts``) with drift inputs of dimension <= 8, the whole closure is the native
+  rollout (csrc/mm_pathwise_policy.hip): forward only when nothing requires a gradient, else ONE differentiable op
+  (``pathwise.PolicyRolloutFunction``: the stream pass also emits the paths' Jacobians, the reverse sweep is one kernel).
+  Otherwise -- ``native=False``, another wiring, a gradient the native sweep does not cover -- the torch composition through
+  ``DynamicalSystem.solve_forward`` runs, saying so once (the paths stay on the device and are differentiable in x)."""
+  from . import ops
+  from .pathwise import PathwiseSVGP, PolicyRollout, PolicyRolloutFunction
+  drift = system.drift
+  if not isinstance(drift, PathwiseSVGP):
+    raise TypeError("pathwise_policy_loss_closure needs a PathwiseSVGP drift (gpflow_pilco/loops/pilco.py:230-236)")
+  H = int(num_steps)
+  why_not: list = []
+  parts = None if native is False else _native_parts(system, objective, why_not, moment_solver=False)
+  if native is True and parts is None:
+    raise ValueError(f"native=True: {why_not[0] if why_not else 'the system is not the shape the native rollout implements'}")
+  warned = []
+
+  def _fallback(reason):
+    if native is not False and not warned:
+      warned.append(reason)
+      warnings.warn(f"pathwise_policy_loss_closure: falling back to the torch composition of the rollout ({reason})",
+                    RuntimeWarning, stacklevel=3)
+
+  def _torch_loss(x0, pth):
+    times = dt * np.arange(1, 1 + H, dtype=np.float64)
+    enc = system.encoder
+
+    def _accumulate_loss(t, state, loss):                              # pilco.py:272-275
+      return loss + objective(x=state if enc is None else enc(state), t=t)
+    loss0 = torch.zeros(x0.shape[:-1], dtype=x0.dtype, device=x0.device)
+    solver = Euler()
+    with drift.set_temporary_paths(pth):
+      _, loss = solver(func=system.forward, initial_time=0.0, initial_state=x0, solution_times=times,
+                       callbacks_and_initializers=((_accumulate_loss, loss0),), iterator="foldl")
+    return loss
+
+  def _closure():
+    x0 = state_initializer()
+    pth = paths if paths is not None else drift.generate_paths(x0.shape[0], num_bases, dtype=x0.dtype, device=x0.device,
+                                                                generator=generator)
+    if parts is None or not x0.is_cuda or x0.ndim != 2:
+      if x0.is_cuda and native is not False:
+        _fallback(why_not[0] if why_not else f"state of rank {x0.ndim}")
+      return _torch_loss(x0, pth)
+    enc, pm_, _, bj, head_constants = parts
+    nx, na = x0.shape[-1], len(enc.active_dims)
+    if nx + na + 1 > 8 or pm_.inducing_variable.inducing_variables[0].Z.shape[0] > 256:
+      _fallback("drift inputs of dimension > 8 or a policy of more than 256 centres")
+      return _torch_loss(x0, pth)
+    outside = {"the policy head's Scale.scale": bj[0].scale, "the policy head's Shift.shift": bj[1].shift,
+               "objective.target": objective.target, "objective.precis": objective.precis}
+    grad = torch.is_grad_enabled()
+    if grad:
+      for name, t in outside.items():
+        if isinstance(t, torch.Tensor) and t.requires_grad:
+          _fallback(f"{name} requires a gradient (the native reverse sweep covers the policy SVGP's parameters and the initial states)")
+          return _torch_loss(x0, pth)
+    scale, shift = head_constants()
+    pol_pack = pm_.packed(torch.float64, False, x0.device)
+    roll = PolicyRollout(pth, pol_pack, nx=nx, active_dims=enc.active_dims, head_scale=scale, head_shift=shift,
+                         target=objective.target, precis=objective.precis)
+    needs = grad and (x0.requires_grad or any(t.requires_grad for t in pm_._parameters()))
+    if not needs:
+      with torch.no_grad():
+        cost, _ = roll(x0, H, dt=dt)
+      return cost.sum(0)
+    Zp, lsp, varp, betap, _, mcp = pm_.precompute(x0.device)
+    if mcp is None:
+      mcp = torch.zeros(1, dtype=Zp.dtype, device=x0.device)
+    return PolicyRolloutFunction.apply(x0, Zp, lsp, varp, betap, mcp, roll, H, dt).sum(1).to(x0.dtype)
+
+  return _closure

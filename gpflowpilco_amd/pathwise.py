@@ -54,7 +54,10 @@ class Paths:
     return self.num_samples, L, self.zs.shape[-1], Kp, d
 
   def __call__(self, x: torch.Tensor) -> torch.Tensor:
-    """f_s(x_s): x [S, d] -> [S, L]."""
+    """f_s(x_s): x [S, d] -> [S, L].  Differentiable in x where the Jacobian pass exists (d <= 8): the torch composition of a
+    sample rollout (``loops.pathwise_policy_loss_closure``'s fallback) then carries gradients through the paths."""
+    if torch.is_grad_enabled() and x.requires_grad:
+      return _PathsEval.apply(x, self)
     _require_device(x, self.wb)
     S, L, Mp, Kp, d = self._dims()
     if x.shape != (S, d) or x.dtype != self.dtype:
@@ -100,6 +103,21 @@ class Paths:
                                         self.wb.data_ptr(), _ptr(traj), _stream(x.device))
     check(rc, "mm_pathwise_rollout")
     return (x, traj) if keep_trajectory else x
+
+
+class _PathsEval(torch.autograd.Function):
+  """f = paths(x) with d f / d x from the same weight-stream pass (``mm_pathwise_eval_jac``)."""
+
+  @staticmethod
+  def forward(ctx, x, paths):
+    f, jac = paths.eval_jac(x.detach())
+    ctx.save_for_backward(jac)
+    return f
+
+  @staticmethod
+  def backward(ctx, g):
+    (jac,) = ctx.saved_tensors
+    return torch.einsum('sl,sld->sd', g, jac), None
 
 
 def paths_from_arrays(omega, phase, w, v, Z, lengthscales, variance, mean_c=None, dtype=torch.float32,

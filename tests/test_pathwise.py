@@ -266,3 +266,64 @@ def test_gpu_policy_gradient_of_the_mean_sample_loss(device):
   fd = (oracle_loss(c["pol"], c["x0"] + h * dirx) - oracle_loss(c["pol"], c["x0"] - h * dirx)) / (2 * h)
   an = float((g_native["x0"].cpu().numpy() * dirx).sum())
   assert abs(fd - an) < 1e-6 * max(1.0, abs(fd)), ("x0", fd, an)
+
+
+@pytest.mark.gpu
+def test_pathwise_policy_loss_closure_native_equals_the_torch_composition(device):
+  """loops.pathwise_policy_loss_closure (PathwisePILCO._policy_loss_closure, loops/pilco.py:263-298): the native closure and
+  the torch composition through DynamicalSystem / Euler on the SAME sample paths give the same per-sample loss and the same
+  gradient of its mean w.r.t. the policy parameters and the initial states; unsupported gradients warn and take the torch path."""
+  import warnings
+  from gpflowpilco_amd import bijectors as tfb, dynamics, models as gp
+  from gpflowpilco_amd.components import GaussianObjective, TrigonometricEncoder
+  from gpflowpilco_amd.loops import pathwise_policy_loss_closure
+  from gpflowpilco_amd.pathwise import PathwiseSVGP
+  F64 = torch.float64
+  S, H = 41, 4
+  base = make_svgp(4, 48, 6, seed=31, ls_bounds=(0.9, 3.0)).to_model(device)
+  drift = PathwiseSVGP(kernel=base.kernel, inducing_variable=base.inducing_variable, q_mu=base.q_mu, q_sqrt=base.q_sqrt, whiten=True,
+                       num_latent_gps=4)
+  pol_o = random_svgp_params(seed=32, L=1, M=14, d=5, whiten=True, ls_bounds=(0.9, 2.0), mean=False)
+  pol_o.q_mu = 0.2 * pol_o.q_mu
+  pol = gp_model_from_oracle(pol_o, device)
+  kern = pol.kernel.kernels[0]
+  params = [pol.q_mu, pol.inducing_variable.inducing_variables[0].Z, kern.lengthscales, kern.variance]
+  for t in params:
+    t.requires_grad_(True)
+  policy = gp.InverseLinkWrapper(gp.KernelRegressor(pol), invlink=tfb.Chain([tfb.Scale(2.0), tfb.Shift(-0.5), tfb.NormalCDF()]))
+  system = dynamics.DynamicalSystem(drift=drift, policy=policy, encoder=TrigonometricEncoder(active_dims=(1,)), solver=dynamics.Euler())
+  target = torch.tensor([0.0, 1.0, 0.2, 0.0, 0.1], dtype=F64, device=device)
+  objective = GaussianObjective(target=target, precis=2.0 * torch.eye(5, dtype=F64, device=device))
+  g = torch.Generator(device=device).manual_seed(3)
+  x0 = (0.2 + 0.6 * torch.rand(S, 4, dtype=F64, device=device, generator=g)).requires_grad_(True)
+  paths = drift.generate_paths(S, 256, dtype=F64, device=device, generator=g)
+
+  def run(native):
+    for t in params + [x0]:
+      t.grad = None
+    loss = pathwise_policy_loss_closure(system, objective, lambda: x0, H, dt=0.5, paths=paths, native=native)()
+    loss.mean().backward()
+    return loss.detach(), [t.grad.detach().clone() for t in params + [x0]]
+  with warnings.catch_warnings():
+    warnings.simplefilter("error", RuntimeWarning)
+    ln, gn = run(None)
+  lt, gt = run(False)
+  assert ln.shape == (S,) and float((ln - lt).abs().max()) < 1e-10
+  for a_, b_ in zip(gn, gt):
+    assert float((a_ - b_).abs().max()) < 1e-8 * max(1e-12, float(b_.abs().max()))
+  # forward only (nothing requires a gradient): the same numbers without the Jacobian tape
+  with torch.no_grad():
+    l0 = pathwise_policy_loss_closure(system, objective, lambda: x0.detach(), H, dt=0.5, paths=paths)()
+  assert float((l0 - ln).abs().max()) < 1e-12
+  # fresh paths on every call (pilco.py:281-284) with float32 states: runs, finite, and differs between calls
+  x32 = x0.detach().float()
+  cl = pathwise_policy_loss_closure(system, objective, lambda: x32, H, dt=0.5, num_bases=256)
+  with torch.no_grad():
+    a1, a2 = cl(), cl()
+  assert a1.dtype == torch.float32 and torch.isfinite(a1).all() and not torch.equal(a1, a2)
+  # a gradient the native sweep does not cover: warned, carried by the torch composition
+  target.requires_grad_(True)
+  with pytest.warns(RuntimeWarning, match="objective.target requires a gradient"):
+    loss = pathwise_policy_loss_closure(system, objective, lambda: x0, H, dt=0.5, paths=paths)()
+  loss.mean().backward()
+  assert target.grad is not None and float(target.grad.abs().max()) > 0.0
