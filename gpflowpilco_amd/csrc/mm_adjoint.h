@@ -635,7 +635,7 @@ __host__ __device__ inline void mma_policy_small_bwd(Ctx c, int M, int d, const 
     for (int j = sub; j < M; j += ns) {
       double delta = rs[i] + rs[j] + cst;
       for (int k = 0; k < d; ++k) delta = fma(zs[i * d + k], gz[j * d + k], delta);
-      const double Ex = expm1(delta);
+      const double Ex = expm1(fmin(delta, MM_EXP_CAP_F64));                    // (mm_common.h: exponent caps)
       const double om = ws[i] * ws[j] * (Ex + 1.0);
       ci = fma(Ex, ws[j], ci); Ki += om;
       for (int k = 0; k < d; ++k) pu[k] = fma(om, zs[j * d + k], pu[k]);

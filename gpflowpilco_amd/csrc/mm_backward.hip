@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_bwd_sums(const double* __restrict__ Z64
       double delta = ra[i] + gam;
 #pragma unroll
       for (int k = 0; k < DK; ++k) if (k < d) delta += zrow[(size_t)i * Kz + k] * g[k];
-      const double E = expm1(delta), e = E + 1.0;
+      const double E = expm1(fmin(delta, MM_EXP_CAP_F64)), e = E + 1.0;     // (mm_common.h: exponent caps)
       const double wi = wr[i];
       const double om = wi * e;                       // Omega_ij / w'_j
       Ks += om;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_bwd_sums(const double* __restrict__ Z64
       double delta = rho + cb[(size_t)d * Mp + j];
 #pragma unroll
       for (int k = 0; k < DK; ++k) if (k < d) delta += zi[k] * cb[(size_t)k * Mp + j];
-      const double E = expm1(delta);
+      const double E = expm1(fmin(delta, MM_EXP_CAP_F64));
       const double wj = wc[j];
       Rs += wj * (E + 1.0);
       rs += wj * E;
@@ -141,6 +141,7 @@ __device__ __forceinline__ void mmb_expm1_poly8(const double (&x)[8], double (&e
 
 // expm1 for any argument (k ln2 + r reduction), the forward's general path
 __device__ __forceinline__ double mmb_expm1_any(double x) {
+  x = fmin(x, MM_EXP_CAP_F64);                   // (mm_common.h: a zero weight must meet a finite factor)
   const double kf = rint(x * 1.4426950408889634);
   double r = fma(-kf, 6.93147180369123816490e-01, x);
   r = fma(-kf, 1.90821492927058770002e-10, r);

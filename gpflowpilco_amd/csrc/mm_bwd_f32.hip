@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
           for (int r = 0; r < 8; ++r)
 #pragma unroll
             for (int e2 = 0; e2 < 2; ++e2) {
-              const float x = xx[r][e2];
+              const float x = fminf(xx[r][e2], MM_EXP_CAP_F32);   // (mm_common.h: exponent caps)
               const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
               const float big = (__builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f) - fmaf(0.5f * x, x, x);
               v[r][e2] = wq[r][e2] * ((fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big);

@@ -159,6 +159,13 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 // [0, npanel * ncc) of the item's slab, ncc = min(MM_ROUTE_CSPLIT, NS / npanel)
 #define MM_ROUTE_CSPLIT 8
 static inline int mm_route_ncc(int NS, int npanel) { int n = NS / npanel; return n < 1 ? 1 : (n > MM_ROUTE_CSPLIT ? MM_ROUTE_CSPLIT : n); }
+// Exponent caps of the reduce kernels.  Every entry Q_ij = q_i q_j e^{delta_ij} is bounded by var_a var_a', but its factors are
+// not: with lengthscales far below the state's distance to an inducing point (the reference's tests draw them down to 0.01) the
+// bilinear part b_ij reaches several hundred while q_i q_j is e^{-thousands}.  Whenever b_ij is that large the entry itself is
+// negligible (b_ij <= (zeta_i^T G zeta_i + zeta_j^T G zeta_j) / 2 and the weights carry e^{-zeta^T P zeta / 2} with P >= G), so the
+// exponents are capped below the overflow of their type: a zero weight then multiplies a finite number instead of inf.
+#define MM_EXP_CAP_F64 700.0
+#define MM_EXP_CAP_F32 80.0f
 // Rows per workgroup of the generic reduce kernel / columns per workgroup.
 #define MM_GEN_ROWS 64
 #define MM_GEN_COLS 256
@@ -178,6 +185,9 @@ struct MMWorkspaceLayout {
   size_t w64;      // [B][L][Mp] f64  beta_i q_i
   size_t q64;      // [B][L][Mp] f64  q_i = <k_a(x, z_i)>
   size_t w;        // [B][L][Mp] T    (aliases w64 when T is f64)
+  size_t lq;       // [B][L][Mp] f64  log q_i (-1e30 in the padding): k_pairvec forms every factored weight as ONE exponential
+                   //                 beta_i exp(log q_i + rho_i) -- with short lengthscales q_i underflows to 0 where e^{rho_i}
+                   //                 overflows (the reference's own test designs: lengthscales down to 0.01), and 0 x inf is a NaN
   size_t rowD;     // [B][L][Mp] f64        rho_i          diagonal pairs
   size_t colD;     // [B][L][d+1][Mp] f64   g_j, gamma'_j  diagonal pairs
   size_t qhR;      // [B][L][Mp] f64  diagonal pairs, factored weights of the f64 MFMA reduce: u_i e^{rho_i}, u = q with
@@ -230,6 +240,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.q64 = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.w = o.w64;
   if (dtype != MM_F64) { o.w = off; off = mm_align_up(off + (size_t)B * L * o.Mp * es, A); }
+  o.lq = off;      off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.rowD = off;    off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.colD = off;    off = mm_align_up(off + (size_t)B * L * (d + 1) * o.Mp * 8, A);
   o.qhR = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);

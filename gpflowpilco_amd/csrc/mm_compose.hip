@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256) void k_policy_match_small(const double* __rest
         double delta = rs[i] + base;
 #pragma unroll
         for (int k = 0; k < DK; ++k) delta = fma(zs[i][k], g[k], delta);
-        colsum = fma(ws[i], expm1(delta), colsum);
+        colsum = fma(ws[i], expm1(fmin(delta, MM_EXP_CAP_F64)), colsum);      // (mm_common.h: exponent caps)
       }
       colsum *= ws[j];
     }

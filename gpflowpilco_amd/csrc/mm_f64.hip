@@ -81,6 +81,7 @@ __device__ __forceinline__ void mm_decode_pair_f(int p, int L, int& a, int& a2) 
 // 0.35^12/13! = 5e-16 relative), 2^k (1 + p) - 1 = fma(2^k, p, 2^k - 1).  No clamp: v_cvt_i32_f64
 // saturates and v_ldexp_f64 over/underflows to inf/0, which is the right limit.
 __device__ __forceinline__ double mm_expm1_f64(double x) {
+  x = fmin(x, MM_EXP_CAP_F64);                   // (mm_common.h: a zero weight must meet a finite factor)
   const double kf = rint(x * 1.4426950408889634);
   double r = fma(-kf, 6.93147180369123816490e-01, x);
   r = fma(-kf, 1.90821492927058770002e-10, r);
@@ -99,6 +100,31 @@ __device__ __forceinline__ double mm_expm1_f64(double x) {
   const double p = q * r;                       // expm1(r)
   const double s = ldexp(1.0, (int)kf);
   return fma(s, p, s - 1.0);                    // 2^k (1 + p) - 1
+}
+
+// e^x, any argument, by the same reduction: 2^k (1 + p).  The diagonal pairs reduce q^_i [D_ij] e^{b_ij} q^'_j with the O(1)
+// parts of delta_ij factored into the weights, so b_ij alone can be far below -36 where e^b < 2^-53: expm1(b) + 1 is then
+// exactly 0 and the entry -- whose weights are correspondingly large -- was lost (found on the reference's own single-output
+// test design: one entry of 3e-10 on a variance of 3.5e-5, tests/golden/refdesign_svgp_so.npz)
+__device__ __forceinline__ double mm_exp_f64(double x) {
+  x = fmin(x, MM_EXP_CAP_F64);
+  const double kf = rint(x * 1.4426950408889634);
+  double r = fma(-kf, 6.93147180369123816490e-01, x);
+  r = fma(-kf, 1.90821492927058770002e-10, r);
+  double q = 2.08767569878681e-09;              // 1/12!
+  q = fma(q, r, 2.505210838544172e-08);
+  q = fma(q, r, 2.755731922398589e-07);
+  q = fma(q, r, 2.7557319223985893e-06);
+  q = fma(q, r, 2.48015873015873e-05);
+  q = fma(q, r, 1.984126984126984e-04);
+  q = fma(q, r, 1.388888888888889e-03);
+  q = fma(q, r, 8.333333333333333e-03);
+  q = fma(q, r, 4.1666666666666664e-02);
+  q = fma(q, r, 1.6666666666666666e-01);
+  q = fma(q, r, 0.5);
+  q = fma(q, r, 1.0);
+  const double s = ldexp(1.0, (int)kf);         // (x << 0: 2^k underflows to 0, the right limit)
+  return fma(s, q * r, s);                      // 2^k (1 + expm1(r))
 }
 
 // expm1 without range reduction: Taylor to degree DEG, x * (1 + x/2! + ... + x^(DEG-1)/DEG!).
@@ -314,8 +340,7 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : (DIAG && KS4 <= MM_F64_3WAVE_K
       double pv = 0.0;                                                                    \
       _Pragma("unroll") for (int rt = 0; rt < 2; ++rt)                                    \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                   \
-          double e = EXPM1_(cacc[rt][ct][r]);                                             \
-          if (DIAG) e += 1.0;                                                             \
+          const double e = DIAG ? mm_exp_f64(cacc[rt][ct][r]) : EXPM1_(cacc[rt][ct][r]);  \
           if (withC) pv = fma(dreg[rt][ct][r] * e, o.rw[rt][r], pv);                      \
           else pv = fma(o.rw[rt][r], e, pv);                                              \
         }                                                                                 \

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
                                               double* __restrict__ w64, double* __restrict__ q64, T* __restrict__ w,
                                               double* __restrict__ f1raw, double* __restrict__ rho1,
                                               T* __restrict__ f1, T* __restrict__ cross, T* __restrict__ q_out,
-                                              double* __restrict__ mu64) {
+                                              double* __restrict__ mu64, double* __restrict__ lq) {
   const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   // P_a = (Sigma + Lambda_a)^-1 and E_a, zero padded to DK x DK: compile-time LDS offsets (wide broadcast reads)
   __shared__ double Pa[DK * DK], Ea[DK * DK];
@@ -421,8 +421,9 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
   double* qb64 = q64 + ((size_t)b * L + a) * Mp;
   T* wb = w + ((size_t)b * L + a) * Mp;
   double* r1 = rho1 + ((size_t)b * L + a) * Mp;
+  double* lqb = lq + ((size_t)b * L + a) * Mp;
   for (int m = tid; m < Mp; m += 256) {
-    double wv = 0.0, qv = 0.0, rv = 0.0;
+    double wv = 0.0, qv = 0.0, rv = 0.0, lqv = -1.0e30;
     if (m < M) {
       double z[DK];
 #pragma unroll
@@ -463,7 +464,8 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
 #pragma unroll 2
         for (int i = 0; i < DK; ++i) row(i);
       }
-      qv = exp(lognorm - 0.5 * maha);
+      lqv = lognorm - 0.5 * maha;
+      qv = exp(lqv);
       wv = beta64[(size_t)a * M + m] * qv;
       acc_f += wv;
 #pragma unroll
@@ -473,6 +475,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
     wb64[m] = wv;
     qb64[m] = qv;
     r1[m] = rv;
+    lqb[m] = lqv;
     if (sizeof(T) != 8) wb[m] = (T)wv;
   }
   // the DK + 1 workgroup sums together: wave butterflies, one LDS stage, one barrier (fixed order: reproducible)
@@ -517,7 +520,8 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
                                                  const double* __restrict__ w64, double* __restrict__ whR,
                                                  double* __restrict__ whC, unsigned int* __restrict__ amax,
                                                  const double* __restrict__ q64, double* __restrict__ qhR,
-                                                 double* __restrict__ qhC, int with_unc, int nblk) {
+                                                 double* __restrict__ qhC, int with_unc, int nblk,
+                                                 const double* __restrict__ lq, const double* __restrict__ beta64) {
   static_assert(DK > 8, "d <= 8 takes k_pairvec_reg");
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
   // pair's matrix is fetched once per workgroup, not once per chunk
@@ -587,7 +591,10 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
       zc[k] = (m < M) ? (vc - vl[k]) * vl[2 * DK + k] : 0.0;
     }
     const double r1r = r1a[m], r1c = r1b[m];
-    const double wrv = w64[((size_t)b * L + a) * Mp + m], wcv = w64[((size_t)b * L + a2) * Mp + m];
+    // weights in the log domain: beta exp(log q + ...) as ONE exponential (q alone underflows where the rest overflows)
+    const int mc = m < M ? m : M - 1;
+    const double lqr = lq[((size_t)b * L + a) * Mp + m], lqc = lq[((size_t)b * L + a2) * Mp + m];
+    const double btr = beta64[(size_t)a * M + mc], btc = beta64[(size_t)a2 * M + mc];
     double tA = 0.0, tg = 0.0, corrA = 0.0, corrg = 0.0;
     double asq = 0.0;
 #pragma unroll 2      // not fully: the compiler would hoist all the LDS reads (> 256 VGPRs)
@@ -617,8 +624,8 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
       a2max = fmaxf(a2max, (float)asq * 1.000001f);           // rounded up: the bound must not be under-estimated
       double whr = 0.0, whc = 0.0;
       if (m < M) {
-        whr = wrv * exp(-0.5 * rho_q + cst - corrA);
-        whc = wcv * exp(-0.5 * gam_q);
+        whr = btr * exp(fmin(lqr - 0.5 * rho_q + cst - corrA, (double)MM_EXP_CAP_F32));
+        whc = btc * exp(fmin(lqc - 0.5 * gam_q, (double)MM_EXP_CAP_F32));
       }
       rO[(size_t)d * Mp + m] = (T)whr;
       cO[m] = (T)whc;
@@ -633,9 +640,9 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
         // factored weights of the f64 MFMA reduce (mm_f64.hip): e^{delta_ij} = e^{rho_i} e^{gamma'_j} e^{zc_i . g_j};
         // u = q with model uncertainty (the fused sum runs over q_i q_j D_ij e^{delta}), w without
         const size_t qi = ((size_t)b * L + p) * Mp + m;
-        const double u = (m < M) ? (with_unc ? q64[qi] : wrv) : 0.0;
-        qhR[qi] = u * exp(rowv);
-        qhC[qi] = u * exp(colv);
+        const double u = (m < M) ? (with_unc ? 1.0 : btr) : 0.0;
+        qhR[qi] = u * exp(fmin(lqr + rowv, MM_EXP_CAP_F64));
+        qhC[qi] = u * exp(fmin(lqr + colv, MM_EXP_CAP_F64));
       } else { raO[m] = (T)rowv; cbO[(size_t)d * Mp + m] = (T)colv; }
     }
   }
@@ -673,7 +680,8 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
                                                     double* __restrict__ whC, unsigned int* __restrict__ amax,
                                                     const double* __restrict__ q64, double* __restrict__ qhR,
                                                     double* __restrict__ qhC, int with_unc, int nblk, int a, int a2,
-                                                    double (*vecs)[DK]) {
+                                                    double (*vecs)[DK], const double* __restrict__ lq,
+                                                    const double* __restrict__ beta64) {
   constexpr bool diag = MODE == 0;
   const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   const int Po = P - L;
@@ -681,10 +689,13 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
   const double* zB = Zt64 + (size_t)a2 * d * Mp;
   const double* r1a = rho1 + ((size_t)b * L + a) * Mp;
   const double* r1b = rho1 + ((size_t)b * L + a2) * Mp;
-  const double* wa = w64 + ((size_t)b * L + a) * Mp;
-  const double* wb = w64 + ((size_t)b * L + a2) * Mp;
-  const double* qa = q64 + ((size_t)b * L + a) * Mp;
-  struct Ops { double zr[DK], zc[diag ? 1 : DK], r1r, r1c, wr, wc; };
+  // weights in the log domain: every factored weight is beta exp(log q + ...) as ONE exponential -- q alone underflows to 0
+  // where e^{rho} overflows (lengthscales far below the state's distance to the inducing point), and 0 x inf is a NaN
+  const double* wa = lq + ((size_t)b * L + a) * Mp;        // log q of the row latent
+  const double* wb = lq + ((size_t)b * L + a2) * Mp;       // ... of the column latent
+  const double* ba = beta64 + (size_t)a * M;
+  const double* bb = beta64 + (size_t)a2 * M;
+  struct Ops { double zr[DK], zc[diag ? 1 : DK], r1r, r1c, wr, wc, br, bc; };
   auto load_ops = [&](int mblk, Ops& o) {
     int m = mblk * 256 + tid;
     m = m < Mp ? m : Mp - 1;
@@ -696,8 +707,9 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
     }
     o.r1r = r1a[m];
     o.wr = wa[m];
-    if constexpr (!diag) { o.r1c = r1b[m]; o.wc = wb[m]; }
-    else if (with_unc) o.wc = qa[m];                         // diagonal pair: the weight of the fused sum is q, not w
+    const int mb = m < M ? m : M - 1;
+    o.br = ba[mb];
+    if constexpr (!diag) { o.r1c = r1b[m]; o.wc = wb[m]; o.bc = bb[mb]; }
   };
   Ops oA, oB;
   load_ops(blockIdx.x, oA);
@@ -770,9 +782,9 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
         const double colv = rowv + cst - corr;
         // factored weights of the f64 MFMA reduce (mm_f64.hip): e^{delta_ij} = e^{rho_i} e^{gamma'_j} e^{zc_i . g_j};
         // u = q with model uncertainty (the fused sum runs over q_i q_j D_ij e^{delta}), w without
-        const double uw = with_unc ? o.wc : o.wr;
+        const double uw = with_unc ? 1.0 : o.br;             // the weight of the fused sum is q with model uncertainty, else w = beta q
         raD[m] = rowv; cbD[rowd + m] = colv;
-        qR[m] = uw * exp(rowv); qC[m] = uw * exp(colv);
+        qR[m] = uw * exp(fmin(o.wr + rowv, MM_EXP_CAP_F64)); qC[m] = uw * exp(fmin(o.wr + colv, MM_EXP_CAP_F64));
       } else {
 #pragma unroll
         for (int i = 0; i < DK; ++i) cbD[rowi(i) + m] = 0.0;
@@ -809,8 +821,8 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
           rO[rowi(i) + m] = (T)av;
         }
         a2max = fmaxf(a2max, (float)asq * 1.000001f);        // rounded up: the bound must not be under-estimated
-        const double whr = o.wr * exp(-0.5 * (o.r1r - tA) + cst - corrA);
-        const double whc = o.wc * exp(-0.5 * (o.r1c - tg));
+        const double whr = o.br * exp(fmin(o.wr - 0.5 * (o.r1r - tA) + cst - corrA, (double)MM_EXP_CAP_F32));
+        const double whc = o.bc * exp(fmin(o.wc - 0.5 * (o.r1c - tg), (double)MM_EXP_CAP_F32));
         rO[rowd + m] = (T)whr; cO[m] = (T)whc; hR[m] = whr; hC[m] = whc;
       } else {
 #pragma unroll
@@ -877,14 +889,15 @@ __global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict
                                                         const double* __restrict__ w64, double* __restrict__ whR,
                                                         double* __restrict__ whC, unsigned int* __restrict__ amax,
                                                         const double* __restrict__ q64, double* __restrict__ qhR,
-                                                        double* __restrict__ qhC, int with_unc, int nblk) {
+                                                        double* __restrict__ qhC, int with_unc, int nblk,
+                                                        const double* __restrict__ lq, const double* __restrict__ beta64) {
   static_assert(DK <= 8, "register form: d <= 8");
   __shared__ double vecs[5][DK];      // mu | 1/Lam_a | 1/Lam_a' | (mu - zbar_a') / Lam_a' | (mu - zbar_a) / Lam_a
   int a, a2;
   mm_decode_pair((int)blockIdx.y, L, a, a2);
 #define MM_PV_BODY(MODE_)                                                                                           \
   mm_pairvec_reg_body<T, DK, MODE_>(Zt64, zbar, ls2, L, M, Mp, d, P, mu, pairmat, rho1, rowD, colD, rowO, colO, w64, \
-                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs)
+                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64)
   if ((int)blockIdx.y < L) MM_PV_BODY(0);
   else if (sizeof(T) == 4) MM_PV_BODY(1);
   else MM_PV_BODY(2);
@@ -948,9 +961,9 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
       if (k < d) delta += (ROWVEC ? ra[(size_t)k * Mp + i] : zrow[(size_t)i * Kz + k]) * g[k];
     // ROWVEC (f32 off-diagonal pairs): only the remainder expm1(b) - b - b^2/2 is reduced here, the
     // rest comes from the f64 weight moments (k_spoly); evaluated in f64 (portable cross-check kernel)
-    const double dd = (double)delta;
+    const double dd = fmin((double)delta, sizeof(T) == 8 ? MM_EXP_CAP_F64 : (double)MM_EXP_CAP_F32);   // (mm_common.h: exponent caps)
     const T e = ROWVEC ? (T)(expm1(dd) - dd - 0.5 * dd * dd - dd * dd * dd * fma(sub1, dd, sub0))
-                       : mm_expm1(delta);
+                       : (T)expm1(dd);
     accB += (ROWVEC ? ra[(size_t)d * Mp + i] : wr[i]) * e;
     if (withC) {
       const double cij = Cm[((size_t)a * Mp + i) * Mp + jj];
@@ -1164,7 +1177,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
                      (const double*)(packed + ml.Zt64), (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
                      L, M, wl.Mp, d, mu, latmat, (double*)(ws + wl.w64), (double*)(ws + wl.q64), (T*)(ws + wl.w),
-                     (double*)(ws + wl.f1raw), (double*)(ws + wl.rho1), f1, cross, q_out, (double*)(ws + wl.mu64));
+                     (double*)(ws + wl.f1raw), (double*)(ws + wl.rho1), f1, cross, q_out, (double*)(ws + wl.mu64), (double*)(ws + wl.lq));
   MM_CHECK_LAUNCH();
   {
     const int nblk = (wl.Mp + 255) / 256;                  // 256-row chunks = wsum slots per (b, pair)
@@ -1176,7 +1189,8 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     (const double*)(packed + ml.Zt64), (const double*)(packed + ml.zbar), ls2, L, M, wl.Mp, d, wl.P, mu, pairmat,            \
     (const double*)(ws + wl.rho1), (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO), \
     (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), amax,                                      \
-    (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC), (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk
+    (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC), (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk, \
+    (const double*)(ws + wl.lq), (const double*)(packed + ml.beta64)
     if constexpr (DK <= 8) {
       hipLaunchKernelGGL((k_pairvec_reg<T, DK>), dim3(nsplit, wl.P, B), dim3(256), 0, s, MM_PAIRVEC_ARGS);
     } else {

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
 #pragma unroll
           for (int e2 = 0; e2 < 2; ++e2) {
             // |b| > 1: exp2 on the transcendental unit, then the three leading terms subtracted
-            const float x = xx[r][e2];
+            const float x = fminf(xx[r][e2], MM_EXP_CAP_F32);     // (mm_common.h: exponent caps)
             const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
             const float big = (__builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f) - fmaf(0.5f * x, x, x);
             float e = (fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big;

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
       double x = 0.0;
 #pragma unroll
       for (int k = 0; k < DK; ++k) x = fma(A[k], z[k], x);
+      x = fmin(x, MM_EXP_CAP_F64);                          // (mm_common.h: exponent caps)
       double r = mmx_rem(x);
       if (!AGG) r -= (x * x) * x * fma(sub1, x, sub0);
       const double v = wj * r;

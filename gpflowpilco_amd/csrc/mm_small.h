@@ -246,7 +246,7 @@ __host__ __device__ inline void mms_gp_fwd(Ctx c, int L, int M, int d, const dou
         double delta = cp_ + rho[i] + gam[j];
 #pragma unroll
         for (int k = 0; k < DK; ++k) if (k < d) delta = fma(uv[i * d + k], sb[(size_t)j * d + k], delta);
-        const double E = expm1(delta);
+        const double E = expm1(fmin(delta, MM_EXP_CAP_F64));                 // (mm_common.h: exponent caps)
         accB = fma(wa[i] * E, wb[j], accB);
         if (withC) accC = fma(Ca[(size_t)i * ldc + j] * qa[i] * (E + 1.0), qa[j], accC);
         i += di; j += dj;

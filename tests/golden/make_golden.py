@@ -61,6 +61,20 @@ def main():
                            ls_bounds=(0.1, 10.0), W_rows=W_rows)
     mu = rng.uniform(size=(2, 4)); Sigma = generate_covariance(rng, 4, (2,), 0.05)
     svgp_fixture(name, p, mu, Sigma)
+  # the reference's OWN designs at its own sizes (d = 4, M = 16, B = 2, input std 0.01, lengthscales log-U[0.01, 10]; the draws of
+  # oracle/quadrature_pin.py:reference_design, pinned to the 24^4-node quadrature by qp.main() above)
+  for kind in ("svgp_so", "svgp_mo_lcm"):
+    model, mx, Sxx, _, _ = qp.reference_design(kind, 501)
+    svgp_fixture("refdesign_" + kind, model, mx, Sxx)
+  gm, mx, Sxx, _, _ = qp.reference_design("gpr", 501)
+  out = dict(X=gm.X, Y=gm.Y, lengthscales=gm.lengthscales, variance=np.array(gm.variance), noise_variance=np.array(gm.noise_variance),
+             mean_c=np.array(gm.mean_c), mu=mx, Sigma=Sxx)
+  for unc in (True, False):
+    f1, Sff, cross = mo.mm_gauss_gpr(mx, Sxx, gm, model_uncertainty=unc)
+    tag = "unc" if unc else "nounc"
+    out[f"f1_{tag}"], out[f"Sff_{tag}"], out[f"cross_{tag}"] = f1, Sff, cross
+  np.savez_compressed(os.path.join(HERE, "gpr_refdesign.npz"), **out)
+  print("wrote gpr_refdesign")
   # kernel-expectation design: d=2, 32 inducing points, two different kernels
   d = 2
   mu = rng.standard_normal((1, d)); Sigma = generate_covariance(rng, d, (1,), 0.1)

@@ -15,7 +15,7 @@ from tests.helpers import gp_model_from_oracle, scale_err, to_dev
 
 HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SVGP_FIXTURES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(HERE, "*.npz"))
-                       if "kernel_expectation" not in p)
+                       if "kernel_expectation" not in p and not os.path.basename(p).startswith("gpr_"))
 
 
 def load(name):
@@ -42,6 +42,21 @@ def test_oracle_reproduces_fixture(name):
     g1, Gff, gc = fr.moment_match(z["mu"], z["Sigma"], p, beta, C)
     assert scale_err(g1, z["f1_unc"]) < 1e-9 and scale_err(Gff, z["Sff_unc"]) < 1e-6
     assert scale_err(gc, z["cross_unc"]) < 1e-9
+
+
+def load_gpr(name="gpr_refdesign"):
+  z = np.load(os.path.join(HERE, name + ".npz"))
+  return z, mo.GPRParams(X=z["X"], Y=z["Y"], lengthscales=z["lengthscales"], variance=float(z["variance"]),
+                         noise_variance=float(z["noise_variance"]), mean_c=float(z["mean_c"]))
+
+
+def test_oracle_reproduces_the_gpr_reference_design():
+  """tests/test_moment_matching.py:88-136 at the reference's own sizes (pinned to quadrature: tests/test_oracle_pin.py)."""
+  z, p = load_gpr()
+  for unc, tag in ((True, "unc"), (False, "nounc")):
+    f1, Sff, cross = mo.mm_gauss_gpr(z["mu"], z["Sigma"], p, model_uncertainty=unc)
+    assert scale_err(f1, z[f"f1_{tag}"]) < 1e-12 and scale_err(Sff, z[f"Sff_{tag}"]) < 1e-10
+    assert scale_err(cross, z[f"cross_{tag}"]) < 1e-10
 
 
 def test_kernel_expectation_fixture():
@@ -78,3 +93,26 @@ def test_gpu_reproduces_fixture(name, dtype, device):
     _, _, tmu, tS = ops.rollout_closed(pm, x.mean(), x.covariance(), z["traj_mu"].shape[0], keep_trajectory=True)
     assert scale_err(tmu, z["traj_mu"]) < tol["Sff"] and scale_err(tS, z["traj_Sigma"]) < tol["Sff"]
     assert scale_err(tmu[0], z["mu_next"]) < tol["Sff"] and scale_err(tS[0], z["Sigma_next"]) < tol["Sff"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_gpu_reproduces_the_gpr_reference_design(dtype, device):
+  from gpflowpilco_amd import models as gp
+  from gpflowpilco_amd.moment_matching import GaussianMoments, moment_matching
+  z, p = load_gpr()
+  t = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=device)
+  model = gp.GPR(data=(t(p.X), t(p.Y)), kernel=gp.SquaredExponential(variance=t(p.variance), lengthscales=t(p.lengthscales)),
+                 mean_function=gp.Constant(t([p.mean_c])), noise_variance=t(p.noise_variance))
+  x = GaussianMoments((to_dev(z["mu"], device, dtype), to_dev(z["Sigma"], device, dtype)), centered=True)
+  tol = dict(f1=1e-9, Sff=1e-6) if dtype == torch.float64 else dict(f1=2e-6, Sff=2e-5)
+  for unc, tag in ((True, "unc"), (False, "nounc")):
+    m = moment_matching(x, model, model_uncertainty=unc)
+    want = (z[f"f1_{tag}"], z[f"Sff_{tag}"], z[f"cross_{tag}"])
+    if dtype == torch.float32:
+      # lengthscales down to 0.013 against a state rounded to f32: d cross / d mu ~ 1 / ls^2 turns the INPUT's rounding (6e-8)
+      # into 6e-6 of the output -- the kernels are compared with the oracle at the state they were given
+      want = mo.mm_gauss_gpr(x.mean().double().cpu().numpy(), x.covariance().double().cpu().numpy(), p, model_uncertainty=unc)
+    assert scale_err(m.y.mean(), want[0]) < tol["f1"]
+    assert scale_err(m.y.covariance(), want[1]) < tol["Sff"]
+    assert scale_err(m.cross[0], want[2]) < tol["f1"]

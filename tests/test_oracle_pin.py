@@ -73,3 +73,16 @@ def test_euler_moment_update_matches_quadrature(d, model_uncertainty):
   """MomentMatchingEuler.step (dynamics/solvers.py:110-135): moments of x + dt f(x), dt = 0.7."""
   errs = qp.check_euler(27 + d, d, GH[d], model_uncertainty=model_uncertainty)
   assert all(v <= 1e-9 for v in errs.values()), errs
+
+
+# ---- digits, on the reference's OWN test designs: d = 4, M = 16, B = 2, input std 0.01, lengthscales log-U[0.01, 10] ------------
+@pytest.mark.parametrize("kind,seed", qp.REFERENCE_DESIGNS, ids=[f"{k}-{s}" for k, s in qp.REFERENCE_DESIGNS])
+def test_reference_designs_match_quadrature_at_d4(kind, seed):
+  """tests/test_moment_matching.py:88-136 (GPR), :140-194 (single-output SVGP, whiten=False), :199-264 (LinearCoregionalization
+  2 -> 3, whiten=False, Constant mean) at the reference's own sizes, where it accepts 1e-2 from 1e6 Monte-Carlo samples: the
+  24^4-node Gauss-Hermite rule of the same definition pins mean, FULL covariance and cross-covariance of the oracle to 1e-8
+  absolute (measured <= 1.1e-10; 1e-6 relative to each quantity's own scale)."""
+  errs, scale = qp.check_reference_design(kind, seed, 24)
+  assert all(v <= 1e-8 for v in errs.values()), (errs, scale)
+  for k in errs:
+    assert errs[k] <= 1e-6 * scale[k] + 1e-14, (k, errs[k], scale[k])
