@@ -79,11 +79,15 @@ def moment_match(mu, Sigma, model: mo.SVGPParams, beta, C, model_uncertainty=Tru
         rho = -0.5 * np.einsum('id,de,ie->i', zr, Dr, zr)
         gam = -0.5 * np.einsum('id,de,ie->i', zc, Dc, zc)
         delta = rho[:, None] + gam[None, :] + const + zr @ G @ zc.T
-        E = np.expm1(delta)
-        val = w[a] @ E @ w[a2]
+        # Q_ij = q_i q_j e^{delta_ij} in the LOG domain: with lengthscales far below |z - mu| (the reference's own test designs
+        # draw them down to 0.01) q underflows to 0 where e^{delta} overflows, although their product is bounded by var_a var_a'
+        lQ = lq[a][:, None] + lq[a2][None, :] + delta
+        Qn = np.exp(lQ)                                            # <k_a(z_i, x) k_a'(x, z_j)>
+        qq = np.exp(lq[a][:, None] + lq[a2][None, :])              # q_i q'_j
+        centred = np.where(np.abs(delta) < 1.0, qq * np.expm1(np.clip(delta, -1.0, 1.0)), Qn - qq)     # q q' (e^delta - 1)
+        val = beta[a] @ centred @ beta[a2]
         if a == a2 and model_uncertainty:
-          qa = np.exp(lq[a])
-          val += var[a] + np.sum(C[a] * (qa[:, None] * (E + 1.0) * qa[None, :]))
+          val += var[a] + np.sum(C[a] * Qn)
         Sff[b, a, a2] = Sff[b, a2, a] = val
   if model.mean_c is not None and model.W is None:
     f1 = f1 + np.asarray(model.mean_c)[None]
