@@ -254,7 +254,14 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
   double arow_n[2][KS4], rinit_n[2][4];
   if (PFB) load_first(0, arow_n, rinit_n);
 
-  for (int it = 0; it < nt; ++it) {
+  // MMB_EXPERIMENT_HALF (timing experiment only, WRONG results): diagonal pairs visit the tiles it <= jt alone -- what a
+  // symmetric sweep would compute, WITHOUT the row-side sums it would have to add per tile: a lower bound on its time
+#ifdef MMB_EXPERIMENT_HALF
+  const int nt_run = (!SWAP && diag) ? jt + 1 : nt;
+#else
+  const int nt_run = nt;
+#endif
+  for (int it = 0; it < nt_run; ++it) {
     const int rbase = it * 64 + rh * 32;
     // ---- this iteration's 32 "rows" -------------------------------------------------------------
     double arow[2][KS4], rinit[2][4], rwt[2][4], rq[2][4];
