@@ -69,14 +69,6 @@ SIGNATURES = {
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                       C.c_void_p, C.c_void_p]),
-    "mm_rollout_small_supported": (C.c_int, [C.c_int] * 4),
-    "mm_rollout_composed_engine": (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
-                                             C.c_void_p, C.c_size_t, C.c_int, C.c_int,
-                                             C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(C.c_int32),
-                                             C.c_double, C.c_double, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                                             C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
-                                             C.c_void_p, C.c_void_p]),
     "mm_compose_tape_bytes": (C.c_size_t, [C.c_int] * 6),
     "mm_rollout_composed_taped": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int,
                                             C.c_void_p, C.c_size_t, C.c_int, C.c_int,

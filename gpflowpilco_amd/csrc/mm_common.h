@@ -184,7 +184,7 @@ struct MMWorkspaceLayout {
   size_t rho1;     // [B][L][Mp] f64  zeta_i^T E_a zeta_i (the pair-independent part of rho_i / gamma_j)
   size_t w64;      // [B][L][Mp] f64  beta_i q_i
   size_t q64;      // [B][L][Mp] f64  q_i = <k_a(x, z_i)>
-  size_t w;        // [B][L][Mp] T    (aliases w64 when T is f64)
+  size_t w;        // = w64 (the f64 mode's generic kernel reads it; an f32 copy used to be written and was read by nothing)
   size_t lq;       // [B][L][Mp] f64  log q_i (-1e30 in the padding): k_pairvec forms every factored weight as ONE exponential
                    //                 beta_i exp(log q_i + rho_i) -- with short lengthscales q_i underflows to 0 where e^{rho_i}
                    //                 overflows (the reference's own test designs: lengthscales down to 0.01), and 0 x inf is a NaN
@@ -239,7 +239,6 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.w64 = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.q64 = off;     off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.w = o.w64;
-  if (dtype != MM_F64) { o.w = off; off = mm_align_up(off + (size_t)B * L * o.Mp * es, A); }
   o.lq = off;      off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.rowD = off;    off = mm_align_up(off + (size_t)B * L * o.Mp * 8, A);
   o.colD = off;    off = mm_align_up(off + (size_t)B * L * (d + 1) * o.Mp * 8, A);

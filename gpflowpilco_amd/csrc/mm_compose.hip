@@ -514,18 +514,11 @@ static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, 
   return 0;
 }
 
-// csrc/mm_rollout_small.hip: the whole rollout in one launch, for the shapes mm_rollout_small_supported admits
-extern "C" int mm_rollout_small_supported(int nx, int na, int drift_M, int policy_M);
-int mm_rollout_small_launch(const void* drift_packed, size_t drift_bytes, int drift_M, const void* policy_packed, size_t policy_bytes,
-                            int policy_M, int dtype, int B, int H, double dt, const MMComposeDims& D, double scale, double shift,
-                            const void* target, const void* precis, void* mx, void* Sxx, void* cost, void* traj_mu, void* traj_S,
-                            int32_t* status, hipStream_t s);
-
-// engine: 0 = choose, 1 = the multi-launch path, 2 = the one-launch kernel or an error.  "Choose" is the multi-launch path
-// today: measured on MI355X at cartpole sizes the one-launch kernel takes 271 us per step against 64 (DESIGN.md section 8:
-// the M x M sweeps and the d x d factorisations of a step, spread over 14-36 workgroups by the multi-launch kernels, run on ONE
-// compute unit there, and that costs more than the nine launch boundaries save)
-static int mm_rollout_composed_impl(int engine, const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
+// (A ONE-launch kernel for small models -- the whole H-step rollout in one 512-thread workgroup per batch element, everything in
+// LDS -- was built in round 3, parity-green, and measured 271 us per step against 64 for this multi-launch path at cartpole sizes
+// (one compute unit does what 14-36 workgroups do here): removed from the library in round 4; DESIGN.md section 8 keeps its
+// stage profile.)
+static int mm_rollout_composed_impl(const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
                                     const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
                                     int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
                                     double head_scale, double head_shift, const void* target, const void* precis,
@@ -534,7 +527,7 @@ static int mm_rollout_composed_impl(int engine, const void* drift_packed, size_t
                                     void* ws_compose, size_t ws_compose_bytes, void* tape, size_t tape_bytes,
                                     int32_t* status, void* stream) {
   if (!drift_packed || !policy_packed || !mx || !Sxx) return MM_E_ARG;
-  if (engine != 2 && (!ws_drift || !ws_policy || (!ws_compose && !tape))) return MM_E_ARG;
+  if (!ws_drift || !ws_policy || (!ws_compose && !tape)) return MM_E_ARG;
   if (B <= 0 || H <= 0 || drift_M <= 0 || policy_M <= 0) return MM_E_ARG;
   if (dtype != MM_F32 && dtype != MM_F64) return MM_E_DTYPE;
   if (cost && (!target || !precis)) return MM_E_ARG;
@@ -543,14 +536,9 @@ static int mm_rollout_composed_impl(int engine, const void* drift_packed, size_t
   if (rc) return rc;
   if (drift_L != nx || drift_d != D.nd || policy_d != D.ne) return MM_E_STATE;
   const MMComposeLayout cl = mm_compose_layout(B, nx, na, dtype);
-  if (engine != 2 && !tape && ws_compose_bytes < cl.total) return MM_E_WORKSPACE;
+  if (!tape && ws_compose_bytes < cl.total) return MM_E_WORKSPACE;
   if (tape && tape_bytes < mm_tape_layout(B, H, nx, na, drift_M, dtype).total) return MM_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  const bool small_ok = !tape && mm_rollout_small_supported(nx, na, drift_M, policy_M) != 0;
-  if (engine == 2 && !small_ok) return MM_E_DIM;
-  if (small_ok && engine == 2)
-    return mm_rollout_small_launch(drift_packed, drift_bytes, drift_M, policy_packed, policy_bytes, policy_M, dtype, B, H, dt, D,
-                                   head_scale, head_shift, target, precis, mx, Sxx, cost, traj_mu, traj_Sigma, status, s);
   if (dtype == MM_F64)
     return mm_rollout_composed_t<double>(drift_packed, drift_bytes, drift_M, policy_packed, policy_bytes, policy_M, dtype, B, H, dt,
                                          D, head_scale, head_shift, (const double*)target, (const double*)precis, (double*)mx,
@@ -569,25 +557,8 @@ extern "C" int mm_rollout_composed(const void* drift_packed, size_t drift_bytes,
                                    void* mx, void* Sxx, void* cost, void* traj_mu, void* traj_Sigma,
                                    void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
                                    void* ws_compose, size_t ws_compose_bytes, int32_t* status, void* stream) {
-  return mm_rollout_composed_impl(0, drift_packed, drift_bytes, drift_L, drift_M, drift_d, policy_packed, policy_bytes, policy_M, policy_d,
+  return mm_rollout_composed_impl(drift_packed, drift_bytes, drift_L, drift_M, drift_d, policy_packed, policy_bytes, policy_M, policy_d,
                                   dtype, B, H, dt, nx, na, active_dims, head_scale, head_shift, target, precis, mx, Sxx, cost,
-                                  traj_mu, traj_Sigma, ws_drift, ws_drift_bytes, ws_policy, ws_policy_bytes, ws_compose,
-                                  ws_compose_bytes, nullptr, 0, status, stream);
-}
-
-// The same rollout with the engine chosen by the caller: engine 1 = the multi-launch path (what mm_rollout_composed does for
-// shapes the one-launch kernel does not take), engine 2 = the one-launch kernel k_rollout_small (MM_E_DIM if the shapes
-// are not mm_rollout_small_supported; the workspaces may then be NULL).  Tests and bench.py compare the two.
-extern "C" int mm_rollout_composed_engine(int engine, const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
-                                          const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
-                                          int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
-                                          double head_scale, double head_shift, const void* target, const void* precis,
-                                          void* mx, void* Sxx, void* cost, void* traj_mu, void* traj_Sigma,
-                                          void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
-                                          void* ws_compose, size_t ws_compose_bytes, int32_t* status, void* stream) {
-  if (engine < 0 || engine > 2) return MM_E_ARG;
-  return mm_rollout_composed_impl(engine, drift_packed, drift_bytes, drift_L, drift_M, drift_d, policy_packed, policy_bytes, policy_M,
-                                  policy_d, dtype, B, H, dt, nx, na, active_dims, head_scale, head_shift, target, precis, mx, Sxx, cost,
                                   traj_mu, traj_Sigma, ws_drift, ws_drift_bytes, ws_policy, ws_policy_bytes, ws_compose,
                                   ws_compose_bytes, nullptr, 0, status, stream);
 }
@@ -608,7 +579,7 @@ extern "C" int mm_rollout_composed_taped(const void* drift_packed, size_t drift_
                                          void* ws_policy, size_t ws_policy_bytes, void* tape, size_t tape_bytes,
                                          int32_t* status, void* stream) {
   if (!tape) return MM_E_ARG;
-  return mm_rollout_composed_impl(1, drift_packed, drift_bytes, drift_L, drift_M, drift_d, policy_packed, policy_bytes, policy_M, policy_d,
+  return mm_rollout_composed_impl(drift_packed, drift_bytes, drift_L, drift_M, drift_d, policy_packed, policy_bytes, policy_M, policy_d,
                                   dtype, B, H, dt, nx, na, active_dims, head_scale, head_shift, target, precis, mx, Sxx, cost,
                                   nullptr, nullptr, ws_drift, ws_drift_bytes, ws_policy, ws_policy_bytes, nullptr, 0, tape, tape_bytes,
                                   status, stream);

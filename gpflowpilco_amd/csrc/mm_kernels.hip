@@ -419,7 +419,6 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
   for (int k = 0; k < DK; ++k) acc_s[k] = 0.0;
   double* wb64 = w64 + ((size_t)b * L + a) * Mp;
   double* qb64 = q64 + ((size_t)b * L + a) * Mp;
-  T* wb = w + ((size_t)b * L + a) * Mp;
   double* r1 = rho1 + ((size_t)b * L + a) * Mp;
   double* lqb = lq + ((size_t)b * L + a) * Mp;
   for (int m = tid; m < Mp; m += 256) {
@@ -476,7 +475,6 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
     qb64[m] = qv;
     r1[m] = rv;
     lqb[m] = lqv;
-    if (sizeof(T) != 8) wb[m] = (T)wv;
   }
   // the DK + 1 workgroup sums together: wave butterflies, one LDS stage, one barrier (fixed order: reproducible)
   __shared__ double red9[4][DK + 1];

@@ -378,8 +378,6 @@ class ComposedRollout:
       self._wsc[B] = ws
     return ws
 
-  ENGINES = {"auto": 0, "multi": 1, "small": 2}
-
   def _policy_pack(self, policy: Optional[PackedModel]) -> PackedModel:
     """``policy`` (another pack of the same shape: the current parameters of a trainable policy) or ``self.policy``; a pack
     of another (L, M, d, dtype) would be read through the wrong layout -- the C side only sees a byte count."""
@@ -398,16 +396,10 @@ class ComposedRollout:
       raise ValueError(f"expected mx [B,{self.nx}], Sxx [B,{self.nx},{self.nx}]")
     return B
 
-  def small_supported(self) -> bool:
-    """Whether the one-launch kernel (csrc/mm_rollout_small.hip) takes these shapes."""
-    return bool(lib().mm_rollout_small_supported(self.nx, self.na, self.drift.M, self.policy.M))
-
   def __call__(self, mx: torch.Tensor, Sxx: torch.Tensor, num_steps: int, dt: float = 1.0, keep_trajectory: bool = False,
-               policy: Optional[PackedModel] = None, engine: str = "auto"):
+               policy: Optional[PackedModel] = None):
     """``policy``: another pack of the same shape to evaluate instead of ``self.policy`` (the current parameters of a
-    trainable policy, packed by the caller).  ``engine``: "auto" = "multi" (the multi-launch path), or "small": the
-    one-launch kernel of csrc/mm_rollout_small.hip (an error where the shapes do not fit) -- measured slower at cartpole
-    sizes, kept as the cross-check and the record of that experiment."""
+    trainable policy, packed by the caller)."""
     pol = self._policy_pack(policy)
     B = self._check_state(mx, Sxx)
     dt_ = self.drift.dtype
@@ -419,14 +411,14 @@ class ComposedRollout:
     wd = self.drift.workspace(B, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY)
     wp = pol.workspace(B, MM_FULL_OUTPUT_COV)
     wc = self._compose_ws(B)
-    rc = lib().mm_rollout_composed_engine(self.ENGINES[engine], self.drift.buf.data_ptr(), self.drift.nbytes, self.drift.L, self.drift.M, self.drift.d,
+    rc = lib().mm_rollout_composed(self.drift.buf.data_ptr(), self.drift.nbytes, self.drift.L, self.drift.M, self.drift.d,
                                    pol.buf.data_ptr(), pol.nbytes, pol.M, pol.d,
                                    _dtype_code(dt_), B, H, float(dt), self.nx, self.na, self._act,
                                    self.scale, self.shift, self.target.data_ptr(), self.precis.data_ptr(),
                                    mx.data_ptr(), Sxx.data_ptr(), cost.data_ptr(), _ptr(tmu), _ptr(tS),
                                    wd.data_ptr(), wd.numel(), wp.data_ptr(), wp.numel(), wc.data_ptr(), wc.numel(),
                                    self.drift.status().data_ptr(), _stream(mx.device))
-    check(rc, "mm_rollout_composed_engine")
+    check(rc, "mm_rollout_composed")
     out = (mx, Sxx, cost.T.contiguous())
     return out + (tmu, tS) if keep_trajectory else out
 

@@ -189,24 +189,6 @@ int mm_rollout_composed(const void* drift_packed, size_t drift_bytes, int drift_
                         void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
                         void* ws_compose, size_t ws_compose_bytes, int32_t* status, void* stream);
 
-/* The engine behind mm_rollout_composed.  Besides the multi-launch path there is a ONE-launch kernel for small models
- * (mm_rollout_small_supported: encoded and drift input dims <= 8, policy M <= 128, the LDS image of one batch element
- * <= 152 KB -- the cartpole wiring of BASELINE configs[0]): one 512-thread workgroup per batch element runs the whole H-step
- * rollout with the state and every intermediate in LDS (csrc/mm_rollout_small.hip, csrc/mm_small.h) -- the persistent kernel
- * SURVEY.md section 7 step 6 suggests.  Measured on MI355X at cartpole sizes it is SLOWER than the multi-launch path (271 vs
- * 64 us per step: the step's M x M sweeps and d x d factorisations run on one compute unit instead of 14-36), so
- * mm_rollout_composed (engine 0) does not choose it; mm_rollout_composed_engine exposes both: engine 0 = as
- * mm_rollout_composed, 1 = the multi-launch path, 2 = the one-launch kernel (MM_E_DIM if unsupported; the workspaces may be
- * NULL).  Same results to rounding (tests/test_compose.py). */
-int mm_rollout_small_supported(int nx, int na, int drift_M, int policy_M);
-int mm_rollout_composed_engine(int engine, const void* drift_packed, size_t drift_bytes, int drift_L, int drift_M, int drift_d,
-                               const void* policy_packed, size_t policy_bytes, int policy_M, int policy_d,
-                               int dtype, int B, int H, double dt, int nx, int na, const int32_t* active_dims,
-                               double head_scale, double head_shift, const void* target, const void* precis,
-                               void* mx, void* Sxx, void* cost, void* traj_mu, void* traj_Sigma,
-                               void* ws_drift, size_t ws_drift_bytes, void* ws_policy, size_t ws_policy_bytes,
-                               void* ws_compose, size_t ws_compose_bytes, int32_t* status, void* stream);
-
 /* The same rollout, RECORDED for differentiation: every per-step intermediate and the states x_0 .. x_H are written into
  * `tape` (mm_compose_tape_bytes) instead of a reused workspace; mx / Sxx / cost as above.  Where H copies of the drift's
  * workspace fit in 512 MB the tape also keeps the drift match's q stage of every step (the reverse sweep then does not

@@ -107,30 +107,3 @@ extern "C" void hc_pair_poly(int d, const double* G, const double* dmu, const do
 extern "C" void hc_pair_convert(int d, const double* dmu2, double* T) { mma_pair_convert(MMAHostCtx(), d, dmu2, T); }
 extern "C" int hc_mono_off(int n, int d) { return mm_mono_off(n, d); }
 extern "C" int hc_mono_rank(const int* k, int n) { return mm_mono_rank_unsorted(n > 0 ? k[0] : 0, n > 1 ? k[1] : 0, n > 2 ? k[2] : 0, n > 3 ? k[3] : 0, n); }
-
-// ---- forward stages of the one-workgroup rollout (csrc/mm_small.h), on one host thread -------------------------------------
-#include "../../gpflowpilco_amd/csrc/mm_small.h"
-
-extern "C" int hc_gp_fwd(int L, int M, int d, const double* Z, const double* beta, const double* ls2, const double* var,
-                         const double* meanc, const double* Cm, int ldc, const double* mu, const double* Sigma, double* f1,
-                         double* Sff, double* cross) {
-  std::vector<double> sm(mms_gp_scratch(L, M, d, 1) + 8);
-  bool ok = true;
-  mms_gp_fwd<MMAHostCtx, 8>(MMAHostCtx(), L, M, d, Z, beta, ls2, var, meanc, Cm, ldc, mu, Sigma, f1, Sff, cross, sm.data(), &ok);
-  return ok ? 0 : 1;
-}
-
-extern "C" int hc_rollout_small(int nx, int na, const int32_t* act, int H, double dt, double scale, double shift,
-                                int dM, const double* dZ, const double* dbeta, const double* dls2, const double* dvar,
-                                const double* dmeanc, const double* dC, int pM, const double* pZ, const double* pbeta,
-                                const double* pls2, const double* pvar, const double* pmeanc, const double* target,
-                                const double* precis, double* mx, double* Sxx, double* cost, double* traj_mu, double* traj_S) {
-  MMComposeDims D = dims(nx, na, act);
-  MMSmallModel drift{nx, dM, D.nd, dM, dZ, dbeta, dls2, dvar, dmeanc, dC};
-  MMSmallModel pol{1, pM, D.ne, 0, pZ, pbeta, pls2, pvar, pmeanc, nullptr};
-  std::vector<double> sm(mms_rollout_scratch(nx, na, dM, pM, 1) + 8);
-  bool ok = true;
-  mms_rollout<MMAHostCtx, double, 8>(MMAHostCtx(), D, H, dt, scale, shift, drift, pol, target, precis, mx, Sxx, cost, 1, traj_mu,
-                                     (size_t)nx, traj_S, (size_t)nx * nx, sm.data(), &ok);
-  return ok ? 0 : 1;
-}

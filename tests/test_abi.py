@@ -92,8 +92,6 @@ def test_argument_validation_of_the_gradient_entry_points_without_gpu():
   assert lib.mm_compose_tape_bytes(1, 30, 4, 5, 100, F64) == 0                         # more angles than state dims
   assert lib.mm_compose_backward_workspace_bytes(1, 4, 1, 100) > lib.mm_moment_match_backward_bytes(1, 4, 100, 6, 3) > 0
   assert lib.mm_policy_grad_bytes(2, 30, 5) == 2 * (30 * 5 + 30 + 5 + 2) * 8
-  assert lib.mm_rollout_small_supported(4, 1, 100, 30) == 1
-  assert lib.mm_rollout_small_supported(4, 1, 100, 200) == 0 and lib.mm_rollout_small_supported(6, 2, 100, 30) == 0
   # backward of the composed rollout: f64 only, pointers required, shapes must compose, small policy only
   args = lambda dtype=F64, tapep=p, pol_M=30, drift_d=6: (
       p, 64, 4, 100, drift_d, p, 64, pol_M, 5, dtype, 1, 30, 1.0, 4, 1, act, 2.0, -0.5, p, p, tapep, 64, p, p, None, None,
@@ -116,8 +114,3 @@ def test_argument_validation_of_the_gradient_entry_points_without_gpu():
   assert lib.mm_moment_match_backward(*mb(mu=None)) == -1
   assert lib.mm_moment_match_backward(*mb(d=40)) == -2
   assert lib.mm_moment_match_backward(*mb()) == -4                                 # workspaces too small
-  # engine selector
-  eng = lambda e: (e, p, 64, 4, 100, 6, p, 64, 30, 5, F64, 1, 3, 1.0, 4, 1, act, 2.0, -0.5, p, p, p, p, None, None, None,
-                   p, 64, p, 64, p, 64, None, None)
-  assert lib.mm_rollout_composed_engine(*eng(3)) == -1
-  assert lib.mm_rollout_composed_engine(*eng(1)) == -4                             # compose workspace too small

@@ -338,57 +338,3 @@ def test_pair_polynomial_part_and_recentring_equal_brute_force(hc, d, M):
   assert _rel(T, brute(zc2)) < 1e-12
   hc.hc_pair_convert(d, _p(_c(dmu2)), _p(T))
   assert _rel(T, brute(zc2 - dmu2)) < 1e-12
-
-
-# ---- forward stages of the one-workgroup rollout (csrc/mm_small.h) on the host, against the oracle --------------------------
-def _packed(p):
-  """beta = Kuu^-1 u and C of an oracle model (the precompute the product does in gpflowpilco_amd/models.py)."""
-  from oracle import mm_fused_ref as fr
-  return fr.precompute(p)
-
-
-@pytest.mark.parametrize("L,M,d,unc", [(4, 40, 6, True), (1, 30, 5, False), (3, 25, 2, True), (2, 33, 8, True)])
-def test_small_gp_match_equals_oracle(hc, L, M, d, unc):
-  from oracle import mm_oracle as mo
-  from tests.helpers import random_svgp_params
-  p = random_svgp_params(seed=5 + L + d, L=L, M=M, d=d, whiten=True, ls_bounds=(0.6, 2.0), mean=True)
-  rng = np.random.default_rng(9)
-  mu = rng.uniform(0.2, 0.8, size=(1, d)); Sigma = generate_covariance(rng, d, (1,), 0.2)
-  f1o, Sffo, cro = mo.mm_gauss_svgp_mo(mu, Sigma, p, True, unc, 0.0)
-  beta, Cm = _packed(p)
-  f1 = np.zeros(L); Sff = np.zeros((L, L)); cross = np.zeros((d, L))
-  rc = hc.hc_gp_fwd(L, M, d, _p(_c(p.Z)), _p(_c(beta)), _p(_c(p.lengthscales ** 2)), _p(_c(p.variance)), _p(_c(p.mean_c)),
-                    _p(_c(Cm)) if unc else None, M, _p(_c(mu[0])), _p(_c(Sigma[0])), _p(f1), _p(Sff), _p(cross))
-  assert rc == 0
-  assert _rel(f1, f1o[0]) < 1e-10 and _rel(cross, cro[0]) < 1e-10 and _rel(Sff, Sffo[0]) < 1e-7
-
-
-def test_small_rollout_equals_oracle_rollout(hc):
-  """mms_rollout (the body of k_rollout_small) on one host thread: cartpole wiring, H = 6, against
-  oracle/mm_compose_oracle.py policy_rollout_loss."""
-  from oracle import mm_compose_oracle as co
-  from tests.helpers import oracle_params, random_svgp_params
-  from gpflowpilco_amd.synthetic import make_svgp
-  drift_o = oracle_params(make_svgp(4, 40, 6, seed=10, ls_bounds=(0.8, 3.0)))
-  drift_o.Z = drift_o.Z * np.array([1, 1, 1, 1, 1, 4.0]) - np.array([0, 0, 0, 0, 0, 2.0])
-  pol_o = random_svgp_params(seed=11, L=1, M=12, d=5, whiten=True, ls_bounds=(0.7, 2.0), mean=False)
-  pol_o.q_mu = 0.3 * pol_o.q_mu
-  rng = np.random.default_rng(12)
-  mu = np.array([[0.4, 0.2, 0.5, 0.3]]); S = generate_covariance(rng, 4, (1,), 0.05)
-  target = np.array([0.0, 1.0, 0, 0, 0])
-  precis = 16 * np.array([[0.25, 0, -0.5, 0, 0], [0, 0.25, 0, 0, 0], [-0.5, 0, 1, 0, 0], [0] * 5, [0] * 5], dtype=float)
-  scale, shift, active, H = 2.0, -0.5, (1,), 6
-  loss_o, traj_o = co.policy_rollout_loss(mu, S, drift_o, lambda s: co.mm_policy(s, pol_o, scale, shift), active, target, precis, H, keep=True)
-  bd, Cd = _packed(drift_o); bp, _ = _packed(pol_o)
-  mx = _c(mu[0]).copy(); Sxx = _c(S[0]).copy(); cost = np.zeros(H); tm = np.zeros((H, 4)); tS = np.zeros((H, 4, 4))
-  act = np.array(active, dtype=np.int32)
-  zero1 = np.zeros(1); zero4 = np.zeros(4)
-  rc = hc.hc_rollout_small(4, 1, _ip(act), H, C.c_double(1.0), C.c_double(scale), C.c_double(shift),
-                           40, _p(_c(drift_o.Z)), _p(_c(bd)), _p(_c(drift_o.lengthscales ** 2)), _p(_c(drift_o.variance)), _p(zero4), _p(_c(Cd)),
-                           12, _p(_c(pol_o.Z)), _p(_c(bp)), _p(_c(pol_o.lengthscales ** 2)), _p(_c(pol_o.variance)), _p(zero1),
-                           _p(_c(target)), _p(_c(precis)), _p(mx), _p(Sxx), _p(cost), _p(tm), _p(tS))
-  assert rc == 0
-  for h in range(H):
-    assert _rel(tm[h], traj_o[h][0][0]) < 1e-8 and _rel(tS[h], traj_o[h][1][0]) < 1e-8, h
-  assert abs(cost.sum() - float(loss_o[0])) < 1e-8 * abs(float(loss_o[0]))
-  assert _rel(mx, traj_o[-1][0][0]) < 1e-8

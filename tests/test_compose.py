@@ -273,46 +273,3 @@ def test_native_closure_follows_in_place_parameter_updates(device):
   objective.target.add_(0.1)                                # objective, in place
   n3, t3 = both()
   assert scale_err(n3, t3.cpu().numpy()) < 1e-9 and (n3 - n2).abs().max() > 1e-6
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
-def test_one_launch_rollout_equals_multi_launch_and_oracle(dtype, device):
-  """k_rollout_small (csrc/mm_rollout_small.hip): the whole H = 30 rollout of the cartpole wiring in ONE launch, one
-  workgroup per batch element -- against the multi-launch path of the same library and against the numpy oracle rollout
-  (config-1 sizes: drift M = 100, policy M = 30)."""
-  from gpflowpilco_amd import ops
-  drift_syn = make_svgp(4, 100, 6, seed=10, ls_bounds=(0.8, 3.0))
-  drift_o = oracle_params(drift_syn)
-  drift_o.Z = drift_o.Z * np.array([1, 1, 1, 1, 1, 4.0]) - np.array([0, 0, 0, 0, 0, 2.0])
-  pol_o = random_svgp_params(seed=11, L=1, M=30, d=5, whiten=True, ls_bounds=(0.7, 2.0), mean=False)
-  pol_o.q_mu = 0.3 * pol_o.q_mu
-  rng = np.random.default_rng(12)
-  mu = np.array([[0.4, 0.2, 0.5, 0.3], [0.6, -0.1, 0.4, 0.5], [0.5, 0.0, 0.45, 0.4]])
-  S = generate_covariance(rng, 4, (3,), 0.05)
-  target = np.array([0.0, 1.0, 0, 0, 0])
-  precis = 16 * np.array([[0.25, 0, -0.5, 0, 0], [0, 0.25, 0, 0, 0], [-0.5, 0, 1, 0, 0], [0] * 5, [0] * 5], dtype=float)
-  scale, shift, active, H = 2.0, -0.5, (1,), 30
-  loss_o, traj_o = co.policy_rollout_loss(mu, S, drift_o, lambda s: co.mm_policy(s, pol_o, scale, shift), active, target, precis, H, keep=True)
-  drift = gp_model_from_oracle(drift_o, device)
-  pol_model = gp_model_from_oracle(pol_o, device)
-  roll = ops.ComposedRollout(drift.packed(dtype, True, device), pol_model.packed(dtype, False, device), nx=4,
-                             active_dims=active, head_scale=scale, head_shift=shift,
-                             target=to_dev(target, device, dtype), precis=to_dev(precis, device, dtype))
-  assert roll.small_supported()
-  mx, Sx = to_dev(mu, device, dtype), to_dev(S, device, dtype)
-  outs = {e: roll(mx, Sx, H, keep_trajectory=True, engine=e) for e in ("small", "multi", "auto")}
-  roll.drift.check_status(3)
-  tol = 1e-7 if dtype == torch.float64 else 2e-4
-  m_H, S_H, cost, tmu, tS = outs["small"]
-  for h in (0, 1, H // 2, H - 1):
-    assert scale_err(tmu[h], traj_o[h][0]) < tol and scale_err(tS[h], traj_o[h][1]) < tol, h
-  assert scale_err(cost.sum(1), loss_o) < tol
-  assert torch.equal(m_H, tmu[-1]) and torch.equal(S_H, tS[-1])
-  for a_, b_ in zip(outs["multi"], outs["auto"]):
-    assert torch.equal(a_, b_)                              # "auto" is the multi-launch path (the faster one: DESIGN.md section 8)
-  tol2 = 1e-9 if dtype == torch.float64 else 2e-4
-  for a_, b_ in zip(outs["small"], outs["multi"]):
-    assert scale_err(a_, b_.double().cpu().numpy()) < tol2
-  # shapes it does not take are refused
-  assert not ops.lib().mm_rollout_small_supported(4, 1, 100, 200) and not ops.lib().mm_rollout_small_supported(6, 2, 100, 30)
