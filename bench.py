@@ -1033,8 +1033,21 @@ def grad_bench(args, rank, world, dev, dist):
     out["cpu_baseline"] = {"value": round(1.0 / tc, 4), "unit": out["unit"], "cores": os.cpu_count(), "kind": "port",
                            "sample": f"ONE batch element of the same workload (forward + torch autograd backward of the materialised "
                                      f"[36, {M}, {M}] float64 evaluation, {tc:.1f} s on {os.cpu_count()} threads)"}
-    gm = gmu[:0]  # (parity of the GPU gradient is the tests' job; here only the baseline's clock)
-    del gm
+    # parity of the SAME element: the HIP backward on the f32 pack (B = 1 call) against that float64 autograd gradient, and
+    # against the f64 pack of the same model (every pair swept in f64)
+    m1, S1 = draws_mu[0, :1].contiguous(), draws_S[0, :1].contiguous()
+    pm.status().zero_()
+    ga = ops.moment_match_backward(pm, m1, S1, g1[:1], g2[:1], g3[:1], True, True)
+    pm64 = model.packed(torch.float64, True, dev)
+    gb = ops.moment_match_backward(pm64, m1.double(), S1.double(), g1[:1], g2[:1], g3[:1], True, True)
+    gc = (mu_c.grad, 0.5 * (S_c.grad + S_c.grad.transpose(1, 2)))
+    rel = lambda x, y: float((x.cpu() - y.cpu()).abs().amax() / y.abs().amax())
+    out["parity"] = {"vs": "float64 torch autograd of the materialised evaluation on the CPU (autodiff.moment_match_torch), same element, same "
+                           "f32-rounded state; and the HIP backward on an f64 pack of the same model", "B": 1,
+                     "max_err_over_scale_vs_cpu_autograd": {"g_mu": rel(ga[0], gc[0]), "g_Sigma": rel(ga[1], gc[1])},
+                     "max_err_over_scale_vs_f64_pack": {"g_mu": rel(ga[0], gb[0]), "g_Sigma": rel(ga[1], gb[1])},
+                     "f64_pack_vs_cpu_autograd": {"g_mu": rel(gb[0], gc[0]), "g_Sigma": rel(gb[1], gc[1])},
+                     "items_routed_to_f64_in_this_backward": pm.routed()[1]}
   if rank == 0:
     print(json.dumps(out))
   if world > 1:
