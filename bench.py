@@ -727,23 +727,30 @@ def main():
     g1, g2, g3 = (torch.randn(s_, generator=gg, dtype=torch.float64).to(dev) for s_ in ((B, L), (B, L, L), (B, d, L)))
     fl = ops.make_flags(True, True)
 
-    def fwd_bwd(with_bwd):
+    def fwd_bwd(mode):
+      if mode == "one_sweep":        # what a differentiating caller runs (autodiff.MomentMatchFunction): the backward's sweeps give the value too
+        _, _, _, sums, g_ = ops.moment_match_with_sums(pm_, mu_, S_)
+        ops.moment_match_backward(pm_, mu_, S_, g1, g2, g3, True, True, forward_generation=g_, sums=sums)
+        return
       ops.moment_match(pm_, mu_, S_)
-      if with_bwd:
+      if mode == "two_pass":
         ops.moment_match_backward(pm_, mu_, S_, g1, g2, g3, True, True, forward_generation=pm_.workspace_generation(B, fl))
     t_ms = {}
-    for name_, wb in (("forward_ms", False), ("forward_backward_ms", True)):
-      fwd_bwd(wb)
+    for name_, mode_ in (("forward_ms", "forward"), ("forward_backward_ms", "one_sweep"), ("two_pass_forward_backward_ms", "two_pass")):
+      fwd_bwd(mode_)
       e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
       e0.record()
       for _ in range(5):
-        fwd_bwd(wb)
+        fwd_bwd(mode_)
       e1.record(); torch.cuda.synchronize()
       t_ms[name_] = round(e0.elapsed_time(e1) / 5, 4)
-    out["next_rows"] = {"f-1": dict(t_ms, what="moment match forward / forward + backward (vector-Jacobian product w.r.t. mu, Sigma) on the f32 "
-                                         "pack, first step's inputs of the primary regime, B elements; stage times and roofline: "
-                                         "bench.py --config c3_grad", B=B,
-                                    forward_backward_over_forward=round(t_ms["forward_backward_ms"] / t_ms["forward_ms"], 2))}
+    out["next_rows"] = {"f-1": dict(t_ms, what="moment match forward / value + vector-Jacobian product w.r.t. (mu, Sigma) on the f32 pack, first "
+                                         "step's inputs of the primary regime, B elements.  forward_backward_ms: what a differentiating caller "
+                                         "runs -- mm_moment_match_with_sums (q stage + the BACKWARD's two M x M sweeps, which contain the forward's "
+                                         "sums) + the chain rule; two_pass_forward_backward_ms: mm_moment_match, then mm_moment_match_backward "
+                                         "(four sweeps; rounds 2-3).  Stage times and roofline: bench.py --config c3_grad", B=B,
+                                    forward_backward_over_forward=round(t_ms["forward_backward_ms"] / t_ms["forward_ms"], 2),
+                                    two_pass_over_forward=round(t_ms["two_pass_forward_backward_ms"] / t_ms["forward_ms"], 2))}
   for r in results.values():
     r.pop("_fused", None); r.pop("_ctx", None)
   if len(results) > 1 or args.regimes:
@@ -986,6 +993,31 @@ def grad_bench(args, rank, world, dev, dist):
   mu, S = draws_mu[(steps - 1) % ndraw], draws_S[(steps - 1) % ndraw]
   gmu1, gS1 = ops.moment_match_backward(pm, mu, S, g1, g2, g3, True, True)
   same = float((gmu1 - gmu).abs().amax()) <= 1e-12 * float(gmu1.abs().amax()) and float((gS1 - gS).abs().amax()) <= 1e-12 * float(gS1.abs().amax())
+  # the product's default for a differentiating caller: value AND sums from one pair of sweeps, then the chain rule alone
+  def one_sweep_step(k, ev=None):
+    mu_k, S_k = draws_mu[k % ndraw], draws_S[k % ndraw]
+    if ev: ev[0].record()
+    f1_, Sff_, cr_, sums_, g_ = ops.moment_match_with_sums(pm, mu_k, S_k)
+    if ev: ev[1].record()
+    gm_, gS_ = ops.moment_match_backward(pm, mu_k, S_k, g1, g2, g3, True, True, forward_generation=g_, sums=sums_)
+    if ev: ev[2].record()
+    return Sff_, gm_, gS_
+  one_sweep_step(0)
+  evs1 = []
+  for k in range(steps):
+    ev = [Ev() for _ in range(3)]
+    Sff1, gm1, gS1s = one_sweep_step(k, ev)
+    evs1.append(ev)
+  torch.cuda.synchronize()
+  os_fwd = sum(e[0].elapsed_time(e[1]) for e in evs1) / steps
+  os_bwd = sum(e[1].elapsed_time(e[2]) for e in evs1) / steps
+  one_sweep = {"value_and_sums_ms": round(os_fwd, 4), "chain_rule_ms": round(os_bwd, 4), "total_ms": round(os_fwd + os_bwd, 4),
+               "over_forward": round((os_fwd + os_bwd) / seg["forward"], 2),
+               "Sff_max_diff_over_scale_vs_forward": float((Sff1 - Sff).abs().amax() / Sff.abs().amax()),
+               "gradient_equals_two_pass": bool(torch.equal(gm1, gmu) and torch.equal(gS1s, gS)),
+               "what": "mm_moment_match_with_sums + mm_moment_match_backward(MM_SUMS_CURRENT): the backward's sweeps do not depend on the "
+                       "incoming gradient and contain the forward's sums, so value + gradient need ONE diagonal and ONE off-diagonal "
+                       "sweep (autodiff.MomentMatchFunction's default); the timed region above is the two-pass form, stage by stage"}
   Po, Mp = L * (L - 1) // 2, -(-M // 128) * 128
   nmono = 1 + d + d * (d + 1) // 2
   e_off = float(B) * Po * M * M
@@ -1017,7 +1049,9 @@ def grad_bench(args, rank, world, dev, dist):
                     "parallelism": f"dp{world} over B ({scaling}); no collective on the data path",
                     "row": "SURVEY 8(f) f-1 -- not BASELINE.json's metric", "staged_equals_one_call": same,
                     "forward_ms": round(seg["forward"], 4), "backward_ms": round(ms - seg["forward"], 4),
-                    "backward_over_forward": round((ms - seg["forward"]) / seg["forward"], 2)},
+                    "backward_over_forward": round((ms - seg["forward"]) / seg["forward"], 2),
+                    "forward_backward_over_forward": round(ms / seg["forward"], 2),
+                    "one_sweep_value_and_gradient": one_sweep},
          "segments_ms": {k: round(v, 4) for k, v in seg.items()},
          "roofline": r_off, "roofline_other": r_diag}
   if not same:

@@ -27,6 +27,7 @@ MM_FORCE_WORST_TIER = 64
 MM_WORKSPACE_CURRENT = 128
 MM_FORCE_ROUTE = 256
 MM_NO_ROUTE = 512
+MM_SUMS_CURRENT = 1024
 
 ERRORS = {
     -1: "MM_E_ARG: NULL pointer or non-positive size",
@@ -100,6 +101,11 @@ SIGNATURES = {
                                            C.c_void_p, C.c_void_p, C.c_int,
                                            C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                            C.c_void_p, C.c_void_p]),
+    "mm_moment_match_with_sums": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                            C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                            C.c_void_p, C.c_void_p, C.c_void_p,
+                                            C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                            C.c_void_p, C.c_void_p]),
     "mm_backward_bytes": (C.c_size_t, [C.c_int] * 5),
     "mm_backward_sums": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),

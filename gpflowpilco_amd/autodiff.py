@@ -285,11 +285,21 @@ class MomentMatchFunction(torch.autograd.Function):
   ``moment_match_differentiable(..., backward_dtype=torch.float64)`` keeps the float64-pack backward reachable."""
 
   @staticmethod
-  def forward(ctx, mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty):
+  def forward(ctx, mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty, fused=True):
+    ctx.sums = None
+    ctx.pm_bwd, ctx.pre, ctx.flags = pm_bwd, pre, (full_output_cov, model_uncertainty)
+    if fused and pm_bwd is pm and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and mu.shape[0] > 0:
+      # value AND sums in one pass (mm_moment_match_with_sums): the backward's M x M sweeps do not depend on the incoming
+      # gradient and contain the forward's sums, so a call that will be differentiated runs THEM instead of the forward's
+      # sweeps and its backward is the chain rule alone.  The sums (C3 shape, B = 256: 0.5 GB) live on this node until its
+      # backward has run
+      f1, Sff, cross, ctx.sums, ctx.generation = ops.moment_match_with_sums(pm, mu, Sigma, full_output_cov=full_output_cov,
+                                                                            model_uncertainty=model_uncertainty)
+      ctx.save_for_backward(mu, Sigma)
+      return f1, Sff, cross
     f1, Sff, cross = ops.moment_match(pm, mu, Sigma, full_output_cov=full_output_cov,
                                       model_uncertainty=model_uncertainty)
     ctx.save_for_backward(mu, Sigma)
-    ctx.pm_bwd, ctx.pre, ctx.flags = pm_bwd, pre, (full_output_cov, model_uncertainty)
     # the backward may reuse the q stage this forward left on the workspace, if it runs on the same pack and nothing else
     # touches that workspace in between (ops.PackedModel.workspace_generation)
     ctx.generation = (pm.workspace_generation(mu.shape[0], ops.make_flags(full_output_cov, model_uncertainty))
@@ -305,17 +315,22 @@ class MomentMatchFunction(torch.autograd.Function):
     # native: M x M sweeps, M-sized moments and the d x d chain rule all on the device (mm_moment_match_backward);
     # moment_match_backward / _reference above are the torch forms it is tested against
     gmu, gS = ops.moment_match_backward(pmb, mub.contiguous(), Sb.contiguous(), g_f1, g_Sff, g_cross, full, unc,
-                                        forward_generation=ctx.generation)
-    return gmu.to(mu.dtype), gS.to(Sigma.dtype), None, None, None, None, None
+                                        forward_generation=ctx.generation, sums=ctx.sums)
+    ctx.sums = None
+    return gmu.to(mu.dtype), gS.to(Sigma.dtype), None, None, None, None, None, None
 
 
 def moment_match_differentiable(model, mu: torch.Tensor, Sigma: torch.Tensor, full_output_cov: bool = True,
-                                model_uncertainty: bool = True, backward_dtype: Optional[torch.dtype] = None):
+                                model_uncertainty: bool = True, backward_dtype: Optional[torch.dtype] = None,
+                                fused: bool = True):
   """(mu, Sigma) -> (f1, Sff, cross_pre) with gradients flowing back to (mu, Sigma).
 
   ``backward_dtype``: None = the forward's own pack where it has a backward (float64 models; float32 models with d <= 8,
   under the accuracy contract stated on ``MomentMatchFunction``), else a float64 pack of the model; ``torch.float64`` =
-  always differentiate through the float64 pack (every pair swept in f64: 2.3 x the time at C3 shape)."""
+  always differentiate through the float64 pack (every pair swept in f64: 2.3 x the time at C3 shape).
+  ``fused`` (default): when (mu, Sigma) require grad and the backward runs on the forward's own pack, the forward is
+  ``mm_moment_match_with_sums`` -- the backward's sweeps, run once, give the value too -- and the backward is the chain rule
+  alone; ``False`` keeps the two-pass form (forward's sweeps, then the backward's)."""
   if backward_dtype not in (None, torch.float64, mu.dtype):
     raise ValueError(f"backward_dtype must be None, torch.float64 or the state's dtype, got {backward_dtype}")
   pm = model.packed(dtype=mu.dtype, with_C=bool(model_uncertainty), device=mu.device)
@@ -324,7 +339,7 @@ def moment_match_differentiable(model, mu: torch.Tensor, Sigma: torch.Tensor, fu
     raise NotImplementedError("this pack has no backward of its own (float32 with d > 8): use backward_dtype=torch.float64")
   pm_bwd = pm if own else model.packed(dtype=torch.float64, with_C=bool(model_uncertainty), device=mu.device)
   pre = model._cache._pre
-  return MomentMatchFunction.apply(mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty)
+  return MomentMatchFunction.apply(mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty, bool(fused))
 
 
 def moment_match_torch(mu, Sigma, Z, ls, var, beta, C=None, mean_c=None, full_output_cov: bool = True,

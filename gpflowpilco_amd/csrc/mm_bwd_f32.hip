@@ -121,6 +121,10 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
   // tile -- sum over the tiles of (max|b|^3)^2 sum what'_j^2; rows' squares and the (1 + X + X^2) factor of rho (X = the lane's
   // largest |b|) once per sweep
   float est = 0.0f, xall = 0.0f;
+  // slot 0 (psi = 1) ALSO in plain f32: the row sums sum_j V_ij feed the forward VALUE when the caller takes it from this sweep
+  // (mm_moment_match_with_sums); through the bf16 (hi, lo) split they carry 2^-18 per entry -- 4x the forward sweep's error on the
+  // off-diagonal covariances at C3 -- so the lane keeps the exact f32 sum of its 16 columns per tile beside the MFMA product
+  float rsum[2] = {0.f, 0.f};
 
   f32x16 acc2[2][2];
 #pragma unroll
@@ -219,6 +223,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x2 val = v[4 * s + q];
+            rsum[rt] += val[0] + val[1];
             const unsigned int hi = mmr_pk_bf16(val);
             vh[s][q] = hi;
             vl[s][q] = mmr_pk_bf16(val - mmr_unpk_bf16(hi));
@@ -298,6 +303,15 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
 #pragma unroll
       for (int r = 0; r < 16; ++r) Bm[(32 * rt + 8 * (r >> 2) + 4 * h + (r & 3)) * MMR_BS + l31] = acc2[rt][nb][r];
     wave_sync();
+    if (nb == 0) {                              // slot 0 from the plain f32 row sums (the lane's half of the columns + the other half's)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        double t = (double)rsum[rt];
+        t += __shfl_xor(t, 32, 64);
+        if (h == 0) Bm[(32 * rt + l31) * MMR_BS] = (float)t;
+      }
+      wave_sync();
+    }
     for (int c = lane; c < ncomb; c += 64) {
       int kind, k = 0, k2 = 0, slot;
       if (c < nslot) { kind = 0; slot = c; }

@@ -37,6 +37,8 @@ extern "C" void mm_stage_profile_set_bwd(void* device_buffer) {
 #define MMB_PROF_CTX(c_) do {} while (0)
 #endif
 
+enum { MMB_MODE_ALL = 0, MMB_MODE_SWEEPS = 1, MMB_MODE_CHAIN = 2 };
+
 #define MMB_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -176,8 +178,14 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
                                          const void* g_f1, const void* g_Sff, const void* g_cross,
                                          void* g_mu, void* g_Sigma, int accumulate_Sigma,
                                          void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
-                                         int32_t* status, void* stream, bool workspace_is_current, bool skip_sum = false) {
-  if (!packed || !mu || !Sigma || !g_f1 || !g_Sff || !g_cross || !g_mu || !g_Sigma || !workspace || !bwd_ws) return MM_E_ARG;
+                                         int32_t* status, void* stream, bool workspace_is_current, bool skip_sum = false,
+                                         int mode = MMB_MODE_ALL) {
+  // mode: MMB_MODE_ALL = sweeps + chain rule; MMB_MODE_SWEEPS = everything that does NOT depend on the incoming gradient (the two
+  // M x M sweeps, the full moment GEMM, the pair aggregates: mm_moment_match_with_sums leaves them on bwd_ws);
+  // MMB_MODE_CHAIN = the chain rule alone on sums a MMB_MODE_SWEEPS call left on bwd_ws (MM_SUMS_CURRENT)
+  const bool do_sweeps = mode != MMB_MODE_CHAIN, do_chain = mode != MMB_MODE_SWEEPS;
+  if (!packed || !mu || !Sigma || !workspace || !bwd_ws) return MM_E_ARG;
+  if (do_chain && (!g_f1 || !g_Sff || !g_cross || !g_mu || !g_Sigma)) return MM_E_ARG;
   if (L <= 0 || M <= 0 || d <= 0 || B <= 0) return MM_E_ARG;
   if (d > MM_DMAX) return MM_E_DIM;
   if (dtype != MM_F64 && dtype != MM_F32) return MM_E_DTYPE;
@@ -185,7 +193,7 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
   // MM_STAGE_* (measurement, as in mm_Q_reduce_forward): DIAG = the f64 sweep (f64 packs: of every pair), OFFDIAG = the f32
   // remainder sweep, FINALIZE = everything M-sized and smaller (moment GEMM, aggregates, item moments, items, sum)
   int stages = flags & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE);
-  if (!stages) stages = MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE;
+  if (!stages || mode != MMB_MODE_ALL) stages = MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE;
   flags &= ~(MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE);
   if (f32 && !mm_bwd_f32_supported(d)) return MM_E_DTYPE;     // d > 8: differentiate through an f64 pack of the model
   const MMGpBwdLayout bl = mm_gp_bwd_layout(B, L, M, d, dtype, flags);
@@ -222,22 +230,24 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     if (rc) return rc;
     mu64 = (const double*)(bw + bl.mu64);
     S64 = (const double*)(bw + bl.S64);
-    if (stages & MM_STAGE_DIAG) {
+    if (do_sweeps && (stages & MM_STAGE_DIAG)) {
       rc = mm_backward_sums_impl(pk, ml, ws, wl, L, M, d, B, mu64, flags, with_unc, true, (double*)(bw + bl.sums), s);
       if (rc) return rc;
     }
     if (wl.Po > 0) {
-      rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)(bw + bl.slab),
-                                     (double*)(bw + bl.pagg), status, s, stages);
-      if (rc) return rc;
+      if (do_sweeps) {
+        rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)(bw + bl.slab),
+                                       (double*)(bw + bl.pagg), status, s, stages);
+        if (rc) return rc;
+      }
       pagg = (const double*)(bw + bl.pagg);
     }
-  } else if (stages & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG)) {
+  } else if (do_sweeps && (stages & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG))) {
     rc = mm_backward_sums(packed, packed_bytes, L, M, d, dtype, B, mu, flags, workspace, workspace_bytes, bw + bl.sums,
                           mm_backward_bytes(B, L, M, d, flags), stream);
     if (rc) return rc;
   }
-  if (!(stages & MM_STAGE_FINALIZE)) return 0;
+  if (!do_chain || !(stages & MM_STAGE_FINALIZE)) return 0;
   const int col_pairs = f32 ? L : P;
   const double* col = (const double*)(bw + bl.sums);
   const double* row = col + (size_t)B * P * (3 + d) * Mp;       // (f64 packs; not read with aggregates)
@@ -280,9 +290,92 @@ extern "C" int mm_moment_match_backward(const void* packed, size_t packed_bytes,
                                         void* g_mu, void* g_Sigma, int accumulate_Sigma,
                                         void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
                                         int32_t* status, void* stream) {
-  return mm_moment_match_backward_impl(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags & ~MM_WORKSPACE_CURRENT, g_f1, g_Sff,
+  return mm_moment_match_backward_impl(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma,
+                                       flags & ~(MM_WORKSPACE_CURRENT | MM_SUMS_CURRENT), g_f1, g_Sff,
                                        g_cross, g_mu, g_Sigma, accumulate_Sigma, workspace, workspace_bytes, bwd_ws, bwd_ws_bytes,
-                                       status, stream, (flags & MM_WORKSPACE_CURRENT) != 0);
+                                       status, stream, (flags & MM_WORKSPACE_CURRENT) != 0, false,
+                                       (flags & MM_SUMS_CURRENT) ? MMB_MODE_CHAIN : MMB_MODE_ALL);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Value AND sums in one pass.  Nothing the backward's M x M sweeps compute depends on the incoming gradient: the column sums of
+// the diagonal pairs (K, c, cC, U) and the off-diagonal aggregates are functions of the state alone, and they CONTAIN the forward's
+// sums:   Sff_aa = sum_j (w_j c_j + q_j cC_j) + var + jitter,   Sff_aa' = pagg[0] - (sum w)(sum w')   (f64 packs: sum_j w'_j c_j).
+// A caller that will differentiate therefore runs the q stage and the BACKWARD's sweeps once, reads the value off them, and its
+// backward is the chain rule alone (MM_SUMS_CURRENT) -- the forward's own two sweeps are never run.
+// ---------------------------------------------------------------------------------------------------------------------
+// one wave per (b, pair); col [B][col_pairs][3 + d][Mp]; w, q [B][L][Mp]
+template <typename T>
+__global__ __launch_bounds__(256) void k_sff_from_sums(const double* __restrict__ col, int col_pairs, const double* __restrict__ pagg,
+                                                       int nT, const double* __restrict__ w, const double* __restrict__ q,
+                                                       const double* __restrict__ f1raw, const double* __restrict__ var,
+                                                       int B, int L, int M, int Mp, int d, int P, int full, int with_unc,
+                                                       double jitter, T* __restrict__ Sff) {
+  const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (idx >= B * P) return;
+  const int b = idx / P, p = idx - b * P;
+  int a = p, a2 = p;
+  if (p >= L) { int r = p - L, i = 0; while (r >= L - 1 - i) { r -= L - 1 - i; ++i; } a = i; a2 = i + 1 + r; }
+  double s = 0.0;
+  if (p < col_pairs) {
+    const double* c = col + ((size_t)b * col_pairs + p) * (size_t)(3 + d) * Mp;
+    const double* w2 = w + ((size_t)b * L + a2) * Mp;
+    const double* q2 = q + ((size_t)b * L + a2) * Mp;
+    const bool cterm = (a == a2) && with_unc;
+    for (int j = lane; j < M; j += 64) {
+      s = fma(w2[j], c[(size_t)Mp + j], s);
+      if (cterm) s = fma(q2[j], c[(size_t)2 * Mp + j], s);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  } else {
+    s = pagg[((size_t)b * (P - L) + (p - L)) * nT] - f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a2];
+  }
+  if (lane != 0) return;
+  if (a == a2) {
+    if (with_unc) s += var[a];
+    s += jitter;
+    if (full) Sff[((size_t)b * L + a) * L + a] = (T)s; else Sff[(size_t)b * L + a] = (T)s;
+  } else {
+    Sff[((size_t)b * L + a) * L + a2] = (T)s;
+    Sff[((size_t)b * L + a2) * L + a] = (T)s;
+  }
+}
+
+extern "C" int mm_moment_match_with_sums(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                         const void* mu, const void* Sigma, int flags, double jitter,
+                                         void* f1, void* Sff, void* cross_pre,
+                                         void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
+                                         int32_t* status, void* stream) {
+  if (!packed || !mu || !Sigma || !f1 || !Sff || !cross_pre || !workspace || !bwd_ws) return MM_E_ARG;
+  if (L <= 0 || M <= 0 || d <= 0 || B <= 0) return MM_E_ARG;
+  if (d > MM_DMAX) return MM_E_DIM;
+  if (dtype != MM_F64 && dtype != MM_F32) return MM_E_DTYPE;
+  if (dtype == MM_F32 && !mm_bwd_f32_supported(d)) return MM_E_DTYPE;
+  flags &= ~(MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE | MM_WORKSPACE_CURRENT | MM_SUMS_CURRENT);
+  int rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, f1, cross_pre, nullptr, workspace, workspace_bytes,
+                        status, stream);
+  if (rc) return rc;
+  rc = mm_moment_match_backward_impl(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, nullptr, nullptr, nullptr, nullptr,
+                                     nullptr, 0, workspace, workspace_bytes, bwd_ws, bwd_ws_bytes, status, stream, true, false,
+                                     MMB_MODE_SWEEPS);
+  if (rc) return rc;
+  const bool f32 = dtype == MM_F32;
+  const MMGpBwdLayout bl = mm_gp_bwd_layout(B, L, M, d, dtype, flags);
+  const MMModelLayout ml = mm_model_layout(L, M, d, dtype, 1);
+  const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
+  const char* bw = (const char*)bwd_ws; const char* ws = (const char*)workspace; const char* pk = (const char*)packed;
+  const int n = B * wl.P, full = (flags & MM_FULL_OUTPUT_COV) ? 1 : 0, with_unc = (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0;
+  hipStream_t s = (hipStream_t)stream;
+#define MM_SFF_LAUNCH(T_)                                                                                                        \
+  hipLaunchKernelGGL((k_sff_from_sums<T_>), dim3((n + 3) / 4), dim3(256), 0, s, (const double*)(bw + bl.sums), f32 ? L : wl.P,   \
+                     (f32 && wl.Po > 0) ? (const double*)(bw + bl.pagg) : (const double*)nullptr, mma_pair_agg_len(d),            \
+                     (const double*)(ws + wl.w64), (const double*)(ws + wl.q64), (const double*)(ws + wl.f1raw),                  \
+                     (const double*)(pk + ml.var), B, L, M, wl.Mp, d, wl.P, full, with_unc, jitter, (T_*)Sff)
+  if (f32) MM_SFF_LAUNCH(float); else MM_SFF_LAUNCH(double);
+#undef MM_SFF_LAUNCH
+  MMB_CHECK();
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -69,6 +69,10 @@ extern "C" {
  * sweep's result as it is: what rounds 1-3 returned). */
 #define MM_FORCE_ROUTE 256
 #define MM_NO_ROUTE 512
+/* mm_moment_match_backward only: `bwd_ws` holds the sums mm_moment_match_with_sums left for exactly this (mu, Sigma, flags):
+ * the M x M sweeps are not run again, the call is the chain rule alone.  Combine with MM_WORKSPACE_CURRENT when `workspace`
+ * is untouched as well; without it the q stage (only) is re-run. */
+#define MM_SUMS_CURRENT 1024
 
 /* error codes */
 #define MM_E_ARG      (-1)  /* NULL pointer / non-positive size                  */
@@ -264,6 +268,18 @@ int mm_moment_match_backward(const void* packed, size_t packed_bytes, int L, int
                              void* g_mu, void* g_Sigma, int accumulate_Sigma,
                              void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
                              int32_t* status, void* stream);
+/* Value AND gradient without sweeping twice (what tf.GradientTape + tape.gradient cost the reference together,
+ * utils/optimizers.py:51-56).  Nothing the backward's M x M sweeps compute depends on the incoming gradient, and their sums
+ * contain the forward's: Sff_aa = sum_j (w_j c_j + q_j cC_j) + var + jitter, Sff_aa' = pagg[0] - (sum w)(sum w').
+ * mm_moment_match_with_sums = mm_moment_match (same outputs, same types; Sff to the backward sweeps' accuracy, which is the
+ * forward's or better) computed from the q stage + the BACKWARD's sweeps, which stay on `bwd_ws`
+ * (mm_moment_match_backward_bytes_dtype); the matching mm_moment_match_backward(flags | MM_SUMS_CURRENT [| MM_WORKSPACE_CURRENT])
+ * on the same bwd_ws is then the chain rule alone.  MM_F32 packs need d <= 8 (MM_E_DTYPE otherwise). */
+int mm_moment_match_with_sums(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                              const void* mu, const void* Sigma, int flags, double jitter,
+                              void* f1, void* Sff, void* cross_pre,
+                              void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
+                              int32_t* status, void* stream);
 
 /* ---- pathwise (decoupled-sampling) rollout: SURVEY.md row f-3, BASELINE.json configs[4] ---------
  * f[s,a] = scale_a sum_k w[s,a,k] cos(2 pi (omega_t[a,:,k].x_s + phase[a,k]))

@@ -1,0 +1,99 @@
+"""Value and gradient from ONE pair of M x M sweeps (``mm_moment_match_with_sums`` + ``MM_SUMS_CURRENT``):
+the backward's sweeps do not depend on the incoming gradient and contain the forward's sums.  The value must equal the plain
+forward's (and the oracle's), the gradient the two-pass backward's, for both pack types."""
+import numpy as np
+import pytest
+import torch
+
+from gpflowpilco_amd import autodiff, ops
+from gpflowpilco_amd.synthetic import make_inputs, make_svgp
+from oracle import mm_oracle as mo
+from tests.helpers import oracle_params, to_dev
+
+pytestmark = pytest.mark.gpu
+F64 = torch.float64
+
+SHAPES = [((3, 200, 8, 3), True, True), ((1, 150, 4, 2), True, True), ((4, 130, 3, 5), False, True),
+          ((2, 520, 8, 2), True, False), ((3, 77, 5, 1), True, True)]
+IDS = ["L3d8", "L1", "diag_only_cov", "no_model_unc", "M77B1"]
+
+
+def _setup(shape, dtype, device, seed=11):
+  L, M, d, B = shape
+  syn = make_svgp(L, M, d, seed=seed + L + d, device=str(device), ls_bounds=(0.5, 2.5))
+  model = syn.to_model(device)
+  mu, S = make_inputs(B, d, seed=seed, scale=0.1, lo=0.2, hi=0.8)
+  mu, S = to_dev(mu, device, dtype), to_dev(S, device, dtype)
+  return syn, model, mu, S
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("shape,full,unc", SHAPES, ids=IDS)
+def test_value_from_the_backward_sweeps_equals_the_forward(shape, full, unc, dtype, device):
+  syn, model, mu, S = _setup(shape, dtype, device)
+  pm = model.packed(dtype, unc, device)
+  f1, Sff, cross = ops.moment_match(pm, mu, S, full, unc)
+  g1, Sgg, gcross, sums, gen = ops.moment_match_with_sums(pm, mu, S, full, unc)
+  pm.check_status(mu.shape[0])
+  assert torch.equal(f1, g1) and torch.equal(cross, gcross)                    # the same q stage
+  scale = float(Sff.abs().max())
+  tol = 1e-9 if dtype == torch.float64 else 2e-6      # f64: two summation orders of the C-weighted sums (|C| ~ 1e6)
+  assert float((Sff - Sgg).abs().max()) <= tol * scale, (float((Sff - Sgg).abs().max()), scale)
+  # and the oracle (literal restatement of the reference), at the state the kernels saw
+  o1, oS, _ = mo.mm_gauss_svgp_mo(mu.double().cpu().numpy(), S.double().cpu().numpy(), oracle_params(syn),
+                                  full_output_cov=full, model_uncertainty=unc)
+  otol = 1e-6 if dtype == torch.float64 else 2e-5
+  assert np.abs(Sgg.double().cpu().numpy() - oS).max() <= otol * max(scale, np.abs(oS).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("shape,full,unc", SHAPES, ids=IDS)
+def test_chain_rule_on_kept_sums_equals_the_two_pass_backward(shape, full, unc, dtype, device):
+  syn, model, mu, S = _setup(shape, dtype, device, seed=23)
+  pm = model.packed(dtype, unc, device)
+  B, L, d = mu.shape[0], pm.L, pm.d
+  gen = torch.Generator(device="cpu").manual_seed(5)
+  g_f1 = torch.randn(B, L, generator=gen, dtype=F64).to(device)
+  g_Sff = torch.randn((B, L, L) if full else (B, L), generator=gen, dtype=F64).to(device)
+  g_cross = torch.randn(B, d, L, generator=gen, dtype=F64).to(device)
+  ref_mu, ref_S = ops.moment_match_backward(pm, mu, S, g_f1, g_Sff, g_cross, full, unc)
+  _, _, _, sums, generation = ops.moment_match_with_sums(pm, mu, S, full, unc)
+  gmu, gS = ops.moment_match_backward(pm, mu, S, g_f1, g_Sff, g_cross, full, unc, forward_generation=generation, sums=sums)
+  pm.check_status(B)
+  assert torch.equal(gmu, ref_mu) and torch.equal(gS, ref_S)                   # the same sweeps, the same chain rule
+  # another match on the pack's workspace in between: the q stage is re-run, the kept sums are still this state's
+  _, _, _, sums, generation = ops.moment_match_with_sums(pm, mu, S, full, unc)
+  ops.moment_match(pm, mu * 0.5, S * 2.0, full, unc)
+  gmu2, gS2 = ops.moment_match_backward(pm, mu, S, g_f1, g_Sff, g_cross, full, unc, forward_generation=generation, sums=sums)
+  pm.check_status(B)
+  assert torch.equal(gmu2, ref_mu) and torch.equal(gS2, ref_S)
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+def test_autograd_takes_the_fused_path_and_agrees_with_two_passes(dtype, device, monkeypatch):
+  syn, model, mu, S = _setup((3, 200, 8, 3), dtype, device, seed=31)
+  calls = {"fused": 0, "plain": 0}
+  real_fused, real_plain = ops.moment_match_with_sums, ops.moment_match
+  monkeypatch.setattr(ops, "moment_match_with_sums", lambda *a, **k: (calls.__setitem__("fused", calls["fused"] + 1), real_fused(*a, **k))[1])
+  monkeypatch.setattr(ops, "moment_match", lambda *a, **k: (calls.__setitem__("plain", calls["plain"] + 1), real_plain(*a, **k))[1])
+
+  def loss_and_grad(fused):
+    m_, S_ = mu.clone().requires_grad_(True), S.clone().requires_grad_(True)
+    f1, Sff, cross = autodiff.moment_match_differentiable(model, m_, S_, True, True, fused=fused)
+    loss = (f1.double() ** 2).sum() + (Sff.double() * torch.arange(Sff.numel(), device=device, dtype=F64).reshape(Sff.shape).cos()).sum() \
+        + cross.double().sin().sum()
+    loss.backward()
+    return float(loss), m_.grad.clone(), S_.grad.clone()
+
+  l1, gm1, gS1 = loss_and_grad(True)
+  assert calls == {"fused": 1, "plain": 0}
+  l0, gm0, gS0 = loss_and_grad(False)
+  assert calls == {"fused": 1, "plain": 1}
+  tol = 1e-10 if dtype == torch.float64 else 2e-5
+  assert abs(l1 - l0) <= tol * abs(l0)
+  assert float((gm1 - gm0).abs().max()) <= tol * float(gm0.abs().max())
+  assert float((gS1 - gS0).abs().max()) <= tol * float(gS0.abs().max())
+  # no gradient asked for: the plain forward
+  with torch.no_grad():
+    autodiff.moment_match_differentiable(model, mu, S, True, True)
+  assert calls == {"fused": 1, "plain": 2}
