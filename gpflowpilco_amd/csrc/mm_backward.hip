@@ -16,7 +16,9 @@
 // Must follow mm_q_forward / mm_moment_match on the same workspace (w, q and the streamed operands).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <type_traits>
 #include "mm_common.h"
+#include "mm_exp_f64.h"
 
 __device__ __forceinline__ void mmb_decode_pair(int p, int L, int& a, int& a2) {
   if (p < L) { a = p; a2 = p; return; }
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
                                                      const double* __restrict__ w, const double* __restrict__ q,
                                                      const double* __restrict__ rowD, const double* __restrict__ colD,
                                                      const double* __restrict__ rowO, const double* __restrict__ colO,
-                                                     double* __restrict__ out, int B, int nwork) {
+                                                     double* __restrict__ out, int B, int nwork, int p0) {
   const int Po = P - L;
   // 1-D grid, XCD-aware (blocks i and i + 8 share an XCD: consecutive work items go to the same XCD), batch element fastest:
   // the B workgroups of one (pair, column tile) sweep the same 64-column strip of C_a (Mp x 64 doubles) at the same pace and
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
   const int b = wi % B, rest = wi / B;
   const int ntc = Mp / 64;
   const int jt = rest % ntc, lp = rest / ntc;
-  const int p = SWAP ? L + lp : lp;
+  const int p = SWAP ? L + lp : p0 + lp;               // (p0: the column sums of the pairs [p0, P); the diagonal ones have k_bwd_diag)
   int a, a2;
   mmb_decode_pair(p, L, a, a2);
   const bool diag = p < L;
@@ -439,6 +441,303 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Diagonal pairs (a == a'), factored form (the forward's: mm_f64.hip).  e^{delta_ij} = e^{rho_i} e^{gamma'_j} e^{b_ij} with the
+// rank-one parts in the workspace's factored weights qhR_i = u_i e^{rho_i}, qhC_j = u_j e^{gamma'_j} (u = q with model
+// uncertainty, w without), so the polynomial argument is b_ij = zc_i . g_j alone (lower range tiers, no accumulator
+// initialisation, e^b directly instead of expm1 + 1) and every sum is taken WITHOUT the column's factor, applied once per
+// column at the end:
+//     t_ij = qhR_i e^{b_ij}
+//     with C:    S_j = sum_i beta_i t_ij,  Cs_j = sum_i C_ij t_ij,  om_ij = (C_ij + beta_i beta_j) t_ij
+//                c_j = e^{gamma'_j} S_j - sum_i w_i,   cC_j = e^{gamma'_j} Cs_j,   (K_j | U_j) = qhC_j sum_i om_ij (1 | zc_i)
+//     without:   om_ij = t_ij (qhR = w_i e^{rho_i}),  c_j = e^{gamma'_j} sum_i t_ij - sum_i w_i,  (K_j | U_j) = qhC_j sum_i t_ij (1 | zc_i)
+// Per entry: the tier polynomial (5 ... 12 FMAs) + 5 operations, against expm1 tiers on |delta| (7 ... 15) + 7 before.
+// LOWP (f32 packs): the forward's near-minimax tiers (1e-15 absolute); f64 packs: Taylor tiers (2e-18), as the forward.
+// Same work decomposition, launch order and epilogue as k_bwd_mfma<., ., false>.
+// ---------------------------------------------------------------------------------------------
+#ifndef MMB_DIAG_WAVES
+#define MMB_DIAG_WAVES 2
+#endif
+// NB: batch elements per workgroup -- the C tile, beta_i, zc_i are the same for every batch element; a workgroup that sweeps for
+// NB of them issues those loads once (grid: ceil(B / NB) groups; an odd last group repeats its element and writes it once).
+// Measured at C3 shape, B = 256 (same box): NB 1 at two waves per SIMD (205 VGPRs) 14.6 ms; NB 2 at two waves (256 VGPRs +
+// 192 B scratch) 17.1; NB 2 at one wave 20.8; NB 1 at three waves (168 VGPRs + 168 B scratch) 23.7 -- the default stays
+#ifndef MMB_DIAG_NB
+#define MMB_DIAG_NB 1
+#endif
+template <int KS4, int NU, bool WITHC, bool LOWP, int NB>
+__global__ __launch_bounds__(256, (NU >= 2 ? 1 : (KS4 <= 2 ? MMB_DIAG_WAVES : 2))) void k_bwd_diag(const double* __restrict__ Zc, int Kz,
+                                                     const double* __restrict__ zbar, const double* __restrict__ Cm,
+                                                     const double* __restrict__ beta, const double* __restrict__ mu,
+                                                     int L, int M, int Mp, int d, int P,
+                                                     const double* __restrict__ qhR, const double* __restrict__ qhC,
+                                                     const double* __restrict__ colD, const double* __restrict__ f1raw,
+                                                     double* __restrict__ out, int B, int nwork) {
+  const int orig = blockIdx.x;
+  const int xcd = orig & 7, slotx = orig >> 3;
+  const int qn = nwork >> 3, rn = nwork & 7;
+  const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slotx;
+  // (the divisions run on the vector unit: readfirstlane puts the work item's coordinates -- and every base pointer derived
+  // from them -- back into scalar registers, which is what lets the loads below take an SGPR base)
+  const int BG = (B + NB - 1) / NB;
+  const int bg = __builtin_amdgcn_readfirstlane(wi % BG), rest = wi / BG;
+  const int ntc = Mp / 64;
+  const int jt = __builtin_amdgcn_readfirstlane(rest % ntc), a = __builtin_amdgcn_readfirstlane(rest / ntc);
+  const int lane = threadIdx.x & 63, l15 = lane & 15, kq = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int rh = wv >> 1, cw = wv & 1;
+  const int cbase = jt * 64 + cw * 32;
+  const int nt = Mp / 64;
+
+  int bb[NB];
+  const double* gcol[NB];
+  const double* qR[NB];
+#pragma unroll
+  for (int e = 0; e < NB; ++e) {
+    bb[e] = bg * NB + e < B ? bg * NB + e : B - 1;
+    gcol[e] = colD + ((size_t)bb[e] * L + a) * (size_t)(d + 1) * Mp;
+    qR[e] = qhR + ((size_t)bb[e] * L + a) * Mp;
+  }
+  const double* zc_a = Zc + (size_t)a * Mp * Kz;
+  const double* be = beta + (size_t)a * M;
+  const double* Ca = WITHC ? Cm + (size_t)a * Mp * Mp : nullptr;
+
+  double bfix[NB][2][KS4], bcol[2];
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    const int col = cbase + ct * 16 + l15;
+#pragma unroll
+    for (int e = 0; e < NB; ++e)
+#pragma unroll
+      for (int s = 0; s < KS4; ++s) {
+        const int k = 4 * s + kq;
+        const double v = gcol[e][(size_t)(k < d ? k : d) * Mp + col];
+        bfix[e][ct][s] = (k < d) ? v : 0.0;
+      }
+    bcol[ct] = (WITHC && col < M) ? be[col] : 0.0;
+  }
+  f64x4b Uacc[NB][2][NU];
+  double pS[NB][2], pC[NB][2];
+#pragma unroll
+  for (int e = 0; e < NB; ++e)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u) Uacc[e][ct][u] = (f64x4b){0.0, 0.0, 0.0, 0.0};
+      pS[e][ct] = 0.0; pC[e][ct] = 0.0;
+    }
+  double zmul[NU], zadd[NU];
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    const int k = 16 * u + l15;
+    zmul[u] = (k < d && k < Kz) ? 1.0 : 0.0;
+    zadd[u] = (k == d) ? 1.0 : 0.0;
+  }
+  // Addresses: every load of the sweep is  (uniform base, advanced per iteration by scalar adds) [per-lane 32-bit offset, fixed
+  // for the whole sweep] + a compile-time constant  (global_load with an SGPR base): the per-load 64-bit index arithmetic of
+  // the first version was ~120 integer VALU instructions per iteration
+  unsigned int offA[KS4], offZ[NU];
+#pragma unroll
+  for (int s = 0; s < KS4; ++s) { const int k = 4 * s + kq; offA[s] = (unsigned)((rh * 32 + l15) * Kz + (k < Kz ? k : Kz - 1)); }
+#pragma unroll
+  for (int u = 0; u < NU; ++u) { const int k = 16 * u + l15; offZ[u] = (unsigned)((rh * 32 + kq) * Kz + (k < Kz ? k : Kz - 1)); }
+  const unsigned int offR = (unsigned)(rh * 32 + kq);                                   // rows kq + 4 r of the wave's half
+  const unsigned int offC = (unsigned)((rh * 32 + kq) * Mp + cbase + l15);
+  auto load_first = [&](int it, double (&ar)[2][KS4]) {
+    const double* zu = zc_a + (size_t)it * 64 * Kz;                                     // uniform
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int s = 0; s < KS4; ++s) ar[rt][s] = (zu + rt * 16 * Kz)[offA[s]];
+  };
+  double arow_n[2][KS4];
+  load_first(0, arow_n);
+
+  // TAIL: the row tile reaches beyond M (beta is not padded): clamped, masked loads there, plain ones in the body of the sweep
+  auto sweep_tile = [&](int it, auto tail_tag) {
+    constexpr bool tail = decltype(tail_tag)::value;
+    const double* bu = be + it * 64;                                                     // uniform bases of this row tile
+    const double* zu = zc_a + (size_t)it * 64 * Kz;
+    const double* cu = WITHC ? Ca + (size_t)it * 64 * Mp : nullptr;
+    double arow[2][KS4], rq[NB][2][4], rb_[2][4];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+#pragma unroll
+      for (int s = 0; s < KS4; ++s) arow[rt][s] = (4 * s + kq < Kz) ? arow_n[rt][s] : 0.0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int e = 0; e < NB; ++e) rq[e][rt][r] = (qR[e] + it * 64 + rt * 16 + 4 * r)[offR];
+        if (WITHC) {
+          if (!tail) rb_[rt][r] = (bu + rt * 16 + 4 * r)[offR];
+          else {
+            const int row = it * 64 + rh * 32 + rt * 16 + kq + 4 * r;
+            const double bv = be[row < M ? row : M - 1];
+            rb_[rt][r] = row < M ? bv : 0.0;
+          }
+        }
+      }
+    }
+    double creg[2][2][4], zB[NU][8];
+    if (WITHC) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) creg[rt][ct][r] = (cu + (size_t)(rt * 16 + 4 * r) * Mp + ct * 16)[offC];
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const double zv = (zu + ((i >> 2) * 16 + 4 * (i & 3)) * Kz)[offZ[u]];
+        zB[u][i] = fma(zv, zmul[u], zadd[u]);
+      }
+    load_first(it + 1 < nt ? it + 1 : it, arow_n);
+#pragma unroll
+    for (int e = 0; e < NB; ++e) {
+      f64x4b acc[2][2];
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          f64x4b c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int s = 0; s < KS4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[rt][s], bfix[e][ct][s], c, 0, 0, 0);
+          acc[rt][ct] = c;
+        }
+      unsigned int mxh = 0u;
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double av = acc[rt][ct][r];
+            const unsigned int ah = (unsigned int)__double2hiint(av) & 0x7fffffffu;
+            mxh = ah > mxh ? ah : mxh;
+          }
+#define MMB_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))
+      const int tier = !__any(mxh >= MMB_HI32(0.015625)) ? 0 : !__any(mxh >= MMB_HI32(0.03125)) ? 1
+                     : !__any(mxh >= MMB_HI32(0.0625)) ? 2 : !__any(mxh >= MMB_HI32(0.125)) ? 3
+                     : !__any(mxh >= MMB_HI32(0.25)) ? 4 : !__any(mxh >= (LOWP ? MMB_HI32(0.75) : MMB_HI32(0.5))) ? 5 : 6;
+#undef MMB_HI32
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) {
+        double x[8], ex[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = acc[i >> 2][ct][i & 3];
+        // e^x of the 8 entries, Horner steps vertical (independent FMAs)
+#define MMB_POLYC(N_, TBL_)                                                                                         \
+        { _Pragma("unroll") for (int i = 0; i < 8; ++i) ex[i] = fma(MMExpMM::TBL_[N_ - 1], x[i], MMExpMM::TBL_[N_ - 2]); \
+          _Pragma("unroll") for (int k = N_ - 3; k >= 0; --k)                                                        \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) ex[i] = fma(ex[i], x[i], MMExpMM::TBL_[k]);                 \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) ex[i] = fma(ex[i], x[i], 1.0); }
+#define MMB_POLYT(DEG_)                                                                                             \
+        { _Pragma("unroll") for (int i = 0; i < 8; ++i) ex[i] = fma(mmb_inv_fact(DEG_), x[i], mmb_inv_fact(DEG_ - 1)); \
+          _Pragma("unroll") for (int k = DEG_ - 2; k >= 1; --k)                                                      \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) ex[i] = fma(ex[i], x[i], mmb_inv_fact(k));                  \
+          _Pragma("unroll") for (int i = 0; i < 8; ++i) ex[i] = fma(ex[i], x[i], 1.0); }
+        constexpr bool MMX = LOWP && MM_LOWP_MINIMAX;
+        if (tier == 0) { if (MMX) MMB_POLYC(5, t0) else MMB_POLYT(7) }
+        else if (tier == 1) { if (MMX) MMB_POLYC(6, t1) else MMB_POLYT(8) }
+        else if (tier == 2) { if (MMX) MMB_POLYC(7, t2) else MMB_POLYT(9) }
+        else if (tier == 3) { if (MMX) MMB_POLYC(8, t3) else MMB_POLYT(10) }
+        else if (tier == 4) { if (MMX) MMB_POLYC(9, t4) else MMB_POLYT(12) }
+        else if (tier == 5) { if (MMX) MMB_POLYC(12, t5) else MMB_POLYT(15) }
+        else {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ex[i] = mm_exp_f64(x[i]);
+        }
+#undef MMB_POLYC
+#undef MMB_POLYT
+        double om[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const double t = rq[e][i >> 2][i & 3] * ex[i];
+          if (WITHC) {
+            const double cij = creg[i >> 2][ct][i & 3], bi = rb_[i >> 2][i & 3];
+            pS[e][ct] = fma(bi, t, pS[e][ct]);
+            pC[e][ct] = fma(cij, t, pC[e][ct]);
+            om[i] = fma(bi, bcol[ct], cij) * t;
+          } else {
+            om[i] = t;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            Uacc[e][ct][u] = __builtin_amdgcn_mfma_f64_16x16x4f64(om[i], zB[u][i], Uacc[e][ct][u], 0, 0, 0);
+      }
+    }
+  };
+  const int nt_full = M / 64;
+  for (int it = 0; it < nt_full; ++it) sweep_tile(it, std::false_type{});
+  for (int it = nt_full; it < nt; ++it) sweep_tile(it, std::true_type{});
+
+  __shared__ double Us[2][2][2][NU][4][64];      // [rh][cw][ct][u][r][lane]
+  __shared__ double Ps[2][2][2][2][64];          // [which][rh][cw][ct][lane]
+#pragma unroll
+  for (int e = 0; e < NB; ++e) {
+    if (e > 0) {
+      if (bg * NB + e >= B) break;                 // (uniform) the odd last group's repeated element
+      __syncthreads();
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+#pragma unroll
+      for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Us[rh][cw][ct][u][r][lane] = Uacc[e][ct][u][r];
+      Ps[0][rh][cw][ct][lane] = pS[e][ct];
+      Ps[1][rh][cw][ct][lane] = pC[e][ct];
+    }
+    __syncthreads();
+    const int b = bb[e];
+    const double* qC = qhC + ((size_t)b * L + a) * Mp;
+    double* o = out + ((size_t)b * P + a) * (size_t)(3 + d) * Mp;      // out [B][P][3 + d][Mp]: the diagonal pairs are the first L
+    const double F = f1raw[(size_t)b * L + a];
+    // U / K (and, without C, c from K): D layout of the transposed product: lane (l15 = k, kq), register r <-> column kq + 4 r
+    for (int idx = threadIdx.x; idx < 64 * (d + 1); idx += 256) {
+      const int c = idx & 63, k = idx >> 6;                   // k == d: K_j
+      const int ccw = c >> 5, cct = (c >> 4) & 1, j16 = c & 15, ckq = j16 & 3, cr = j16 >> 2;
+      const int u = k >> 4, kl = k & 15;
+      const int ln = 16 * ckq + kl, lnK = 16 * ckq + (d & 15), uK = d >> 4;
+      const int col = jt * 64 + c;
+      const double qc = qC[col];
+      const double val = Us[0][ccw][cct][u][cr][ln] + Us[1][ccw][cct][u][cr][ln];
+      if (k == d) {
+        o[col] = qc * val;
+        if (!WITHC) {
+          o[(size_t)Mp + col] = fma(exp(fmin(gcol[e][(size_t)d * Mp + col], MM_EXP_CAP_F64)), val, -F);
+          o[(size_t)2 * Mp + col] = 0.0;
+        }
+      } else {
+        const double Kj = Us[0][ccw][cct][uK][cr][lnK] + Us[1][ccw][cct][uK][cr][lnK];
+        o[(size_t)(3 + k) * Mp + col] = qc * fma(zbar[a * d + k] - mu[(size_t)b * d + k], Kj, val);
+      }
+    }
+    if (WITHC && threadIdx.x < 64) {
+      const int c = threadIdx.x, ccw = c >> 5, cct = (c >> 4) & 1, cl = c & 15;
+      double sS = 0.0, sC = 0.0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          sS += Ps[0][h][ccw][cct][16 * g + cl];
+          sC += Ps[1][h][ccw][cct][16 * g + cl];
+        }
+      const int col = jt * 64 + c;
+      const double eg = exp(fmin(gcol[e][(size_t)d * Mp + col], MM_EXP_CAP_F64));
+      o[(size_t)Mp + col] = fma(eg, sS, -F);
+      o[(size_t)2 * Mp + col] = eg * sC;
+    }
+  }
+}
+
 extern "C" size_t mm_backward_bytes(int B, int L, int M, int d, int flags) {
   if (B <= 0 || L <= 0 || M <= 0 || d <= 0 || d > MM_DMAX) return 0;
   const int Mp = mm_round_up_int(M, MM_M_ALIGN), P = mm_num_pairs(L, flags), Po = P - L;
@@ -458,17 +757,35 @@ int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* w
     const double* Zc = (const double*)(pk + ml.Zc64);
     const double* zb = (const double*)(pk + ml.zbar);
     const int ks4 = (d + 3) / 4, nu = (d + 16) / 16;          // (d + 1) <= 16 nu
-    const long long nwc = (long long)(wl.Mp / 64) * Pk * B, nwr = (long long)(wl.Mp / 64) * Pok * B;
-    if (nwc > 0x7fffffffLL || nwr > 0x7fffffffLL) return MM_E_DIM;
-    const int nw_col = (int)nwc, nw_row = (int)nwr;
+    // diagonal pairs: k_bwd_diag (factored form); off-diagonal pairs of an f64 pack: column sums k_bwd_mfma<., ., false> from
+    // pair L on, row sums <., ., true>.  MM_FORCE_WORST_TIER keeps the unfactored kernel for every pair (its cross-check)
+    const bool old_diag = (flags & MM_FORCE_WORST_TIER) != 0;
+    const int pc0 = old_diag ? 0 : L;
+    const int nbd = nu == 1 ? MMB_DIAG_NB : 1, nbg = (B + nbd - 1) / nbd;       // batch elements per workgroup of k_bwd_diag
+    const long long nwd = (long long)(wl.Mp / 64) * L * nbg, nwc = (long long)(wl.Mp / 64) * (Pk - pc0) * B,
+                    nwr = (long long)(wl.Mp / 64) * Pok * B;
+    if (nwd > 0x7fffffffLL || nwc > 0x7fffffffLL || nwr > 0x7fffffffLL) return MM_E_DIM;
+    const int nw_diag = (int)nwd, nw_col = (int)nwc, nw_row = (int)nwr;
+    const bool lowp = diag_only;                       // the f32 packs (their diagonal pairs alone run here): the forward's LOWP tiers
 #define MMB_M_ARGS Zc, ml.Kz, zb, Cm, mu, L, wl.Mp, d, Pk, (const double*)(ws + wl.w64),                              \
                    (const double*)(ws + wl.q64), (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD),       \
                    (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO)
+#define MMB_D_ARGS Zc, ml.Kz, zb, Cm, (const double*)(pk + ml.beta64), mu, L, M, wl.Mp, d, Pk, (const double*)(ws + wl.qhR),  \
+                   (const double*)(ws + wl.qhC), (const double*)(ws + wl.colD), (const double*)(ws + wl.f1raw), out_col, B, nw_diag
+#define MMB_D_LAUNCH(KS_, NU_)                                                                                      \
+    do {                                                                                                            \
+      if (Cm && lowp) hipLaunchKernelGGL((k_bwd_diag<KS_, NU_, true, true, (NU_ == 1 ? MMB_DIAG_NB : 1)>), dim3(nw_diag), dim3(256), 0, s, MMB_D_ARGS);    \
+      else if (Cm) hipLaunchKernelGGL((k_bwd_diag<KS_, NU_, true, false, (NU_ == 1 ? MMB_DIAG_NB : 1)>), dim3(nw_diag), dim3(256), 0, s, MMB_D_ARGS);      \
+      else if (lowp) hipLaunchKernelGGL((k_bwd_diag<KS_, NU_, false, true, (NU_ == 1 ? MMB_DIAG_NB : 1)>), dim3(nw_diag), dim3(256), 0, s, MMB_D_ARGS);    \
+      else hipLaunchKernelGGL((k_bwd_diag<KS_, NU_, false, false, (NU_ == 1 ? MMB_DIAG_NB : 1)>), dim3(nw_diag), dim3(256), 0, s, MMB_D_ARGS);             \
+    } while (0)
 #define MMB_M_LAUNCH(KS_, NU_)                                                                                      \
     do {                                                                                                            \
-      hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, false>), dim3(nw_col), dim3(256), 0, s, MMB_M_ARGS, out_col, B, nw_col); \
+      if (!old_diag) MMB_D_LAUNCH(KS_, NU_);                                                                        \
+      if (nw_col > 0)                                                                                               \
+        hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, false>), dim3(nw_col), dim3(256), 0, s, MMB_M_ARGS, out_col, B, nw_col, pc0); \
       if (Pok > 0)                                                                                                  \
-        hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, true>), dim3(nw_row), dim3(256), 0, s, MMB_M_ARGS, out_row, B, nw_row); \
+        hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, true>), dim3(nw_row), dim3(256), 0, s, MMB_M_ARGS, out_row, B, nw_row, 0); \
     } while (0)
     if (ks4 <= 1) MMB_M_LAUNCH(1, 1);
     else if (ks4 == 2) MMB_M_LAUNCH(2, 1);
@@ -477,6 +794,8 @@ int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* w
     else if (ks4 <= 6) MMB_M_LAUNCH(6, 2);
     else MMB_M_LAUNCH(8, 2);
 #undef MMB_M_LAUNCH
+#undef MMB_D_LAUNCH
+#undef MMB_D_ARGS
 #undef MMB_M_ARGS
     hipError_t em = hipGetLastError();
     return em == hipSuccess ? 0 : (int)em;
