@@ -1036,7 +1036,7 @@ def grad_bench(args, rank, world, dev, dist):
   r_off["executed_mfma_frac_of_bf16_peak"] = (round(r_off["executed_mfma_tflops"] / PEAK_TFLOPS["bf16"], 4)
                                               if r_off["executed_mfma_tflops"] else None)
   r_off.pop("frac_null_reason", None)
-  r_diag = roofline_block("k_bwd_mfma", seg["bwd_diag_f64"], flops_diag, PEAK_TFLOPS["f64"], pmc, pmc_src, pscale, "f64", "k_bwd_mfma",
+  r_diag = roofline_block("k_bwd_diag", seg["bwd_diag_f64"], flops_diag, PEAK_TFLOPS["f64"], pmc, pmc_src, pscale, "f64", "k_bwd_diag",
                           "E_d (2d + 12 + 2 (d + 1) + 6): bilinear form, expm1, the column product Omega^T (zc | 1), the C-weighted sums; "
                           "E_d = B L M^2 (every entry: column sums use no symmetry)")
   r_diag.pop("frac_null_reason", None)

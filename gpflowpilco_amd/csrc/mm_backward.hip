@@ -759,7 +759,9 @@ int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* w
     const int ks4 = (d + 3) / 4, nu = (d + 16) / 16;          // (d + 1) <= 16 nu
     // diagonal pairs: k_bwd_diag (factored form); off-diagonal pairs of an f64 pack: column sums k_bwd_mfma<., ., false> from
     // pair L on, row sums <., ., true>.  MM_FORCE_WORST_TIER keeps the unfactored kernel for every pair (its cross-check)
-    const bool old_diag = (flags & MM_FORCE_WORST_TIER) != 0;
+    // ... and so do models of one or two column tiles (cartpole sizes: the sweeps are launch-bound there, and an f64 pack's diagonal and
+    // off-diagonal pairs are ONE launch of the unfactored kernel against two)
+    const bool old_diag = (flags & MM_FORCE_WORST_TIER) != 0 || (wl.Mp <= 128 && !diag_only);
     const int pc0 = old_diag ? 0 : L;
     const int nbd = nu == 1 ? MMB_DIAG_NB : 1, nbg = (B + nbd - 1) / nbd;       // batch elements per workgroup of k_bwd_diag
     const long long nwd = (long long)(wl.Mp / 64) * L * nbg, nwc = (long long)(wl.Mp / 64) * (Pk - pc0) * B,

@@ -70,6 +70,8 @@ struct MMTapeLayout {
   size_t slot_bytes;         // = mm_compose_layout(...).total
   size_t xm, xS;             // [H+1][B][nx], [H+1][B][nx][nx] T
   size_t ws, ws_stride;      // [H][ws_stride]: the drift match's workspace of every step (ws_stride = 0: not kept)
+  size_t gp, gp_stride;      // [H][gp_stride]: the drift match's backward buffer of every step with the SUMS of its sweeps on it
+                             // (mm_moment_match_with_sums; gp_stride = 0: not kept, the reverse sweep runs the sweeps itself)
   size_t total;
 };
 
@@ -89,6 +91,15 @@ static inline MMTapeLayout mm_tape_layout(int B, int H, int nx, int na, int drif
   const size_t wsb = mm_align_up(mm_workspace_layout(B, nx, drift_M, nx + na + 1, dtype, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY).total, A);
   o.ws = off; o.ws_stride = 0;
   if (wsb * (size_t)H <= MM_TAPE_WS_LIMIT) { o.ws_stride = wsb; off += wsb * (size_t)H; }
+  // ... and, where they fit too, the sums of the drift match's backward sweeps: nothing in them depends on the incoming
+  // gradient and they contain the forward's sums, so the taped forward runs THEM instead of the forward's two reduces
+  // (mm_moment_match_with_sums) and the reverse step is the chain rule alone -- two launches less per step and direction
+  o.gp = off; o.gp_stride = 0;
+  if (o.ws_stride) {
+    const size_t gpb = mm_align_up(mm_moment_match_backward_bytes_dtype(B, nx, drift_M, nx + na + 1, dtype,
+                                                                        MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY), A);
+    if (gpb && (wsb + gpb) * (size_t)H <= MM_TAPE_WS_LIMIT) { o.gp_stride = gpb; off += gpb * (size_t)H; }
+  }
   o.total = off;
   return o;
 }

@@ -211,7 +211,7 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, bw + bl.f1, bw + bl.cross, nullptr,
                       workspace, workspace_bytes, status, stream);
     if (rc) return rc;
-  } else if (status) {
+  } else if (status && mode != MMB_MODE_SWEEPS) {          // (SWEEPS: called by mm_moment_match_with_sums right after its own q stage)
     const int n = B * d;
     if (f32) hipLaunchKernelGGL((k_check_workspace_current<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)mu,
                                 (const double*)(ws + wl.mu64), B, d, status);
@@ -615,17 +615,20 @@ extern "C" int mm_rollout_composed_backward(const void* drift_packed, size_t dri
     MMB_CHECK();
     // the drift's match: (g df1, g dSff, g dcross) -> g md (assigned), g Sdd (accumulated onto the bookkeeping's part)
     const bool kept = tl.ws_stride != 0;                   // the tape holds this step's q-stage workspace
+    const bool sums = tl.gp_stride != 0;                   // ... and the sums of its backward sweeps: chain rule alone
     void* wsd = kept ? (void*)(const_cast<char*>(tp) + tl.ws + (size_t)h * tl.ws_stride) : ws_drift;
+    char* gslot = sums ? const_cast<char*>(tp) + tl.gp + (size_t)h * tl.gp_stride : gw;
     rc = mm_moment_match_backward_impl(drift_packed, drift_bytes, nx, drift_M, nd, dtype, B, sl + cl.md, sl + cl.Sdd, dflags,
                                        cr(kl.cdf1), cr(kl.cdSff), cr(kl.cdcross), cr(kl.cmd), cr(kl.cSdd), 1, wsd,
-                                       kept ? tl.ws_stride : ws_drift_bytes, gw, gp_bytes, status, stream, kept, true);
+                                       kept ? tl.ws_stride : ws_drift_bytes, gslot, sums ? tl.gp_stride : gp_bytes, status, stream,
+                                       kept, true, sums ? MMB_MODE_CHAIN : MMB_MODE_ALL);
     if (rc) return rc;
     hipLaunchKernelGGL(k_policy_head_bwd_small, dim3(B), dim3(256), lds_pol, s, policy_M, ne, head_scale, head_shift,
                        (const double*)(pp + pl.Z64), (const double*)(pp + pl.beta64), (const double*)(pp + pl.ls2),
                        (const double*)(pp + pl.var), (const double*)(sl + cl.me), (const double*)(sl + cl.See),
                        (const double*)(sl + cl.pf1), (const double*)(sl + cl.pSff), (const double*)(sl + cl.pcross),
                        (const double*)cr(kl.cmd), (const double*)cr(kl.cSdd), (const double*)cr(kl.ccp), cr(kl.cme), cr(kl.cSee),
-                       (double*)g_policy, status, (const double*)(gw + gbl.items), nx + nx * (nx + 1) / 2);
+                       (double*)g_policy, status, (const double*)(gslot + gbl.items), nx + nx * (nx + 1) / 2);
     MMB_CHECK();
   }
   if (g_mx0) {
