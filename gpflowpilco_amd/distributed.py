@@ -5,7 +5,9 @@ Every tensor of the hot path has B as an untouched leading axis
 the rollout shards cleanly: one process per GPU, a contiguous slice of B each, the model
 replicated, NO communication inside the H-step loop, and ONE all-gather of the per-step cost
 matrix ``[B_local, H] -> [B, H]`` after the rollout (``torch.distributed``: RCCL on GPUs,
-gloo in the CPU tests).  The reference has no distributed code; this is new design.
+gloo in the CPU tests).  The policy UPDATE over a sharded batch of initial states adds the one exchange a gradient step
+has: ONE all-reduce of (the policy-parameter gradient | loss sum) per evaluation -- a few hundred doubles, latency-bound
+(``distributed_loss_and_grad``).  The reference has no distributed code; this is new design.
 """
 from __future__ import annotations
 
@@ -57,3 +59,39 @@ def distributed_rollout_costs(rollout_fn: Callable, mu: torch.Tensor, Sigma: tor
   else:
     mu_l, S_l = mu, Sigma
   return gather_costs(rollout_fn(mu_l, S_l), B, group)
+
+
+def distributed_loss_and_grad(loss_fn: Callable, params, mu: torch.Tensor, Sigma: torch.Tensor, group=None):
+  """Mean policy loss over ALL B initial states and its gradient w.r.t. ``params`` (tensors that require grad), data
+  parallel: every rank evaluates ``loss_fn(mu_local, Sigma_local) -> per-element loss [B_local]`` on its contiguous shard
+  (the native closures of ``loops``: taped rollout + reverse sweep, no communication inside), then ONE all-reduce sums
+  the bucket (flattened gradients | local loss sum) over the ranks -- the reference's single-device
+  ``tape.gradient(loss, variables)`` (``utils/optimizers.py:51-56``) for a batch that does not fit one GPU.
+  Returns (loss, [grad per param]); identical on every rank.  Ragged and empty shards are handled (an empty shard
+  contributes zeros)."""
+  params = list(params)
+  B = mu.shape[0]
+  multi = dist.is_initialized() and dist.get_world_size(group) > 1
+  if multi:
+    mu_l, S_l = shard_batch(mu, Sigma, dist.get_rank(group), dist.get_world_size(group))
+  else:
+    mu_l, S_l = mu, Sigma
+  if mu_l.shape[0] > 0:
+    local = loss_fn(mu_l, S_l).sum()
+    grads = torch.autograd.grad(local, params, allow_unused=True)
+    grads = [torch.zeros_like(p) if g is None else g for g, p in zip(grads, params)]
+    local = local.detach()
+  else:
+    grads = [torch.zeros_like(p) for p in params]
+    local = torch.zeros((), dtype=params[0].dtype if params else mu.dtype, device=mu.device)
+  dtype = torch.float64
+  bucket = torch.cat([g.reshape(-1).to(dtype) for g in grads] + [local.reshape(1).to(dtype)])
+  if multi:
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
+  bucket = bucket / B
+  out, off = [], 0
+  for p in params:
+    n = p.numel()
+    out.append(bucket[off:off + n].reshape(p.shape).to(p.dtype))
+    off += n
+  return bucket[off], out

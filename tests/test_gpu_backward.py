@@ -379,6 +379,21 @@ def test_native_policy_gradient_at_H30_all_parameters_and_initial_state(device):
   for name, want, got in checks:
     assert abs(want - float(got)) < 2e-5 * max(1.0, abs(want)), (name, want, float(got))
 
+  # the data-parallel form of the same evaluation (distributed.distributed_loss_and_grad; one process here, two ranks with
+  # gloo in tests/test_distributed.py): mean loss over the batch and its gradient through the native differentiable op
+  from gpflowpilco_amd import distributed as D
+  from gpflowpilco_amd.loops import native_policy_loss
+  f = native_policy_loss(system, objective, H)
+  plist = list(params.values())
+  loss_d, g_d = D.distributed_loss_and_grad(f.with_grad, plist, m0.detach(), S0.detach())
+  for t in plist:
+    t.grad = None
+  lm = policy_loss_closure(system, objective, get_state_initializer(m0.detach(), S0.detach()), H, native=None)().mean()
+  lm.backward()
+  assert abs(float(loss_d) - float(lm)) < 1e-12 * max(1.0, abs(float(lm)))
+  for t, g in zip(plist, g_d):
+    assert float((t.grad - g).abs().max()) <= 1e-12 * max(1e-12, float(t.grad.abs().max()))
+
 
 def test_policy_update_with_native_gradients_lowers_the_loss(device):
   """The real caller (examples/cartpole_swingup/train_utils.py:91-105): Adam on the rollout loss.  Forward and backward are
