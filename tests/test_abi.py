@@ -30,7 +30,7 @@ def test_header_constants_match_python():
   text = open(HEADER).read()
   for name in ("MM_F32", "MM_F64", "MM_DMAX", "MM_M_ALIGN", "MM_FULL_OUTPUT_COV", "MM_MODEL_UNCERTAINTY",
                "MM_FORCE_GENERIC", "MM_STAGE_DIAG", "MM_STAGE_OFFDIAG", "MM_STAGE_FINALIZE",
-               "MM_FORCE_WORST_TIER"):
+               "MM_FORCE_WORST_TIER", "MM_WORKSPACE_CURRENT", "MM_FORCE_ROUTE", "MM_NO_ROUTE", "MM_SUMS_CURRENT"):
     m = re.search(rf"#define\s+{name}\s+(\d+)", text)
     assert m and int(m.group(1)) == getattr(_lib, name), name
 
@@ -114,3 +114,10 @@ def test_argument_validation_of_the_gradient_entry_points_without_gpu():
   assert lib.mm_moment_match_backward(*mb(mu=None)) == -1
   assert lib.mm_moment_match_backward(*mb(d=40)) == -2
   assert lib.mm_moment_match_backward(*mb()) == -4                                 # workspaces too small
+  # value + sums in one pass: the same checks as the two calls it stands for; the tape keeps the sums where they fit
+  ws = lambda dtype=F64, mu=p, d=4: (p, 64, 2, 16, d, dtype, 2, mu, p, 3, 0.0, p, p, p, p, 64, p, 64, None, None)
+  assert lib.mm_moment_match_with_sums(*ws(mu=None)) == -1 and lib.mm_moment_match_with_sums(*ws(d=40)) == -2
+  assert lib.mm_moment_match_with_sums(*ws(dtype=F32, d=12)) == -3                 # f32 packs: d <= 8 only
+  assert lib.mm_moment_match_with_sums(*ws()) == -4                                # workspaces too small
+  assert tape >= (31 * lib.mm_compose_workspace_bytes(1, 4, 1, F64) + 30 * lib.mm_workspace_bytes(1, 4, 100, 6, F64, 3)
+                  + 30 * lib.mm_moment_match_backward_bytes_dtype(1, 4, 100, 6, F64, 3))
