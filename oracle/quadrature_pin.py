@@ -12,7 +12,8 @@ module pins those cases by the DEFINITION the reference's Monte-Carlo estimator 
     Cov(x, f)  = E[(x - mu) F_mu(x)^T]
 
 evaluated with an n^d-node Gauss-Hermite rule in d = 2, 3 -- and in d = 4 on the reference's OWN three test designs at their own
-sizes (``reference_design`` / ``check_reference_design``: 24^4 nodes).  The integrands are sums of products of
+sizes (``reference_design`` / ``check_reference_design``: 24^4 nodes); the kernel expectations themselves on the reference's own
+kernel-expectation design (``check_kernel_expectation_design``: d = 2, 160^2 nodes, 1e-14).  The integrands are sums of products of
 squared-exponential kernels in x (entire functions), so the rule converges geometrically; the
 ``predict_f`` used is ``pin_oracle.svgp_predict_f`` / ``gpr_predict_f`` (gpflow's published
 conditional), which shares no kernel-expectation code with the moment-matching oracle.
@@ -211,8 +212,49 @@ def check_reference_design(kind, seed, n=24):
   return errs, scale
 
 
+def check_kernel_expectation_design(seed, n=160):
+  """The reference's kernel-expectation test (tests/test_kernel_expectation.py:51-93) at its own sizes -- d = 2, two SE kernels
+  with lengthscales log-uniform in [0.1, 10], 32 inducing points each (half drawn near the mode of p(x), half uniform), input
+  std 0.1, signal std 0.89 -- with its 1e6-sample Monte-Carlo estimate (accepted at 1e-2) replaced by the n^2-node Gauss-Hermite
+  rule of the SAME definitions:  <k(x, A)>,  <k(x, B)>,  <k2(A, x) k3(x, B)>  and the same-kernel  <k2(A, x) k2(x, A)>  (both
+  branches of utils/kernel_expectation.py:167-185).  -> max abs errors of the oracle's closed forms."""
+  rng = np.random.default_rng(seed)
+  mx = rng.standard_normal(2)
+  Sxx = po.generate_covariance(rng, 2, scale=0.10)
+
+  def kernel_and_inducing():
+    ls = np.exp(rng.uniform(np.log(0.1), np.log(10.0), size=2))
+    Z1 = po.draw_samples_mvn(rng, mx, 0.1 * Sxx, 16)
+    Z2 = rng.uniform(size=(16, 2))
+    return ls, np.concatenate([Z1, Z2], 0)
+  lsA, A = kernel_and_inducing()
+  lsB, Bz = kernel_and_inducing()
+  var = 0.89 ** 2
+  eA = mo.eKfu_se(mx[None], Sxx[None], A, lsA, var)[0]
+  eB = mo.eKfu_se(mx[None], Sxx[None], Bz, lsB, var)[0]
+  eAB = mo.eKuffu_se_pair(mx[None], Sxx[None], lsA, var, A, lsB, var, Bz, False, False)[0]
+  eAA = mo.eKuffu_se_pair(mx[None], Sxx[None], lsA, var, A, lsA, var, A, True, True)[0]
+  eAA2 = mo.eKuffu_se_pair(mx[None], Sxx[None], lsA, var, A, lsA, var, A, False, False)[0]
+  X, W = gauss_hermite_nodes(mx, Sxx, n)
+  KA = mo.se_kernel(A, X, lsA, var); KB = mo.se_kernel(Bz, X, lsB, var)           # [32, K]
+  errs = {'eKfu_A': np.abs(eA - KA @ W).max(), 'eKfu_B': np.abs(eB - KB @ W).max(),
+          'eKuffu_AB': np.abs(eAB - (KA * W[None]) @ KB.T).max(),
+          'eKuffu_AA_same_kernel_branch': np.abs(eAA - (KA * W[None]) @ KA.T).max(),
+          'eKuffu_AA_general_branch': np.abs(eAA2 - (KA * W[None]) @ KA.T).max()}
+  scale = {'eKfu': max(np.abs(eA).max(), np.abs(eB).max()), 'eKuffu': max(np.abs(eAB).max(), np.abs(eAA).max())}
+  return errs, scale
+
+
+KERNEL_EXPECTATION_SEEDS = (601, 602, 603)
+
+
 def main():
   ok = True
+  for seed in KERNEL_EXPECTATION_SEEDS:
+    errs, scale = check_kernel_expectation_design(seed)
+    print(f'[reference kernel-expectation design seed={seed} d=2 n=160] ' + ' '.join(f'{k}={v:.2e}' for k, v in errs.items()) +
+          '  | scale ' + ' '.join(f'{k}={v:.2e}' for k, v in scale.items()))
+    ok &= all(v <= 1e-12 for v in errs.values())
   for d, n in ((2, 60), (3, 40)):
     for kw in (dict(whiten=True), dict(whiten=True, model_uncertainty=False), dict(whiten=False),
                dict(whiten=False, lcm_outputs=4), dict(whiten=True, single_output=True)):
