@@ -212,12 +212,9 @@ def check_reference_design(kind, seed, n=24):
   return errs, scale
 
 
-def check_kernel_expectation_design(seed, n=160):
-  """The reference's kernel-expectation test (tests/test_kernel_expectation.py:51-93) at its own sizes -- d = 2, two SE kernels
-  with lengthscales log-uniform in [0.1, 10], 32 inducing points each (half drawn near the mode of p(x), half uniform), input
-  std 0.1, signal std 0.89 -- with its 1e6-sample Monte-Carlo estimate (accepted at 1e-2) replaced by the n^2-node Gauss-Hermite
-  rule of the SAME definitions:  <k(x, A)>,  <k(x, B)>,  <k2(A, x) k3(x, B)>  and the same-kernel  <k2(A, x) k2(x, A)>  (both
-  branches of utils/kernel_expectation.py:167-185).  -> max abs errors of the oracle's closed forms."""
+def kernel_expectation_design(seed):
+  """One draw of the reference's kernel-expectation test design (tests/test_kernel_expectation.py:51-93) at its own sizes
+  -> (mx [2], Sxx [2,2], lsA [2], A [32,2], lsB [2], B [32,2], variance)."""
   rng = np.random.default_rng(seed)
   mx = rng.standard_normal(2)
   Sxx = po.generate_covariance(rng, 2, scale=0.10)
@@ -229,7 +226,16 @@ def check_kernel_expectation_design(seed, n=160):
     return ls, np.concatenate([Z1, Z2], 0)
   lsA, A = kernel_and_inducing()
   lsB, Bz = kernel_and_inducing()
-  var = 0.89 ** 2
+  return mx, Sxx, lsA, A, lsB, Bz, 0.89 ** 2
+
+
+def check_kernel_expectation_design(seed, n=160):
+  """The reference's kernel-expectation test (tests/test_kernel_expectation.py:51-93) at its own sizes -- d = 2, two SE kernels
+  with lengthscales log-uniform in [0.1, 10], 32 inducing points each (half drawn near the mode of p(x), half uniform), input
+  std 0.1, signal std 0.89 -- with its 1e6-sample Monte-Carlo estimate (accepted at 1e-2) replaced by the n^2-node Gauss-Hermite
+  rule of the SAME definitions:  <k(x, A)>,  <k(x, B)>,  <k2(A, x) k3(x, B)>  and the same-kernel  <k2(A, x) k2(x, A)>  (both
+  branches of utils/kernel_expectation.py:167-185).  -> max abs errors of the oracle's closed forms."""
+  mx, Sxx, lsA, A, lsB, Bz, var = kernel_expectation_design(seed)
   eA = mo.eKfu_se(mx[None], Sxx[None], A, lsA, var)[0]
   eB = mo.eKfu_se(mx[None], Sxx[None], Bz, lsB, var)[0]
   eAB = mo.eKuffu_se_pair(mx[None], Sxx[None], lsA, var, A, lsB, var, Bz, False, False)[0]

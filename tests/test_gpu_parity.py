@@ -133,6 +133,44 @@ def test_stage_api_q_terms(device):
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("seed", [601, 603])
+def test_reference_kernel_expectation_design_on_the_gpu(seed, dtype, device):
+  """Rows a-4 / a-5 on the reference's OWN kernel-expectation design (tests/test_kernel_expectation.py:51-93: d = 2, two kernels,
+  32 inducing points each, lengthscales log-U[0.1, 10]; oracle/quadrature_pin.py pins the oracle's closed forms there to 1e-14):
+  the q terms <k(x, Z)> of both kernels through the stage API, and the pair expectation <k2(A, x) k3(x, B)> -- which the HIP
+  path never materialises -- through Sff = beta^T (<k k^T> - <k><k>^T) beta' with two random weight vectors."""
+  from oracle import quadrature_pin as qp
+  mx, Sxx, lsA, A, lsB, Bz, var = qp.kernel_expectation_design(seed)
+  rng = np.random.default_rng(seed + 1)
+  beta = rng.standard_normal((2, 32))
+  eA = mo.eKfu_se(mx[None], Sxx[None], A, lsA, var)[0]
+  eB = mo.eKfu_se(mx[None], Sxx[None], Bz, lsB, var)[0]
+  eAB = mo.eKuffu_se_pair(mx[None], Sxx[None], lsA, var, A, lsB, var, Bz, False, False)[0]
+  eAA = mo.eKuffu_se_pair(mx[None], Sxx[None], lsA, var, A, lsA, var, A, True, True)[0]
+  eBB = mo.eKuffu_se_pair(mx[None], Sxx[None], lsB, var, Bz, lsB, var, Bz, True, True)[0]
+  want = np.array([[beta[0] @ (eAA - np.outer(eA, eA)) @ beta[0], beta[0] @ (eAB - np.outer(eA, eB)) @ beta[1]],
+                   [0.0, beta[1] @ (eBB - np.outer(eB, eB)) @ beta[1]]])
+  want[1, 0] = want[0, 1]
+  t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=device)
+  pm = ops.pack_model(t64(np.stack([A, Bz])), t64(np.stack([lsA, lsB])), t64(np.full(2, var)), t64(beta), None, None, dtype=dtype)
+  mu_t, S_t = to_dev(mx[None], device, dtype), to_dev(Sxx[None], device, dtype)
+  flags = ops.make_flags(True, False)
+  f1, cross, q = ops.q_forward(pm, mu_t, S_t, flags, want_q=True)
+  Sff = ops.Q_reduce_forward(pm, 1, flags)
+  pm.check_status(1)
+  # the f32 pack sees the f32-rounded state: compare at it (lengthscales down to 0.1 make <k> sensitive to 1e-8 of x)
+  if dtype == torch.float32:
+    m32, S32 = mu_t.double().cpu().numpy()[0], S_t.double().cpu().numpy()[0]
+    eA = mo.eKfu_se(m32[None], S32[None], A, lsA, var)[0]; eB = mo.eKfu_se(m32[None], S32[None], Bz, lsB, var)[0]
+  qtol, stol = (1e-12, 1e-11) if dtype == torch.float64 else (2e-6, 2e-5)
+  assert scale_err(q[0, 0], eA) < qtol and scale_err(q[0, 1], eB) < qtol
+  if dtype == torch.float64:
+    assert scale_err(Sff[0], want) < stol, (Sff[0].cpu().numpy(), want)
+  else:
+    assert np.abs(Sff[0].double().cpu().numpy() - want).max() < stol * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
 def test_euler_and_rollout(dtype, device):
   """MomentMatchingEuler.step and a 5-step closed rollout vs the oracle (solvers.py:67-135)."""
   L = d = 4
