@@ -93,9 +93,14 @@ __global__ __launch_bounds__(256) void k_gp_bwd_moments(int L, int M, int Mp, in
 }
 
 // chunk of centres per workgroup of k_gp_bwd_moments (0: the items kernel sums over the centres itself)
+// (d <= 8, C3 shape, B = 256: chunks of 512 / 256 / 128 / 64 / 32 centres -> the chain rule of one match takes 2.77 / 1.46 /
+// 1.00 / 0.99 / 1.44 ms: short workgroups with four barrier phases each, so more of them in flight wins until the partials dominate)
+#ifndef MM_GP_CHUNK8
+#define MM_GP_CHUNK8 128
+#endif
 static inline int mm_gp_moment_chunk(int M, int d) {
   if (M < 512 || d > 16) return 0;
-  return d <= 8 ? 256 : 128;
+  return d <= 8 ? MM_GP_CHUNK8 : 128;
 }
 
 // grid B, 64 threads: gmu [B][d] = sum of the items; gS [B][d][d] (+)= the symmetrised sum.
@@ -147,7 +152,8 @@ static inline MMGpBwdLayout mm_gp_bwd_layout(int B, int L, int M, int d, int dty
   o.mu64 = off;  off = mm_align_up(off + (f32 ? (size_t)B * d * 8 : 0), A);
   o.S64 = off;   off = mm_align_up(off + (f32 ? (size_t)B * d * d * 8 : 0), A);
   const int chunk = mm_gp_moment_chunk(M, d);
-  o.pre = off;   off = mm_align_up(off + (chunk ? (size_t)B * (L + P) * ((M + chunk - 1) / chunk) * 3 * mma_gp_ncol(d) * 8 : 0), A);
+  // (items that need moment partials: the latents and the pairs that do not come as aggregates -- f32 packs: the diagonal ones)
+  o.pre = off;   off = mm_align_up(off + (chunk ? (size_t)B * (f32 ? 2 * L : L + P) * ((M + chunk - 1) / chunk) * 3 * mma_gp_ncol(d) * 8 : 0), A);
   o.total = off;
   return o;
 }
