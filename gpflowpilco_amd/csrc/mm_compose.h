@@ -66,6 +66,13 @@ static inline int mm_compose_dims(int nx, int na, const int32_t* active_dims, MM
 // H + 1 slots with the compose-workspace layout: slot h holds everything step h produced from x_h (me, See, Sxe of
 // the encoding of x_h; the policy match, cpol, md, Sdd; the drift match), slot H only the encoding of x_H; then the
 // states x_0 .. x_H.  The forward kernels write straight into the slots (no copies).
+// mm_compose_bwd.hip: mm_moment_match_with_sums with the choice of stamping the sums with their state (the public entry does)
+int mm_moment_match_with_sums_impl(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                   const void* mu, const void* Sigma, int flags, double jitter,
+                                   void* f1, void* Sff, void* cross_pre,
+                                   void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
+                                   int32_t* status, void* stream, bool stamp);
+
 struct MMTapeLayout {
   size_t slot_bytes;         // = mm_compose_layout(...).total
   size_t xm, xS;             // [H+1][B][nx], [H+1][B][nx][nx] T

@@ -490,9 +490,9 @@ static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, 
     void* wsd = (tape && tl.ws_stride) ? (void*)(tape + tl.ws + (size_t)h * tl.ws_stride) : ws_drift;
     const size_t wsd_bytes = (tape && tl.ws_stride) ? tl.ws_stride : ws_drift_bytes;
     if (tape && tl.gp_stride)     // the sums of the backward's sweeps stay on the tape and give this step's value too (mm_compose.h)
-      rc = mm_moment_match_with_sums(drift, drift_bytes, nx, Md, nd, dtype, B, c.md, c.Sdd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY,
-                                     0.0, c.df1, c.dSff, c.dcross, wsd, wsd_bytes, tape + tl.gp + (size_t)h * tl.gp_stride,
-                                     tl.gp_stride, status, (void*)s);
+      rc = mm_moment_match_with_sums_impl(drift, drift_bytes, nx, Md, nd, dtype, B, c.md, c.Sdd,
+                                          MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY, 0.0, c.df1, c.dSff, c.dcross, wsd, wsd_bytes,
+                                          tape + tl.gp + (size_t)h * tl.gp_stride, tl.gp_stride, status, (void*)s, false);
     else
       rc = mm_moment_match(drift, drift_bytes, nx, Md, nd, dtype, B, c.md, c.Sdd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY, 0.0,
                            c.df1, c.dSff, c.dcross, wsd, wsd_bytes, status, (void*)s);

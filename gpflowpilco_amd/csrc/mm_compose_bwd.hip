@@ -124,15 +124,22 @@ __global__ __launch_bounds__(64) void k_gp_bwd_sum(int nitems, int d, const doub
 // MM_WORKSPACE_CURRENT is a promise of the caller ("the q stage of exactly this state is still on the workspace"): verify the part
 // of it the device can see -- the q stage stamped the mean it read into the workspace (MMWorkspaceLayout::mu64) -- and flag a stale
 // workspace through the status word ([0] = B - b, [1] = -1) instead of differentiating another state's q stage silently
+// (code -1: the q-stage workspace; -2: the kept sums of mm_moment_match_with_sums, stamped with the mean they were swept for)
 template <typename T>
-__global__ void k_check_workspace_current(const T* __restrict__ mu, const double* __restrict__ mu64, int B, int d, int32_t* status) {
+__global__ void k_check_workspace_current(const T* __restrict__ mu, const double* __restrict__ mu64, int B, int d, int32_t* status,
+                                          int code) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * d) return;
-  if ((double)mu[i] != mu64[i]) { atomicMax(status, B - i / d); status[1] = -1; }
+  if ((double)mu[i] != mu64[i]) { atomicMax(status, B - i / d); status[1] = code; }
+}
+template <typename T>
+__global__ void k_stamp_state(const T* __restrict__ mu, double* __restrict__ stamp, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stamp[i] = (double)mu[i];
 }
 
 struct MMGpBwdLayout {
-  size_t sums, items, cbuf, f1, cross, slab, pagg, mu64, S64, pre, total;
+  size_t sums, items, cbuf, f1, cross, slab, pagg, mu64, S64, pre, stamp, total;
 };
 // dtype MM_F64: the sums of all P pairs; MM_F32 (d <= 8): the L diagonal pairs' sums, the off-diagonal pairs' remainder slabs
 // and aggregates (mm_bwd_f32.hip), and f64 copies of the f32 state
@@ -154,6 +161,7 @@ static inline MMGpBwdLayout mm_gp_bwd_layout(int B, int L, int M, int d, int dty
   const int chunk = mm_gp_moment_chunk(M, d);
   // (items that need moment partials: the latents and the pairs that do not come as aggregates -- f32 packs: the diagonal ones)
   o.pre = off;   off = mm_align_up(off + (chunk ? (size_t)B * (f32 ? 2 * L : L + P) * ((M + chunk - 1) / chunk) * 3 * mma_gp_ncol(d) * 8 : 0), A);
+  o.stamp = off; off = mm_align_up(off + (size_t)B * d * 8, A);   // the mean the kept sums were swept for (MM_SUMS_CURRENT is verified)
   o.total = off;
   return o;
 }
@@ -185,7 +193,7 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
                                          void* g_mu, void* g_Sigma, int accumulate_Sigma,
                                          void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
                                          int32_t* status, void* stream, bool workspace_is_current, bool skip_sum = false,
-                                         int mode = MMB_MODE_ALL) {
+                                         int mode = MMB_MODE_ALL, bool verify_sums = true) {
   // mode: MMB_MODE_ALL = sweeps + chain rule; MMB_MODE_SWEEPS = everything that does NOT depend on the incoming gradient (the two
   // M x M sweeps, the full moment GEMM, the pair aggregates: mm_moment_match_with_sums leaves them on bwd_ws);
   // MMB_MODE_CHAIN = the chain rule alone on sums a MMB_MODE_SWEEPS call left on bwd_ws (MM_SUMS_CURRENT)
@@ -220,9 +228,17 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
   } else if (status && mode != MMB_MODE_SWEEPS) {          // (SWEEPS: called by mm_moment_match_with_sums right after its own q stage)
     const int n = B * d;
     if (f32) hipLaunchKernelGGL((k_check_workspace_current<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)mu,
-                                (const double*)(ws + wl.mu64), B, d, status);
+                                (const double*)(ws + wl.mu64), B, d, status, -1);
     else hipLaunchKernelGGL((k_check_workspace_current<double>), dim3((n + 255) / 256), dim3(256), 0, s, (const double*)mu,
-                            (const double*)(ws + wl.mu64), B, d, status);
+                            (const double*)(ws + wl.mu64), B, d, status, -1);
+    MMB_CHECK();
+  }
+  if (mode == MMB_MODE_CHAIN && status && verify_sums) {   // MM_SUMS_CURRENT is a promise too: the sums carry the mean they belong to
+    const int n = B * d;
+    if (f32) hipLaunchKernelGGL((k_check_workspace_current<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)mu,
+                                (const double*)(bw + bl.stamp), B, d, status, -2);
+    else hipLaunchKernelGGL((k_check_workspace_current<double>), dim3((n + 255) / 256), dim3(256), 0, s, (const double*)mu,
+                            (const double*)(bw + bl.stamp), B, d, status, -2);
     MMB_CHECK();
   }
   const int P = wl.P, Mp = wl.Mp;
@@ -252,6 +268,12 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     rc = mm_backward_sums(packed, packed_bytes, L, M, d, dtype, B, mu, flags, workspace, workspace_bytes, bw + bl.sums,
                           mm_backward_bytes(B, L, M, d, flags), stream);
     if (rc) return rc;
+  }
+  if (mode == MMB_MODE_SWEEPS && verify_sums) {
+    const int n = B * d;
+    if (f32) hipLaunchKernelGGL((k_stamp_state<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)mu, (double*)(bw + bl.stamp), n);
+    else hipLaunchKernelGGL((k_stamp_state<double>), dim3((n + 255) / 256), dim3(256), 0, s, (const double*)mu, (double*)(bw + bl.stamp), n);
+    MMB_CHECK();
   }
   if (!do_chain || !(stages & MM_STAGE_FINALIZE)) return 0;
   const int col_pairs = f32 ? L : P;
@@ -348,11 +370,12 @@ __global__ __launch_bounds__(256) void k_sff_from_sums(const double* __restrict_
   }
 }
 
-extern "C" int mm_moment_match_with_sums(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
-                                         const void* mu, const void* Sigma, int flags, double jitter,
-                                         void* f1, void* Sff, void* cross_pre,
-                                         void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
-                                         int32_t* status, void* stream) {
+// stamp: leave the mean on bwd_ws for the backward's check of MM_SUMS_CURRENT (the composed rollout's own tape needs none)
+int mm_moment_match_with_sums_impl(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                   const void* mu, const void* Sigma, int flags, double jitter,
+                                   void* f1, void* Sff, void* cross_pre,
+                                   void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
+                                   int32_t* status, void* stream, bool stamp) {
   if (!packed || !mu || !Sigma || !f1 || !Sff || !cross_pre || !workspace || !bwd_ws) return MM_E_ARG;
   if (L <= 0 || M <= 0 || d <= 0 || B <= 0) return MM_E_ARG;
   if (d > MM_DMAX) return MM_E_DIM;
@@ -364,7 +387,7 @@ extern "C" int mm_moment_match_with_sums(const void* packed, size_t packed_bytes
   if (rc) return rc;
   rc = mm_moment_match_backward_impl(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, nullptr, nullptr, nullptr, nullptr,
                                      nullptr, 0, workspace, workspace_bytes, bwd_ws, bwd_ws_bytes, status, stream, true, false,
-                                     MMB_MODE_SWEEPS);
+                                     MMB_MODE_SWEEPS, stamp);
   if (rc) return rc;
   const bool f32 = dtype == MM_F32;
   const MMGpBwdLayout bl = mm_gp_bwd_layout(B, L, M, d, dtype, flags);
@@ -382,6 +405,15 @@ extern "C" int mm_moment_match_with_sums(const void* packed, size_t packed_bytes
 #undef MM_SFF_LAUNCH
   MMB_CHECK();
   return 0;
+}
+
+extern "C" int mm_moment_match_with_sums(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
+                                         const void* mu, const void* Sigma, int flags, double jitter,
+                                         void* f1, void* Sff, void* cross_pre,
+                                         void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
+                                         int32_t* status, void* stream) {
+  return mm_moment_match_with_sums_impl(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, jitter, f1, Sff, cross_pre,
+                                        workspace, workspace_bytes, bwd_ws, bwd_ws_bytes, status, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -627,7 +659,7 @@ extern "C" int mm_rollout_composed_backward(const void* drift_packed, size_t dri
     rc = mm_moment_match_backward_impl(drift_packed, drift_bytes, nx, drift_M, nd, dtype, B, sl + cl.md, sl + cl.Sdd, dflags,
                                        cr(kl.cdf1), cr(kl.cdSff), cr(kl.cdcross), cr(kl.cmd), cr(kl.cSdd), 1, wsd,
                                        kept ? tl.ws_stride : ws_drift_bytes, gslot, sums ? tl.gp_stride : gp_bytes, status, stream,
-                                       kept, true, sums ? MMB_MODE_CHAIN : MMB_MODE_ALL);
+                                       kept, true, sums ? MMB_MODE_CHAIN : MMB_MODE_ALL, false /* the tape is this rollout's own */);
     if (rc) return rc;
     hipLaunchKernelGGL(k_policy_head_bwd_small, dim3(B), dim3(256), lds_pol, s, policy_M, ne, head_scale, head_shift,
                        (const double*)(pp + pl.Z64), (const double*)(pp + pl.beta64), (const double*)(pp + pl.ls2),

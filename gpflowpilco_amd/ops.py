@@ -110,6 +110,11 @@ class PackedModel:
           f"moment_match_backward was told the workspace still holds the forward's q stage (MM_WORKSPACE_CURRENT), but batch "
           f"element {B - st[0]} of it belongs to another state: something wrote the workspace in between without going "
           "through PackedModel.workspace() (a graph replay, another stream, an external ABI caller)")
+    if st[0] != 0 and st[1] == -2:
+      self._status.zero_()
+      raise RuntimeError(
+          f"moment_match_backward was given kept sums (MM_SUMS_CURRENT) that were swept for another state: batch element "
+          f"{B - st[0]} of `sums` does not belong to this (mu, Sigma)")
     if st[0] != 0:
       self._status.zero_()
       raise FloatingPointError(

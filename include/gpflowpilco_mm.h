@@ -71,7 +71,8 @@ extern "C" {
 #define MM_NO_ROUTE 512
 /* mm_moment_match_backward only: `bwd_ws` holds the sums mm_moment_match_with_sums left for exactly this (mu, Sigma, flags):
  * the M x M sweeps are not run again, the call is the chain rule alone.  Combine with MM_WORKSPACE_CURRENT when `workspace`
- * is untouched as well; without it the q stage (only) is re-run. */
+ * is untouched as well; without it the q stage (only) is re-run.  The sums are stamped with the mean they were swept for and
+ * the device verifies it: sums of another state are reported as status = {B - b, -2}. */
 #define MM_SUMS_CURRENT 1024
 
 /* error codes */

@@ -97,3 +97,21 @@ def test_autograd_takes_the_fused_path_and_agrees_with_two_passes(dtype, device,
   with torch.no_grad():
     autodiff.moment_match_differentiable(model, mu, S, True, True)
   assert calls == {"fused": 1, "plain": 2}
+
+
+def test_sums_of_another_state_are_reported(device):
+  """MM_SUMS_CURRENT is verified on the device (the sums carry the mean they were swept for): kept sums handed to the backward
+  of a DIFFERENT state raise instead of differentiating silently with them."""
+  syn, model, mu, S = _setup((3, 200, 8, 3), torch.float32, device, seed=41)
+  pm = model.packed(torch.float32, True, device)
+  B, L, d = mu.shape[0], pm.L, pm.d
+  g_f1 = torch.ones(B, L, dtype=F64, device=device); g_Sff = torch.ones(B, L, L, dtype=F64, device=device)
+  g_cross = torch.ones(B, d, L, dtype=F64, device=device)
+  _, _, _, sums, generation = ops.moment_match_with_sums(pm, mu, S)
+  pm.check_status(B)
+  other = mu.clone(); other[1] += 0.25
+  ops.moment_match_backward(pm, other, S, g_f1, g_Sff, g_cross, forward_generation=None, sums=sums)
+  with pytest.raises(RuntimeError, match="kept sums"):
+    pm.check_status(B)
+  ops.moment_match_backward(pm, mu, S, g_f1, g_Sff, g_cross, forward_generation=None, sums=sums)    # the right state: accepted
+  pm.check_status(B)
