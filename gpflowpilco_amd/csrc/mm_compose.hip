@@ -116,17 +116,15 @@ __global__ __launch_bounds__(64) void k_compose_encode(MMComposeDims D, const T*
 // ---------------------------------------------------------------------------------------------
 // k_compose_policy: policy GP output (mean-only) -> u = scale (Phi(f) + shift); joint moments of d = (e, u)
 // ---------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(64) void k_compose_policy(MMComposeDims D, double scale, double shift,
-                                                       const T* __restrict__ me, const T* __restrict__ See,
-                                                       const T* __restrict__ pf1, const T* __restrict__ pSff,
-                                                       const T* __restrict__ pcross,
-                                                       T* __restrict__ md, T* __restrict__ Sdd, double* __restrict__ cpol) {
-  const int b = blockIdx.x, lane = threadIdx.x, ne = D.ne, nd = D.nd;
+// Body of the head for one batch element, called by EVERY thread of the block (any block size that is a multiple of 64; barriers
+// inside): mf, vx = the policy GP's output moments, pc [ne] = its pre-inverted cross term (any address space).
+template <typename T, typename TC>
+__device__ __forceinline__ void mmc_policy_head(const MMComposeDims& D, double scale, double shift, const T* __restrict__ me,
+                                                const T* __restrict__ See, double mf, double vx, const TC* pc,
+                                                T* __restrict__ md, T* __restrict__ Sdd, double* __restrict__ cpol, int b) {
+  const int tid = threadIdx.x, nth = blockDim.x, lane = tid & 63, ne = D.ne, nd = D.nd;
   __shared__ double cp[MMC_ND], Seu[MMC_ND];
   __shared__ double hv[4];                     // mu_u, Suu, head_pre
-  const double mf = (double)pf1[b];
-  double vx = (double)pSff[b];
   vx = vx > 0.0 ? vx : 0.0;                    // variance of the regressor's mean under x ~ N: >= 0 up to rounding
   // bijectors.py:39-69, 1-D branch
   const double isq = rsqrt(vx + 1.0), z = isq * mf;
@@ -143,11 +141,11 @@ __global__ __launch_bounds__(64) void k_compose_policy(MMComposeDims D, double s
   const double owen = 0.5 * aa * part * 0.15915494309189533577;        // / (2 pi)
   const double y2 = y1 - 2.0 * owen;                                   // E[Phi^2]
   const double head_pre = isq * 0.39894228040143267794 * exp(-0.5 * z * z) * scale;   // Var(f)^-1 Cov(f, u)
-  if (lane == 0) { hv[0] = scale * (y1 + shift); hv[1] = scale * scale * (y2 - y1 * y1); }
+  if (tid == 0) { hv[0] = scale * (y1 + shift); hv[1] = scale * scale * (y2 - y1 * y1); }      // (every wave holds the same values)
   // chain rule (gaussian.py:66-83): Cov(e,e)^-1 Cov(e, u) = cross_pre(GP) * head_pre
-  for (int k = lane; k < ne; k += 64) cp[k] = (double)pcross[(size_t)b * ne + k] * head_pre;
+  for (int k = tid; k < ne; k += nth) cp[k] = (double)pc[k] * head_pre;
   __syncthreads();
-  for (int k = lane; k < ne; k += 64) {
+  for (int k = tid; k < ne; k += nth) {
     double s = 0.0;
     for (int l = 0; l < ne; ++l) s = fma((double)See[((size_t)b * ne + k) * ne + l], cp[l], s);
     Seu[k] = s;
@@ -156,8 +154,8 @@ __global__ __launch_bounds__(64) void k_compose_policy(MMComposeDims D, double s
   __syncthreads();
   T* mdb = md + (size_t)b * nd;
   T* Sdb = Sdd + (size_t)b * nd * nd;
-  for (int k = lane; k < nd; k += 64) mdb[k] = k < ne ? me[(size_t)b * ne + k] : (T)hv[0];
-  for (int idx = lane; idx < nd * nd; idx += 64) {           // gaussian.py:53-63
+  for (int k = tid; k < nd; k += nth) mdb[k] = k < ne ? me[(size_t)b * ne + k] : (T)hv[0];
+  for (int idx = tid; idx < nd * nd; idx += nth) {           // gaussian.py:53-63
     const int i = idx / nd, j = idx - i * nd;
     double v;
     if (i < ne && j < ne) v = (double)See[((size_t)b * ne + i) * ne + j];
@@ -166,6 +164,16 @@ __global__ __launch_bounds__(64) void k_compose_policy(MMComposeDims D, double s
     else v = hv[1];
     Sdb[idx] = (T)v;
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_compose_policy(MMComposeDims D, double scale, double shift,
+                                                       const T* __restrict__ me, const T* __restrict__ See,
+                                                       const T* __restrict__ pf1, const T* __restrict__ pSff,
+                                                       const T* __restrict__ pcross,
+                                                       T* __restrict__ md, T* __restrict__ Sdd, double* __restrict__ cpol) {
+  const int b = blockIdx.x;
+  mmc_policy_head<T, T>(D, scale, shift, me, See, (double)pf1[b], (double)pSff[b], pcross + (size_t)b * D.ne, md, Sdd, cpol, b);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -262,14 +270,18 @@ __global__ __launch_bounds__(64) void k_compose_tail(MMComposeDims D, double dt,
 // Requires L == 1, M <= 128, d <= 8 (else the general mm_moment_match is used).  A non-PD Sigma + V sets the status
 // word exactly as k_prep does.
 // ---------------------------------------------------------------------------------------------
+// HEAD: the workgroup goes on with the policy head (mmc_policy_head: NormalCDF / Scale / Shift, joint moments of d = (e, u)) on the
+// moments it has just formed -- the rollout's policy step is ONE launch (it was this kernel + k_compose_policy: a launch is
+// ~ 5 us of the 51 us a cartpole-sized step takes).
 #define MMS_MMAX 128
-template <typename T>
+template <typename T, bool HEAD>
 __global__ __launch_bounds__(256) void k_policy_match_small(const double* __restrict__ Z64, const double* __restrict__ beta64,
                                                             const double* __restrict__ ls2, const double* __restrict__ var,
                                                             const double* __restrict__ meanc, int M, int d,
                                                             const T* __restrict__ mu, const T* __restrict__ Sigma, double jitter,
                                                             T* __restrict__ f1, T* __restrict__ Sff, T* __restrict__ cross,
-                                                            int32_t* status) {
+                                                            int32_t* status, MMComposeDims D, double scale, double shift,
+                                                            T* __restrict__ md, T* __restrict__ Sdd, double* __restrict__ cpol) {
   constexpr int DK = 8, DP = DK + 1;
   const int b = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   __shared__ double Sg[DK * DP], Am[4][DK * DP], Ym[4][DK * DP], Em[DK * DK], Gm[DK * DK];
@@ -409,16 +421,23 @@ __global__ __launch_bounds__(256) void k_policy_match_small(const double* __rest
     f1[b] = (T)(sv[DK] + meanc[0]);
     Sff[b] = (T)(sv[DK + 1] + jitter);
   }
+  __shared__ double hcross[DK];
   if (tid < d) {
     double s = 0.0;
     for (int k = 0; k < d; ++k) s += Pm[tid * DP + k] * sv[k];     // Sigma^-1 Cov(x, f) = P sum_i w_i zeta_i  (models.py:263-277)
     cross[(size_t)b * d + tid] = (T)s;
+    if (HEAD) hcross[tid] = (double)(T)s;                           // (what the two-launch form reads back)
   }
   if (!ok && tid == 0 && status) {
     atomicMax(status, (int)gridDim.x - b);                          // B - b: the host decodes the smallest failing b
     status[1] = 0;
   }
   MM_STAMP(9);
+  if constexpr (HEAD) {
+    __syncthreads();
+    mmc_policy_head<T, double>(D, scale, shift, mu, Sigma, (double)(T)(sv[DK] + meanc[0]), (double)(T)(sv[DK + 1] + jitter), hcross,
+                               md, Sdd, cpol, b);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -474,18 +493,20 @@ static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, 
       const MMModelLayout pl = mm_model_layout(1, Mpol, ne, dtype, 1);
       if (policy_bytes < pl.Cm) return MM_E_WORKSPACE;         // the packed buffer must hold everything the kernel reads
       const char* pp = (const char*)policy;
-      hipLaunchKernelGGL((k_policy_match_small<T>), dim3(B), dim3(256), 0, s, (const double*)(pp + pl.Z64),
+      // (policy match AND head in one launch: the head's inputs (me, See) are this kernel's (mu, Sigma))
+      hipLaunchKernelGGL((k_policy_match_small<T, true>), dim3(B), dim3(256), 0, s, (const double*)(pp + pl.Z64),
                          (const double*)(pp + pl.beta64), (const double*)(pp + pl.ls2), (const double*)(pp + pl.var),
-                         (const double*)(pp + pl.meanc), Mpol, ne, (const T*)c.me, (const T*)c.See, 0.0, c.pf1, c.pSff, c.pcross, status);
+                         (const double*)(pp + pl.meanc), Mpol, ne, (const T*)c.me, (const T*)c.See, 0.0, c.pf1, c.pSff, c.pcross, status,
+                         D, scale, shift, c.md, c.Sdd, c.cpol);
       MMC_CHECK();
     } else {
       rc = mm_moment_match(policy, policy_bytes, 1, Mpol, ne, dtype, B, c.me, c.See, MM_FULL_OUTPUT_COV, 0.0,
                            c.pf1, c.pSff, c.pcross, ws_policy, ws_policy_bytes, status, (void*)s);
       if (rc) return rc;
+      hipLaunchKernelGGL((k_compose_policy<T>), dim3(B), dim3(64), 0, s, D, scale, shift, (const T*)c.me, (const T*)c.See,
+                         (const T*)c.pf1, (const T*)c.pSff, (const T*)c.pcross, c.md, c.Sdd, c.cpol);
+      MMC_CHECK();
     }
-    hipLaunchKernelGGL((k_compose_policy<T>), dim3(B), dim3(64), 0, s, D, scale, shift, (const T*)c.me, (const T*)c.See,
-                       (const T*)c.pf1, (const T*)c.pSff, (const T*)c.pcross, c.md, c.Sdd, c.cpol);
-    MMC_CHECK();
     // (taped, small enough: the match runs in the tape's own workspace slot of this step, which the reverse sweep reads)
     void* wsd = (tape && tl.ws_stride) ? (void*)(tape + tl.ws + (size_t)h * tl.ws_stride) : ws_drift;
     const size_t wsd_bytes = (tape && tl.ws_stride) ? tl.ws_stride : ws_drift_bytes;
