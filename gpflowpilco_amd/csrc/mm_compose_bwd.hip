@@ -193,7 +193,7 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
                                          void* g_mu, void* g_Sigma, int accumulate_Sigma,
                                          void* workspace, size_t workspace_bytes, void* bwd_ws, size_t bwd_ws_bytes,
                                          int32_t* status, void* stream, bool workspace_is_current, bool skip_sum = false,
-                                         int mode = MMB_MODE_ALL, bool verify_sums = true) {
+                                         int mode = MMB_MODE_ALL, bool verify_sums = true /* check the caller's MM_*_CURRENT promises on the device */) {
   // mode: MMB_MODE_ALL = sweeps + chain rule; MMB_MODE_SWEEPS = everything that does NOT depend on the incoming gradient (the two
   // M x M sweeps, the full moment GEMM, the pair aggregates: mm_moment_match_with_sums leaves them on bwd_ws);
   // MMB_MODE_CHAIN = the chain rule alone on sums a MMB_MODE_SWEEPS call left on bwd_ws (MM_SUMS_CURRENT)
@@ -225,7 +225,8 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, bw + bl.f1, bw + bl.cross, nullptr,
                       workspace, workspace_bytes, status, stream);
     if (rc) return rc;
-  } else if (status && mode != MMB_MODE_SWEEPS) {          // (SWEEPS: called by mm_moment_match_with_sums right after its own q stage)
+  } else if (status && mode != MMB_MODE_SWEEPS && verify_sums) {   // (SWEEPS: mm_moment_match_with_sums has just run the q stage itself;
+                                                                    //  !verify: the composed rollout's own tape holds the workspace)
     const int n = B * d;
     if (f32) hipLaunchKernelGGL((k_check_workspace_current<float>), dim3((n + 255) / 256), dim3(256), 0, s, (const float*)mu,
                                 (const double*)(ws + wl.mu64), B, d, status, -1);
