@@ -63,6 +63,22 @@ def test_wide_state_offdiagonal_block_at_its_own_scale(device):
   assert dg <= 2e-5 * np.abs(Sffo).max()
 
 
+def test_wide_state_value_from_the_backward_sweeps_keeps_the_contract(device):
+  """mm_moment_match_with_sums takes the off-diagonal covariances from the backward's remainder aggregates: its sweep carries the
+  same error estimate and routes the same kind of items, so the wide-state draw meets the same bound there."""
+  p, model, mu32, S32 = _wide_case(device)
+  pm = model.packed(torch.float32, True, device)
+  pm.status().zero_()
+  _, Sff, _, sums, _ = ops.moment_match_with_sums(pm, mu32, S32)
+  pm.check_status(mu32.shape[0])
+  assert pm.routed()[1] > 0                                  # (counted as backward-sweep routes: that is the sweep that ran)
+  _, Sffo, _ = mo.mm_gauss_svgp_mo(mu32.double().cpu().numpy(), S32.double().cpu().numpy(), p)
+  own = np.abs(_offdiag(Sffo)).max()
+  err = np.abs(_offdiag(Sff.double().cpu().numpy()) - _offdiag(Sffo)).max()
+  assert err <= 1e-4 * own, (err, own)
+  assert np.abs(np.diagonal(Sff.double().cpu().numpy(), axis1=1, axis2=2) - np.diagonal(Sffo, axis1=1, axis2=2)).max() <= 2e-6 * np.abs(Sffo).max()
+
+
 @pytest.mark.parametrize("L,M,d,B", [(3, 150, 3, 3), (2, 300, 6, 2), (4, 200, 8, 5), (3, 260, 12, 2), (2, 130, 20, 3)])
 def test_forced_route_equals_the_f64_pack(L, M, d, B, device):
   """Every off-diagonal item through k_route_f64 (all four input-dimension instantiations, M not a multiple of the panel):
