@@ -236,16 +236,47 @@ __device__ __forceinline__ void mmc_step_body(const MMComposeDims& D, double dt,
 // dependency latency: two launches fewer per step.  One wave per batch element; the stages communicate through the
 // wave's own global writes (visible after the workgroup barrier).
 // ---------------------------------------------------------------------------------------------
+// What the tail needs to form the drift match's Sff itself from the reduce kernels' partial slabs (k_finalize's sum, mm_kernels.hip,
+// for an f64 pack with full output covariance and model uncertainty: the composed rollout's drift) -- one launch less per step.
+struct MMTailFinalize {
+  const double *partB, *partC, *var, *f1raw;
+  int P, NS, ns_diag, ns_off, nsC, enabled;
+};
+
 template <typename T>
 __global__ __launch_bounds__(64) void k_compose_tail(MMComposeDims D, double dt, const double* cpol, const T* Sdd,
-                                                     const T* df1, const T* dSff, const T* dcross, const double* Sxe_in, T* mx, T* Sxx,
+                                                     const T* df1, T* dSff, const T* dcross, const double* Sxe_in, T* mx, T* Sxx,
                                                      T* traj_mu, T* traj_S, T* me, T* See, double* Sxe,
-                                                     const T* target, const T* precis, T* cost) {
+                                                     const T* target, const T* precis, T* cost, MMTailFinalize fin) {
   // (me, See, Sxe: the NEW state's encoding; Sxe_in: Cov(x, e) of the state the step started from -- the same buffer
   // in an ordinary rollout, consecutive tape slots in a taped one)
   extern __shared__ double csm[];
   const int b = blockIdx.x, lane = threadIdx.x;
   MM_STAMP_INIT();
+  if (fin.enabled) {
+    // Sff_aa' = sum of the pair's slab (fixed order) [- (sum w)^2 + var_a on the diagonal: factored f64 reduce], symmetric fill
+    const int L = D.nx;
+    for (int p = lane; p < fin.P; p += 64) {
+      int a = p, a2 = p;
+      if (p >= L) { int r = p - L, i = 0; while (r >= L - 1 - i) { r -= L - 1 - i; ++i; } a = i; a2 = i + 1 + r; }
+      const double* pb = fin.partB + ((size_t)b * fin.P + p) * fin.NS;
+      double s = 0.0;
+      const int ns = a == a2 ? fin.ns_diag : fin.ns_off;
+      for (int k = 0; k < ns; ++k) s += pb[k];
+      if (a == a2) {
+        const double* pc = fin.partC + ((size_t)b * L + a) * fin.NS;
+        for (int k = 0; k < fin.nsC; ++k) s += pc[k];
+        const double f = fin.f1raw[(size_t)b * L + a];
+        s = s - f * f + fin.var[a];
+        dSff[((size_t)b * L + a) * L + a] = (T)s;
+      } else {
+        dSff[((size_t)b * L + a) * L + a2] = (T)s;
+        dSff[((size_t)b * L + a2) * L + a] = (T)s;
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
   mmc_step_body<T>(D, dt, Sxe_in, cpol, Sdd, df1, dSff, dcross, mx, Sxx, traj_mu, traj_S, b, lane);
   __syncthreads();
   MM_STAMP(0);
@@ -273,6 +304,7 @@ __global__ __launch_bounds__(64) void k_compose_tail(MMComposeDims D, double dt,
 // HEAD: the workgroup goes on with the policy head (mmc_policy_head: NormalCDF / Scale / Shift, joint moments of d = (e, u)) on the
 // moments it has just formed -- the rollout's policy step is ONE launch (it was this kernel + k_compose_policy: a launch is
 // ~ 5 us of the 51 us a cartpole-sized step takes).
+int mm_f64_num_slots(int Mp, int diag);      // mm_f64.hip
 #define MMS_MMAX 128
 template <typename T, bool HEAD>
 __global__ __launch_bounds__(256) void k_policy_match_small(const double* __restrict__ Z64, const double* __restrict__ beta64,
@@ -485,6 +517,11 @@ static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, 
     hipLaunchKernelGGL((k_compose_encode<T>), dim3(B), dim3(64), 0, s, D, (const T*)mx, (const T*)Sxx, c0.me, c0.See, c0.Sxe);
     MMC_CHECK();
   }
+  // the drift's layouts (the tail may finalize its Sff itself): f64 packs whose two reduces fit the one-launch form (mm_f64.hip)
+  const MMModelLayout dml = mm_model_layout(nx, Md, nd, dtype, 1);
+  const MMWorkspaceLayout dwl = mm_workspace_layout(B, nx, Md, nd, dtype, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY);
+  const bool tail_finalizes = sizeof(T) == 8 && dwl.Po > 0 && nd <= 16 && drift_bytes >= dml.total &&
+                              (long long)B * (dwl.P + nx) * mm_f64_num_slots(dwl.Mp, 0) <= 4096;
   for (int h = 0; h < H; ++h) {
     MMCSlot<T> c = slot(h), n = slot(h + 1);
     // policy: mean-only regressor (models.py:34-41: model_uncertainty = False), one latent
@@ -515,17 +552,27 @@ static int mm_rollout_composed_t(const void* drift, size_t drift_bytes, int Md, 
                                           MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY, 0.0, c.df1, c.dSff, c.dcross, wsd, wsd_bytes,
                                           tape + tl.gp + (size_t)h * tl.gp_stride, tl.gp_stride, status, (void*)s, false);
     else
-      rc = mm_moment_match(drift, drift_bytes, nx, Md, nd, dtype, B, c.md, c.Sdd, MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY, 0.0,
+      // (small f64 drift: the tail kernel sums the reduce kernels' slabs itself -- no k_finalize launch)
+      rc = mm_moment_match(drift, drift_bytes, nx, Md, nd, dtype, B, c.md, c.Sdd,
+                           MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY | (tail_finalizes ? (MM_STAGE_DIAG | MM_STAGE_OFFDIAG) : 0), 0.0,
                            c.df1, c.dSff, c.dcross, wsd, wsd_bytes, status, (void*)s);
     if (rc) return rc;
+    MMTailFinalize fin = {};
+    if (tail_finalizes && !(tape && tl.gp_stride)) {
+      const char* wq = (const char*)wsd;
+      fin.partB = (const double*)(wq + dwl.partB); fin.partC = (const double*)(wq + dwl.partC);
+      fin.var = (const double*)((const char*)drift + dml.var); fin.f1raw = (const double*)(wq + dwl.f1raw);
+      fin.P = dwl.P; fin.NS = dwl.NS; fin.ns_diag = mm_f64_num_slots(dwl.Mp, 1); fin.ns_off = mm_f64_num_slots(dwl.Mp, 0);
+      fin.nsC = fin.ns_diag; fin.enabled = 1;
+    }
     // Euler update, the new state's encoding (the cost statistic of this step, pilco.py:199-205, and the next step's
     // policy input) and the expected cost: one launch
     T* tm = tape ? xm + (size_t)(h + 1) * B * nx : (traj_mu ? traj_mu + (size_t)h * B * nx : (T*)nullptr);
     T* tS = tape ? xS + (size_t)(h + 1) * B * nx * nx : (traj_S ? traj_S + (size_t)h * B * nx * nx : (T*)nullptr);
     hipLaunchKernelGGL((k_compose_tail<T>), dim3(B), dim3(64), mm_cost_lds_bytes(ne), s, D, dt, (const double*)c.cpol,
-                       (const T*)c.Sdd, (const T*)c.df1, (const T*)c.dSff, (const T*)c.dcross, (const double*)c.Sxe, mx, Sxx,
+                       (const T*)c.Sdd, (const T*)c.df1, c.dSff, (const T*)c.dcross, (const double*)c.Sxe, mx, Sxx,
                        tm, tS, n.me, n.See, n.Sxe, target, precis,
-                       cost ? cost + (size_t)h * B : (T*)nullptr);
+                       cost ? cost + (size_t)h * B : (T*)nullptr, fin);
     MMC_CHECK();
     if (tape && traj_mu) {
       hipError_t e1 = hipMemcpyAsync(traj_mu + (size_t)h * B * nx, tm, (size_t)B * nx * sizeof(T), hipMemcpyDeviceToDevice, s);

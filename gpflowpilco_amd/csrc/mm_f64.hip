@@ -111,24 +111,25 @@ struct MMF64Operands {
 // i.e. sum w expm1 w' + sum C q exp(delta) q' with two FMAs per entry instead of three; D is formed
 // once per workgroup from the C tile.  delta_ij = rho_i + gamma'_j + zc_i . g_j: the two O(1) terms
 // initialise the MFMA accumulator (one add per entry; an extra K step would cost a whole MFMA).
+// (the kernel's body as a device function of the block index `orig`: k_qred_f64_mfma below runs it for one kind of pair,
+// k_qred_f64_both for the diagonal AND the off-diagonal pairs of a small f64 model in one launch)
 template <int KS4, bool DIAG, bool WITHC, bool LOWP>
-__global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : (DIAG && KS4 <= MM_F64_3WAVE_KS4 ? 3 : 2))) void k_qred_f64_mfma(const double* __restrict__ Zc, int Kz,
-                                                          const double* __restrict__ Cm,
-                                                          const double* __restrict__ beta, int M,
-                                                          int L, int Mp, int d, int P, int NS, int p0,
-                                                          int B, int bchunk, int np, int nslots, int nchunk, int nwork,
-                                                          int force_worst,
-                                                          const double* __restrict__ w,
-                                                          const double* __restrict__ q,
-                                                          const double* __restrict__ rowA,
-                                                          const double* __restrict__ colB,
-                                                          double* __restrict__ partB,
-                                                          double* __restrict__ partC) {
+__device__ __forceinline__ void mmq_f64_body(const double* __restrict__ Zc, int Kz,
+                                             const double* __restrict__ Cm,
+                                             const double* __restrict__ beta, int M,
+                                             int L, int Mp, int d, int P, int NS, int p0,
+                                             int B, int bchunk, int np, int nslots, int nchunk, int nwork,
+                                             int force_worst,
+                                             const double* __restrict__ w,
+                                             const double* __restrict__ q,
+                                             const double* __restrict__ rowA,
+                                             const double* __restrict__ colB,
+                                             double* __restrict__ partB,
+                                             double* __restrict__ partC, int orig, double (*stage)[256], double (*part16)[16]) {
   // 1-D grid, XCD-aware: workgroups b and b + 8 share an XCD (round-robin dispatch), so the remap
   // hands every XCD one contiguous range of work items ordered (pair, batch chunk, tile): the
   // per-batch-element operands of one latent stay in ONE XCD's L2.  Bijective for any nwork.
   const int nt = Mp / MM_F64_TILE;
-  const int orig = blockIdx.x;
   const int xcd = orig & 7, slot = orig >> 3;
   const int qn = nwork >> 3, rn = nwork & 7;
   const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slot;
@@ -196,8 +197,6 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : (DIAG && KS4 <= MM_F64_3WAVE_K
   }
   const size_t goff = (size_t)d * Mp;
 
-  __shared__ double stage[MM_F64_NB][256];
-  __shared__ double part16[MM_F64_NB][16];
   const int b0 = chunk * bchunk;
   const int b1 = (b0 + bchunk < B) ? b0 + bchunk : B;
   // per-b operand pointers advance by constant strides (no 64-bit multiplies in the loop)
@@ -391,6 +390,50 @@ __global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : (DIAG && KS4 <= MM_F64_3WAVE_K
   }
 }
 
+template <int KS4, bool DIAG, bool WITHC, bool LOWP>
+__global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : (DIAG && KS4 <= MM_F64_3WAVE_KS4 ? 3 : 2))) void k_qred_f64_mfma(const double* __restrict__ Zc, int Kz,
+                                                          const double* __restrict__ Cm,
+                                                          const double* __restrict__ beta, int M,
+                                                          int L, int Mp, int d, int P, int NS, int p0,
+                                                          int B, int bchunk, int np, int nslots, int nchunk, int nwork,
+                                                          int force_worst,
+                                                          const double* __restrict__ w,
+                                                          const double* __restrict__ q,
+                                                          const double* __restrict__ rowA,
+                                                          const double* __restrict__ colB,
+                                                          double* __restrict__ partB,
+                                                          double* __restrict__ partC) {
+  __shared__ double stage[MM_F64_NB][256];
+  __shared__ double part16[MM_F64_NB][16];
+  mmq_f64_body<KS4, DIAG, WITHC, LOWP>(Zc, Kz, Cm, beta, M, L, Mp, d, P, NS, p0, B, bchunk, np, nslots, nchunk, nwork, force_worst,
+                                       w, q, rowA, colB, partB, partC, (int)blockIdx.x, stage, part16);
+}
+
+// Both reduces of a SMALL f64 model in one launch (cartpole sizes: every kernel of the step costs ~ 4-5 us whatever it does, so
+// the step is its number of launches): blocks [0, nwork_d) are the diagonal pairs' work items, the rest the off-diagonal pairs'.
+struct MMF64Side {
+  int p0, bchunk, np, nslots, nchunk, nwork;
+  const double *w, *q, *rowA, *colB;
+};
+template <int KS4, bool WITHC>
+__global__ __launch_bounds__(256, (KS4 >= 6 ? 1 : 2)) void k_qred_f64_both(const double* __restrict__ Zc, int Kz,
+                                                                           const double* __restrict__ Cm,
+                                                                           const double* __restrict__ beta, int M, int L, int Mp, int d,
+                                                                           int P, int NS, int B, int force_worst, MMF64Side sd,
+                                                                           MMF64Side so, double* __restrict__ partB,
+                                                                           double* __restrict__ partC) {
+  __shared__ double stage[MM_F64_NB][256];
+  __shared__ double part16[MM_F64_NB][16];
+  const int orig = (int)blockIdx.x;
+  if (orig < sd.nwork)
+    mmq_f64_body<KS4, true, WITHC, false>(Zc, Kz, Cm, beta, M, L, Mp, d, P, NS, sd.p0, B, sd.bchunk, sd.np, sd.nslots, sd.nchunk, sd.nwork,
+                                          force_worst, sd.w, sd.q, sd.rowA, sd.colB, partB, partC, orig, stage, part16);
+  else
+    mmq_f64_body<KS4, false, false, false>(Zc, Kz, nullptr, beta, M, L, Mp, d, P, NS, so.p0, B, so.bchunk, so.np, so.nslots, so.nchunk,
+                                           so.nwork, force_worst, so.w, so.q, so.rowA, so.colB, partB, partC, orig - sd.nwork, stage,
+                                           part16);
+}
+
 int mm_f64_num_slots(int Mp, int diag) {
   const int nt = Mp / MM_F64_TILE;
   return diag ? nt * (nt + 1) / 2 : nt * nt;
@@ -398,6 +441,59 @@ int mm_f64_num_slots(int Mp, int diag) {
 
 // Launch over `npairs` pairs starting at global pair index p0.  diag != 0: pairs are (a, a).
 // lowp != 0: the model is f32 (diagonal pairs only need ~1e-14 relative accuracy of expm1).
+// batch chunking of one side (the rule of mm_launch_qred_f64 below)
+static void mm_f64_side_chunks(int nslots, int npairs, int B, int diag, int& bchunk, int& nchunk) {
+  long long per_chunk = (long long)nslots * npairs;
+  nchunk = (int)((MM_F64_TARGET_WGS + per_chunk - 1) / per_chunk);
+  if (nchunk > B / 16) nchunk = B / 16;
+  if (nchunk < 1) nchunk = 1;
+  if (!diag) {
+    nchunk = (int)((6144 + per_chunk - 1) / per_chunk);
+    const int cap = (B + 3) / 4;
+    if (nchunk > cap) nchunk = cap;
+    if (nchunk < 1) nchunk = 1;
+  }
+  bchunk = (B + nchunk - 1) / nchunk;
+  nchunk = (B + bchunk - 1) / bchunk;
+}
+
+// Diagonal AND off-diagonal pairs of an f64 model in ONE launch, where that is worth more than the diagonal kernel's third wave
+// per SIMD: small models (<= MM_F64_BOTH_MAX_WGS workgroups in total, d <= 16).  Returns 1 if it launched, 0 if the caller should
+// use the two launches, < 0 / > 0 on error.
+#ifndef MM_F64_BOTH_MAX_WGS
+#define MM_F64_BOTH_MAX_WGS 1024
+#endif
+int mm_launch_qred_f64_both(const double* Zc, int Kz, const double* Cm, const double* beta, int M, int L, int Mp, int d, int P, int NS,
+                            int Po, int B, int force_worst, const double* qhR, const double* qhC, const double* rowD,
+                            const double* colD, const double* w64, const double* q64, const double* rowO, const double* colO,
+                            double* partB, double* partC, hipStream_t stream, bool* launched) {
+  *launched = false;
+  if (Po <= 0 || d > 16) return 0;
+  MMF64Side sd, so;
+  sd.p0 = 0; sd.np = L; sd.nslots = mm_f64_num_slots(Mp, 1);
+  so.p0 = L; so.np = Po; so.nslots = mm_f64_num_slots(Mp, 0);
+  if (sd.nslots > NS || so.nslots > NS) return MM_E_WORKSPACE;
+  mm_f64_side_chunks(sd.nslots, L, B, 1, sd.bchunk, sd.nchunk);
+  mm_f64_side_chunks(so.nslots, Po, B, 0, so.bchunk, so.nchunk);
+  const long long nd = (long long)sd.nslots * L * sd.nchunk, no = (long long)so.nslots * Po * so.nchunk;
+  if (nd + no > MM_F64_BOTH_MAX_WGS) return 0;
+  sd.nwork = (int)nd; so.nwork = (int)no;
+  sd.w = qhR; sd.q = qhC; sd.rowA = rowD; sd.colB = colD;
+  so.w = w64; so.q = q64; so.rowA = rowO; so.colB = colO;
+  const int ks4 = (d + 3) / 4;
+  dim3 grid((unsigned)(nd + no));
+#define MM_BOTH_(KS_, WC_) hipLaunchKernelGGL((k_qred_f64_both<KS_, WC_>), grid, dim3(256), 0, stream, Zc, Kz, Cm, beta, M, L, Mp, d, P, \
+                                             NS, B, force_worst, sd, so, partB, partC)
+#define MM_BOTH(KS_) do { if (Cm) MM_BOTH_(KS_, true); else MM_BOTH_(KS_, false); } while (0)
+  if (ks4 <= 1) MM_BOTH(1); else if (ks4 == 2) MM_BOTH(2); else if (ks4 == 3) MM_BOTH(3); else MM_BOTH(4);
+#undef MM_BOTH
+#undef MM_BOTH_
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  *launched = true;
+  return 0;
+}
+
 int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double* beta, int M, int L, int Mp, int d,
                        int P, int NS, int p0, int npairs, int B, int diag, int lowp, int force_worst,
                        const double* w, const double* q, const double* rowA, const double* colB,

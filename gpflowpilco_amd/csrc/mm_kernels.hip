@@ -1086,6 +1086,10 @@ extern "C" int mm_mfma_supported(int d);
 int mm_mfma_num_slots(int Mp);
 // f64 MFMA reduce (mm_f64.hip): diagonal pairs of both modes, off-diagonal pairs of the f64 mode
 int mm_f64_num_slots(int Mp, int diag);
+int mm_launch_qred_f64_both(const double* Zc, int Kz, const double* Cm, const double* beta, int M, int L, int Mp, int d, int P, int NS,
+                            int Po, int B, int force_worst, const double* qhR, const double* qhC, const double* rowD,
+                            const double* colD, const double* w64, const double* q64, const double* rowO, const double* colO,
+                            double* partB, double* partC, hipStream_t stream, bool* launched);
 int mm_launch_qred_f64(const double* Zc, int Kz, const double* Cm, const double* beta, int M, int L, int Mp, int d,
                        int P, int NS, int p0, int npairs, int B, int diag, int lowp, int force_worst,
                        const double* w, const double* q, const double* rowA, const double* colB,
@@ -1228,8 +1232,18 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
   // A function of the flags alone: the stage calls of one match (bench.py) agree on it.  Not with the forced worst tier (its
   // tile ranges are fake)
   const bool routes = use_mfma32 && wl.Po > 0 && !(flags & (MM_FORCE_WORST_TIER | MM_NO_ROUTE));
+  // small f64 models: both kinds of pairs in one launch (mm_f64.hip) -- the two sweeps then run side by side on the device
+  bool both = false;
+  if (sizeof(T) == 8 && !generic && wl.Po > 0 && (stages & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG)) == (MM_STAGE_DIAG | MM_STAGE_OFFDIAG)) {
+    const int rc = mm_launch_qred_f64_both((const double*)(packed + ml.Zc64), ml.Kz, Cm, (const double*)(packed + ml.beta64), M, L,
+                                           wl.Mp, d, wl.P, wl.NS, wl.Po, B, (flags & MM_FORCE_WORST_TIER) ? 1 : 0,
+                                           (const double*)(ws + wl.qhR), (const double*)(ws + wl.qhC), (const double*)(ws + wl.rowD),
+                                           (const double*)(ws + wl.colD), (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
+                                           (const double*)(ws + wl.rowO), (const double*)(ws + wl.colO), partB, partC, s, &both);
+    if (rc) return rc;
+  }
   // (1) diagonal pairs: always f64
-  if (stages & MM_STAGE_DIAG) {
+  if (!both && (stages & MM_STAGE_DIAG)) {
     if (generic) {
       hipLaunchKernelGGL((k_qred_generic<double, DK, false>), dim3(nrb * ncb, L, B), dim3(256), 0, s,
                          (const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS, ncb, 0,
@@ -1248,7 +1262,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
     }
   }
   // (2) off-diagonal pairs in T
-  if (wl.Po > 0 && (stages & MM_STAGE_OFFDIAG)) {
+  if (!both && wl.Po > 0 && (stages & MM_STAGE_OFFDIAG)) {
     if (use_mfma32) {
       int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, flags, s);
       if (rc) return rc;
