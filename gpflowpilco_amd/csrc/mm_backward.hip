@@ -158,20 +158,21 @@ __device__ __forceinline__ double mmb_expm1_any(double x) {
 // KS4: K = 4 steps covering d; NU: 16-wide blocks of the U product ((d + 1) <= 16 NU).
 // grid (Mp / 64, npairs, B).  SWAP == false: pairs [0, P), out_col [B][P][3 + d][Mp].
 //                             SWAP == true : pairs L + blockIdx.y, out_row [B][Po][2][Mp].
+// (the kernel's body as a function of the block index: k_bwd_mfma runs one kind of sweep, k_bwd_mfma_both the column AND the row
+// sweep of a small f64 model in one launch)
 template <int KS4, int NU, bool SWAP>
-__global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const double* __restrict__ Zc, int Kz,
-                                                     const double* __restrict__ zbar, const double* __restrict__ Cm,
-                                                     const double* __restrict__ mu, int L, int Mp, int d, int P,
-                                                     const double* __restrict__ w, const double* __restrict__ q,
-                                                     const double* __restrict__ rowD, const double* __restrict__ colD,
-                                                     const double* __restrict__ rowO, const double* __restrict__ colO,
-                                                     double* __restrict__ out, int B, int nwork, int p0) {
+__device__ __forceinline__ void mmb_mfma_body(const double* __restrict__ Zc, int Kz,
+                                              const double* __restrict__ zbar, const double* __restrict__ Cm,
+                                              const double* __restrict__ mu, int L, int Mp, int d, int P,
+                                              const double* __restrict__ w, const double* __restrict__ q,
+                                              const double* __restrict__ rowD, const double* __restrict__ colD,
+                                              const double* __restrict__ rowO, const double* __restrict__ colO,
+                                              double* __restrict__ out, int B, int nwork, int p0, int orig) {
   const int Po = P - L;
   // 1-D grid, XCD-aware (blocks i and i + 8 share an XCD: consecutive work items go to the same XCD), batch element fastest:
   // the B workgroups of one (pair, column tile) sweep the same 64-column strip of C_a (Mp x 64 doubles) at the same pace and
   // share it in that XCD's L2.  In (column tile, pair, b) launch order every workgroup streamed its strip from HBM --
   // B L Mp^2 x 8 bytes = 8.6 GB at C3 shape with B = 32: the kernel ran at HBM speed, not at its arithmetic.
-  const int orig = blockIdx.x;
   const int xcd = orig & 7, slotx = orig >> 3;
   const int qn = nwork >> 3, rn = nwork & 7;
   const int wi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + slotx;
@@ -441,6 +442,33 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const doubl
   }
 }
 
+
+template <int KS4, int NU, bool SWAP>
+__global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma(const double* __restrict__ Zc, int Kz,
+                                                     const double* __restrict__ zbar, const double* __restrict__ Cm,
+                                                     const double* __restrict__ mu, int L, int Mp, int d, int P,
+                                                     const double* __restrict__ w, const double* __restrict__ q,
+                                                     const double* __restrict__ rowD, const double* __restrict__ colD,
+                                                     const double* __restrict__ rowO, const double* __restrict__ colO,
+                                                     double* __restrict__ out, int B, int nwork, int p0) {
+  mmb_mfma_body<KS4, NU, SWAP>(Zc, Kz, zbar, Cm, mu, L, Mp, d, P, w, q, rowD, colD, rowO, colO, out, B, nwork, p0, (int)blockIdx.x);
+}
+
+// Column sums (all pairs) and row sums (off-diagonal pairs) of a SMALL f64 model in one launch: the two sweeps are independent and
+// a cartpole-sized one does not fill the device, so side by side they take the time of the longer one (9.7 + 6.5 -> ~ 10 us).
+template <int KS4, int NU>
+__global__ __launch_bounds__(256, (NU >= 2 ? 1 : 2)) void k_bwd_mfma_both(const double* __restrict__ Zc, int Kz,
+                                                     const double* __restrict__ zbar, const double* __restrict__ Cm,
+                                                     const double* __restrict__ mu, int L, int Mp, int d, int P,
+                                                     const double* __restrict__ w, const double* __restrict__ q,
+                                                     const double* __restrict__ rowD, const double* __restrict__ colD,
+                                                     const double* __restrict__ rowO, const double* __restrict__ colO,
+                                                     double* __restrict__ out_col, double* __restrict__ out_row, int B,
+                                                     int nw_col, int nw_row) {
+  const int orig = (int)blockIdx.x;
+  if (orig < nw_col) mmb_mfma_body<KS4, NU, false>(Zc, Kz, zbar, Cm, mu, L, Mp, d, P, w, q, rowD, colD, rowO, colO, out_col, B, nw_col, 0, orig);
+  else mmb_mfma_body<KS4, NU, true>(Zc, Kz, zbar, Cm, mu, L, Mp, d, P, w, q, rowD, colD, rowO, colO, out_row, B, nw_row, 0, orig - nw_col);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Diagonal pairs (a == a'), factored form (the forward's: mm_f64.hip).  e^{delta_ij} = e^{rho_i} e^{gamma'_j} e^{b_ij} with the
@@ -783,6 +811,11 @@ int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* w
     } while (0)
 #define MMB_M_LAUNCH(KS_, NU_)                                                                                      \
     do {                                                                                                            \
+      if (old_diag && Pok > 0 && (long long)nw_col + nw_row <= 1024) {                                              \
+        hipLaunchKernelGGL((k_bwd_mfma_both<KS_, NU_>), dim3(nw_col + nw_row), dim3(256), 0, s, MMB_M_ARGS, out_col, out_row, B, \
+                           nw_col, nw_row);                                                                         \
+        break;                                                                                                      \
+      }                                                                                                             \
       if (!old_diag) MMB_D_LAUNCH(KS_, NU_);                                                                        \
       if (nw_col > 0)                                                                                               \
         hipLaunchKernelGGL((k_bwd_mfma<KS_, NU_, false>), dim3(nw_col), dim3(256), 0, s, MMB_M_ARGS, out_col, B, nw_col, pc0); \
