@@ -439,7 +439,9 @@ int mm_launch_route(const char* packed, const MMModelLayout& ml, char* ws, const
 
 int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
                               int B, int L, int M, int d, int flags, const float* mu, double* slab, double* pagg, int32_t* status,
-                              hipStream_t stream, int stages = MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE) {
+                              hipStream_t stream, int stages = MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE, int agg_threads = 512) {
+  // agg_threads: workgroup size of k_pair_agg -- 512 on its own (256 / 1024 measured 13 % / 30 % slower), 256 when it runs on a side
+  // stream BESIDE the diagonal sweep (mm_compose_bwd.hip): one wave per SIMD and 80 KB of LDS fit next to that kernel's two waves
   if (wl.Po <= 0) return 0;
   if (!mm_bwd_f32_supported(d)) return MM_E_DIM;
   const int npanel = (wl.Mp + 255) / 256;
@@ -466,9 +468,11 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
 #undef MMR_LAUNCH
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  }
   // items whose estimated f32 / bf16 rounding error is beyond MM_ROUTE_TOL of the block's scale: remainder aggregates in f64
-  const int rcr = mm_launch_route(packed, ml, ws, wl, B, L, M, d, flags, 1, slab, status, stream);
-  if (rcr) return rcr;
+  if (((stages & MM_STAGE_OFFDIAG) && !(stages & MM_ISTAGE_NO_ROUTE)) || (stages & MM_ISTAGE_ROUTE)) {
+    const int rcr = mm_launch_route(packed, ml, ws, wl, B, L, M, d, flags, 1, slab, status, stream);
+    if (rcr) return rcr;
   }
   if (!(stages & MM_STAGE_FINALIZE)) return 0;
   const int rc = mm_launch_wmom_full(packed, ml, ws, wl, B, L, d, stream);
@@ -481,7 +485,7 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
     e = mmr_set_max_lds_once((const void*)k_pair_agg, (int)shm_max, agg_attr_set);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k_pair_agg, dim3(wl.Po, B), dim3(512), shm2, stream, (const double*)(ws + wl.mom), ml.KMp,
+  hipLaunchKernelGGL(k_pair_agg, dim3(wl.Po, B), dim3(agg_threads), shm2, stream, (const double*)(ws + wl.mom), ml.KMp,
                      (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), mu, L, d, wl.P, npanel,
                      (const double*)slab, (const short*)(packed + ml.rtab), pagg);
   e = hipGetLastError();

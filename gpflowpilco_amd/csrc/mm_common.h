@@ -10,6 +10,11 @@ static inline size_t mm_elem_size(int dtype) { return dtype == MM_F64 ? 8 : 4; }
 
 // Number of (a, a') kernel pairs that are reduced: all a <= a' with full output
 // covariance (models.py:244-248), only a == a' otherwise (:249-252).
+// internal stage bits of mm_launch_bwd_offdiag_f32 (mm_bwd_f32.hip), beside the public MM_STAGE_*: the re-reduce of the routed items
+// can be split off the remainder sweep (it then runs on the side stream with the aggregate chain, mm_compose_bwd.hip)
+#define MM_ISTAGE_NO_ROUTE (1 << 20)      /* with MM_STAGE_OFFDIAG: the sweep alone */
+#define MM_ISTAGE_ROUTE (1 << 21)         /* the route decision + the f64 re-reduce of the routed items alone */
+
 static inline int mm_num_pairs(int L, int flags) {
   return (flags & MM_FULL_OUTPUT_COV) ? L * (L + 1) / 2 : L;
 }

@@ -23,7 +23,7 @@ extern "C" int mm_bwd_f32_supported(int d);
 size_t mm_bwd_f32_slab_bytes(int B, int Po, int Mp, int d);
 int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
                               int B, int L, int M, int d, int flags, const float* mu, double* slab, double* pagg, int32_t* status,
-                              hipStream_t stream, int stages);
+                              hipStream_t stream, int stages, int agg_threads = 512);
 int mm_launch_cast_f32_f64(const float* x, double* y, size_t n, hipStream_t stream);
 
 // stage profile (tools/profile_c1_stages.py; -DMM_STAGE_PROFILE builds only): cycles per stage of block 0
@@ -38,6 +38,35 @@ extern "C" void mm_stage_profile_set_bwd(void* device_buffer) {
 #endif
 
 enum { MMB_MODE_ALL = 0, MMB_MODE_SWEEPS = 1, MMB_MODE_CHAIN = 2 };
+
+// f32 packs, all stages in one call: the aggregate chain of the off-diagonal pairs (re-reduce of the routed items 0.6 ms + full
+// moment GEMM 0.5 ms + k_pair_agg 1.4 ms at C3 shape: latency-bound, few or short workgroups) runs on a SIDE STREAM beside the diagonal pairs' f64 sweep,
+// which leaves 96 VGPRs per SIMD lane and 112 KB of LDS per CU free: with 256-thread workgroups the chain hides completely
+// (value + sums 35.9 -> 34.2 ms; with 512-thread workgroups, which cannot co-reside, 35.5).  One side stream and two events per
+// device, created on first use; the enqueue sequence is serialised by a mutex (the events are shared by the device's callers);
+// under stream capture the side stream joins the capture through the events (fork / join).
+#include <atomic>
+#include <mutex>
+struct MMFork { hipStream_t s2; hipEvent_t fork, join; bool ok; std::mutex seq; };
+static MMFork* mm_fork_get() {
+  static MMFork forks[64];
+  static std::atomic<unsigned long long> made{0ull};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  MMFork& f = forks[dev];
+  if (!(made.load(std::memory_order_acquire) & (1ull << dev))) {
+    static std::mutex mu_;
+    std::lock_guard<std::mutex> g(mu_);
+    if (!(made.load(std::memory_order_acquire) & (1ull << dev))) {
+      f.ok = hipStreamCreateWithFlags(&f.s2, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess;
+      made.fetch_or(1ull << dev, std::memory_order_release);
+    }
+  }
+  return f.ok ? &f : nullptr;
+}
+
 
 #define MMB_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
@@ -253,6 +282,23 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     if (rc) return rc;
     mu64 = (const double*)(bw + bl.mu64);
     S64 = (const double*)(bw + bl.S64);
+    MMFork* fork = (do_sweeps && wl.Po > 0 && stages == (MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE)) ? mm_fork_get() : nullptr;
+    if (fork) {
+      std::lock_guard<std::mutex> guard(fork->seq);
+      // remainder sweep first; then [moment GEMM + pair aggregates on the side stream] beside [the diagonal sweep]
+      rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)(bw + bl.slab),
+                                     (double*)(bw + bl.pagg), status, s, MM_STAGE_OFFDIAG | MM_ISTAGE_NO_ROUTE);
+      if (rc) return rc;
+      if (hipEventRecord(fork->fork, s) != hipSuccess || hipStreamWaitEvent(fork->s2, fork->fork, 0) != hipSuccess) return MM_E_ARG;
+      rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)(bw + bl.slab),
+                                     (double*)(bw + bl.pagg), status, fork->s2, MM_ISTAGE_ROUTE | MM_STAGE_FINALIZE, 256);
+      if (rc) return rc;
+      if (hipEventRecord(fork->join, fork->s2) != hipSuccess) return MM_E_ARG;
+      rc = mm_backward_sums_impl(pk, ml, ws, wl, L, M, d, B, mu64, flags, with_unc, true, (double*)(bw + bl.sums), s);
+      if (rc) return rc;
+      if (hipStreamWaitEvent(s, fork->join, 0) != hipSuccess) return MM_E_ARG;
+      pagg = (const double*)(bw + bl.pagg);
+    } else {
     if (do_sweeps && (stages & MM_STAGE_DIAG)) {
       rc = mm_backward_sums_impl(pk, ml, ws, wl, L, M, d, B, mu64, flags, with_unc, true, (double*)(bw + bl.sums), s);
       if (rc) return rc;
@@ -264,6 +310,7 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
         if (rc) return rc;
       }
       pagg = (const double*)(bw + bl.pagg);
+    }
     }
   } else if (do_sweeps && (stages & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG))) {
     rc = mm_backward_sums(packed, packed_bytes, L, M, d, dtype, B, mu, flags, workspace, workspace_bytes, bw + bl.sums,

@@ -115,3 +115,40 @@ def test_sums_of_another_state_are_reported(device):
     pm.check_status(B)
   ops.moment_match_backward(pm, mu, S, g_f1, g_Sff, g_cross, forward_generation=None, sums=sums)    # the right state: accepted
   pm.check_status(B)
+
+
+def test_value_and_gradient_replay_from_a_hip_graph(device):
+  """The f32 pack's aggregate chain runs on a side stream beside the diagonal sweep (fork / join by events, mm_compose_bwd.hip):
+  under stream capture the side stream must join the capture -- a replayed graph returns what the eager calls return."""
+  syn, model, mu, S = _setup((3, 200, 8, 3), torch.float32, device, seed=51)
+  pm = model.packed(torch.float32, True, device)
+  B, L, d = mu.shape[0], pm.L, pm.d
+  gen = torch.Generator(device="cpu").manual_seed(6)
+  g_f1 = torch.randn(B, L, generator=gen, dtype=F64).to(device)
+  g_Sff = torch.randn(B, L, L, generator=gen, dtype=F64).to(device)
+  g_cross = torch.randn(B, d, L, generator=gen, dtype=F64).to(device)
+
+  def run(m_, S_):
+    f1, Sff, cross, sums, generation = ops.moment_match_with_sums(pm, m_, S_)
+    gmu, gS = ops.moment_match_backward(pm, m_, S_, g_f1, g_Sff, g_cross, forward_generation=generation, sums=sums)
+    return f1, Sff, cross, gmu, gS
+  want = [t.clone() for t in run(mu, S)]
+  pm.check_status(B)
+  ms, Ss = mu.clone(), S.clone()
+  side = torch.cuda.Stream(device)
+  side.wait_stream(torch.cuda.current_stream(device))
+  with torch.cuda.stream(side):
+    for _ in range(2):
+      run(ms, Ss)
+  torch.cuda.current_stream(device).wait_stream(side)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    outs = run(ms, Ss)
+  ms.copy_(mu * 0.9); Ss.copy_(S * 1.1)                    # another state through the same graph ...
+  graph.replay()
+  ms.copy_(mu); Ss.copy_(S)                                # ... and the first one again
+  graph.replay()
+  torch.cuda.synchronize()
+  pm.check_status(B)
+  for got, ref in zip(outs, want):
+    assert torch.equal(got, ref)
