@@ -24,6 +24,7 @@
 #include <math.h>
 #include <atomic>
 #include "mm_common.h"
+#include "mm_fork.h"
 #include "mm_mono.h"
 #include "mm_f32_tile.h"
 #include "mm_adjoint.h"
@@ -475,6 +476,7 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
     if (rcr) return rcr;
   }
   if (!(stages & MM_STAGE_FINALIZE)) return 0;
+  if (mm_fork_join_wait(stream)) return MM_E_ARG;   // the q stage's k_spoly (side stream) still reads the table the full GEMM overwrites
   const int rc = mm_launch_wmom_full(packed, ml, ws, wl, B, L, d, stream);
   if (rc) return rc;
   const int nT = mma_pair_agg_len(d);

@@ -42,30 +42,8 @@ enum { MMB_MODE_ALL = 0, MMB_MODE_SWEEPS = 1, MMB_MODE_CHAIN = 2 };
 // f32 packs, all stages in one call: the aggregate chain of the off-diagonal pairs (re-reduce of the routed items 0.6 ms + full
 // moment GEMM 0.5 ms + k_pair_agg 1.4 ms at C3 shape: latency-bound, few or short workgroups) runs on a SIDE STREAM beside the diagonal pairs' f64 sweep,
 // which leaves 96 VGPRs per SIMD lane and 112 KB of LDS per CU free: with 256-thread workgroups the chain hides completely
-// (value + sums 35.9 -> 34.2 ms; with 512-thread workgroups, which cannot co-reside, 35.5).  One side stream and two events per
-// device, created on first use; the enqueue sequence is serialised by a mutex (the events are shared by the device's callers);
-// under stream capture the side stream joins the capture through the events (fork / join).
-#include <atomic>
-#include <mutex>
-struct MMFork { hipStream_t s2; hipEvent_t fork, join; bool ok; std::mutex seq; };
-static MMFork* mm_fork_get() {
-  static MMFork forks[64];
-  static std::atomic<unsigned long long> made{0ull};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  MMFork& f = forks[dev];
-  if (!(made.load(std::memory_order_acquire) & (1ull << dev))) {
-    static std::mutex mu_;
-    std::lock_guard<std::mutex> g(mu_);
-    if (!(made.load(std::memory_order_acquire) & (1ull << dev))) {
-      f.ok = hipStreamCreateWithFlags(&f.s2, hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess;
-      made.fetch_or(1ull << dev, std::memory_order_release);
-    }
-  }
-  return f.ok ? &f : nullptr;
-}
+// (value + sums 35.9 -> 34.2 ms; with 512-thread workgroups, which cannot co-reside, 35.5).  (mm_fork.h)
+#include "mm_fork.h"
 
 
 #define MMB_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)

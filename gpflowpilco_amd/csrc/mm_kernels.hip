@@ -30,7 +30,36 @@
 #include "mm_dev.h"
 #include "mm_mono.h"
 
+#include <atomic>
+#include "mm_fork.h"
+
 #define MM_ABI_VERSION 2
+
+MMFork* mm_fork_get() {
+  static MMFork forks[64];
+  static std::atomic<unsigned long long> made{0ull};
+  static std::mutex mu_;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  MMFork& f = forks[dev];
+  if (!(made.load(std::memory_order_acquire) & (1ull << dev))) {
+    std::lock_guard<std::mutex> g(mu_);
+    if (!(made.load(std::memory_order_acquire) & (1ull << dev))) {
+      f.ok = hipStreamCreateWithFlags(&f.s2, hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess;
+      made.fetch_or(1ull << dev, std::memory_order_release);
+    }
+  }
+  return f.ok ? &f : nullptr;
+}
+
+int mm_fork_join_wait(hipStream_t stream) {
+  MMFork* fork = mm_fork_get();
+  if (!fork || stream == fork->s2) return 0;        // (the side stream itself is in order)
+  std::lock_guard<std::mutex> guard(fork->seq);
+  return hipStreamWaitEvent(stream, fork->join, 0) == hipSuccess ? 0 : MM_E_ARG;
+}
 
 // ---------------------------------------------------------------------------------------------
 // small device helpers
@@ -1156,7 +1185,8 @@ extern "C" int mm_pack_model(void* packed, size_t packed_bytes, int L, int M, in
 template <typename T, int DK>
 static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
                           int L, int M, int d, int B, const T* mu, const T* Sigma, int flags,
-                          T* f1, T* cross, T* q_out, int32_t* status, hipStream_t s) {
+                          T* f1, T* cross, T* q_out, int32_t* status, hipStream_t s, bool joins) {
+  // joins: the caller runs the Q stage in the same call (and so joins the side stream this q stage may open)
   const double* ls2 = (const double*)(packed + ml.ls2);
   const double* var = (const double*)(packed + ml.var);
   const double* Z64 = (const double*)(packed + ml.Z64);
@@ -1202,9 +1232,25 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   }
   MM_CHECK_LAUNCH();
   if (sizeof(T) == 4 && wl.Po > 0) {
-    // exact (f64) polynomial part of the off-diagonal sums from the weight moments (mm_moments.hip)
-    const int rc = mm_launch_moments(packed, ml, ws, wl, B, L, d, (const void*)mu, flags, s);
-    if (rc) return rc;
+    // exact (f64) polynomial part of the off-diagonal sums from the weight moments (mm_moments.hip): s12 is read by the route decision
+    // and by k_finalize only -- AFTER both sweeps -- so the chain (k_wmom_perm, k_wmom_gemm, k_spoly: 0.5 ms at C3, a small f64 GEMM
+    // and latency-bound contractions) runs on the side stream beside the diagonal pairs' sweep; mm_Q_reduce_t joins it before it
+    // reads s12.  Not while capturing unless this call joins itself (`joins`): a capture must not end with the side stream open.
+    MMFork* fork = mm_fork_get();
+    if (fork && !joins) {
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) fork = nullptr;
+    }
+    if (fork) {
+      std::lock_guard<std::mutex> guard(fork->seq);
+      if (hipEventRecord(fork->fork, s) != hipSuccess || hipStreamWaitEvent(fork->s2, fork->fork, 0) != hipSuccess) return MM_E_ARG;
+      const int rc = mm_launch_moments(packed, ml, ws, wl, B, L, d, (const void*)mu, flags, fork->s2);
+      if (rc) return rc;
+      if (hipEventRecord(fork->join, fork->s2) != hipSuccess) return MM_E_ARG;
+    } else {
+      const int rc = mm_launch_moments(packed, ml, ws, wl, B, L, d, (const void*)mu, flags, s);
+      if (rc) return rc;
+    }
   }
   MM_CHECK_LAUNCH();
   return 0;
@@ -1267,6 +1313,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
       int rc = mm_launch_qred_mfma(packed, ml, ws, wl, B, L, d, flags, s);
       if (rc) return rc;
       if (routes) {
+        // (mm_launch_route joins the q stage's moment chain on the side stream: s12 is the route decision's scale)
         rc = mm_launch_route(packed, ml, ws, wl, B, L, M, d, flags, 0, partB, status, s);
         if (rc) return rc;
       }
@@ -1286,6 +1333,9 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
                          (sizeof(T) == 4 && mm_moment_deg(d) >= 4) ? (const double*)(packed + ml.zmax2) : (const double*)nullptr);
       MM_CHECK_LAUNCH();
     }
+  }
+  if ((stages & MM_STAGE_FINALIZE) && sizeof(T) == 4 && wl.Po > 0) {
+    if (mm_fork_join_wait(s)) return MM_E_ARG;      // the q stage's moment chain (side stream): k_finalize adds s12
   }
   if (stages & MM_STAGE_FINALIZE) {
     const int n = B * wl.P;
@@ -1315,7 +1365,7 @@ static int mm_moment_match_t(const char* packed, size_t packed_bytes, int L, int
   if (ws_bytes < wl.total) return MM_E_WORKSPACE;
   int rc = 0;
   if (do_q) {
-    rc = mm_q_forward_t<T, DK>(packed, ml, ws, wl, L, M, d, B, mu, Sigma, flags, f1, cross, q_out, status, s);
+    rc = mm_q_forward_t<T, DK>(packed, ml, ws, wl, L, M, d, B, mu, Sigma, flags, f1, cross, q_out, status, s, do_Q);
     if (rc) return rc;
   }
   if (do_Q) rc = mm_Q_reduce_t<T, DK>(packed, ml, has_C, ws, wl, L, M, d, B, flags, jitter, Sff, status, s);
