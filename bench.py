@@ -31,7 +31,11 @@ The default N = 1 run of c3 times all three in one process (each with the same -
 under `regimes`; `value`, `ms_per_step`, `segments_ms`, `roofline`, `parity`, `cpu_baseline` describe the baseline one.
 
 The JSON line carries
-  roofline     -- the kernel with the largest measured share of the step, HIP-event timed inside the timed region on
+  (timing: the K timed steps call the product's entry point, ONE mm_moment_match per step -- its q stage overlaps the
+  off-diagonal operands and the moment chain with the diagonal sweep on a side stream; `segments_ms` and the roofline's kernel
+  time come from a separate pass of the SAME kernels run stage by stage through the stage API, where nothing overlaps, so
+  sum(segments_ms) >= ms_per_step by what the overlap hides)
+  roofline     -- the kernel with the largest measured share of the step, HIP-event timed in that staged pass on
                   the launch stream: `achieved` = SURVEY 8d ALGORITHMIC flops per launch (E (2d + 12)) / that time,
                   `frac` = achieved / dense peak of the dtype (null with a reason where the algorithmic rate exceeds
                   the peak, i.e. the launch does not execute 8d's per-entry work); `issue_frac` = the kernel's OWN
@@ -453,27 +457,36 @@ def main():
       state["h"] = 0
       state["rollouts"] += 1
 
-    def one_step(timed):
+    extra = base & ~(F.MM_FULL_OUTPUT_COV | F.MM_MODEL_UNCERTAINTY | F.MM_FORCE_GENERIC)
+
+    def one_step(timed, staged=False):
+      """One rollout step.  The TIMED steps call the product's entry point, mm_moment_match (one call: its q stage puts the
+      off-diagonal operands and the moment chain on a side stream beside the diagonal sweep, and joins); `staged` steps run the
+      same kernels through the stage API one stage at a time -- no overlap -- so that HIP events give clean per-stage times
+      (`segments_ms`, the roofline's kernel time) and rocprofv3 per-kernel durations."""
       h = state["h"]
       if rec["independent"]:
         state["mu"], state["S"] = draws_mu[h], draws_S[h]
       elif h == 0:
         state["mu"], state["S"] = mu0.clone(), S0.clone()
-      e = [Ev() for _ in range(5)] if timed else None
-      if timed: e[0].record()
-      f1, cross, _ = ops.q_forward(pm, state["mu"], state["S"], base)
-      if timed: e[1].record()
-      ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_DIAG)
-      if timed: e[2].record()
-      ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_OFFDIAG)
-      if timed: e[3].record()
-      Sff = ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_FINALIZE)
+      e = [Ev() for _ in range(5)] if staged else None
+      if staged:
+        e[0].record()
+        f1, cross, _ = ops.q_forward(pm, state["mu"], state["S"], base)
+        e[1].record()
+        ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_DIAG)
+        e[2].record()
+        ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_OFFDIAG)
+        e[3].record()
+        Sff = ops.Q_reduce_forward(pm, B, base | F.MM_STAGE_FINALIZE)
+      else:
+        f1, Sff, cross = ops.moment_match(pm, state["mu"], state["S"], True, True, 0.0, args.force_generic, extra)
       if cfg["closed"]:
         state["mu"], state["S"] = ops.euler_update(state["mu"], state["S"], f1, Sff, cross, 1.0)
         traj_mu[h].copy_(state["mu"]); traj_S[h].copy_(state["S"])
       else:
         traj_mu[h].copy_(f1); traj_S[h].copy_(Sff)            # the predicted increment's moments carry the cost statistic
-      if timed:
+      if staged:
         e[4].record(); ev.append(e)
       state["h"] = h + 1
       if state["h"] == H:
@@ -496,7 +509,7 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(steps):
-      one_step(True)
+      one_step(True, staged=args.pmc_run)                    # (counter passes: stage by stage, one kernel at a time)
     if state["h"] != 0 and not args.pmc_run:
       finish_rollout(state["h"])                             # the partial last rollout's costs + collective
     fence()
@@ -507,6 +520,13 @@ def main():
       elapsed = float(tmax.item())
     pm.check_status(B)
     rollouts_timed, collectives_timed = state["rollouts"], state["collectives"]
+    # per-stage times: a separate, untimed pass of staged steps (<= one rollout of them)
+    if not args.pmc_run:
+      ev.clear()
+      state["h"] = 0
+      for _ in range(min(steps, H)):
+        one_step(False, staged=True)
+      torch.cuda.synchronize()
     # regime of the off-diagonal reduce over one (untimed) rollout: its kernels' time depends on it
     collapsed = [0, 0, 0]
     routed = 0
@@ -525,7 +545,7 @@ def main():
       if not torch.isfinite(state["cost"]).all():
         raise SystemExit("non-finite per-step costs")
 
-    # ---- per-segment device time (HIP events on the launch stream, inside the timed region) -------------------
+    # ---- per-segment device time (HIP events on the launch stream; the staged pass above / the counter passes' steps) -------------
     seg = {k: float(np.mean([e[i].elapsed_time(e[i + 1]) for e in ev])) for i, k in enumerate(("q_stage", "diag", "offdiag", "tail"))}
     pmc, pmc_src = load_pmc(f"{args.config}_{recipe_name}", fallback=args.config if (recipe_name == cfg["recipe"] and args.config != "c3") else None)
     pscale, pmc_src = pmc_scale(pmc, pmc_src, B, cfg["B"])

@@ -262,7 +262,7 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     S64 = (const double*)(bw + bl.S64);
     MMFork* fork = (do_sweeps && wl.Po > 0 && stages == (MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE)) ? mm_fork_get() : nullptr;
     if (fork) {
-      std::lock_guard<std::mutex> guard(fork->seq);
+      std::lock_guard<std::recursive_mutex> guard(fork->seq);
       // remainder sweep first; then [moment GEMM + pair aggregates on the side stream] beside [the diagonal sweep]
       rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)(bw + bl.slab),
                                      (double*)(bw + bl.pagg), status, s, MM_STAGE_OFFDIAG | MM_ISTAGE_NO_ROUTE);

@@ -12,7 +12,7 @@ struct MMFork {
   hipStream_t s2;
   hipEvent_t fork, join;
   bool ok;
-  std::mutex seq;
+  std::recursive_mutex seq;     // (recursive: a sequence that holds it calls launchers that join-wait themselves)
 };
 MMFork* mm_fork_get();      // nullptr if the stream / events could not be created (callers then stay on the main stream)
 // Make `stream` wait for everything the side stream has been given so far (the q stage's moment chain): called by whoever reads

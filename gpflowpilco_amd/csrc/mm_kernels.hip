@@ -57,7 +57,7 @@ MMFork* mm_fork_get() {
 int mm_fork_join_wait(hipStream_t stream) {
   MMFork* fork = mm_fork_get();
   if (!fork || stream == fork->s2) return 0;        // (the side stream itself is in order)
-  std::lock_guard<std::mutex> guard(fork->seq);
+  std::lock_guard<std::recursive_mutex> guard(fork->seq);
   return hipStreamWaitEvent(stream, fork->join, 0) == hipSuccess ? 0 : MM_E_ARG;
 }
 
@@ -548,11 +548,11 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
                                                  double* __restrict__ whC, unsigned int* __restrict__ amax,
                                                  const double* __restrict__ q64, double* __restrict__ qhR,
                                                  double* __restrict__ qhC, int with_unc, int nblk,
-                                                 const double* __restrict__ lq, const double* __restrict__ beta64) {
+                                                 const double* __restrict__ lq, const double* __restrict__ beta64, int p0) {
   static_assert(DK > 8, "d <= 8 takes k_pairvec_reg");
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
   // pair's matrix is fetched once per workgroup, not once per chunk
-  const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int p = p0 + (int)blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
   int a, a2;
   mm_decode_pair(p, L, a, a2);
   // With zeta = z - mu, A_i = G^T zeta_i (row side, latent a), g_j = G zeta'_j (column side, latent a'):
@@ -708,9 +708,9 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
                                                     const double* __restrict__ q64, double* __restrict__ qhR,
                                                     double* __restrict__ qhC, int with_unc, int nblk, int a, int a2,
                                                     double (*vecs)[DK], const double* __restrict__ lq,
-                                                    const double* __restrict__ beta64) {
+                                                    const double* __restrict__ beta64, int p) {
   constexpr bool diag = MODE == 0;
-  const int p = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int b = blockIdx.z, tid = threadIdx.x;
   const int Po = P - L;
   const double* zA = Zt64 + (size_t)a * d * Mp;
   const double* zB = Zt64 + (size_t)a2 * d * Mp;
@@ -917,15 +917,18 @@ __global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict
                                                         double* __restrict__ whC, unsigned int* __restrict__ amax,
                                                         const double* __restrict__ q64, double* __restrict__ qhR,
                                                         double* __restrict__ qhC, int with_unc, int nblk,
-                                                        const double* __restrict__ lq, const double* __restrict__ beta64) {
+                                                        const double* __restrict__ lq, const double* __restrict__ beta64, int p0) {
+  // (grid.y = the pairs [p0, p0 + gridDim.y): the q stage launches the diagonal pairs' operands first -- the diagonal sweep needs
+  // nothing else -- and the off-diagonal pairs' on the side stream beside that sweep)
   static_assert(DK <= 8, "register form: d <= 8");
   __shared__ double vecs[5][DK];      // mu | 1/Lam_a | 1/Lam_a' | (mu - zbar_a') / Lam_a' | (mu - zbar_a) / Lam_a
+  const int p = p0 + (int)blockIdx.y;
   int a, a2;
-  mm_decode_pair((int)blockIdx.y, L, a, a2);
+  mm_decode_pair(p, L, a, a2);
 #define MM_PV_BODY(MODE_)                                                                                           \
   mm_pairvec_reg_body<T, DK, MODE_>(Zt64, zbar, ls2, L, M, Mp, d, P, mu, pairmat, rho1, rowD, colD, rowO, colO, w64, \
-                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64)
-  if ((int)blockIdx.y < L) MM_PV_BODY(0);
+                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64, p)
+  if (p < L) MM_PV_BODY(0);
   else if (sizeof(T) == 4) MM_PV_BODY(1);
   else MM_PV_BODY(2);
 #undef MM_PV_BODY
@@ -1212,45 +1215,55 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
                      (double*)(ws + wl.f1raw), (double*)(ws + wl.rho1), f1, cross, q_out, (double*)(ws + wl.mu64), (double*)(ws + wl.lq));
   MM_CHECK_LAUNCH();
   {
+    // The streamed operands of the reduces, one launch per kind of pair: the diagonal pairs' first (all the diagonal sweep needs),
+    // then the off-diagonal pairs' and -- f32 packs -- the moment chain behind them (k_wmom_perm, k_wmom_gemm, k_spoly: the exact
+    // polynomial part of the off-diagonal sums, mm_moments.hip; s12 is read after both sweeps only).  Where the call can fork, the
+    // second group runs on the SIDE STREAM beside the diagonal pairs' sweep (mm_fork.h): HBM-bound operand writes and a small f64
+    // GEMM next to an f64 issue-bound kernel.  mm_Q_reduce_t joins before the off-diagonal sweep.
     const int nblk = (wl.Mp + 255) / 256;                  // 256-row chunks = wsum slots per (b, pair)
-    long long per = (long long)wl.P * B;                   // workgroups per chunk split
-    int nsplit = (int)((4096 + per - 1) / per);            // >= 16 workgroups per CU, else one per (b, pair)
-    if (nsplit > nblk) nsplit = nblk;
-    if (nsplit < 1) nsplit = 1;
+    auto nsplit_for = [&](int npairs) {
+      long long per = (long long)npairs * B;               // workgroups per chunk split
+      int ns = (int)((4096 + per - 1) / per);              // >= 16 workgroups per CU, else one per (b, pair)
+      if (ns > nblk) ns = nblk;
+      return ns < 1 ? 1 : ns;
+    };
 #define MM_PAIRVEC_ARGS                                                                                                     \
     (const double*)(packed + ml.Zt64), (const double*)(packed + ml.zbar), ls2, L, M, wl.Mp, d, wl.P, mu, pairmat,            \
     (const double*)(ws + wl.rho1), (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO), \
     (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), amax,                                      \
     (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC), (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk, \
     (const double*)(ws + wl.lq), (const double*)(packed + ml.beta64)
-    if constexpr (DK <= 8) {
-      hipLaunchKernelGGL((k_pairvec_reg<T, DK>), dim3(nsplit, wl.P, B), dim3(256), 0, s, MM_PAIRVEC_ARGS);
-    } else {
-      hipLaunchKernelGGL((k_pairvec<T, DK>), dim3(nsplit, wl.P, B), dim3(256), 0, s, MM_PAIRVEC_ARGS);
+    auto pairvec = [&](int p0, int npairs, hipStream_t st) {
+      if (npairs <= 0) return;
+      if constexpr (DK <= 8) {
+        hipLaunchKernelGGL((k_pairvec_reg<T, DK>), dim3(nsplit_for(npairs), npairs, B), dim3(256), 0, st, MM_PAIRVEC_ARGS, p0);
+      } else {
+        hipLaunchKernelGGL((k_pairvec<T, DK>), dim3(nsplit_for(npairs), npairs, B), dim3(256), 0, st, MM_PAIRVEC_ARGS, p0);
+      }
+    };
+    pairvec(0, L, s);
+    MM_CHECK_LAUNCH();
+    if (wl.Po > 0) {
+      // (only a call that joins itself forks -- mm_moment_match, the rollouts: a stand-alone mm_q_forward returns with everything it
+      // enqueued on the caller's stream, so that the caller's stream order -- and its allocator's -- covers the workspace)
+      MMFork* fork = joins ? mm_fork_get() : nullptr;
+      if ((long long)wl.P * B < 512) fork = nullptr;        // (small problems: nothing to hide behind, and launches are what counts)
+      hipStream_t s2 = s;
+      std::unique_lock<std::recursive_mutex> guard;
+      if (fork) {
+        guard = std::unique_lock<std::recursive_mutex>(fork->seq);
+        if (hipEventRecord(fork->fork, s) != hipSuccess || hipStreamWaitEvent(fork->s2, fork->fork, 0) != hipSuccess) return MM_E_ARG;
+        s2 = fork->s2;
+      }
+      pairvec(L, wl.Po, s2);
+      MM_CHECK_LAUNCH();
+      if (sizeof(T) == 4) {
+        const int rc = mm_launch_moments(packed, ml, ws, wl, B, L, d, (const void*)mu, flags, s2);
+        if (rc) return rc;
+      }
+      if (fork && hipEventRecord(fork->join, fork->s2) != hipSuccess) return MM_E_ARG;
     }
 #undef MM_PAIRVEC_ARGS
-  }
-  MM_CHECK_LAUNCH();
-  if (sizeof(T) == 4 && wl.Po > 0) {
-    // exact (f64) polynomial part of the off-diagonal sums from the weight moments (mm_moments.hip): s12 is read by the route decision
-    // and by k_finalize only -- AFTER both sweeps -- so the chain (k_wmom_perm, k_wmom_gemm, k_spoly: 0.5 ms at C3, a small f64 GEMM
-    // and latency-bound contractions) runs on the side stream beside the diagonal pairs' sweep; mm_Q_reduce_t joins it before it
-    // reads s12.  Not while capturing unless this call joins itself (`joins`): a capture must not end with the side stream open.
-    MMFork* fork = mm_fork_get();
-    if (fork && !joins) {
-      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) fork = nullptr;
-    }
-    if (fork) {
-      std::lock_guard<std::mutex> guard(fork->seq);
-      if (hipEventRecord(fork->fork, s) != hipSuccess || hipStreamWaitEvent(fork->s2, fork->fork, 0) != hipSuccess) return MM_E_ARG;
-      const int rc = mm_launch_moments(packed, ml, ws, wl, B, L, d, (const void*)mu, flags, fork->s2);
-      if (rc) return rc;
-      if (hipEventRecord(fork->join, fork->s2) != hipSuccess) return MM_E_ARG;
-    } else {
-      const int rc = mm_launch_moments(packed, ml, ws, wl, B, L, d, (const void*)mu, flags, s);
-      if (rc) return rc;
-    }
   }
   MM_CHECK_LAUNCH();
   return 0;
@@ -1281,6 +1294,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
   // small f64 models: both kinds of pairs in one launch (mm_f64.hip) -- the two sweeps then run side by side on the device
   bool both = false;
   if (sizeof(T) == 8 && !generic && wl.Po > 0 && (stages & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG)) == (MM_STAGE_DIAG | MM_STAGE_OFFDIAG)) {
+    if (mm_fork_join_wait(s)) return MM_E_ARG;       // (it reads the off-diagonal operands too)
     const int rc = mm_launch_qred_f64_both((const double*)(packed + ml.Zc64), ml.Kz, Cm, (const double*)(packed + ml.beta64), M, L,
                                            wl.Mp, d, wl.P, wl.NS, wl.Po, B, (flags & MM_FORCE_WORST_TIER) ? 1 : 0,
                                            (const double*)(ws + wl.qhR), (const double*)(ws + wl.qhC), (const double*)(ws + wl.rowD),
@@ -1307,6 +1321,8 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
       if (rc) return rc;
     }
   }
+  // (the off-diagonal pairs' operands and the moment chain may still be on the q stage's side stream)
+  if (wl.Po > 0 && (stages & (MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE)) && mm_fork_join_wait(s)) return MM_E_ARG;
   // (2) off-diagonal pairs in T
   if (!both && wl.Po > 0 && (stages & MM_STAGE_OFFDIAG)) {
     if (use_mfma32) {
@@ -1333,9 +1349,6 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
                          (sizeof(T) == 4 && mm_moment_deg(d) >= 4) ? (const double*)(packed + ml.zmax2) : (const double*)nullptr);
       MM_CHECK_LAUNCH();
     }
-  }
-  if ((stages & MM_STAGE_FINALIZE) && sizeof(T) == 4 && wl.Po > 0) {
-    if (mm_fork_join_wait(s)) return MM_E_ARG;      // the q stage's moment chain (side stream): k_finalize adds s12
   }
   if (stages & MM_STAGE_FINALIZE) {
     const int n = B * wl.P;
