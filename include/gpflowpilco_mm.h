@@ -11,15 +11,20 @@
  *   - every pointer is a DEVICE pointer unless it says "host"; row-major contiguous; the batch
  *     axis B is the leading axis, so a B-shard is a pointer offset;
  *   - the caller owns every buffer including the workspace (size from *_bytes queries);
- *   - calls only enqueue work on `stream` (a hipStream_t passed as void*); no allocation,
- *     no synchronisation, no global state (re-entrant across streams, graph-capturable);
+ *   - calls only enqueue work (no allocation, no synchronisation; graph-capturable) in the order of `stream` (a hipStream_t
+ *     passed as void*): when `stream` reaches the end of a call's work, everything the call enqueued is complete.  Some calls
+ *     (mm_moment_match, the rollouts, mm_moment_match_with_sums / _backward) run independent latency-bound kernel chains on ONE
+ *     library-owned side stream per device beside a long sweep and join it to `stream` before they return (fork / join by events;
+ *     under stream capture the side stream joins the capture).  The only process-wide state is that stream and its two events
+ *     (created on first use, shared by the device's callers, their enqueue order serialised by a mutex); the stage API
+ *     (mm_q_forward, mm_Q_reduce_forward) never leaves work on it;
  *   - return value: 0 ok, <0 bad argument (MM_E_*), >0 a hipError_t;
  *   - `status` (device int32[4], zeroed by the caller, may be NULL): [0] = B - b for the smallest
  *     batch index b whose (Sigma + V) Cholesky was not positive definite (0 = all fine; outputs
  *     of that b are NaN), [1] = an item code.  The reference raises InvalidArgumentError there
  *     (kernel_expectation.py:125-126, models.py:271).  [2] / [3] (MM_F32 packs; ABI version 2): running counts of the
  *     (batch element, off-diagonal pair) items the forward / the backward re-reduced in f64 because the f32 sweep's own
- *     rounding-error estimate exceeded MM_ROUTE_TOL (1e-4) of the batch element's off-diagonal covariance scale
+ *     rounding-error estimate exceeded MM_ROUTE_TOL (3e-4) of the batch element's off-diagonal covariance scale
  *     (csrc/mm_route.hip): the f32 pack's accuracy contract -- what stays in f32 is within ~1e-5 of
  *     that scale, the rest has f64 accuracy.  The reference computes these terms in float64 throughout
  *     (kernel_expectation.py:158-165).
