@@ -152,3 +152,40 @@ def test_value_and_gradient_replay_from_a_hip_graph(device):
   pm.check_status(B)
   for got, ref in zip(outs, want):
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64], ids=["f32", "f64"])
+def test_forward_with_the_side_stream_replays_from_a_hip_graph(dtype, device):
+  """mm_moment_match puts the off-diagonal operands and the moment chain on the side stream beside the diagonal sweep when the
+  problem is large enough (P B >= 512) and joins before the off-diagonal sweep: captured, the side stream must join the capture."""
+  L, M, d, B = 6, 300, 8, 32                                    # P B = 21 * 32 = 672
+  syn = make_svgp(L, M, d, seed=61, device=str(device), ls_bounds=(0.5, 2.5))
+  model = syn.to_model(device)
+  pm = model.packed(dtype, True, device)
+  mu, S = make_inputs(B, d, seed=62, scale=0.1, lo=0.2, hi=0.8)
+  mu, S = to_dev(mu, device, dtype), to_dev(S, device, dtype)
+  want = [t.clone() for t in ops.moment_match(pm, mu, S)]
+  pm.check_status(B)
+  ms, Ss = mu.clone(), S.clone()
+  side = torch.cuda.Stream(device)
+  side.wait_stream(torch.cuda.current_stream(device))
+  with torch.cuda.stream(side):
+    for _ in range(2):
+      ops.moment_match(pm, ms, Ss)
+  torch.cuda.current_stream(device).wait_stream(side)
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph):
+    outs = ops.moment_match(pm, ms, Ss)
+  ms.copy_(mu * 0.9); Ss.copy_(S * 1.2)
+  graph.replay()
+  ms.copy_(mu); Ss.copy_(S)
+  graph.replay()
+  torch.cuda.synchronize()
+  pm.check_status(B)
+  for got, ref in zip(outs, want):
+    assert torch.equal(got, ref)
+  # and the stage API, which stays on the caller's stream, gives the same numbers
+  flags = ops.make_flags(True, True)
+  f1, cross, _ = ops.q_forward(pm, mu, S, flags)
+  Sff = ops.Q_reduce_forward(pm, B, flags)
+  assert torch.equal(f1, want[0]) and torch.equal(Sff, want[1]) and torch.equal(cross, want[2])
