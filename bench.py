@@ -30,7 +30,11 @@ Recipes (the reduce kernels choose range tiers per tile, so their time depends o
 The default N = 1 run of c3 times all three in one process (each with the same --steps / --warmup) and reports them
 under `regimes`; `value`, `ms_per_step`, `segments_ms`, `roofline`, `parity`, `cpu_baseline` describe the baseline one.
 
-The JSON line carries
+Output: rank 0 prints ONE compact strict-JSON line (< 6000 bytes: the contract keys, `config`, `roofline` with numbers only,
+`cpu_baseline`, `parity` numbers, `segments_ms`, per regime {value, ms_per_step, kernel_ms, frac}) and writes the full result --
+everything below, with its definitions -- to bench_detail.json (and gpurun_out/bench_detail.json when that directory exists).
+
+The full result carries
   (timing: the K timed steps call the product's entry point, ONE mm_moment_match per step -- its q stage overlaps the
   off-diagonal operands and the moment chain with the diagonal sweep on a side stream; `segments_ms` and the roofline's kernel
   time come from a separate pass of the SAME kernels run stage by stage through the stage API, where nothing overlaps, so
@@ -100,6 +104,147 @@ PEAK_CLOCK_HZ = 2.4e9
 N_SIMD = 1024
 ISSUE = {"mfma_bf16_32x32x16": 32.0, "mfma_f64_16x16x4": 64.0, "valu_f32": 4.0, "valu_f64": 5.0, "valu_other": 4.0,
          "valu_trans": 8.0}
+
+
+# ---- the ONE line the driver parses ----------------------------------------------------------
+# Round 4's line grew to 22 KB (three regimes x four roofline blocks with prose definitions) and the driver's record came
+# back `parsed: null`.  Now: the full result goes to bench_detail.json (all definitions: DESIGN.md section 4.4), stdout gets
+# one compact strict-JSON line, hard-limited in size (tests/test_bench_helpers.py).
+LINE_LIMIT = 6000
+DETAIL_FILE = "bench_detail.json"
+_ROOF_KEYS = ("bound", "kernel", "kernel_ms", "achieved", "peak", "unit", "frac", "traffic", "issue_frac",
+              "issue_frac_at_measured_clock", "mfma_busy_frac", "measured_clock_ghz", "entries_per_launch",
+              "algorithmic_flops_per_launch", "bytes_per_launch", "executed_mfma_frac_of_bf16_peak")
+_CFG_DROP = ("value_is", "offdiag_items_one_rollout", "policy_gradient", "one_sweep_value_and_gradient", "launch", "row")
+
+
+def _finite(x):
+  """Strict JSON has no NaN / Infinity: non-finite floats become null, everything else passes through."""
+  if isinstance(x, float):
+    return x if x == x and x not in (float("inf"), float("-inf")) else None
+  if isinstance(x, dict):
+    return {str(k): _finite(v) for k, v in x.items()}
+  if isinstance(x, (list, tuple)):
+    return [_finite(v) for v in x]
+  if hasattr(x, "item") and not isinstance(x, (str, bytes)):      # numpy / torch scalars
+    try:
+      return _finite(x.item())
+    except Exception:
+      return str(x)
+  return x
+
+
+def _sig(x, n=6):
+  return float(f"{x:.{n}g}") if isinstance(x, float) else x
+
+
+def _short(s, n):
+  s = str(s)
+  return s if len(s) <= n else s[:n - 1] + "~"
+
+
+_DROP = object()
+
+
+def _numbers_only(x, depth=0):
+  """The numeric leaves of a parity block (strings and prose dropped)."""
+  if isinstance(x, dict):
+    out = {}
+    for k, v in x.items():
+      w = _numbers_only(v, depth + 1)
+      if w is not _DROP and w != {}:
+        out[k] = w
+    return out
+  if isinstance(x, bool) or x is None:                  # null = a non-finite number (_finite): it stays visible
+    return x
+  if isinstance(x, (int, float)):
+    return _sig(x, 4)
+  return _DROP
+
+
+def compact_roofline(r):
+  if not isinstance(r, dict):
+    return None
+  c = {k: _sig(r[k]) for k in _ROOF_KEYS if k in r}
+  if "kernel" in c:
+    c["kernel"] = _short(c["kernel"], 72)
+  if isinstance(r.get("pipes"), dict):
+    c["pipes"] = {k: v.get("frac") for k, v in r["pipes"].items() if isinstance(v, dict)}
+  if r.get("pmc"):
+    c["pmc"] = _short(r["pmc"], 64)
+  return c
+
+
+def compact_line(out):
+  """The compact dict printed on stdout: contract keys, `config` (sizes + recipe), `roofline` (numbers only), `cpu_baseline`,
+  `parity` (numbers only), `segments_ms`, and per regime just {value, ms_per_step, kernel_ms, frac}."""
+  out = _finite(out)
+  c = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                           "vs_baseline", "dtype", "data") if k in out}
+  c["unit"] = _short(c.get("unit", ""), 60)
+  cfg = {}
+  for k, v in (out.get("config") or {}).items():
+    if k in _CFG_DROP or isinstance(v, (dict, list)):
+      continue
+    cfg[k] = _short(v, 200 if k == "workload" else 80) if isinstance(v, str) else v
+  c["config"] = cfg
+  if "segments_ms" in out:
+    c["segments_ms"] = out["segments_ms"]
+  c["roofline"] = compact_roofline(out.get("roofline"))
+  if out.get("roofline_other"):
+    ro = compact_roofline(out["roofline_other"])
+    c["roofline_other"] = {k: ro[k] for k in ("kernel", "kernel_ms", "achieved", "peak", "frac", "traffic", "issue_frac") if k in ro}
+  cb = out.get("cpu_baseline")
+  if cb:
+    c["cpu_baseline"] = {"value": cb.get("value"), "unit": _short(cb.get("unit", ""), 60), "cores": cb.get("cores"),
+                         "kind": cb.get("kind"), "sample": _short(cb.get("sample", ""), 160)}
+  cm = out.get("cpu_baseline_matched")
+  if cm:
+    c["cpu_baseline_matched"] = {"value": cm.get("value"), "cores": cm.get("cores"), "kind": cm.get("kind")}
+  if out.get("parity"):
+    c["parity"] = _numbers_only(out["parity"])
+  if out.get("regimes"):
+    c["regimes"] = {n: {"value": r.get("value"), "ms_per_step": r.get("ms_per_step"),
+                        "kernel_ms": (r.get("roofline") or {}).get("kernel_ms"), "frac": (r.get("roofline") or {}).get("frac")}
+                    for n, r in out["regimes"].items()}
+  nr = out.get("next_rows")
+  if isinstance(nr, dict):
+    c["next_rows"] = {row: {k: _sig(v, 4) for k, v in blk.items() if isinstance(v, (int, float)) and not isinstance(v, bool)}
+                      for row, blk in nr.items() if isinstance(blk, dict)}
+  c["detail"] = DETAIL_FILE
+  return c
+
+
+def render_line(out):
+  """compact_line -> ONE line of strict JSON no longer than LINE_LIMIT; optional blocks are dropped, least important
+  first, if a future field makes it too long (the contract keys, config, roofline and cpu_baseline never are)."""
+  c = compact_line(out)
+  for victim in (None, "next_rows", "roofline_other", "cpu_baseline_matched", "segments_ms", "regimes", "parity"):
+    if victim is not None:
+      c.pop(victim, None)
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(line) <= LINE_LIMIT:
+      return line
+  raise SystemExit(f"bench line is {len(line)} bytes even without its optional blocks")
+
+
+def emit(out, detail_path=None):
+  """Rank 0: full result -> bench_detail.json (+ gpurun_out/ when it exists, so a gpurun call brings it back); stdout gets the
+  compact line, flushed, as the LAST thing the process prints."""
+  full = _finite(out)
+  paths = [detail_path or os.path.join(ROOT, DETAIL_FILE)]
+  scratch = os.path.join(ROOT, "gpurun_out")
+  if detail_path is None and os.path.isdir(scratch):
+    paths.append(os.path.join(scratch, DETAIL_FILE))
+  for p in paths:
+    try:
+      with open(p, "w") as fh:
+        json.dump(full, fh, allow_nan=False, indent=1)
+        fh.write("\n")
+    except OSError as e:                                   # a read-only tree must not cost the measurement
+      print(f"bench: could not write {p}: {e}", file=sys.stderr)
+  sys.stdout.flush()
+  print(render_line(out), flush=True)
 
 
 def parse():
@@ -776,7 +921,7 @@ def main():
   if len(results) > 1 or args.regimes:
     out["regimes"] = {n: {k: v for k, v in r.items() if k not in ("roofline_q_stage",)} for n, r in results.items()}
   if rank == 0:
-    print(json.dumps(out))
+    emit(out)
   if world > 1:
     dist.destroy_process_group()
 
@@ -920,7 +1065,7 @@ def composed_bench(args, rank, world, dev, dist):
                      "max_abs": {"mu_H": float(np.abs(traj_o[-1][0]).max()), "Sigma_H": float(np.abs(traj_o[-1][1]).max()),
                                  "loss": float(np.abs(loss_o).max())}}
   if rank == 0:
-    print(json.dumps(out))
+    emit(out)
   if world > 1:
     dist.destroy_process_group()
 
@@ -1107,7 +1252,7 @@ def grad_bench(args, rank, world, dev, dist):
                      "f64_pack_vs_cpu_autograd": {"g_mu": rel(gb[0], gc[0]), "g_Sigma": rel(gb[1], gc[1])},
                      "items_routed_to_f64_in_this_backward": pm.routed()[1]}
   if rank == 0:
-    print(json.dumps(out))
+    emit(out)
   if world > 1:
     dist.destroy_process_group()
 
@@ -1202,7 +1347,7 @@ def pathwise_bench(args, rank, world, dev, dist):
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     out.update(pathwise_extras(args, dev, c, paths, x0, dtype))
   if rank == 0:
-    print(json.dumps(out))
+    emit(out)
   if world > 1:
     dist.destroy_process_group()
 
