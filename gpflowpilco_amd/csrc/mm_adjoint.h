@@ -928,6 +928,22 @@ MMA_FN void mma_pair_convert(Ctx c, int d, const double* dmu2, double* T) {
   for (int k = lane; k < d; k += nl) T[oK1 + k] -= dmu2[k] * N0;
 }
 
+// T (zc, .) -> (zeta, .), zeta_i = zc_i - dmu: the ROW side's counterpart of mma_pair_convert, for the polynomial part of an item
+// whose bilinear form runs on rows centred at the centroid (mma_pair_poly called with a zero shift; mm_mono.h) while the
+// aggregates' row monomials are those of zeta.  In place; one sync inside, none at the end.
+MMA_FN void mma_pair_convert_rows(Ctx c, int d, const double* dmu, double* T) {
+  const int lane = c.lane(), nl = c.nl();
+  const int oR1 = 1, oR2 = 1 + d, oK1 = 1 + d + d * d, oXC = 1 + 2 * d + 2 * d * d;
+  const double N0 = T[0];
+  for (int idx = lane; idx < d * d; idx += nl) {
+    const int k = idx / d, l = idx - k * d;
+    T[oR2 + idx] += -dmu[k] * T[oR1 + l] - T[oR1 + k] * dmu[l] + dmu[k] * dmu[l] * N0;
+    T[oXC + idx] -= dmu[k] * T[oK1 + l];
+  }
+  c.sync();
+  for (int k = lane; k < d; k += nl) T[oR1 + k] -= dmu[k] * N0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // mma_gp_item_bwd: one (latent | kernel pair) item of d(f1, Sff, cross)/d(mu, Sigma) of a frozen model, from the M-sized
 // sums of mm_backward_sums (csrc/mm_backward.hip).  Pair order: the L diagonal pairs, then a < a' row by row.

@@ -373,7 +373,8 @@ static size_t mmr_rem_lds_bytes(int d, int Mp) {
 __global__ __launch_bounds__(512) void k_pair_agg(const double* __restrict__ mom, int KMp, const double* __restrict__ pairmat,
                                                   const double* __restrict__ zbar, const float* __restrict__ mu, int L, int d,
                                                   int P, int npanel, const double* __restrict__ slab,
-                                                  const short* __restrict__ rtab, double* __restrict__ pagg) {
+                                                  const short* __restrict__ rtab, const unsigned int* __restrict__ amax,
+                                                  double* __restrict__ pagg) {
   extern __shared__ double smd[];
   const int po = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, Po = P - L, p = L + po;
   int a, a2;
@@ -384,8 +385,10 @@ __global__ __launch_bounds__(512) void k_pair_agg(const double* __restrict__ mom
   double* G = qh + KMp;             // [d][d]
   double* dmu = G + d * d;          // [d] mu - zbar_a
   double* dmu2 = dmu + d;           // [d] mu - zbar_a'
-  double* T = dmu2 + d;             // [nT]
+  double* dmuP = dmu2 + d;          // [d] the shift inside b_ij: zero where k_pairvec recentred the rows (mm_mono.h), else dmu
+  double* T = dmuP + d;             // [nT]
   double* scr = T + nT;             // mma_pair_poly_scratch(d)
+  const bool rcen = mm_rows_recentred(amax[(size_t)b * Po + po]);
   {
     const double* nm = mom + (((size_t)b * Po + po) * 2 + 0) * MM_MOM_SPLIT * KMp;
     const double* qm = mom + (((size_t)b * Po + po) * 2 + 1) * MM_MOM_SPLIT * KMp;
@@ -401,10 +404,17 @@ __global__ __launch_bounds__(512) void k_pair_agg(const double* __restrict__ mom
       const double m = (double)mu[(size_t)b * d + tid];
       dmu[tid] = m - zbar[a * d + tid];
       dmu2[tid] = m - zbar[a2 * d + tid];
+      dmuP[tid] = rcen ? 0.0 : dmu[tid];
     }
   }
   __syncthreads();
-  mma_pair_poly(MMADevCtx(), d, G, dmu, nh, qh, T, scr, rtab);
+  mma_pair_poly(MMADevCtx(), d, G, dmuP, nh, qh, T, scr, rtab);
+  if (rcen) {
+    // the polynomial part came out with the row monomials of zc_i: to those of zeta_i = zc_i - dmu, as the remainder slabs have them
+    __syncthreads();
+    mma_pair_convert_rows(MMADevCtx(), d, dmu, T);
+    __syncthreads();
+  }
   const double* sl = slab + ((size_t)b * Po + po) * npanel * nT;
   for (int idx = tid; idx < nT; idx += blockDim.x) {
     double s = 0.0;
@@ -481,16 +491,16 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
   const int rc = mm_launch_wmom_full(packed, ml, ws, wl, B, L, d, stream);
   if (rc) return rc;
   const int nT = mma_pair_agg_len(d);
-  const size_t shm2 = (size_t)(2 * ml.KMp + d * d + 2 * d + nT + mma_pair_poly_scratch(d)) * sizeof(double);
+  const size_t shm2 = (size_t)(2 * ml.KMp + d * d + 3 * d + nT + mma_pair_poly_scratch(d)) * sizeof(double);
   {
     static std::atomic<unsigned long long> agg_attr_set{0ull};
-    const size_t shm_max = (size_t)(2 * mm_moment_cols(8) + 64 + 16 + mma_pair_agg_len(8) + mma_pair_poly_scratch(8)) * sizeof(double);
+    const size_t shm_max = (size_t)(2 * mm_moment_cols(8) + 64 + 24 + mma_pair_agg_len(8) + mma_pair_poly_scratch(8)) * sizeof(double);
     e = mmr_set_max_lds_once((const void*)k_pair_agg, (int)shm_max, agg_attr_set);
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(k_pair_agg, dim3(wl.Po, B), dim3(agg_threads), shm2, stream, (const double*)(ws + wl.mom), ml.KMp,
                      (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), mu, L, d, wl.P, npanel,
-                     (const double*)slab, (const short*)(packed + ml.rtab), pagg);
+                     (const double*)slab, (const short*)(packed + ml.rtab), (const unsigned int*)(ws + wl.amax), pagg);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

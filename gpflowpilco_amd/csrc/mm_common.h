@@ -43,6 +43,9 @@ static inline size_t mm_rank_table_entries(int d) {
 }
 // columns of the table, rounded up to the 16-wide MFMA tile
 static inline int mm_moment_cols(int d) { return mm_round_up_int(mm_mono_offset(mm_moment_deg(d) + 1, d), 16); }
+// degree-5 and degree-6 monomials (d <= 8: the collapse's bf16 tables, mm_moments6.hip): degree 5 first, then degree 6, colex
+// inside a degree; rounded up to the 128-column tile of the bf16 GEMM.  0 for d > 8 (no collapse).
+static inline int mm_moment56_cols(int d) { return d <= 8 ? mm_round_up_int(mm_mono_count(5, d) + mm_mono_count(6, d), 128) : 0; }
 
 // Packed model: byte offsets inside the caller-owned device buffer.
 struct MMModelLayout {
@@ -68,6 +71,8 @@ struct MMModelLayout {
                   // (slot 0: 1; 1..d: zc_l; then zc_l zc_l', l <= l', row-major; 64 slots, zero beyond) as the B operand of
                   // v_mfma_f32_32x32x16_bf16 -- lane (slot & 31, h) of image (tile, s, nb = slot >> 5, part) holds K slots
                   // t = 0..7 = columns 16 s + 8 (t >> 2) + 4 h + (t & 3) of the tile (mm_bwd_f32.hip); 8 KB per 32 columns
+  size_t Zm56;    // [L][2 (h, m)][N56p][Mp] bf16 (f32 mode, d <= 8): the degree-5 and degree-6 monomials of zc, 2-way split, one
+                  // monomial's Mp values contiguous (the B operand of k_wmom56_gemm reads 8 consecutive m per lane)
   size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
                   // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
@@ -99,6 +104,8 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   o.rtab = off;   off = mm_align_up(off + mm_rank_table_entries(d) * 2, A);
   o.Zq2 = off;
   if (dtype != MM_F64 && d <= 8) off = mm_align_up(off + (size_t)L * (o.Mp / 32) * 8192, A);
+  o.Zm56 = off;
+  if (dtype != MM_F64 && d <= 8) off = mm_align_up(off + (size_t)L * 2 * mm_moment56_cols(d) * o.Mp * 2, A);
   o.Cm = off;
   if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;
@@ -107,14 +114,37 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 
 // k_wmom_gemm: slices of the m range (split-K) per output tile; k_spoly adds the partial moment vectors
 #define MM_MOM_SPLIT 2
-// a (b, pair) is collapsed (cubic + quartic term of the remainder taken from moments, tiles with max|b| inside the first
-// tier skipped after a one-MFMA screening) when max_i |A_i|^2 * max_j |zc_j|^2 <= MM_COLLAPSE_BOUND2 (Cauchy-Schwarz bound on
-// |b_ij|).  0.15^2: below it the screening skips most tiles; above it almost none, and the degree-3/4 moment columns
-// (91 % of the moment GEMM) would be paid for nothing -- measured on the BASELINE recipe with the GEMM rows compacted
-// (k_wmom_perm): threshold 1 -> 0.0225: q stage 1.38 -> 1.05 ms, tile sweep 5.75 -> 5.84, step 10.8 -> 10.6 ms
+// THE MOMENT COLLAPSE (d <= 8; round 5: to degree 6).  For a collapsed (b, pair) the polynomial
+//     p6(x) = x^3 (C0 + C1 x + C2 x^2 + C3 x^3)  ~  r(x) = e^x - 1 - x - x^2/2     on |x| <= MM_C6_MAX = 1/4
+// (near-minimax, |p6 - r| <= 5.8e-10 there: it IS the tile kernel's degree-3 tier, MMRem<3>) is taken from weight moments
+// against model-constant monomial tables -- degrees <= 4 in f64 (k_wmom_gemm, k_spoly), degrees 5 and 6 from a bf16 2-way
+// split GEMM on the matrix pipe with f32 accumulation and a partially-symmetric f32 contraction (mm_moments6.hip) -- and the
+// tile kernel skips every wave tile whose max|b| <= 1/4 after a one-MFMA screening product, reducing the correction r - p6 on
+// the others.  Round 4 stopped at degree 4 (first tier |b| <= 1/20): on the BASELINE recipe 9 % of the wave tiles could be
+// skipped and 18 % of the items were worth collapsing; with rows recentred (mm_mono.h) and degree 6, 92 % of the tiles have
+// max|b| <= 1/4 and 53 % of the items are WHOLLY inside by their Cauchy-Schwarz bound alone (tools/tile_hist_baseline.py).
+// Accuracy of what the skipped tiles leave out (tools/collapse6_study.py, BASELINE recipe at C3, 56 items): <= 1.7e-6 of the
+// batch element's largest off-diagonal covariance (rms 3.7e-7; systematic, cancels the way the sum itself does), rounding of
+// the degree-5/6 moments from the 2-way split <= 1.1e-8.
+// An item is collapsed when max_i |A_i|^2 * max_j |zc_j|^2 <= MM_COLLAPSE_BOUND2 (Cauchy-Schwarz bound on |b_ij|): (1/2)^2 --
+// items with a bound in (1/4, 1/2] have 98 % of their tiles under 1/4, items beyond 1/2 a third.
 #ifndef MM_COLLAPSE_BOUND2
-#define MM_COLLAPSE_BOUND2 0.0225f
+#define MM_COLLAPSE_BOUND2 0.25f
 #endif
+#define MM_C6_MAX 0.25f
+#define MM_C6_C0 1.666663289e-01f
+#define MM_C6_C1 4.166659713e-02f
+#define MM_C6_C2 8.350561373e-03f
+#define MM_C6_C3 1.391559141e-03f
+// what a skipped entry leaves out, as an equivalent relative rounding for the route estimate (mm_route.hip): the independence
+// model with a per-entry amplitude of 1e-10 (the polynomial's error oscillates with amplitude 5.8e-10, but it is a smooth
+// function of b and cancels under the alternating weights: measured total / (|what|_2 |what'|_2) <= 4e-11,
+// tools/collapse6_study.py).  estS = MM_C6_SYS2 * sum what_i^2 * sum what'_j^2 is added to the sweep's E2:
+// (1e-10 / (2^-24 * 2/3))^2
+#define MM_C6_SYS2 6.33e-6f
+// p6 as every f64 consumer evaluates it (k_spoly's coefficients, the routed re-reduce, the portable kernel): the f32 literals
+// widened, so that the moments and the tile kernel's corrected tiers subtract the same polynomial
+#define MM_C6_POLY_F64(x_) (((x_) * (x_)) * (x_) * fma(fma(fma((double)MM_C6_C3, (x_), (double)MM_C6_C2), (x_), (double)MM_C6_C1), (x_), (double)MM_C6_C0))
 // First tier of the f32 remainder: near-minimax r(x) = expm1(x) - x - x^2/2 ~ x^3 (C0 + C1 x) on |x| <= MM_TIER1_MAX
 // (tools/minimax_remainder.py).  It is the polynomial the moment collapse takes from the f64 moments, so its
 // approximation error is SYSTEMATIC (it does not average out over the M^2 entries the way rounding does) and sets the
@@ -144,9 +174,9 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 #else
 #error "MM_TIER1_DIV must be 16, 20, 24 or 32"
 #endif
-// ... and when the bound itself says every |b_ij| <= MM_TIER1_MAX, the whole remainder of the (b, pair) is inside the
+// ... and when the bound itself says every |b_ij| <= MM_C6_MAX, the whole remainder of the (b, pair) is inside the
 // collapsed range: the tile kernel's workgroup writes zero partials and leaves
-#define MM_INSIDE_BOUND2 (0.998f * MM_TIER1_MAX * MM_TIER1_MAX)
+#define MM_INSIDE_BOUND2 (0.998f * MM_C6_MAX * MM_C6_MAX)
 // Accuracy contract of the f32 off-diagonal reduce.  The f32 tile kernels carry, beside their sums, an
 // estimate of the rounding error of each (b, pair)'s remainder sum under an independent-rounding model,
 //     est = 2^-24 * (2/3) * sqrt( sum over lane blocks of (sum_rows what_i^2) what'_j^2 (max|b|^3 (1 + X + X^2))^2 )
@@ -217,6 +247,11 @@ struct MMWorkspaceLayout {
   size_t rlist;    // [B Po] i32   the (b, off-diagonal pair) items k_route_decide hands to the f64 re-reduce
   size_t rcount;   // [4] i32      {entries of rlist (current pass), items routed by the last forward, by the last backward, 0}
   size_t rflag;    // [B Po] i32   1 where the last forward routed the item (k_finalize then sums the route kernel's slots)
+  size_t wsp;      // [B][Po][2 (row, column side)][2 (h, m)][Mp] bf16 (f32 mode, d <= 8): the factored weights, 2-way split, as the A
+                   //              operand of the degree-5/6 moment GEMM (k_pairvec_reg writes them beside whR / whC)
+  size_t mom56;    // [B][Po][2][N56p] f32: sum_m what_m zc_m^alpha over the degree-5 and degree-6 monomials (collapsed items)
+  size_t estS;     // [B][Po] f32: MM_C6_SYS2 sum what^2 sum what'^2 of a collapsed item (0 otherwise): what its skipped tiles leave
+                   //              out, in the units of the sweep's error estimate estO (k_spoly56 writes, k_route_decide adds)
   size_t f1s;      // [B][L] T      rollout scratch outputs
   size_t Sffs;     // [B][L][L] T
   size_t crs;      // [B][d][L] T
@@ -268,6 +303,10 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.rlist = off;   off = mm_align_up(off + nro * 4, A);
   o.rcount = off;  off = mm_align_up(off + 16, A);
   o.rflag = off;   off = mm_align_up(off + nro * 4, A);
+  const size_t n56 = (dtype == MM_F64 || d > 8) ? 0 : (size_t)B * o.Po;
+  o.wsp = off;     off = mm_align_up(off + n56 * 4 * o.Mp * 2, A);
+  o.mom56 = off;   off = mm_align_up(off + n56 * 2 * mm_moment56_cols(d) * 4, A);
+  o.estS = off;    off = mm_align_up(off + n56 * 4, A);
   o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);
   o.Sffs = off;    off = mm_align_up(off + (size_t)B * L * L * es, A);
   o.crs = off;     off = mm_align_up(off + (size_t)B * d * L * es, A);

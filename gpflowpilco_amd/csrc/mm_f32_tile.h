@@ -49,7 +49,7 @@ template <> struct MMRem<1> {
   static constexpr float c[2] = {MM_REM1_C0, MM_REM1_C1};      // mm_common.h: shared with the moment collapse
 };
 template <> struct MMRem<3> {
-  static constexpr float c[4] = {1.666663289e-01f, 4.166659713e-02f, 8.350561373e-03f, 1.391559141e-03f};
+  static constexpr float c[4] = {MM_C6_C0, MM_C6_C1, MM_C6_C2, MM_C6_C3};   // mm_common.h: it IS the collapse's polynomial p6
 };
 template <> struct MMRem<4> {
   static constexpr float c[5] = {1.666666716e-01f, 4.166586325e-02f, 8.333111182e-03f, 1.398149878e-03f, 1.998390071e-04f};

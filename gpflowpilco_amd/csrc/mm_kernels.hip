@@ -548,7 +548,8 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
                                                  double* __restrict__ whC, unsigned int* __restrict__ amax,
                                                  const double* __restrict__ q64, double* __restrict__ qhR,
                                                  double* __restrict__ qhC, int with_unc, int nblk,
-                                                 const double* __restrict__ lq, const double* __restrict__ beta64, int p0) {
+                                                 const double* __restrict__ lq, const double* __restrict__ beta64,
+                                                 const double* __restrict__ zmax2, int p0) {
   static_assert(DK > 8, "d <= 8 takes k_pairvec_reg");
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
   // pair's matrix is fetched once per workgroup, not once per chunk
@@ -567,7 +568,9 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   const double* r1a = rho1 + ((size_t)b * L + a) * Mp;
   const double* r1b = rho1 + ((size_t)b * L + a2) * Mp;
   __shared__ __align__(16) double Ts[DK * DK];
-  __shared__ double vecs[5][DK];      // mu | 1/Lam_a | 1/Lam_a' | (mu - zbar_a') / Lam_a' | (mu - zbar_a) / Lam_a
+  // mu | 1/Lam_a | 1/Lam_a' | (mu - zbar_a') / Lam_a' | (mu - zbar_a) / Lam_a | t0 = T (mu - zbar_a) / Lam_a | c00 = t0 . [3]
+  __shared__ double vecs[7][DK];
+  __shared__ int rcs;
   const double* pm = pairmat + ((size_t)b * P + p) * (d * d + 1);
   for (int idx = tid; idx < DK * DK; idx += 256) {
     const int i = idx / DK, k = idx - i * DK;
@@ -590,6 +593,25 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
   const int Po = P - L;
   // f32 off-diagonal format (mm_mfma.hip): see k_pairvec_reg
   const bool f32off = !diag && sizeof(T) == 4;
+  if (f32off) {
+    // rows recentred at zbar_a (mm_mono.h; as in k_pairvec_reg)
+    if (tid < DK) {
+      double t = 0.0;
+      for (int k = 0; k < DK; ++k) t = fma(Ts[tid * DK + k], vecs[4][k], t);
+      vecs[5][tid] = t;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double sa2 = 0.0, c00 = 0.0;
+      for (int i = 0; i < DK; ++i) { const double sa = vecs[5][i] * vecs[2][i]; sa2 = fma(sa, sa, sa2); c00 = fma(vecs[5][i], vecs[3][i], c00); }
+      const bool rc = sa2 * zmax2[a2] <= MM_RECENTRE_CMAX * MM_RECENTRE_CMAX;
+      rcs = rc ? 1 : 0;
+      vecs[6][0] = rc ? c00 : 0.0;
+      if (!rc) for (int i = 0; i < DK; ++i) vecs[5][i] = 0.0;
+    }
+    __syncthreads();
+  }
+  const bool recentred = f32off ? rcs != 0 : true;
   T* rO = rowO + ((size_t)b * Po + (f32off ? p - L : 0)) * (size_t)(d + 1) * Mp;
   T* cO = colO + ((size_t)b * Po + (f32off ? p - L : 0)) * Mp;
   double* hR = whR + ((size_t)b * Po + (f32off ? p - L : 0)) * Mp;
@@ -623,7 +645,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
     const double lqr = lq[((size_t)b * L + a) * Mp + m], lqc = lq[((size_t)b * L + a2) * Mp + m];
     const double btr = beta64[(size_t)a * M + mc], btc = beta64[(size_t)a2 * M + mc];
     double tA = 0.0, tg = 0.0, corrA = 0.0, corrg = 0.0;
-    double asq = 0.0;
+    double asq = 0.0, cj = vl[6 * DK];
 #pragma unroll 2      // not fully: the compiler would hoist all the LDS reads (> 256 VGPRs)
     for (int i = 0; i < DK; ++i) {
       double u = 0.0, v = 0.0;
@@ -637,7 +659,10 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
       tg = fma(zc[i], v, tg);
       corrA = fma(vl[3 * DK + i], u, corrA);
       corrg = fma(vl[4 * DK + i], v, corrg);
-      const double av = u * vl[2 * DK + i], gv = v * vl[DK + i];
+      // f32 off-diagonal pairs: rows recentred at zbar_a (t0 is zero otherwise and for the other formats)
+      const double t0i = f32off ? vl[5 * DK + i] : 0.0;
+      cj = fma(t0i, zc[i], cj);
+      const double av = (u + t0i) * vl[2 * DK + i], gv = v * vl[DK + i];
       asq = fma(av, av, asq);
       if (i < d) {
         if (f32off) rO[(size_t)i * Mp + m] = (T)av;           // zero for the padding rows m >= M
@@ -652,7 +677,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
       double whr = 0.0, whc = 0.0;
       if (m < M) {
         whr = btr * exp(fmin(lqr - 0.5 * rho_q + cst - corrA, (double)MM_EXP_CAP_F32));
-        whc = btc * exp(fmin(lqc - 0.5 * gam_q, (double)MM_EXP_CAP_F32));
+        whc = btc * exp(fmin(lqc - 0.5 * gam_q - cj, (double)MM_EXP_CAP_F32));
       }
       rO[(size_t)d * Mp + m] = (T)whr;
       cO[m] = (T)whc;
@@ -677,7 +702,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
     // one atomicMax per wave: non-negative floats are ordered like their bit patterns (max is order independent)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a2max = fmaxf(a2max, __shfl_down(a2max, off, 64));
-    if ((tid & 63) == 0) atomicMax(amax + (size_t)b * Po + (p - L), __float_as_uint(a2max));
+    if ((tid & 63) == 0) atomicMax(amax + (size_t)b * Po + (p - L), recentred ? __float_as_uint(a2max) : MM_AMAX_NOT_RECENTRED);
   }
 }
 
@@ -708,7 +733,7 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
                                                     const double* __restrict__ q64, double* __restrict__ qhR,
                                                     double* __restrict__ qhC, int with_unc, int nblk, int a, int a2,
                                                     double (*vecs)[DK], const double* __restrict__ lq,
-                                                    const double* __restrict__ beta64, int p) {
+                                                    const double* __restrict__ beta64, int p, const double* __restrict__ zmax2) {
   constexpr bool diag = MODE == 0;
   const int b = blockIdx.z, tid = threadIdx.x;
   const int Po = P - L;
@@ -771,6 +796,29 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
     vecs[4][tid] = tid < d ? (mv - zbar[a * d + k]) / la : 0.0;
   }
   __syncthreads();
+  bool recentred = true;
+  if constexpr (MODE == 1) {
+    // rows recentred at zbar_a (mm_mono.h): t0 = T (mu - zbar_a) / Lam_a, A_i = (u_i + t0_i) / Lam_a',i, and the column weight
+    // takes e^{-c_j}, c_j = sum_k t0_k zc'_jk / Lam_a',k.  Every thread forms t0 (workgroup-uniform), thread 0 publishes it.
+    double sa2 = 0.0, c00 = 0.0, t0[DK];
+#pragma unroll
+    for (int i = 0; i < DK; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < DK; ++k) t = fma(Tr[tsym(i, k)], vecs[4][k], t);
+      t0[i] = t;
+      const double sa = t * vecs[2][i];
+      sa2 = fma(sa, sa, sa2);
+      c00 = fma(t, vecs[3][i], c00);
+    }
+    recentred = sa2 * zmax2[a2] <= MM_RECENTRE_CMAX * MM_RECENTRE_CMAX;
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < DK; ++i) vecs[5][i] = recentred ? t0[i] : 0.0;
+      vecs[6][0] = recentred ? c00 : 0.0;
+    }
+    __syncthreads();
+  }
   const double cst = pm[d * d];
   float a2max = 0.0f;                                         // max_i |A_i|^2 over this thread's rows (f32 off-diagonal pairs)
   typedef const __attribute__((address_space(3))) double* lds_cptr;
@@ -828,8 +876,13 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
       double* hC = whC + ((size_t)b * Po + (p - L)) * Mp;
       if (live) {
         double sr[DK], sc[DK];
+        double cj = vl[6 * DK];                              // c_j = t0 . (zc'_j / Lam_a'): the row shift's column factor
 #pragma unroll
-        for (int k = 0; k < DK; ++k) { const double muk = vl[k]; sr[k] = (o.zr[k] - muk) * vl[DK + k]; sc[k] = (o.zc[k] - muk) * vl[2 * DK + k]; }
+        for (int k = 0; k < DK; ++k) {
+          const double muk = vl[k];
+          sr[k] = (o.zr[k] - muk) * vl[DK + k]; sc[k] = (o.zc[k] - muk) * vl[2 * DK + k];
+          cj = fma(vl[5 * DK + k], sc[k], cj);
+        }
         double tA = 0.0, tg = 0.0, corrA = 0.0, asq = 0.0;
 #pragma unroll
         for (int i = 0; i < DK; ++i) {
@@ -842,14 +895,14 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
           }
           tA = fma(sr[i], u, tA);
           tg = fma(sc[i], fma(2.0, vh, Tr[tsym(i, i)] * sc[i]), tg);
-          const double av = u * vl[2 * DK + i];
+          const double av = (u + vl[5 * DK + i]) * vl[2 * DK + i];   // A_i = G^T (z_i - zbar_a)  (G^T (z_i - mu) if not recentred)
           asq = fma(av, av, asq);
           corrA = fma(vl[3 * DK + i], u, corrA);
           rO[rowi(i) + m] = (T)av;
         }
         a2max = fmaxf(a2max, (float)asq * 1.000001f);        // rounded up: the bound must not be under-estimated
         const double whr = o.br * exp(fmin(o.wr - 0.5 * (o.r1r - tA) + cst - corrA, (double)MM_EXP_CAP_F32));
-        const double whc = o.bc * exp(fmin(o.wc - 0.5 * (o.r1c - tg), (double)MM_EXP_CAP_F32));
+        const double whc = o.bc * exp(fmin(o.wc - 0.5 * (o.r1c - tg) - cj, (double)MM_EXP_CAP_F32));
         rO[rowd + m] = (T)whr; cO[m] = (T)whc; hR[m] = whr; hC[m] = whc;
       } else {
 #pragma unroll
@@ -902,7 +955,8 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
     // one atomicMax per wave: non-negative floats are ordered like their bit patterns (max is order independent)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) a2max = fmaxf(a2max, __shfl_down(a2max, off, 64));
-    if ((tid & 63) == 0) atomicMax(amax + (size_t)b * Po + (p - L), __float_as_uint(a2max));
+    // rows left centred at mu: marked (mm_mono.h), which also keeps the item out of every collapse predicate
+    if ((tid & 63) == 0) atomicMax(amax + (size_t)b * Po + (p - L), recentred ? __float_as_uint(a2max) : MM_AMAX_NOT_RECENTRED);
   }
 }
 
@@ -917,17 +971,19 @@ __global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict
                                                         double* __restrict__ whC, unsigned int* __restrict__ amax,
                                                         const double* __restrict__ q64, double* __restrict__ qhR,
                                                         double* __restrict__ qhC, int with_unc, int nblk,
-                                                        const double* __restrict__ lq, const double* __restrict__ beta64, int p0) {
+                                                        const double* __restrict__ lq, const double* __restrict__ beta64,
+                                                        const double* __restrict__ zmax2, int p0) {
   // (grid.y = the pairs [p0, p0 + gridDim.y): the q stage launches the diagonal pairs' operands first -- the diagonal sweep needs
   // nothing else -- and the off-diagonal pairs' on the side stream beside that sweep)
   static_assert(DK <= 8, "register form: d <= 8");
-  __shared__ double vecs[5][DK];      // mu | 1/Lam_a | 1/Lam_a' | (mu - zbar_a') / Lam_a' | (mu - zbar_a) / Lam_a
+  // mu | 1/Lam_a | 1/Lam_a' | (mu - zbar_a') / Lam_a' | (mu - zbar_a) / Lam_a | t0 = T (mu - zbar_a) / Lam_a | c00 = t0 . [3]
+  __shared__ double vecs[7][DK];
   const int p = p0 + (int)blockIdx.y;
   int a, a2;
   mm_decode_pair(p, L, a, a2);
 #define MM_PV_BODY(MODE_)                                                                                           \
   mm_pairvec_reg_body<T, DK, MODE_>(Zt64, zbar, ls2, L, M, Mp, d, P, mu, pairmat, rho1, rowD, colD, rowO, colO, w64, \
-                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64, p)
+                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64, p, zmax2)
   if (p < L) MM_PV_BODY(0);
   else if (sizeof(T) == 4) MM_PV_BODY(1);
   else MM_PV_BODY(2);
@@ -1232,7 +1288,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     (const double*)(ws + wl.rho1), (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO), \
     (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), amax,                                      \
     (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC), (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk, \
-    (const double*)(ws + wl.lq), (const double*)(packed + ml.beta64)
+    (const double*)(ws + wl.lq), (const double*)(packed + ml.beta64), (const double*)(packed + ml.zmax2)
     auto pairvec = [&](int p0, int npairs, hipStream_t st) {
       if (npairs <= 0) return;
       if constexpr (DK <= 8) {

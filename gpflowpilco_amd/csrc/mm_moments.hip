@@ -1,8 +1,9 @@
 // Weight moments of the f32 off-diagonal pairs and their per-(b, pair) contraction (gfx950).
 //
 // For an off-diagonal pair (a, a') of an f32 model the tile kernel (mm_mfma.hip) reduces
-//     S = sum_ij what_i what'_j E(b_ij),     b_ij = (zc_i - dmu)^T G zc'_j,   dmu = mu_b - zbar_a,
-// with zc, zc' the model's inducing inputs centred at their per-latent centroids.  Any POLYNOMIAL part
+//     S = sum_ij what_i what'_j E(b_ij),     b_ij = (zc_i - dmu)^T G zc'_j,
+// with zc, zc' the model's inducing inputs centred at their per-latent centroids; dmu = 0 where k_pairvec recentred the rows at the
+// centroid (round 5, mm_mono.h: the usual case), mu_b - zbar_a where it left them centred at mu.  Any POLYNOMIAL part
 // P(x) = sum_n a_n x^n of E collapses to moments of the two weight vectors against model-constant monomial
 // tables -- O(M C(d+n, n)) instead of O(M^2) per (b, pair), and exact in f64:
 //     sum_ij what_i what'_j b_ij^n = < M_n , G^{(x)n} Q_n >,
@@ -269,7 +270,10 @@ __global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, i
       const int i = idx >> LB, j = idx & (DK - 1);
       Gs[idx] = (i < d && j < d) ? pm[i * d + j] : 0.0;
     }
-    if (tid < DK) dmu[tid] = tid < d ? (double)mu[(size_t)b * d + tid] - zbar[a * d + tid] : 0.0;
+    // rows recentred at zbar_a (k_pairvec, mm_mono.h): the row moments are the table's own, no shift; an item that kept its rows
+    // centred at mu (marked in amax) takes the binomial shift by dmu = mu - zbar_a below
+    const bool rcen = mm_rows_recentred(amax[(size_t)b * Po + po]);
+    if (tid < DK) dmu[tid] = (tid < d && !rcen) ? (double)mu[(size_t)b * d + tid] - zbar[a * d + tid] : 0.0;
   }
   __syncthreads();
   const bool coll = allow_collapse && deg >= 4 &&

@@ -44,6 +44,19 @@ __host__ __device__ __forceinline__ void mm_mono_unrank(int r, int n, int* k) {
   }
 }
 
+// Row centring of the f32 off-diagonal operands (round 5).  With zeta_i = z_i - mu the exponent's bilinear part is
+//     zeta_i^T G zc'_j = zc_i^T G zc'_j - dmu^T G zc'_j,     dmu = mu - zbar_a,
+// and the second term depends on the column alone: k_pairvec folds e^{-dmu^T G zc'_j} into the column weight and hands the tile
+// kernels A_i = G^T zc_i, ROWS CENTRED AT THE LATENT'S CENTROID.  |zc_i| is smaller than |z_i - mu| wherever the state is not at
+// the centroid (BASELINE recipe, mu ~ U[0,1]^d: wave tiles with max|b| <= 1/4 go from 84 % to 92 %, items whose Cauchy-Schwarz
+// bound is <= 1/4 from 40 % to 53 %), and the weight moments need no binomial shift.  The fold is only taken where its exponent
+// is harmless: |dmu^T G zc'_j| <= |G^T dmu| max_j |zc'_j| <= MM_RECENTRE_CMAX (with lengthscales far below the state's distance
+// to the centroid it reaches hundreds and the weight would leave the f32 range); an item that keeps its rows centred at mu
+// is marked by amax = FLT_MAX, which also keeps it out of every collapse predicate (they all go through mm_collapse_bound2).
+#define MM_RECENTRE_CMAX 16.0
+#define MM_AMAX_NOT_RECENTRED 0x7f7fffffu
+__host__ __device__ __forceinline__ bool mm_rows_recentred(unsigned int amax_bits) { return amax_bits != MM_AMAX_NOT_RECENTRED; }
+
 // Cauchy-Schwarz bound (squared) on |b_ij| of one (b, off-diagonal pair): max_i |A_i|^2 (k_pairvec, f32 bits, rounded
 // up) times max_j |zc'_j|^2 (pack time).  ONE definition: k_spoly, the f32 tile kernel and the portable kernel must
 // agree on which (b, pair) is collapsed.

@@ -190,18 +190,26 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
     const int row = panel * 256 + tid;
     const bool live = row < M;
     const int rr = live ? row : 0;
+    // zeta_i = z_i - mu: the row monomials of the aggregates (AGG); zb_i: the rows as the q stage centred them for the bilinear
+    // form -- at the latent's centroid, or at mu where k_pairvec kept them there (mm_mono.h)
+    const bool rcen = mm_rows_recentred(amax[(size_t)b * Po + lp]);
     double zeta[DK], A[DK];
 #pragma unroll
     for (int k = 0; k < DK; ++k)
       zeta[k] = (k < d && live) ? Zt64[((size_t)a * d + (k < d ? k : 0)) * Mp + rr] - mu64[(size_t)b * d + (k < d ? k : 0)] : 0.0;
+    {
+      double zb[DK];
 #pragma unroll
-    for (int k = 0; k < DK; ++k) {
-      double s = 0.0;
-      if (k < d) {
+      for (int k = 0; k < DK; ++k) zb[k] = (k < d && live && rcen) ? Zc64[((size_t)a * Mp + rr) * Kz + (k < d ? k : 0)] : zeta[k];
 #pragma unroll
-        for (int l = 0; l < DK; ++l) if (l < d) s = fma(Gs[l * d + k], zeta[l], s);      // A_i = G^T zeta_i
+      for (int k = 0; k < DK; ++k) {
+        double s = 0.0;
+        if (k < d) {
+#pragma unroll
+          for (int l = 0; l < DK; ++l) if (l < d) s = fma(Gs[l * d + k], zb[l], s);      // A_i = G^T zb_i
+        }
+        A[k] = s;
       }
-      A[k] = s;
     }
     const double wr = live ? whR[((size_t)b * Po + lp) * Mp + rr] : 0.0;
     // the forward's collapsed items carry c0 x^3 + c1 x^4 in their moments (k_spoly): the same predicate, the same coefficients

@@ -105,5 +105,6 @@ extern "C" void hc_pair_poly(int d, const double* G, const double* dmu, const do
   mma_pair_poly(MMAHostCtx(), d, G, dmu, mR, mC, T, sm.data());
 }
 extern "C" void hc_pair_convert(int d, const double* dmu2, double* T) { mma_pair_convert(MMAHostCtx(), d, dmu2, T); }
+extern "C" void hc_pair_convert_rows(int d, const double* dmu, double* T) { mma_pair_convert_rows(MMAHostCtx(), d, dmu, T); }
 extern "C" int hc_mono_off(int n, int d) { return mm_mono_off(n, d); }
 extern "C" int hc_mono_rank(const int* k, int n) { return mm_mono_rank_unsorted(n > 0 ? k[0] : 0, n > 1 ? k[1] : 0, n > 2 ? k[2] : 0, n > 3 ? k[3] : 0, n); }

@@ -338,3 +338,29 @@ def test_pair_polynomial_part_and_recentring_equal_brute_force(hc, d, M):
   assert _rel(T, brute(zc2)) < 1e-12
   hc.hc_pair_convert(d, _p(_c(dmu2)), _p(T))
   assert _rel(T, brute(zc2 - dmu2)) < 1e-12
+
+
+@pytest.mark.parametrize("d,M", [(3, 17), (8, 12)])
+def test_pair_polynomial_part_with_rows_recentred_at_the_centroid(hc, d, M):
+  """Round 5: the bilinear form of an off-diagonal item runs on rows centred at the latent's centroid, b_ij = zc_i^T G zc'_j (the
+  shift's column factor e^{-dmu^T G zc'_j} sits in the column weight), while the aggregates keep the row monomials of
+  zeta_i = zc_i - dmu: mma_pair_poly with a zero shift, then mma_pair_convert_rows, equals the brute-force sums."""
+  rng = np.random.default_rng(d * 17 + M)
+  zc = 0.6 * rng.standard_normal((M, d)); zc2 = 0.6 * rng.standard_normal((M + 3, d))
+  wr = rng.standard_normal(M); wc = rng.standard_normal(M + 3)
+  G = 0.4 * rng.standard_normal((d, d)); dmu = 0.3 * rng.standard_normal(d); dmu2 = 0.3 * rng.standard_normal(d)
+  mR = _packed_moments(hc, wr, zc); mC = _packed_moments(hc, wc, zc2)
+  T = np.zeros(1 + 2 * d + 3 * d * d)
+  hc.hc_pair_poly(d, _p(_c(G)), _p(_c(np.zeros(d))), _p(_c(mR)), _p(_c(mC)), _p(T))
+  hc.hc_pair_convert_rows(d, _p(_c(dmu)), _p(T))
+  zeta = zc - dmu
+  b = zc @ G @ zc2.T                                       # rows centred at the centroid inside the exponent
+  Om = wr[:, None] * wc[None, :] * (1.0 + b + 0.5 * b * b)
+
+  def brute(colside):
+    return np.concatenate([[Om.sum()], np.einsum('ij,ik->k', Om, zeta), np.einsum('ij,ik,il->kl', Om, zeta, zeta).ravel(),
+                           np.einsum('ij,jk->k', Om, colside), np.einsum('ij,jk,jl->kl', Om, colside, colside).ravel(),
+                           np.einsum('ij,ik,jl->kl', Om, zeta, colside).ravel()])
+  assert _rel(T, brute(zc2)) < 1e-12
+  hc.hc_pair_convert(d, _p(_c(dmu2)), _p(T))
+  assert _rel(T, brute(zc2 - dmu2)) < 1e-12
