@@ -8,7 +8,7 @@ mkdir -p "${obj}"
 common=(-O3 -std=c++17 --offload-arch=gfx950 -fPIC -Wno-unused-result)
 objs=()
 pids=()
-for src in mm_kernels mm_mfma mm_f64 mm_moments mm_compose mm_compose_bwd mm_pathwise mm_backward mm_bwd_f32 mm_route mm_pathwise_policy; do
+for src in mm_kernels mm_mfma mm_f64 mm_moments mm_moments6 mm_compose mm_compose_bwd mm_pathwise mm_backward mm_bwd_f32 mm_route mm_pathwise_policy; do
   extra=()
   # mm_mfma.hip and mm_bwd_f32.hip are built with -fno-honor-nans: the per-tile range check max(|x|) then folds
   # into one v_max3_f32 per two entries (no canonicalising v_max x, x); inputs are finite by the

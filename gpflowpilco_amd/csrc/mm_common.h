@@ -46,6 +46,22 @@ static inline int mm_moment_cols(int d) { return mm_round_up_int(mm_mono_offset(
 // degree-5 and degree-6 monomials (d <= 8: the collapse's bf16 tables, mm_moments6.hip): degree 5 first, then degree 6, colex
 // inside a degree; rounded up to the 128-column tile of the bf16 GEMM.  0 for d > 8 (no collapse).
 static inline int mm_moment56_cols(int d) { return d <= 8 ? mm_round_up_int(mm_mono_count(5, d) + mm_mono_count(6, d), 128) : 0; }
+// Index tables of the degree-5/6 contraction (k_spoly56, mm_moments6.hip; functions of d alone, written at pack time), with
+// sym(k) = mm_mono_count(k, d) sorted index tuples of length k in colex rank order:
+//   ins  [m = 0..5][J < sym(m)][8] i16: rank inside sym(m + 1) of the tuple J with the index j inserted (0 for j >= d)
+//   last [k = 0..5][I < sym(k)]    i16: the largest index of I (0 for k = 0): appending i >= last keeps I sorted, rank += C(i + k, k + 1)
+//   mult [sym(5) + sym(6)]         f32: multinomial n! / prod(count!) of the tuple (a packed moment stands for that many tensor entries)
+struct MMTab56 { int ins[6], last[6], n_i16, mult5, mult6, n_f32; size_t bytes; };
+static inline MMTab56 mm_tab56(int d) {
+  MMTab56 t;
+  int o = 0;
+  for (int m = 0; m < 6; ++m) { t.ins[m] = o; o += mm_mono_count(m, d) * 8; }
+  for (int k = 0; k < 6; ++k) { t.last[k] = o; o += mm_mono_count(k, d); }
+  t.n_i16 = mm_round_up_int(o, 8);
+  t.mult5 = 0; t.mult6 = mm_mono_count(5, d); t.n_f32 = mm_mono_count(5, d) + mm_mono_count(6, d);
+  t.bytes = (size_t)t.n_i16 * 2 + (size_t)t.n_f32 * 4;
+  return t;
+}
 
 // Packed model: byte offsets inside the caller-owned device buffer.
 struct MMModelLayout {
@@ -73,6 +89,7 @@ struct MMModelLayout {
                   // t = 0..7 = columns 16 s + 8 (t >> 2) + 4 h + (t & 3) of the tile (mm_bwd_f32.hip); 8 KB per 32 columns
   size_t Zm56;    // [L][2 (h, m)][N56p][Mp] bf16 (f32 mode, d <= 8): the degree-5 and degree-6 monomials of zc, 2-way split, one
                   // monomial's Mp values contiguous (the B operand of k_wmom56_gemm reads 8 consecutive m per lane)
+  size_t tab56;   // index tables of k_spoly56 (MMTab56; f32 mode, d <= 8): i16 block, then the f32 multinomials
   size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
                   // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
@@ -106,6 +123,8 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   if (dtype != MM_F64 && d <= 8) off = mm_align_up(off + (size_t)L * (o.Mp / 32) * 8192, A);
   o.Zm56 = off;
   if (dtype != MM_F64 && d <= 8) off = mm_align_up(off + (size_t)L * 2 * mm_moment56_cols(d) * o.Mp * 2, A);
+  o.tab56 = off;
+  if (dtype != MM_F64 && d <= 8) off = mm_align_up(off + mm_tab56(d).bytes, A);
   o.Cm = off;
   if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;
@@ -252,6 +271,9 @@ struct MMWorkspaceLayout {
   size_t mom56;    // [B][Po][2][N56p] f32: sum_m what_m zc_m^alpha over the degree-5 and degree-6 monomials (collapsed items)
   size_t estS;     // [B][Po] f32: MM_C6_SYS2 sum what^2 sum what'^2 of a collapsed item (0 otherwise): what its skipped tiles leave
                    //              out, in the units of the sweep's error estimate estO (k_spoly56 writes, k_route_decide adds)
+  size_t s56;      // [B][Po] f64: C2 <N_5, G^5 Q_5> + C3 <N_6, G^6 Q_6> of a collapsed item (0 otherwise): the degree-5/6 part of p6 from the
+                   //              f32 moments.  Kept apart from s12: an item the accuracy contract re-reduces in f64 (mm_route.hip) takes
+                   //              those two orders from the re-reduce instead (k_finalize skips s56 where rflag is set)
   size_t f1s;      // [B][L] T      rollout scratch outputs
   size_t Sffs;     // [B][L][L] T
   size_t crs;      // [B][d][L] T
@@ -307,6 +329,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.wsp = off;     off = mm_align_up(off + n56 * 4 * o.Mp * 2, A);
   o.mom56 = off;   off = mm_align_up(off + n56 * 2 * mm_moment56_cols(d) * 4, A);
   o.estS = off;    off = mm_align_up(off + n56 * 4, A);
+  o.s56 = off;     off = mm_align_up(off + n56 * 8, A);
   o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);
   o.Sffs = off;    off = mm_align_up(off + (size_t)B * L * L * es, A);
   o.crs = off;     off = mm_align_up(off + (size_t)B * d * L * es, A);

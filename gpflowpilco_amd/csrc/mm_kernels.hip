@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
                                                  const double* __restrict__ q64, double* __restrict__ qhR,
                                                  double* __restrict__ qhC, int with_unc, int nblk,
                                                  const double* __restrict__ lq, const double* __restrict__ beta64,
-                                                 const double* __restrict__ zmax2, int p0) {
+                                                 const double* __restrict__ zmax2, unsigned short* __restrict__ /* wsp: d <= 8 only */, int p0) {
   static_assert(DK > 8, "d <= 8 takes k_pairvec_reg");
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
   // pair's matrix is fetched once per workgroup, not once per chunk
@@ -733,7 +733,8 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
                                                     const double* __restrict__ q64, double* __restrict__ qhR,
                                                     double* __restrict__ qhC, int with_unc, int nblk, int a, int a2,
                                                     double (*vecs)[DK], const double* __restrict__ lq,
-                                                    const double* __restrict__ beta64, int p, const double* __restrict__ zmax2) {
+                                                    const double* __restrict__ beta64, int p, const double* __restrict__ zmax2,
+                                                    unsigned short* __restrict__ wsp) {
   constexpr bool diag = MODE == 0;
   const int b = blockIdx.z, tid = threadIdx.x;
   const int Po = P - L;
@@ -904,10 +905,23 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
         const double whr = o.br * exp(fmin(o.wr - 0.5 * (o.r1r - tA) + cst - corrA, (double)MM_EXP_CAP_F32));
         const double whc = o.bc * exp(fmin(o.wc - 0.5 * (o.r1c - tg) - cj, (double)MM_EXP_CAP_F32));
         rO[rowd + m] = (T)whr; cO[m] = (T)whc; hR[m] = whr; hC[m] = whc;
+        if (wsp) {
+          // bf16 2-way split of both weights: the A operand of the degree-5/6 moment GEMM (mm_moments6.hip), [side][h, m][Mp]
+          unsigned short* sp = wsp + ((size_t)b * Po + (p - L)) * 4 * (size_t)Mp + m;
+          const float fr = (float)whr, fc = (float)whc;
+          const __bf16 rh = (__bf16)fr, ch = (__bf16)fc;
+          const __bf16 rm = (__bf16)(fr - (float)rh), cm = (__bf16)(fc - (float)ch);
+          sp[0] = __builtin_bit_cast(unsigned short, rh); sp[Mp] = __builtin_bit_cast(unsigned short, rm);
+          sp[2 * (size_t)Mp] = __builtin_bit_cast(unsigned short, ch); sp[3 * (size_t)Mp] = __builtin_bit_cast(unsigned short, cm);
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < DK; ++i) rO[rowi(i) + m] = (T)0;  // zero rows: b = 0 in the padding
         rO[rowd + m] = (T)0; cO[m] = (T)0; hR[m] = 0.0; hC[m] = 0.0;
+        if (wsp) {
+          unsigned short* sp = wsp + ((size_t)b * Po + (p - L)) * 4 * (size_t)Mp + m;
+          sp[0] = 0; sp[Mp] = 0; sp[2 * (size_t)Mp] = 0; sp[3 * (size_t)Mp] = 0;
+        }
       }
     } else {
       // off-diagonal pair of the f64 mode: rho_i (row), g_j and gamma'_j (column)
@@ -972,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict
                                                         const double* __restrict__ q64, double* __restrict__ qhR,
                                                         double* __restrict__ qhC, int with_unc, int nblk,
                                                         const double* __restrict__ lq, const double* __restrict__ beta64,
-                                                        const double* __restrict__ zmax2, int p0) {
+                                                        const double* __restrict__ zmax2, unsigned short* __restrict__ wsp, int p0) {
   // (grid.y = the pairs [p0, p0 + gridDim.y): the q stage launches the diagonal pairs' operands first -- the diagonal sweep needs
   // nothing else -- and the off-diagonal pairs' on the side stream beside that sweep)
   static_assert(DK <= 8, "register form: d <= 8");
@@ -983,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict
   mm_decode_pair(p, L, a, a2);
 #define MM_PV_BODY(MODE_)                                                                                           \
   mm_pairvec_reg_body<T, DK, MODE_>(Zt64, zbar, ls2, L, M, Mp, d, P, mu, pairmat, rho1, rowD, colD, rowO, colO, w64, \
-                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64, p, zmax2)
+                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64, p, zmax2, wsp)
   if (p < L) MM_PV_BODY(0);
   else if (sizeof(T) == 4) MM_PV_BODY(1);
   else MM_PV_BODY(2);
@@ -1036,10 +1050,9 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
   const int i1 = (i0 + MM_GEN_ROWS < Mp) ? i0 + MM_GEN_ROWS : Mp;
   T accB = (T)0;
   double sumB = 0.0, sumC = 0.0;
-  // ROWVEC: a collapsed (b, pair) has the cubic and quartic term of the remainder in the moments (mm_moments.hip)
+  // ROWVEC: a collapsed (b, pair) has p6 (mm_common.h) of the remainder in the moments (mm_moments.hip, mm_moments6.hip)
   const bool coll = ROWVEC && amax != nullptr && zmax2 != nullptr &&
                     mm_collapse_bound2(amax[(size_t)b * np + lp], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
-  const double sub0 = coll ? (double)MM_REM1_C0 : 0.0, sub1 = coll ? (double)MM_REM1_C1 : 0.0;
   for (int i = i0; i < i1; ++i) {
     T delta = ROWVEC ? (T)0 : ra[i] + gam;
 #pragma unroll
@@ -1048,7 +1061,7 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
     // ROWVEC (f32 off-diagonal pairs): only the remainder expm1(b) - b - b^2/2 is reduced here, the
     // rest comes from the f64 weight moments (k_spoly); evaluated in f64 (portable cross-check kernel)
     const double dd = fmin((double)delta, sizeof(T) == 8 ? MM_EXP_CAP_F64 : (double)MM_EXP_CAP_F32);   // (mm_common.h: exponent caps)
-    const T e = ROWVEC ? (T)(expm1(dd) - dd - 0.5 * dd * dd - dd * dd * dd * fma(sub1, dd, sub0))
+    const T e = ROWVEC ? (T)(expm1(dd) - dd - 0.5 * dd * dd - (coll ? MM_C6_POLY_F64(dd) : 0.0))
                        : (T)expm1(dd);
     accB += (ROWVEC ? ra[(size_t)d * Mp + i] : wr[i]) * e;
     if (withC) {
@@ -1078,7 +1091,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
                                                   const double* __restrict__ var, int B, int L, int P, int NS,
                                                   int nsB_diag, int nsB_off, int nsC, int full, int with_unc,
                                                   double jitter, const double* __restrict__ f1raw,
-                                                  const double* __restrict__ s12, int diag_factored,
+                                                  const double* __restrict__ s12, const double* __restrict__ s56, int diag_factored,
                                                   const int* __restrict__ rflag, int ns_routed, T* __restrict__ Sff) {
   // one wave per (b, pair): lanes stride over the slab (coalesced), fixed butterfly => reproducible
   const int idx = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -1089,7 +1102,8 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
   const double* pb = partB + ((size_t)b * P + p) * NS;
   int ns = (a == a2) ? nsB_diag : nsB_off;
   // an item the accuracy contract re-reduced in f64 (mm_route.hip): its slab holds the route kernel's npanel x ncc partial sums
-  if (a != a2 && rflag != nullptr && rflag[(size_t)b * (P - L) + (p - L)]) ns = ns_routed;
+  const bool routed = a != a2 && rflag != nullptr && rflag[(size_t)b * (P - L) + (p - L)];
+  if (routed) ns = ns_routed;
   double s = 0.0;
   for (int k = lane; k < ns; k += 64) s += pb[k];
   if (a == a2 && with_unc) {
@@ -1100,7 +1114,9 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
   for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (lane != 0) return;
   // f32 mode: the tile kernel reduced only the remainder; the moments supply 1 + b + b^2/2, and c0 b^3 + c1 b^4 of a collapsed item (k_spoly)
+  // (orders 5 and 6 of a collapsed item: s56, from f32 moments -- a routed item has them in its f64 re-reduce instead)
   if (a != a2 && s12) s += s12[(size_t)b * (P - L) + (p - L)] - f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a2];
+  if (a != a2 && s56 && !routed) s += s56[(size_t)b * (P - L) + (p - L)];
   if (a == a2) {
     // factored f64 reduce: the slabs hold sum_ij u_i u_j [D_ij] e^{delta_ij}; minus (sum_i w_i)^2 gives the centred sum
     if (diag_factored) s -= f1raw[(size_t)b * L + a] * f1raw[(size_t)b * L + a];
@@ -1191,6 +1207,9 @@ int mm_launch_route(const char* packed, const MMModelLayout& ml, char* ws, const
 int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
                       int B, int L, int d, const void* mu_f32, int flags, hipStream_t stream);
 
+// f32 mode, d <= 8: the degree-5/6 monomial tables and the contraction's index tables (mm_moments6.hip)
+int mm_launch_pack56(char* packed, const MMModelLayout& lay, int L, int M, int d, const double* Z, hipStream_t s);
+
 #define MM_CHECK_LAUNCH() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 
 static int mm_check_common(const void* packed, int L, int M, int d, int dtype, int B) {
@@ -1221,6 +1240,10 @@ static int mm_pack_model_t(char* packed, const MMModelLayout& lay, int L, int M,
                            const double* C, const double* mean_c, hipStream_t s) {
   hipLaunchKernelGGL((k_pack_vectors<T>), dim3(L), dim3(256), 0, s, packed, lay, L, M, d, Z, ls, var, beta, mean_c);
   MM_CHECK_LAUNCH();
+  if (sizeof(T) == 4 && d <= 8) {
+    const int rc = mm_launch_pack56(packed, lay, L, M, d, Z, s);
+    if (rc) return rc;
+  }
   if (C) {
     hipLaunchKernelGGL(k_pack_C, dim3((lay.Mp + 255) / 256, lay.Mp, L), dim3(256), 0, s, packed, lay, L, M, C);
     MM_CHECK_LAUNCH();
@@ -1288,7 +1311,8 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     (const double*)(ws + wl.rho1), (double*)(ws + wl.rowD), (double*)(ws + wl.colD), (T*)(ws + wl.rowO), (T*)(ws + wl.colO), \
     (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), amax,                                      \
     (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC), (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk, \
-    (const double*)(ws + wl.lq), (const double*)(packed + ml.beta64), (const double*)(packed + ml.zmax2)
+    (const double*)(ws + wl.lq), (const double*)(packed + ml.beta64), (const double*)(packed + ml.zmax2),                       \
+    ((sizeof(T) == 4 && d <= 8) ? (unsigned short*)(ws + wl.wsp) : (unsigned short*)nullptr)
     auto pairvec = [&](int p0, int npairs, hipStream_t st) {
       if (npairs <= 0) return;
       if constexpr (DK <= 8) {
@@ -1411,7 +1435,8 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
     hipLaunchKernelGGL((k_finalize<T>), dim3((n + 3) / 4), dim3(256), 0, s,
                        partB, partC, (const double*)(packed + ml.var), B, L, wl.P, wl.NS,
                        nsB_diag, nsB_off, nsC, full, with_unc, jitter, (const double*)(ws + wl.f1raw),
-                       sizeof(T) == 4 ? (const double*)(ws + wl.s12) : (const double*)nullptr, generic ? 0 : 1,
+                       sizeof(T) == 4 ? (const double*)(ws + wl.s12) : (const double*)nullptr,
+                       (sizeof(T) == 4 && d <= 8 && wl.Po > 0) ? (const double*)(ws + wl.s56) : (const double*)nullptr, generic ? 0 : 1,
                        routes ? (const int*)(ws + wl.rflag) : (const int*)nullptr,
                        mm_mfma_num_slots(wl.Mp) * mm_route_ncc(wl.NS, mm_mfma_num_slots(wl.Mp)), Sff);
     MM_CHECK_LAUNCH();

@@ -5,12 +5,12 @@
 //     S = sum_ij w_i expm1(delta_ij) w'_j,   delta_ij = rho'_i + gamma_j + b_ij
 //       = sum_ij what_i what'_j (1 + b_ij + b_ij^2/2)  - (sum w)(sum w')        exact, f64 moments (O(M d^2))
 //       + sum_ij what_i what'_j r(b_ij),   r(x) = expm1(x) - x - x^2/2            THIS kernel, f32, O(M^2)
-// Where the model's input dimension allows a degree-4 moment table (d <= 8) and a (b, pair)'s Cauchy-Schwarz bound on
-// |b_ij| is <= 0.15 (MM_COLLAPSE_BOUND2: most of its tiles are then inside the first tier), the (b, pair) is COLLAPSED
-// (mm_moments.hip): the cubic and quartic terms of r -- this kernel's own first-tier approximant c0 x^3 + c1 x^4, exact to
-// 9e-9 |x| on |x| <= 1/20 (MM_TIER1_MAX) -- are taken from f64 moments as well, every wave tile whose max|b| is inside that
-// tier (known after ONE screening MFMA per 32 x 32 block, the (h, h + m) part of the split product) contributes nothing
-// and is skipped, and the other tiles reduce the correction r(x) - c0 x^3 - c1 x^4 with the same range tiers.
+// Where the model's input dimension allows the moment tables (d <= 8) and a (b, pair)'s Cauchy-Schwarz bound on |b_ij| is
+// <= 1/2 (MM_COLLAPSE_BOUND2: nearly all of its tiles are then inside 1/4), the (b, pair) is COLLAPSED (mm_common.h,
+// mm_moments.hip, mm_moments6.hip): p6(x) = x^3 (C0 + .. + C3 x^3) -- this kernel's own degree-3 tier, |p6 - r| <= 5.8e-10 on
+// |x| <= 1/4 -- is taken from weight moments as well, every wave tile whose max|b| is inside 1/4 (known after ONE screening
+// MFMA per 32 x 32 block, the (h, h + m) part of the split product) contributes nothing and is skipped, and the other tiles
+// reduce the correction r(x) - p6(x) with the same range tiers.
 // The bilinear part runs on the bf16 matrix pipe as a 3-way split product with f32 accuracy
 // (v_mfma_f32_32x32x16_bf16), the remainder polynomial + weighted reduction on the VALU in packed
 // f32 (v_pk_fma_f32); MFMA and f32 FMA-class VALU time add on a gfx950 SIMD (tools/ubench_overlap.hip).
@@ -55,11 +55,18 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
 #endif
 // sum_r w_r * x_r^3 * R_DEG(x_r) over the 16 register pairs of a wave tile.  The Horner steps run
 // "vertically" over the pairs so that consecutive v_pk_fma_f32 are independent.
-// sub0, sub1: what a collapsed (b, pair) already has from the moments (c0, c1 of the first tier; 0, 0 otherwise) --
-// wave-uniform, subtracted from the two leading coefficients (both differences are exact in f32: Sterbenz).
-template <int DEG>
-__device__ __forceinline__ f32x2 mm_weighted_rem(const f32x2 (&xx)[16], const f32x2 (&wrow)[2][8], float sub0, float sub1) {
-  const float cc0 = MMRem<DEG>::c[0] - sub0, cc1 = MMRem<DEG>::c[1] - sub1;
+// CC: the (b, pair) is collapsed -- its moments already carry p6 = x^3 (C0 + C1 x + C2 x^2 + C3 x^3) (mm_common.h), which is
+// subtracted from the four leading coefficients at compile time (the corrected polynomial costs no instruction; the
+// differences are exact in f32: Sterbenz)
+template <int DEG, bool CC>
+struct MMRemC {
+  static constexpr float get(int k) {
+    const float c6[4] = {MM_C6_C0, MM_C6_C1, MM_C6_C2, MM_C6_C3};
+    return MMRem<DEG>::c[k] - ((CC && k < 4) ? c6[k] : 0.0f);
+  }
+};
+template <int DEG, bool CC>
+__device__ __forceinline__ f32x2 mm_weighted_rem(const f32x2 (&xx)[16], const f32x2 (&wrow)[2][8]) {
   f32x2 parts[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   // two halves of 8 register pairs (one 32-row MFMA tile each): 8 independent chains cover the packed-FMA latency,
   // and the temporaries of one half are dead before the other starts (register pressure)
@@ -68,12 +75,12 @@ __device__ __forceinline__ f32x2 mm_weighted_rem(const f32x2 (&xx)[16], const f3
     f32x2 pp[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r)
-      pp[r] = mm_pkfma(MM_PK(MMRem<DEG>::c[DEG]), xx[8 * hh + r], MM_PK(DEG - 1 == 1 ? cc1 : MMRem<DEG>::c[DEG - 1]));
+      pp[r] = mm_pkfma(MM_PK((MMRemC<DEG, CC>::get(DEG))), xx[8 * hh + r], MM_PK((MMRemC<DEG, CC>::get(DEG - 1))));
 #pragma unroll
     for (int k = DEG - 2; k >= 0; --k)
 #pragma unroll
       for (int r = 0; r < 8; ++r)
-        pp[r] = mm_pkfma(pp[r], xx[8 * hh + r], MM_PK(k == 0 ? cc0 : (k == 1 ? cc1 : MMRem<DEG>::c[k])));
+        pp[r] = mm_pkfma(pp[r], xx[8 * hh + r], MM_PK((MMRemC<DEG, CC>::get(k))));
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const f32x2 wx = wrow[hh][r] * xx[8 * hh + r];                   // w_i * x
@@ -146,8 +153,8 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
 
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   if constexpr (ND8 == 1) {
-    // Cauchy-Schwarz already bounds every |b_ij| of this (b, pair) by MM_TIER1_MAX: the remainder is the first tier's
-    // c0 x^3 + c1 x^4 everywhere, which the moments carry (k_spoly) -- every tile would be skipped: no sweep at all
+    // Cauchy-Schwarz already bounds every |b_ij| of this (b, pair) by MM_C6_MAX: the remainder is p6 everywhere, which the
+    // moments carry (k_spoly, k_spoly56) -- every tile would be skipped: no sweep at all
     if (!force_worst && zmax2 && mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) <= MM_INSIDE_BOUND2) {
       for (int panel = pgrp * ppw + (int)threadIdx.x; panel < npanel && panel < (pgrp + 1) * ppw; panel += 256) {
         partB[((size_t)b * P + p) * NS + panel] = 0.0;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     const float bound2 = zmax2 ? mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) : 3.0e38f;
     const bool coll = (ND8 == 1) && !force_worst && bound2 <= MM_COLLAPSE_BOUND2;
     // a tile is skipped on the screening product alone: its error is <= 2^-9 sum_k |A_k||Z_k| <= 2^-9 sqrt(bound2)
-    const float thr_skip = MM_TIER1_MAX - 0.00390625f * __builtin_sqrtf(bound2) - 1e-6f;
+    const float thr_skip = MM_C6_MAX - 0.00390625f * __builtin_sqrtf(bound2) - 1e-6f;
 
     // ---- stationary operands --------------------------------------------------------------
     bf16x8 a1[2][ND8], a2v[2][ND8], a3[2][ND8];
@@ -326,24 +333,23 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // collm (compile time): the (b, pair) is collapsed -- the moments already carry c0 x^3 + c1 x^4 of the first tier
     auto reduce_tile = [&](auto collm, const f32x16 (&acc)[2], float mx, float wc) {
       constexpr bool CC = decltype(collm)::value;
-      constexpr float sub0 = CC ? MM_REM1_C0 : 0.0f, sub1 = CC ? MM_REM1_C1 : 0.0f;
       f32x2 xx[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
       f32x2 part2;
       // wave-uniform tier choice (ballots, no cross-lane reduction)
-      if (!__any(mx > MM_TIER1_MAX)) {
-        // a collapsed (b, pair) has nothing left to add in this tier (the moments carry c0 x^3 + c1 x^4)
+      if (!CC && !__any(mx > MM_TIER1_MAX)) {
         // (the folded coefficients cost 64 more VGPRs: only where the operand registers leave room, d <= 8)
+        if constexpr (ND8 == 1) part2 = mm_weighted_rem1(xx, wc0, wc1);
+        else part2 = mm_weighted_rem<1, false>(xx, wrow);
+      } else if (!__any(mx > MM_C6_MAX)) {
+        // a collapsed (b, pair) has nothing left to add below 1/4: its moments carry this tier's own polynomial
         if constexpr (CC) part2 = (f32x2){0.0f, 0.0f};
-        else if constexpr (ND8 == 1) part2 = mm_weighted_rem1(xx, wc0, wc1);
-        else part2 = mm_weighted_rem<1>(xx, wrow, 0.0f, 0.0f);
-      } else if (!__any(mx > 0.25f)) {
-        part2 = mm_weighted_rem<3>(xx, wrow, sub0, sub1);
+        else part2 = mm_weighted_rem<3, false>(xx, wrow);
       } else if (!__any(mx > 0.5f)) {
-        part2 = mm_weighted_rem<4>(xx, wrow, sub0, sub1);
+        part2 = mm_weighted_rem<4, CC>(xx, wrow);
       } else if (!__any(mx > 1.0f)) {
-        part2 = mm_weighted_rem<5>(xx, wrow, sub0, sub1);
+        part2 = mm_weighted_rem<5, CC>(xx, wrow);
       } else {
         part2 = (f32x2){0.0f, 0.0f};
 #pragma unroll
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
             const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
             const float big = (__builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f) - fmaf(0.5f * x, x, x);
             float e = (fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big;
-            if constexpr (CC) e -= (x * x) * x * fmaf(sub1, x, sub0);    // a collapsed pair has |b| <= 1 + rounding
+            if constexpr (CC) e -= (x * x) * x * fmaf(fmaf(fmaf(MM_C6_C3, x, MM_C6_C2), x, MM_C6_C1), x, MM_C6_C0);
             part2[e2] = fmaf(wrow[r >> 3][r & 7][e2], e, part2[e2]);
           }
       }
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
       mfma_tile_m(zA, acc);
       const float mx = force_worst ? 2.0f : tile_max(acc);       // MM_FORCE_WORST_TIER: wave-uniform override
       if constexpr (CM) {
-        if (!__any(mx > MM_TIER1_MAX)) return;                        // first tier of a collapsed pair: all in the moments
+        if (!__any(mx > MM_C6_MAX)) return;                           // inside the collapsed range: all in the moments
       }
       if constexpr (CM) wc = wcf[ct * 32 + l31];
       emx = mx; ewc = wc;
@@ -420,10 +426,9 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
 #endif
       }
     };
-    // A (b, pair) is collapsed only where its bound lets the screening skip most tiles (MM_COLLAPSE_BOUND2 = 0.15^2: measured
-    // on the BASELINE recipe, bound <= 0.12 -> < 12 % of the tiles exceed the first tier, bound >= 0.18 -> > 90 %); up to
-    // round 3 every item with bound <= 1 was collapsed and the ones above 0.15 took a third, unscreened sweep with the
-    // collapsed coefficients -- they paid the cubic / quartic moment columns for nothing.
+    // A (b, pair) is collapsed only where its bound lets the screening skip most tiles (MM_COLLAPSE_BOUND2 = (1/2)^2: on the
+    // BASELINE recipe items with a bound in (1/4, 1/2] have 98 % of their wave tiles under 1/4, items beyond 1/2 a third,
+    // tools/tile_hist_baseline.py).
     // (Two instantiations, not a run-time flag: a non-collapsed item must not pay for the collapsed coefficients -- as a flag
     // they cost the exp2 branch 4 more ops per entry: forced-worst C3 12.5 -> 16.8 ms)
     if (coll) sweep(mm_true{}, mm_true{});

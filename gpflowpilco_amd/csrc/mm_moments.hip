@@ -376,6 +376,9 @@ int mm_launch_wmom_full(const char* packed, const MMModelLayout& ml, char* ws, c
   return e == hipSuccess ? 0 : (int)e;
 }
 
+int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
+                        int B, int L, int d, int allow, hipStream_t stream);
+
 int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl,
                       int B, int L, int d, const void* mu_f32, int flags, hipStream_t stream) {
   const double* Zm = (const double*)(packed + ml.Zm);
@@ -413,12 +416,14 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
                        (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), (const double*)(packed + ml.zmax2), \
                        (const unsigned int*)(ws + wl.amax), (const float*)mu_f32, L, d, wl.P, deg, allow, off1, off2, off3, off4, \
                        (const short*)(packed + ml.rtab),                                                                        \
-                       (double)MM_REM1_C0, (double)MM_REM1_C1, (double*)(ws + wl.s12));                                         \
+                       (double)MM_C6_C0, (double)MM_C6_C1, (double*)(ws + wl.s12));                                             \
   } while (0)
   if (d <= 8) MM_SPOLY(8, 3); else MM_SPOLY(32, 5);
 #undef MM_SPOLY
   e = hipGetLastError();
-  return e == hipSuccess ? 0 : (int)e;
+  if (e != hipSuccess) return (int)e;
+  // orders 5 and 6 of the collapsed items (f32 moments on the bf16 matrix pipe: mm_moments6.hip) -> s56, estS
+  return mm_launch_moments56(packed, ml, ws, wl, B, L, d, some ? 1 : 0, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

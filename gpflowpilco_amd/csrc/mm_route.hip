@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void k_route_decide(const float* __restrict__ e
                                                      const double* __restrict__ f1raw, const unsigned int* __restrict__ amax,
                                                      const double* __restrict__ zmax2, int L, int Po, double tol, int force,
                                                      int* __restrict__ rlist, int* __restrict__ rcount, int* __restrict__ rflag,
-                                                     int slot, int32_t* __restrict__ status) {
+                                                     int slot, int32_t* __restrict__ status, const float* __restrict__ estS) {
   const int b = blockIdx.x, lane = threadIdx.x;
   auto zmax2a2 = [&](int po) { int a, a2; mmx_decode_pair_o(po, L, a, a2); return zmax2[a2]; };
   double sc = 0.0;
@@ -67,6 +67,8 @@ __global__ __launch_bounds__(64) void k_route_decide(const float* __restrict__ e
       const float* e = estO + ((size_t)b * Po + po) * npanel;
       double e2 = 0.0;
       for (int pn = 0; pn < npanel; ++pn) e2 += (double)e[pn];
+      // + what the skipped tiles of a collapsed item leave out (the forward only: mm_common.h, MM_C6_SYS2)
+      if (estS) e2 += (double)estS[(size_t)b * Po + po];
       const double est = mmx_est(e2, amax[(size_t)b * Po + po], zmax2a2(po));
       r = force || est > tol * sc;
       if (rflag) rflag[(size_t)b * Po + po] = r ? 1 : 0;
@@ -90,7 +92,8 @@ __global__ __launch_bounds__(64) void k_route_decide(const float* __restrict__ e
 // Diagnostic: per (b, off-diagonal pair) {est, scale_b} as k_route_decide sees them (after a forward / backward sweep).
 __global__ __launch_bounds__(64) void k_route_report(const float* __restrict__ estO, int npanel, const double* __restrict__ s12,
                                                      const double* __restrict__ f1raw, const unsigned int* __restrict__ amax,
-                                                     const double* __restrict__ zmax2, int L, int Po, double* __restrict__ out) {
+                                                     const double* __restrict__ zmax2, int L, int Po, double* __restrict__ out,
+                                                     const float* __restrict__ estS) {
   const int b = blockIdx.x, lane = threadIdx.x;
   auto zmax2a2 = [&](int po) { int a, a2; mmx_decode_pair_o(po, L, a, a2); return zmax2[a2]; };
   double sc = 0.0;
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(64) void k_route_report(const float* __restrict__ e
     const float* e = estO + ((size_t)b * Po + po) * npanel;
     double e2 = 0.0;
     for (int pn = 0; pn < npanel; ++pn) e2 += (double)e[pn];
+    if (estS) e2 += (double)estS[(size_t)b * Po + po];
     out[((size_t)b * Po + po) * 2 + 0] = mmx_est(e2, amax[(size_t)b * Po + po], zmax2a2(po));
     out[((size_t)b * Po + po) * 2 + 1] = sc;
   }
@@ -123,7 +127,8 @@ extern "C" int mm_route_estimates(const void* packed, size_t packed_bytes, int L
   if (mm_fork_join_wait((hipStream_t)stream)) return MM_E_ARG;
   hipLaunchKernelGGL(k_route_report, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)(ws + wl.estO),
                      (wl.Mp + MM_PANEL_ROWS - 1) / MM_PANEL_ROWS, (const double*)(ws + wl.s12), (const double*)(ws + wl.f1raw),
-                     (const unsigned int*)(ws + wl.amax), (const double*)((const char*)packed + ml.zmax2), L, wl.Po, out);
+                     (const unsigned int*)(ws + wl.amax), (const double*)((const char*)packed + ml.zmax2), L, wl.Po, out,
+                     d <= 8 ? (const float*)(ws + wl.estS) : (const float*)nullptr);
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -212,11 +217,13 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
       }
     }
     const double wr = live ? whR[((size_t)b * Po + lp) * Mp + rr] : 0.0;
-    // the forward's collapsed items carry c0 x^3 + c1 x^4 in their moments (k_spoly): the same predicate, the same coefficients
+    // the forward's collapsed items carry p6 in their moments (k_spoly, k_spoly56): the same predicate, the same coefficients
     bool coll = false;
     if (!AGG && allow_collapse && zmax2 != nullptr && d <= 8)
       coll = mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
-    const double sub0 = coll ? (double)MM_REM1_C0 : 0.0, sub1 = coll ? (double)MM_REM1_C1 : 0.0;
+    // (orders 3 and 4 of p6 stay with the f64 moments; orders 5 and 6 -- s56, from f32 moments -- are dropped for a routed item by
+    // k_finalize, so the re-reduce keeps them: r - C0 x^3 - C1 x^4)
+    const double sub0 = coll ? (double)MM_C6_C0 : 0.0, sub1 = coll ? (double)MM_C6_C1 : 0.0;
     const double* zc = Zc64 + (size_t)a2 * Mp * Kz;         // wave-uniform from here on: scalar loads
     const double* wc = whC + ((size_t)b * Po + lp) * Mp;
     double B0 = 0.0, B1[AGG ? DK : 1], B2[NB2];
@@ -319,7 +326,8 @@ int mm_launch_route(const char* packed, const MMModelLayout& ml, char* ws, const
   hipLaunchKernelGGL(k_route_decide, dim3(B), dim3(64), 0, stream, (const float*)(ws + wl.estO), npanel,
                      (const double*)(ws + wl.s12), (const double*)(ws + wl.f1raw), (const unsigned int*)(ws + wl.amax),
                      (const double*)(packed + ml.zmax2), L, wl.Po, (double)MM_ROUTE_TOL,
-                     (flags & MM_FORCE_ROUTE) ? 1 : 0, rlist, rcount, agg ? (int*)nullptr : (int*)(ws + wl.rflag), agg ? 2 : 1, status);
+                     (flags & MM_FORCE_ROUTE) ? 1 : 0, rlist, rcount, agg ? (int*)nullptr : (int*)(ws + wl.rflag), agg ? 2 : 1, status,
+                     (!agg && d <= 8) ? (const float*)(ws + wl.estS) : (const float*)nullptr);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
   const int ncc = agg ? 1 : mm_route_ncc(wl.NS, npanel);

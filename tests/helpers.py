@@ -50,6 +50,27 @@ def to_dev(a, device, dtype):
   return torch.tensor(np.asarray(a), dtype=dtype, device=device)
 
 
+def contract_err(Sff, Sffo):
+  """The f32 pack's accuracy contract (include/gpflowpilco_mm.h): per batch element the error of the
+  off-diagonal block relative to that block's own scale (its largest |entry|: what MM_ROUTE_TOL is stated against) and of the
+  diagonal relative to the largest variance.  Returns (worst off-diagonal, worst diagonal) over the batch."""
+  got = Sff.detach().double().cpu().numpy() if isinstance(Sff, torch.Tensor) else np.asarray(Sff)
+  L = got.shape[-1]
+  eye = np.eye(L, dtype=bool)
+  err = np.abs(got - Sffo)
+  off = dia = 0.0
+  for b in range(got.shape[0]):
+    if L > 1:
+      off = max(off, float(err[b][~eye].max() / max(np.abs(Sffo[b][~eye]).max(), 1e-300)))
+    dia = max(dia, float(err[b][eye].max() / max(np.abs(Sffo[b][eye]).max(), 1e-300)))
+  return off, dia
+
+
+def f32_state(mu, Sigma):
+  """The state as an f32 pack receives it (the oracle is evaluated there: the comparison point of an f32 tolerance)."""
+  return np.asarray(mu, dtype=np.float32).astype(np.float64), np.asarray(Sigma, dtype=np.float32).astype(np.float64)
+
+
 def scale_err(got, want):
   """max |got - want| relative to max |want| (per tensor)."""
   got = got.detach().double().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)

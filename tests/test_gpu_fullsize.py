@@ -13,7 +13,7 @@ import torch
 from gpflowpilco_amd import ops
 from gpflowpilco_amd.synthetic import make_inputs, make_svgp
 from oracle import mm_fused_ref as fr
-from tests.helpers import oracle_params, scale_err, to_dev
+from tests.helpers import contract_err, f32_state, oracle_params, scale_err, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -147,19 +147,24 @@ def test_forced_worst_tier_gives_the_same_result(device):
 
 def test_wide_sigma_short_lengthscales_f32_is_finite_and_bounded(device):
   """|b| >> 1: input std 1.0 against lengthscales down to 0.3 -- the exp2 branch with factored weights
-  what_i = w_i e^{rho'_i}.  Outputs must be finite (no overflow of the factored weights) and the f32 mode must
-  stay within 2e-3 of the fp64 oracle relative to max |Sff| (test_large_delta_slow_path_f32's bound)."""
+  what_i = w_i e^{rho'_i}.  Outputs must be finite (no overflow of the factored weights); the f64 mode within 1e-6 of the
+  oracle, the f32 mode within its accuracy contract (3e-4 of the off-diagonal block's scale, 2e-5 of the largest variance,
+  oracle at the f32-rounded state: what its own estimate does not cover is re-reduced in f64, csrc/mm_route.hip)."""
   from oracle import mm_oracle as mo
   syn = make_svgp(3, 160, 4, seed=21, ls_bounds=(0.3, 1.0), stable=False)
-  mu, Sigma = make_inputs(5, 4, seed=8, scale=1.0, lo=0.0, hi=1.0)
+  mu, Sigma = f32_state(*make_inputs(5, 4, seed=8, scale=1.0, lo=0.0, hi=1.0))
   f1o, Sffo, cro = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
   model = syn.to_model(device)
-  for dtype, tol in ((torch.float64, 1e-6), (torch.float32, 2e-3)):
+  for dtype in (torch.float64, torch.float32):
     pm = model.packed(dtype, True, device)
     f1, Sff, cross = ops.moment_match(pm, to_dev(mu, device, dtype), to_dev(Sigma, device, dtype))
     pm.check_status(5)
     assert torch.isfinite(f1).all() and torch.isfinite(Sff).all() and torch.isfinite(cross).all()
-    assert scale_err(Sff, Sffo) < tol and scale_err(f1, f1o) < tol
+    if dtype == torch.float64:
+      assert scale_err(Sff, Sffo) < 1e-6 and scale_err(f1, f1o) < 1e-6
+    else:
+      off, dia = contract_err(Sff, Sffo)
+      assert off < 3e-4 and dia < 2e-5 and scale_err(f1, f1o) < 2e-6, (off, dia, scale_err(f1, f1o))
 
 
 @pytest.mark.parametrize("recipe", ["baseline", "pilco"])
