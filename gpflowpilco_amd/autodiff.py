@@ -19,6 +19,8 @@ sweep is a plain VALU kernel (correctness first).
 """
 from __future__ import annotations
 
+import os
+import weakref
 from typing import Optional,  Tuple
 
 import torch
@@ -269,6 +271,22 @@ def moment_match_backward_reference(pm: ops.PackedModel, pre, mu: torch.Tensor, 
   return gmu, _sym(gS)
 
 
+# Byte budget of the FUSED differentiable match (value from the backward's sweeps, ``mm_moment_match_with_sums``): every such match
+# keeps its sums (``ops.backward_workspace_bytes``: 0.5 GB at C3 with B = 256) on its autograd node until its backward has run, so a
+# torch-composed H-step rollout holds H of them.  Above the limit a match takes the two-pass form instead (forward's sweeps now,
+# the backward's sweeps in the backward: nothing kept) -- the native tape caps the same data the same way (MM_TAPE_WS_LIMIT).
+FUSED_SUMS_LIMIT = int(os.environ.get("GPFLOWPILCO_FUSED_SUMS_LIMIT", str(2 << 30)))
+_fused_live = [0]                    # bytes of sums buffers alive on autograd nodes
+
+
+def fused_sums_live_bytes() -> int:
+  return _fused_live[0]
+
+
+def _release_fused(nbytes: int) -> None:
+  _fused_live[0] -= nbytes
+
+
 class MomentMatchFunction(torch.autograd.Function):
   """``ops.moment_match`` as a differentiable function of (mu, Sigma) for a frozen packed model.
 
@@ -288,13 +306,21 @@ class MomentMatchFunction(torch.autograd.Function):
   def forward(ctx, mu, Sigma, pm, pm_bwd, pre, full_output_cov, model_uncertainty, fused=True):
     ctx.sums = None
     ctx.pm_bwd, ctx.pre, ctx.flags = pm_bwd, pre, (full_output_cov, model_uncertainty)
+    need = 0
     if fused and pm_bwd is pm and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) and mu.shape[0] > 0:
+      need = ops.backward_workspace_bytes(pm, mu.shape[0], ops.make_flags(full_output_cov, model_uncertainty))
+      if _fused_live[0] + need > FUSED_SUMS_LIMIT:
+        need = 0                       # over the budget: two passes, nothing kept (see FUSED_SUMS_LIMIT)
+    if need:
       # value AND sums in one pass (mm_moment_match_with_sums): the backward's M x M sweeps do not depend on the incoming
       # gradient and contain the forward's sums, so a call that will be differentiated runs THEM instead of the forward's
       # sweeps and its backward is the chain rule alone.  The sums (C3 shape, B = 256: 0.5 GB) live on this node until its
       # backward has run
       f1, Sff, cross, ctx.sums, ctx.generation = ops.moment_match_with_sums(pm, mu, Sigma, full_output_cov=full_output_cov,
                                                                             model_uncertainty=model_uncertainty)
+      if ctx.sums is not None:
+        _fused_live[0] += need
+        weakref.finalize(ctx.sums, _release_fused, need)      # freed with the buffer: after the backward, or with a dropped graph
       ctx.save_for_backward(mu, Sigma)
       return f1, Sff, cross
     f1, Sff, cross = ops.moment_match(pm, mu, Sigma, full_output_cov=full_output_cov,

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void k_bwd_rem_f32(const unsigned short* __
     {
       const float w0 = ra[(size_t)d * Mp + row0 + l31], w1 = ra[(size_t)d * Mp + row0 + 32 + l31];     // the lane's two rows
       const float xf = fminf(xall, 8.0f);
-      const float pf = fmaf(xf, xf, xf) + 1.0f;
+      const float pf = fmaxf(fmaf(xf, xf, xf) + 1.0f, __expf(xf));   // e^X <= 1 + X + X^2 only up to X = 1.79: the larger of the two (X <= 8)
       est = (est * fmaf(w0, w0, w1 * w1)) * (pf * pf);
     }
   }

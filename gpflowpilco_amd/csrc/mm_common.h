@@ -50,15 +50,15 @@ static inline int mm_moment56_cols(int d) { return d <= 8 ? mm_round_up_int(mm_m
 // sym(k) = mm_mono_count(k, d) sorted index tuples of length k in colex rank order:
 //   ins  [m = 0..5][J < sym(m)][8] i16: rank inside sym(m + 1) of the tuple J with the index j inserted (0 for j >= d)
 //   last [k = 0..5][I < sym(k)]    i16: the largest index of I (0 for k = 0): appending i >= last keeps I sorted, rank += C(i + k, k + 1)
-//   mult [sym(5) + sym(6)]         f32: multinomial n! / prod(count!) of the tuple (a packed moment stands for that many tensor entries)
-struct MMTab56 { int ins[6], last[6], n_i16, mult5, mult6, n_f32; size_t bytes; };
+//   mult2 [sym(2)], mult3 [sym(3)] f32: multinomial n! / prod(count!) of the tuple (a packed entry stands for that many tensor entries)
+struct MMTab56 { int ins[6], last[6], n_i16, mult2, mult3, n_f32; size_t bytes; };
 static inline MMTab56 mm_tab56(int d) {
   MMTab56 t;
   int o = 0;
   for (int m = 0; m < 6; ++m) { t.ins[m] = o; o += mm_mono_count(m, d) * 8; }
   for (int k = 0; k < 6; ++k) { t.last[k] = o; o += mm_mono_count(k, d); }
   t.n_i16 = mm_round_up_int(o, 8);
-  t.mult5 = 0; t.mult6 = mm_mono_count(5, d); t.n_f32 = mm_mono_count(5, d) + mm_mono_count(6, d);
+  t.mult2 = 0; t.mult3 = mm_mono_count(2, d); t.n_f32 = mm_mono_count(2, d) + mm_mono_count(3, d);
   t.bytes = (size_t)t.n_i16 * 2 + (size_t)t.n_f32 * 4;
   return t;
 }
@@ -158,7 +158,8 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 // what a skipped entry leaves out, as an equivalent relative rounding for the route estimate (mm_route.hip): the independence
 // model with a per-entry amplitude of 1e-10 (the polynomial's error oscillates with amplitude 5.8e-10, but it is a smooth
 // function of b and cancels under the alternating weights: measured total / (|what|_2 |what'|_2) <= 4e-11,
-// tools/collapse6_study.py).  estS = MM_C6_SYS2 * sum what_i^2 * sum what'_j^2 is added to the sweep's E2:
+// tools/collapse6_study.py).  estS = MM_C6_SYS2 * min(1, (4 X)^3)^2 * sum what_i^2 * sum what'_j^2 (X = the item's
+// Cauchy-Schwarz bound: near 0 the error of p6 is the perturbation of its leading coefficient, 3.4e-7 |x|^3) is added to the sweep's E2:
 // (1e-10 / (2^-24 * 2/3))^2
 #define MM_C6_SYS2 6.33e-6f
 // p6 as every f64 consumer evaluates it (k_spoly's coefficients, the routed re-reduce, the portable kernel): the f32 literals

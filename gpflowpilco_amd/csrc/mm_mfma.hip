@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
   float estl;
   {
     const float xf = fminf(xall, 8.0f);                     // (beyond |b| = 8 the estimate is astronomically large anyway)
-    const float pf = fmaf(xf, xf, xf) + 1.0f;
+    const float pf = fmaxf(fmaf(xf, xf, xf) + 1.0f, __expf(xf));   // e^X <= 1 + X + X^2 only up to X = 1.79: the larger of the two (X <= 8)
     estl = ((est2[0] + est2[1]) * rowsq) * (pf * pf);
   }
 #pragma unroll

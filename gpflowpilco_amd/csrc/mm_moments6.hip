@@ -15,13 +15,14 @@
 //                   both operands are read 8 consecutive m per lane (what is [row][m], the table [monomial][m]): no transposes;
 //   k_spoly56     : s56[b][po] = C2 <N_5, G^{(x)5} Q_5> + C3 <N_6, G^{(x)6} Q_6> from the PACKED symmetric moments, G applied one
 //                   index at a time on tensors symmetric in the transformed and in the untransformed indices separately
-//                   (tools/spoly56_proto.py: 0.54 M FMA per item at d = 8 against 15 M for full tensors), f32, one 512-thread
+//                   (tools/spoly56_proto.py: 0.54 M FMA per item at d = 8 against 15 M for full tensors), f32, one 1024-thread
 //                   workgroup per collapsed (b, pair); also estS (mm_common.h: MM_C6_SYS2).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
 #include "mm_mono.h"
 #include "mm_f32_tile.h"
+#include <type_traits>
 
 __device__ __forceinline__ void mm6_decode_pair_o(int lp, int L, int& a, int& a2) {
   int r = lp, i = 0;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void k_pack_tab56(char* packed, MMModelLayout 
       i16[t.last[m] + I] = (short)(m ? k[m - 1] : 0);
     }
   }
-  for (int n = 5; n <= 6; ++n) {
+  for (int n = 2; n <= 3; ++n) {
     const int ns = mm_binom_i(d + n - 1, n);
     for (int I = tid; I < ns; I += 256) {
       int k[6] = {0, 0, 0, 0, 0, 0};
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void k_pack_tab56(char* packed, MMModelLayout 
         run = (u > 0 && k[u] == k[u - 1]) ? run + 1 : 1;
         mult /= (double)run;
       }
-      f32[(n == 5 ? t.mult5 : t.mult6) + I] = (float)mult;
+      f32[(n == 2 ? t.mult2 : t.mult3) + I] = (float)mult;
     }
   }
 }
@@ -236,71 +237,116 @@ __global__ __launch_bounds__(256, 2) void k_wmom56_gemm(const unsigned short* __
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_spoly56: grid (Po, B), 512 threads.  LDS: two tensor buffers (even / odd stages), sized for n = 6.
+// k_spoly56: grid (Po, B), MM6_THREADS threads.  MEET IN THE MIDDLE (tools/spoly56_proto.py: contract_mitm): three indices of
+// Q_n are carried to the row side with G,
+//     X[I][J] = sum_l G_{i1 l1} G_{i2 l2} G_{i3 l3} Q_{l1 l2 l3 J},          I in sym(3), J in sym(n - 3),
+// the other n - 3 indices of N_n to the column side with G^T,  Y[J][I] = sum_m N_{I m} G_{m1 j1} .. ,  and
+// <N_n, G^{(x)n} Q_n> = sum_{I, J} mult(I) mult(J) X[I][J] Y[J][I]  (the multinomials are folded into X as it is stored; Y's last
+// step is fused with the dot and never stored).  Every step T_{k+1}[I + {i}][J'] = sum_j G[i][j] T_k[I][J' + {j}], i >= max(I), has
+// sym(n - k - 1) >= 36 values of J' (d = 8): LANES run over J' -- the eight gather offsets ins[J'][.] are loaded once per step and
+// lane -- and the WAVE's I, its largest index and the output row are scalars: no per-lane predicate, no integer division, the
+// tuple-rank arithmetic on the scalar unit.  Measured at C3, BASELINE recipe (6400 collapsed items, tools/q_stage_kernels.py): one
+// flat loop over (I, J') pairs with per-lane bounds 1.19 ms; this form with G in 64 scalar registers (spilled to VGPR lanes)
+// 1.11 ms; G in vector registers, 12 waves 0.88 ms (8 waves 1.03) -- of which 0.16 ms are the loads and the launch of 7168
+// workgroups.  It runs at ~800 cycles per 64-lane work unit and SIMD: the unit's serial chain (decode, gathers, 8-deep FMA chains,
+// branchy stores), not its instruction count.
 // ---------------------------------------------------------------------------------------------
-template <int N>
-__device__ __forceinline__ float mm6_contract(const float* __restrict__ nq, int offn, int d, const int (&sy)[7],
-                                              const short* __restrict__ tabi, const float* __restrict__ mult, const MMTab56& tb,
-                                              const float (&G)[64], float* bufE, float* bufO, int tid) {
-  // T_0 = Q_N (column side: nq[1]), packed
-  const float* Nn = nq + offn;
-  const float* Qn = nq + sy[5] + sy[6] + offn;           // (the kernel's LDS copy: [row side 5 | 6][column side 5 | 6])
-  for (int idx = tid; idx < sy[N]; idx += 512) bufE[idx] = Qn[idx];
-  __syncthreads();
+// MODE 0: store T_{k+1}; 1: X's last step (k = 2 -> 3): store mult3(I3) multJ(J') value, row stride xs; 2: Y's last step fused
+// with the dot against X (acc += value * X[J'][row])
+#ifndef MM6_THREADS
+#define MM6_THREADS 768       // 12 waves = 3 per SIMD: 168 VGPRs (G alone is 64; 1024 threads spilled at 128)
+#endif
+#define MM6_WAVES (MM6_THREADS / 64)
+template <int K, bool TRANSG, int MODE>
+__device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin, int nI, float* __restrict__ Tout, int nJp,
+                                         const short* __restrict__ ins, int d, const float (&G)[64], const float* __restrict__ multJ,
+                                         int xs, float& acc, int wave, int lane) {
+  const int chunks = (nJp + 63) >> 6;
+  // the outputs i = I0 .. 7 of one (I, J'): eight-term dot products of the gathered v with G's rows (columns: TRANSG), the
+  // chains interleaved (one chain per i inside its own branch ran at the FMA's latency, not its issue rate: 4x slower)
+  auto dots = [&](auto i0c, const float (&v)[8], float (&s)[8]) __attribute__((always_inline)) {
+    constexpr int I0 = decltype(i0c)::value;
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    const float* Tin = (k & 1) ? bufO : bufE;
-    float* Tout = (k & 1) ? bufE : bufO;
-    const int nI = sy[k], nJ = sy[N - k - 1], nJin = sy[N - k];
-    const short* ins = tabi + tb.ins[N - k - 1];
-    const short* lastk = tabi + tb.last[k];
-    const int npair = nI * nJ;
-    for (int q0 = 0; q0 < npair; q0 += 512) {
-      const int q = q0 + tid;
-      const bool in = q < npair;
-      const int qq = in ? q : npair - 1;
-      const int I = qq / nJ, J = qq - I * nJ;
-      const short4 ia = *reinterpret_cast<const short4*>(ins + (size_t)J * 8);
-      const short4 ib = *reinterpret_cast<const short4*>(ins + (size_t)J * 8 + 4);
-      const float* tin = Tin + (size_t)I * nJin;
-      const float v0 = tin[ia.x], v1 = tin[ia.y], v2 = tin[ia.z], v3 = tin[ia.w];
-      const float v4 = tin[ib.x], v5 = tin[ib.y], v6 = tin[ib.z], v7 = tin[ib.w];
-      const int lastI = lastk[I];
-      // colex rank: the largest index is monotone in the rank, so the first lane of a wave has the smallest `last`
-      const int lo = __builtin_amdgcn_readfirstlane(lastI);
-      int app = I * nJ + J;                              // + C(i + k, k + 1) nJ for the appended index i
+    for (int i = I0; i < 8; ++i) s[i] = (TRANSG ? G[0 * 8 + i] : G[i * 8 + 0]) * v[0];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        if (i >= lo && i < d) {                          // wave-uniform
-          float s = G[i * 8 + 0] * v0;
-          s = fmaf(G[i * 8 + 1], v1, s); s = fmaf(G[i * 8 + 2], v2, s); s = fmaf(G[i * 8 + 3], v3, s);
-          s = fmaf(G[i * 8 + 4], v4, s); s = fmaf(G[i * 8 + 5], v5, s); s = fmaf(G[i * 8 + 6], v6, s);
-          s = fmaf(G[i * 8 + 7], v7, s);
-          if (in && i >= lastI) Tout[app + mm_binom_i(i + k, k + 1) * nJ] = s;
+    for (int j = 1; j < 8; ++j)
+#pragma unroll
+      for (int i = I0; i < 8; ++i) s[i] = fmaf(TRANSG ? G[j * 8 + i] : G[i * 8 + j], v[j], s[i]);
+  };
+  auto body = [&](int I, int t, int Jp, const int (&off)[8], float mj) __attribute__((always_inline)) {
+    const float* tin = Tin + I * nJin;
+    float v[8], s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = tin[off[j]];
+    // only i >= t (the largest index of I) is needed; t is wave-uniform: three variants of the product
+    if (t < 4) dots(std::integral_constant<int, 0>{}, v, s);
+    else if (t < 6) dots(std::integral_constant<int, 4>{}, v, s);
+    else dots(std::integral_constant<int, 6>{}, v, s);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (i >= t && i < d) {                             // scalar compare: t, d are wave-uniform
+        const int orow = I + mm_binom_i(i + K, K + 1);   // rank of I with i appended (colex)
+        if constexpr (MODE == 0) {
+          Tout[orow * nJp + Jp] = s[i];
+        } else if constexpr (MODE == 1) {
+          // I = (a, t) with a = I - C(t + 1, 2): multinomial of the sorted triple (a, t, i)
+          const int a = I - ((t * (t + 1)) >> 1);
+          const float m3 = a == t ? (i == t ? 1.0f : 3.0f) : (i == t ? 3.0f : 6.0f);
+          Tout[orow * xs + Jp] = (m3 * mj) * s[i];
+        } else {
+          acc = fmaf(s[i], Tout[Jp * xs + orow], acc);   // (Tout = X here)
         }
       }
     }
-    __syncthreads();
+  };
+  auto load_off = [&](int Jc, int (&off)[8]) {
+    const short4 ia = *reinterpret_cast<const short4*>(ins + (size_t)Jc * 8);
+    const short4 ib = *reinterpret_cast<const short4*>(ins + (size_t)Jc * 8 + 4);
+    off[0] = ia.x; off[1] = ia.y; off[2] = ia.z; off[3] = ia.w; off[4] = ib.x; off[5] = ib.y; off[6] = ib.z; off[7] = ib.w;
+  };
+  // work unit = (chunk c of 64 values of J', I), I fastest: the waves take units round robin (the chunk's gather offsets are
+  // reloaded when c changes: one 16-byte load)
+  const int nunit = chunks * nI;
+  const float rnI = 1.0f / (float)nI;
+  int cprev = -1, off[8], Jc = 0;
+  bool jv = false;
+  float mj = 0.0f;
+  for (int u = wave; u < nunit; u += MM6_WAVES) {
+    int c = K == 0 ? u : (int)(((float)u + 0.5f) * rnI);   // u / nI (exact: u < 2^20)
+    c = __builtin_amdgcn_readfirstlane(c);
+    const int I = K == 0 ? 0 : __builtin_amdgcn_readfirstlane(u - c * nI);
+    if (c != cprev) {
+      cprev = c;
+      const int Jp = c * 64 + lane;
+      jv = Jp < nJp;
+      Jc = jv ? Jp : nJp - 1;
+      load_off(Jc, off);
+      if constexpr (MODE == 1) mj = multJ[Jc];
+    }
+    // largest index of the K-tuple of rank I: the tuples whose largest index is t have ranks [C(t + K - 1, K), C(t + K, K))
+    int t = 0;
+    if constexpr (K > 0) {
+#pragma unroll
+      for (int q = 1; q < 8; ++q) t += (I >= mm_binom_i(q + K - 1, K)) ? 1 : 0;
+    }
+    if (jv) body(I, t, Jc, off, mj);                      // (lanes past the end of J' sit the unit out: one exec mask per unit)
   }
-  const float* Tn = (N & 1) ? bufO : bufE;
-  float part = 0.0f;
-  for (int idx = tid; idx < sy[N]; idx += 512) part = fmaf(mult[idx] * Nn[idx], Tn[idx], part);
-  __syncthreads();                                       // (the next degree overwrites the buffers)
-  return part;
 }
 
-__global__ __launch_bounds__(512) void k_spoly56(const float* __restrict__ mom56, int N56p, const double* __restrict__ pairmat,
+__global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict__ mom56, int N56p, const double* __restrict__ pairmat,
                                                  const double* __restrict__ zmax2, const unsigned int* __restrict__ amax,
                                                  const double* __restrict__ whR, const double* __restrict__ whC,
                                                  const char* __restrict__ tab, MMTab56 tb, int L, int d, int P, int Mp, int allow,
                                                  double* __restrict__ s56, float* __restrict__ estS) {
   extern __shared__ __align__(16) float sm6[];
   const int po = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int Po = P - L;
   int a, a2;
   mm6_decode_pair_o(po, L, a, a2);
   const size_t item = (size_t)b * Po + po;
-  const bool coll = allow && mm_collapse_bound2(amax[item], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
+  const float bound2 = mm_collapse_bound2(amax[item], zmax2[a2]);
+  const bool coll = allow && bound2 <= MM_COLLAPSE_BOUND2;
   if (!coll) {
     if (tid == 0) { s56[item] = 0.0; estS[item] = 0.0f; }
     return;
@@ -308,54 +354,91 @@ __global__ __launch_bounds__(512) void k_spoly56(const float* __restrict__ mom56
   int sy[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) sy[k] = mm_binom_i(d + k - 1, k);
-  // LDS: nq [2][sy5 + sy6] | bufE | bufO | red
+  // LDS (floats): nq [2][sy5 + sy6] | X [sy3][sy3 + 1] | A [sy2 sy4] | Bf [sy1 sy5] | red
   const int n56 = sy[5] + sy[6];
-  const int szE = sy[2] * sy[4] > sy[6] ? sy[2] * sy[4] : sy[6];      // even stages of n = 6 (T_0, T_2, T_4, T_6) and of n = 5
-  const int szO = sy[3] * sy[3];                                       // odd stages (T_1, T_3, T_5)
+  const int xs = sy[3] + 1;                              // X's row stride: odd at d = 8 (121): the fused dot reads it along a column
   float* nq = sm6;
-  float* bufE = nq + 2 * n56;
-  float* bufO = bufE + szE;
-  float* red = bufO + szO;                               // [16]
-  for (int idx = tid; idx < 2 * n56; idx += 512) {
+  float* X = nq + 2 * n56;
+  float* A = X + sy[3] * xs;
+  float* Bf = A + sy[2] * sy[4];
+  float* red = sm6 + ((2 * n56 + sy[3] * xs + sy[2] * sy[4] + sy[1] * sy[5] + 1) & ~1);   // [MM6_WAVES][3] doubles (8-byte aligned)
+  for (int idx = tid; idx < 2 * n56; idx += MM6_THREADS) {
     const int side = idx >= n56, c = idx - side * n56;
     nq[idx] = mom56[(item * 2 + side) * N56p + c];
   }
-  float G[64];
-  {
+  // G in VECTOR registers (through LDS): as 64 scalar registers beside the loop's own scalars it spilled to VGPR lanes
+  // (780 v_readlane / v_writelane in the kernel, 47 per work unit)
+  float* Gl = sm6 + ((2 * n56 + sy[3] * xs + sy[2] * sy[4] + sy[1] * sy[5] + 6 * MM6_WAVES + 2 + 3) & ~3);   // [64], 16-byte aligned
+  if (tid < 64) {
+    const int i = tid >> 3, j = tid & 7;
     const double* pm = pairmat + ((size_t)b * P + (L + po)) * (d * d + 1);
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float g = (i < d && j < d) ? (float)pm[(i < d ? i : 0) * d + (j < d ? j : 0)] : 0.0f;
-        G[i * 8 + j] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g)));   // uniform: scalar registers
-      }
+    Gl[tid] = (i < d && j < d) ? (float)pm[i * d + j] : 0.0f;
   }
   // what the skipped tiles leave out, in the units of the sweep's error estimate (mm_common.h: MM_C6_SYS2)
   double s2r = 0.0, s2c = 0.0;
   {
     const double* hr = whR + item * Mp;
     const double* hc = whC + item * Mp;
-    for (int m = tid; m < Mp; m += 512) { const double x = hr[m], y = hc[m]; s2r = fma(x, x, s2r); s2c = fma(y, y, s2c); }
+    for (int m = tid; m < Mp; m += MM6_THREADS) { const double x = hr[m], y = hc[m]; s2r = fma(x, x, s2r); s2c = fma(y, y, s2c); }
   }
   __syncthreads();
+  float G[64];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float4 g4 = *reinterpret_cast<const float4*>(Gl + 4 * q);
+    G[4 * q] = g4.x; G[4 * q + 1] = g4.y; G[4 * q + 2] = g4.z; G[4 * q + 3] = g4.w;
+  }
   const short* tabi = (const short*)tab;
-  const float* mult = (const float*)(tab + (size_t)tb.n_i16 * 2);
-  const float p5 = mm6_contract<5>(nq, 0, d, sy, tabi, mult + tb.mult5, tb, G, bufE, bufO, tid);
-  const float p6 = mm6_contract<6>(nq, sy[5], d, sy, tabi, mult + tb.mult6, tb, G, bufE, bufO, tid);
-  double tot = (double)MM_C6_C2 * (double)p5 + (double)MM_C6_C3 * (double)p6;
+  const float* mult2 = (const float*)(tab + (size_t)tb.n_i16 * 2) + tb.mult2;
+  const float* mult3 = (const float*)(tab + (size_t)tb.n_i16 * 2) + tb.mult3;
+  float acc5 = 0.0f, acc6 = 0.0f, dummy = 0.0f;
+  // ---- n = 6: X = three indices of Q_6 (column side of nq) through G; Y = three indices of N_6 through G^T, fused dot
+  {
+    const float* Q6 = nq + n56 + sy[5];
+    const float* N6 = nq + sy[5];
+    mm6_step<0, false, 0>(Q6, sy[6], 1, Bf, sy[5], tabi + tb.ins[5], d, G, nullptr, 0, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<1, false, 0>(Bf, sy[5], sy[1], A, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<2, false, 1>(A, sy[4], sy[2], X, sy[3], tabi + tb.ins[3], d, G, mult3, xs, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<0, true, 0>(N6, sy[6], 1, Bf, sy[5], tabi + tb.ins[5], d, G, nullptr, 0, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<1, true, 0>(Bf, sy[5], sy[1], A, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<2, true, 2>(A, sy[4], sy[2], X, sy[3], tabi + tb.ins[3], d, G, nullptr, xs, acc6, wave, lane);
+    __syncthreads();
+  }
+  // ---- n = 5: X [sym3][sym2] = three indices of Q_5 through G; Y = two indices of N_5 through G^T, fused dot
+  {
+    const float* Q5 = nq + n56;
+    const float* N5 = nq;
+    mm6_step<0, false, 0>(Q5, sy[5], 1, Bf, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<1, false, 0>(Bf, sy[4], sy[1], A, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<2, false, 1>(A, sy[3], sy[2], X, sy[2], tabi + tb.ins[2], d, G, mult2, xs, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<0, true, 0>(N5, sy[5], 1, Bf, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<1, true, 2>(Bf, sy[4], sy[1], X, sy[3], tabi + tb.ins[3], d, G, nullptr, xs, acc5, wave, lane);
+  }
+  double tot = (double)MM_C6_C2 * (double)acc5 + (double)MM_C6_C3 * (double)acc6;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     tot += __shfl_down(tot, off, 64); s2r += __shfl_down(s2r, off, 64); s2c += __shfl_down(s2c, off, 64);
   }
-  double* redd = reinterpret_cast<double*>(red);         // [8][3]
-  if ((tid & 63) == 0) { redd[(tid >> 6) * 3 + 0] = tot; redd[(tid >> 6) * 3 + 1] = s2r; redd[(tid >> 6) * 3 + 2] = s2c; }
+  double* redd = reinterpret_cast<double*>(red);         // [MM6_WAVES][3]
+  if (lane == 0) { redd[wave * 3 + 0] = tot; redd[wave * 3 + 1] = s2r; redd[wave * 3 + 2] = s2c; }
   __syncthreads();
   if (tid == 0) {
     double t = 0.0, r2 = 0.0, c2 = 0.0;
-    for (int w = 0; w < 8; ++w) { t += redd[w * 3]; r2 += redd[w * 3 + 1]; c2 += redd[w * 3 + 2]; }
+    for (int w = 0; w < MM6_WAVES; ++w) { t += redd[w * 3]; r2 += redd[w * 3 + 1]; c2 += redd[w * 3 + 2]; }
     s56[item] = t;
-    estS[item] = (float)fmin((double)MM_C6_SYS2 * r2 * c2, 3.0e38);
+    // |p6 - r| equioscillates with amplitude 5.8e-10 on [-1/4, 1/4]; near 0 it is the perturbation of the leading
+    // coefficient, (1/6 - C0) |x|^3 = 3.4e-7 |x|^3: an item whose bound X is far inside 1/4 leaves out (4 X)^3 of the amplitude
+    const double f3 = fmin(1.0, 64.0 * (double)bound2 * sqrt((double)bound2));
+    estS[item] = (float)fmin((double)MM_C6_SYS2 * (f3 * f3) * r2 * c2, 3.0e38);
   }
 }
 
@@ -386,15 +469,16 @@ int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, c
   }
   int sy[7];
   for (int k = 0; k < 7; ++k) sy[k] = mm_mono_count(k, d);
-  const int szE = sy[2] * sy[4] > sy[6] ? sy[2] * sy[4] : sy[6], szO = sy[3] * sy[3];
-  const size_t shm = (size_t)(2 * (sy[5] + sy[6]) + szE + szO + 64) * sizeof(float);
+  size_t nfl = (size_t)2 * (sy[5] + sy[6]) + (size_t)sy[3] * (sy[3] + 1) + (size_t)sy[2] * sy[4] + (size_t)sy[1] * sy[5] + 6 * MM6_WAVES + 64 + 16;
+  nfl = (nfl + 1) & ~(size_t)1;                           // (the f64 reduction scratch behind it stays 8-byte aligned)
+  const size_t shm = nfl * sizeof(float);
   static bool attr2_done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr2_done[dev]) {
     if (hipFuncSetAttribute((const void*)k_spoly56, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MM_E_ARG;
     attr2_done[dev] = true;
   }
-  hipLaunchKernelGGL(k_spoly56, dim3(wl.Po, B), dim3(512), shm, stream, (const float*)(ws + wl.mom56), N56p,
+  hipLaunchKernelGGL(k_spoly56, dim3(wl.Po, B), dim3(MM6_THREADS), shm, stream, (const float*)(ws + wl.mom56), N56p,
                      (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zmax2), (const unsigned int*)(ws + wl.amax),
                      (const double*)(ws + wl.whR), (const double*)(ws + wl.whC), packed + ml.tab56, mm_tab56(d), L, d, wl.P, wl.Mp,
                      allow, (double*)(ws + wl.s56), (float*)(ws + wl.estS));

@@ -22,7 +22,7 @@
 //                    f32 kernel's slab entries.  AGG: the backward's 1 + 2d + 3d^2 remainder aggregates instead of the sum.
 // On the estimator: measured 7-50 x above the actual f32 error on four regimes (BASELINE recipe, pilco, wide states, the
 // random-shape draws of tests/test_gpu_backward_f32.py): nothing is routed on the BASELINE / pilco recipes (20 x margin),
-// everything on the ill-conditioned draws whose f32 error was 1e-2; what stays in f32 is within ~2e-5 of its block's scale.
+// everything on the ill-conditioned draws whose f32 error was 1e-2; what stays in f32 is within ~4e-5 of its block's scale.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
@@ -36,7 +36,7 @@ __device__ __forceinline__ void mmx_decode_pair_o(int lp, int L, int& a, int& a2
   a = i; a2 = i + 1 + r;
 }
 
-// est = 2^-24 (2/3) sqrt(E2): E2 from the sweep (rho at every block's max|b|, its e^|x| <= 1 + X + X^2 part at the lane's max)
+// est = 2^-24 (2/3) sqrt(E2): E2 from the sweep (rho at every block's max|b|, its e^|x| part, max(1 + X + X^2, e^X), at the lane's max)
 __device__ __forceinline__ double mmx_est(double e2, unsigned int, double) {
   return 5.9604644775390625e-8 * (2.0 / 3.0) * sqrt(e2);
 }

@@ -214,9 +214,9 @@ def Q_reduce_forward(pm: PackedModel, B: int, flags: int, jitter: float = 0.0):
 
 def offdiag_stats(pm: PackedModel, B: int, flags: int):
   """(collapsed, total, wholly inside) (b, off-diagonal pair) items of the last ``q_forward`` / ``moment_match`` with
-  this B and flags (f32 models with d <= 8; zeros otherwise): items whose cubic + quartic remainder terms come from
-  the f64 moments, all items, and collapsed items whose Cauchy-Schwarz bound puts every |b| <= 1/16 (the tile kernel
-  does nothing for them).  Synchronises."""
+  this B and flags (f32 models with d <= 8; zeros otherwise): items whose degree-3..6 remainder polynomial comes from
+  weight moments (Cauchy-Schwarz bound on |b| <= 1/2), all items, and collapsed items whose bound puts every |b| <= 1/4 (the
+  tile kernel does nothing for them).  Synchronises."""
   ws = pm.workspace(B, flags, peek=True)
   out = torch.zeros(4, dtype=torch.int32, device=pm.device)
   rc = lib().mm_offdiag_stats(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, flags,

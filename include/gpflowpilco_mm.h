@@ -25,8 +25,8 @@
  *     (kernel_expectation.py:125-126, models.py:271).  [2] / [3] (MM_F32 packs; ABI version 2): running counts of the
  *     (batch element, off-diagonal pair) items the forward / the backward re-reduced in f64 because the f32 sweep's own
  *     rounding-error estimate exceeded MM_ROUTE_TOL (3e-4) of the batch element's off-diagonal covariance scale
- *     (csrc/mm_route.hip): the f32 pack's accuracy contract -- what stays in f32 is within ~1e-5 of
- *     that scale, the rest has f64 accuracy.  The reference computes these terms in float64 throughout
+ *     (csrc/mm_route.hip): the f32 pack's accuracy contract -- what stays in f32 is within ~4e-5 of
+ *     that scale (rounding; plus <= ~1e-5 systematic), the rest has f64 accuracy.  The reference computes these terms in float64 throughout
  *     (kernel_expectation.py:158-165).
  *   - `packed` / `packed_bytes`: the buffer filled by mm_pack_model and its size (whether C is
  *     present is inferred from the size).
@@ -160,9 +160,9 @@ int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
                      const void* target, const void* precis, void* cost, void* stream);
 
 /* Diagnostic: after mm_q_forward (f32 model, d <= 8), how many (batch element, off-diagonal pair) items take the
- * moment collapse of csrc/mm_moments.hip (cubic + quartic term of the remainder from f64 moments, tiles with
- * max |b| <= 1/20 skipped: bound <= 0.15), and for how many of those the Cauchy-Schwarz bound alone puts every |b| <= 1/20
- * (no tile work at all).  out: device int32[4] = {collapsed, total, wholly inside, routed}; the first three are zeros where
+ * moment collapse of csrc/mm_moments.hip / mm_moments6.hip (the degree-3..6 polynomial p6 of the remainder from weight
+ * moments, wave tiles with max |b| <= 1/4 skipped: Cauchy-Schwarz bound <= 1/2), and for how many of those the bound alone puts
+ * every |b| <= 1/4 (no tile work at all).  out: device int32[4] = {collapsed, total, wholly inside, routed}; the first three are zeros where
  * the collapse does not apply; routed = the items the last mm_moment_match / mm_Q_reduce_forward on this workspace
  * re-reduced in f64 (csrc/mm_route.hip; meaningful only after such a call on an MM_F32 pack). */
 int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
@@ -170,7 +170,7 @@ int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, int M, int 
 
 /* Diagnostic of the f32 pack's accuracy contract (csrc/mm_route.hip): after mm_moment_match / mm_Q_reduce_forward (or the
  * backward) on an MM_F32 pack, out [B][P-L][2] f64 = per (batch element, off-diagonal pair) {the sweep's estimate of its own
- * rounding error, the scale it is compared with}: an item is re-reduced in f64 when est > 1e-4 scale. */
+ * rounding error, the scale it is compared with}: an item is re-reduced in f64 when est > MM_ROUTE_TOL (3e-4) x scale. */
 int mm_route_estimates(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
                        const void* workspace, size_t workspace_bytes, double* out, void* stream);
 

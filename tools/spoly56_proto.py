@@ -76,3 +76,45 @@ if __name__ == "__main__":
       print(f"d={d} n={n}: {got:+.12e} vs {ref:+.12e}  rel {abs(got - ref) / abs(ref):.1e}")
       assert abs(got - ref) <= 1e-10 * max(abs(ref), 1.0) * 100
   print("ok")
+
+
+def contract_mitm(Nn, Qn, G, n, d, ins, last):
+  """meet in the middle (what k_spoly56 runs): KX = 3 indices of Q_n go to the row side with G, the other n - 3 indices of N_n to
+  the column side with G^T, then one dot over sym(3) x sym(n - 3) entries with both multinomials:
+      X[I][J] (I: 3 transformed, J: n - 3 raw column-side),   Y[J][I] (J: n - 3 transformed, I: 3 raw row-side)"""
+  def steps(T0, Gm, ksteps):
+    T = T0.copy().reshape(1, -1)
+    for k in range(ksteps):
+      nI, nJ = sym(k, d), sym(n - k - 1, d)
+      out = np.full((sym(k + 1, d), nJ), np.nan)
+      for I in range(nI):
+        for J in range(nJ):
+          v = T[I, ins[n - k - 1][J]]
+          for i in range(last[k][I], d):
+            out[I + comb(i + k, k + 1), J] = Gm[i] @ v
+      T = out
+    return T
+  X = steps(Qn, G, 3)                      # [sym3][sym(n-3)]
+  Y = steps(Nn, G.T, n - 3)                # [sym(n-3)][sym3]
+  mult = lambda k: np.array([factorial(k) / np.prod([factorial(c) for c in np.bincount(t, minlength=d)]) for t in tuples(k, d)])
+  return float(np.sum(mult(3)[:, None] * mult(n - 3)[None, :] * X * Y.T))
+
+
+if __name__ == "__main__":
+  rng = np.random.default_rng(1)
+  for d in (8, 4, 2, 1):
+    ins, last, mult = build_tables(d)
+    M = 30
+    zc, zc2 = rng.standard_normal((M, d)), rng.standard_normal((M, d))
+    w, w2 = rng.standard_normal(M), rng.standard_normal(M)
+    G = rng.standard_normal((d, d)) * 0.3
+    bij = zc @ G @ zc2.T
+    for n in (5, 6):
+      ts = tuples(n, d)
+      mono = lambda z: np.stack([np.prod(z[:, list(t)], axis=1) for t in ts], axis=1)
+      Nn, Qn = w @ mono(zc), w2 @ mono(zc2)
+      got = contract_mitm(Nn, Qn, G, n, d, ins, last)
+      ref = float(w @ bij ** n @ w2)
+      print(f"mitm d={d} n={n}: {got:+.12e} vs {ref:+.12e}")
+      assert abs(got - ref) <= 1e-9 * max(abs(ref), 1.0)
+  print("mitm ok")
