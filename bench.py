@@ -69,8 +69,12 @@ CARTPOLE = dict(M=100, Mpol=30, H=30, B=1, dtype="f64", seed=1000, scaling="weak
 CONFIGS = {
     "c1_closed": dict(L=6, M=100, d=6, H=30, B=1, dtype="f64", seed=1000, scaling="weak", recipe="pilco", closed=True,
                label="C1-shaped closed drift rollout: N=100 d=6 D=6 H=30 B=1 fp64 (no encoder / policy)"),
-    "c2": dict(L=5, M=1000, d=5, H=40, B=64, dtype="f64", seed=1001, scaling="weak", recipe="pilco", closed=True,
-               label="C2-shaped (BASELINE configs[1]): N=1000 d=5 D=5 H=40 B=64 fp64 closed drift rollout"),
+    # BASELINE configs[1] AS STATED: d = 5 -> D = 4 has no closed rollout (state dim != input dim): the step kernel on H independent
+    # draws, as C4 (SURVEY 8d "Synthetic inputs").  c2_closed is the D = 5 closed rollout rounds 1-4 ran under the name c2
+    "c2": dict(L=4, M=1000, d=5, H=40, B=64, dtype="f64", seed=1001, scaling="weak", recipe="pilco", closed=False,
+               label="C2 (BASELINE configs[1]): N=1000 d=5 D=4 H=40 B=64 fp64, step kernel on H independent draws"),
+    "c2_closed": dict(L=5, M=1000, d=5, H=40, B=64, dtype="f64", seed=1001, scaling="weak", recipe="pilco", closed=True,
+               label="C2-shaped closed drift rollout: N=1000 d=5 D=5 H=40 B=64 fp64 (state dim = input dim)"),
     # the headline config: `value` is BASELINE.md's own recipe (SURVEY 8d "Synthetic inputs"); the default N = 1 run also
     # times the two other data regimes of the range-tiered reduce kernels and reports them under `regimes`
     "c3": dict(L=8, M=2000, d=8, H=40, B=256, dtype="f32", seed=1002, scaling="weak", recipe="baseline", closed=True,
@@ -725,10 +729,10 @@ def main():
     if step_tf > step_peak:
       roof_step["frac_null_reason"] = "exceeds the peak: the step does not execute 8d's per-entry work in this data regime (see roofline.frac_null_reason)"
     # q stage: HBM-bound operand producers: bytes from the counters / the HIP-event segment is the whole stage
-    qroof = {"bound": "hbm", "kernels": "k_prep + k_qvec + k_pairvec (+ k_wmom_gemm [f64 MFMA GEMM] + k_spoly)", "segment_ms": round(seg["q_stage"], 4),
+    qroof = {"bound": "hbm", "kernels": "k_prep + k_qvec + k_pairvec (+ k_wmom_gemm [f64 MFMA GEMM] + k_spoly + k_wmom56_gemm [bf16 MFMA GEMM] + k_spoly56)", "segment_ms": round(seg["q_stage"], 4),
              "peak": PEAK_HBM_GBS, "unit": "GB/s", "per_kernel": {}}
     if pmc is not None:
-      for pre in ("k_qvec", "k_pairvec", "k_wmom_gemm", "k_spoly"):
+      for pre in ("k_qvec", "k_pairvec", "k_wmom_gemm", "k_spoly<", "k_wmom56_gemm", "k_spoly56"):
         got = pmc_kernel(pmc, pre)
         if got and "hbm_bytes" in got[1]["counters"]:
           qroof["per_kernel"][got[0]] = {"hbm_bytes": got[1]["counters"]["hbm_bytes"] * pscale}

@@ -780,7 +780,7 @@ int mm_backward_sums_impl(const char* pk, const MMModelLayout& ml, const char* w
                           int B, const double* mu, int flags, bool with_unc, bool diag_only, double* out, hipStream_t s) {
   const double* Cm = with_unc ? (const double*)(pk + ml.Cm) : nullptr;
   const int Pk = diag_only ? L : wl.P, Pok = diag_only ? 0 : wl.Po;       // what the kernels see as P / Po
-  if (Pok > 0 && mm_fork_join_wait(s)) return MM_E_ARG;   // (the off-diagonal operands may still be on the q stage's side stream)
+  if (Pok > 0) { if (const int rj = mm_fork_join_wait(s)) return rj; }   // (the off-diagonal operands may still be on the q stage's side stream)
   double* out_col = out;
   double* out_row = out_col + (size_t)B * Pk * (3 + d) * wl.Mp;
   if (!(flags & MM_FORCE_GENERIC) && d <= 31) {

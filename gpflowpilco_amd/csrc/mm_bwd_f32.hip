@@ -455,7 +455,7 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
   // stream BESIDE the diagonal sweep (mm_compose_bwd.hip): one wave per SIMD and 80 KB of LDS fit next to that kernel's two waves
   if (wl.Po <= 0) return 0;
   if (!mm_bwd_f32_supported(d)) return MM_E_DIM;
-  if (mm_fork_join_wait(stream)) return MM_E_ARG;   // the off-diagonal operands / moment chain may still be on the q stage's side stream
+  if (const int rj = mm_fork_join_wait(stream)) return rj;   // the off-diagonal operands / moment chain may still be on the q stage's side stream
   const int npanel = (wl.Mp + 255) / 256;
   hipError_t e = hipSuccess;
   if (stages & MM_STAGE_OFFDIAG) {
@@ -487,7 +487,7 @@ int mm_launch_bwd_offdiag_f32(const char* packed, const MMModelLayout& ml, char*
     if (rcr) return rcr;
   }
   if (!(stages & MM_STAGE_FINALIZE)) return 0;
-  if (mm_fork_join_wait(stream)) return MM_E_ARG;   // the q stage's k_spoly (side stream) still reads the table the full GEMM overwrites
+  if (const int rj = mm_fork_join_wait(stream)) return rj;   // the q stage's k_spoly (side stream) still reads the table the full GEMM overwrites
   const int rc = mm_launch_wmom_full(packed, ml, ws, wl, B, L, d, stream);
   if (rc) return rc;
   const int nT = mma_pair_agg_len(d);

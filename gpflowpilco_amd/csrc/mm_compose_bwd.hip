@@ -260,21 +260,26 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
     if (rc) return rc;
     mu64 = (const double*)(bw + bl.mu64);
     S64 = (const double*)(bw + bl.S64);
-    MMFork* fork = (do_sweeps && wl.Po > 0 && stages == (MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE)) ? mm_fork_get() : nullptr;
+    MMFork* fork = (do_sweeps && wl.Po > 0 && stages == (MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE)) ? mm_fork_get(s) : nullptr;
     if (fork) {
-      std::lock_guard<std::recursive_mutex> guard(fork->seq);
       // remainder sweep first; then [moment GEMM + pair aggregates on the side stream] beside [the diagonal sweep]
       rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)(bw + bl.slab),
                                      (double*)(bw + bl.pagg), status, s, MM_STAGE_OFFDIAG | MM_ISTAGE_NO_ROUTE);
       if (rc) return rc;
-      if (hipEventRecord(fork->fork, s) != hipSuccess || hipStreamWaitEvent(fork->s2, fork->fork, 0) != hipSuccess) return MM_E_ARG;
+      {
+        hipError_t ef = hipEventRecord(fork->fork, s);
+        if (ef == hipSuccess) ef = hipStreamWaitEvent(fork->s2, fork->fork, 0);
+        if (ef != hipSuccess) return (int)ef;
+      }
       rc = mm_launch_bwd_offdiag_f32(pk, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)(bw + bl.slab),
                                      (double*)(bw + bl.pagg), status, fork->s2, MM_ISTAGE_ROUTE | MM_STAGE_FINALIZE, 256);
+      // (joined whatever happened on the side stream: an error return must not strand it, least of all under capture)
+      hipError_t ej = hipEventRecord(fork->join, fork->s2);
+      if (!rc && ej == hipSuccess)
+        rc = mm_backward_sums_impl(pk, ml, ws, wl, L, M, d, B, mu64, flags, with_unc, true, (double*)(bw + bl.sums), s);
+      if (ej == hipSuccess) ej = hipStreamWaitEvent(s, fork->join, 0);
       if (rc) return rc;
-      if (hipEventRecord(fork->join, fork->s2) != hipSuccess) return MM_E_ARG;
-      rc = mm_backward_sums_impl(pk, ml, ws, wl, L, M, d, B, mu64, flags, with_unc, true, (double*)(bw + bl.sums), s);
-      if (rc) return rc;
-      if (hipStreamWaitEvent(s, fork->join, 0) != hipSuccess) return MM_E_ARG;
+      if (ej != hipSuccess) return (int)ej;
       pagg = (const double*)(bw + bl.pagg);
     } else {
     if (do_sweeps && (stages & MM_STAGE_DIAG)) {

@@ -30,35 +30,48 @@
 #include "mm_dev.h"
 #include "mm_mono.h"
 
-#include <atomic>
+#include <mutex>
+#include <unordered_map>
 #include "mm_fork.h"
 
 #define MM_ABI_VERSION 2
 
-MMFork* mm_fork_get() {
-  static MMFork forks[64];
-  static std::atomic<unsigned long long> made{0ull};
-  static std::mutex mu_;
+namespace {
+struct MMForkKey {
+  int dev; hipStream_t stream;
+  bool operator==(const MMForkKey& o) const { return dev == o.dev && stream == o.stream; }
+};
+struct MMForkKeyHash {
+  size_t operator()(const MMForkKey& k) const { return std::hash<const void*>()((const void*)k.stream) * 31u + (size_t)k.dev; }
+};
+std::mutex g_fork_mu;                                       // guards the table only (lookup / insert), never an enqueue
+std::unordered_map<MMForkKey, MMFork*, MMForkKeyHash> g_forks;   // entries live for the process (a few dozen bytes + one stream each)
+
+MMFork* mm_fork_lookup(hipStream_t stream, bool create) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  MMFork& f = forks[dev];
-  if (!(made.load(std::memory_order_acquire) & (1ull << dev))) {
-    std::lock_guard<std::mutex> g(mu_);
-    if (!(made.load(std::memory_order_acquire) & (1ull << dev))) {
-      f.ok = hipStreamCreateWithFlags(&f.s2, hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&f.fork, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&f.join, hipEventDisableTiming) == hipSuccess;
-      made.fetch_or(1ull << dev, std::memory_order_release);
-    }
-  }
-  return f.ok ? &f : nullptr;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const MMForkKey key{dev, stream};
+  std::lock_guard<std::mutex> g(g_fork_mu);
+  auto it = g_forks.find(key);
+  if (it != g_forks.end()) return it->second;               // (nullptr: creation failed once for this stream -- not retried)
+  if (!create) return nullptr;
+  MMFork* f = new MMFork();
+  const bool ok = hipStreamCreateWithFlags(&f->s2, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&f->fork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&f->join, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { delete f; f = nullptr; }
+  g_forks.emplace(key, f);
+  return f;
 }
+}  // namespace
+
+MMFork* mm_fork_get(hipStream_t stream) { return mm_fork_lookup(stream, true); }
 
 int mm_fork_join_wait(hipStream_t stream) {
-  MMFork* fork = mm_fork_get();
-  if (!fork || stream == fork->s2) return 0;        // (the side stream itself is in order)
-  std::lock_guard<std::recursive_mutex> guard(fork->seq);
-  return hipStreamWaitEvent(stream, fork->join, 0) == hipSuccess ? 0 : MM_E_ARG;
+  MMFork* fork = mm_fork_lookup(stream, false);               // a side stream is never a key: in order with itself, nothing to wait for
+  if (!fork) return 0;
+  const hipError_t e = hipStreamWaitEvent(stream, fork->join, 0);
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1326,22 +1339,27 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     if (wl.Po > 0) {
       // (only a call that joins itself forks -- mm_moment_match, the rollouts: a stand-alone mm_q_forward returns with everything it
       // enqueued on the caller's stream, so that the caller's stream order -- and its allocator's -- covers the workspace)
-      MMFork* fork = joins ? mm_fork_get() : nullptr;
-      if ((long long)wl.P * B < 512) fork = nullptr;        // (small problems: nothing to hide behind, and launches are what counts)
+      // (small problems: nothing to hide behind, and launches are what counts)
+      MMFork* fork = (joins && (long long)wl.P * B >= 512) ? mm_fork_get(s) : nullptr;
       hipStream_t s2 = s;
-      std::unique_lock<std::recursive_mutex> guard;
       if (fork) {
-        guard = std::unique_lock<std::recursive_mutex>(fork->seq);
-        if (hipEventRecord(fork->fork, s) != hipSuccess || hipStreamWaitEvent(fork->s2, fork->fork, 0) != hipSuccess) return MM_E_ARG;
+        hipError_t ef = hipEventRecord(fork->fork, s);
+        if (ef == hipSuccess) ef = hipStreamWaitEvent(fork->s2, fork->fork, 0);
+        if (ef != hipSuccess) return (int)ef;
         s2 = fork->s2;
       }
       pairvec(L, wl.Po, s2);
-      MM_CHECK_LAUNCH();
-      if (sizeof(T) == 4) {
-        const int rc = mm_launch_moments(packed, ml, ws, wl, B, L, d, (const void*)mu, flags, s2);
-        if (rc) return rc;
+      int rcs = 0;
+      { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) rcs = (int)e_; }
+      if (!rcs && sizeof(T) == 4) rcs = mm_launch_moments(packed, ml, ws, wl, B, L, d, (const void*)mu, flags, s2);
+      if (fork) {
+        // the join is recorded whatever happened in between: an error return must not leave the side stream unjoined (under
+        // capture that would strand the capture), and the caller's stream waits for it before this call's error is reported
+        hipError_t ej = hipEventRecord(fork->join, fork->s2);
+        if (rcs) { if (ej == hipSuccess) (void)hipStreamWaitEvent(s, fork->join, 0); return rcs; }
+        if (ej != hipSuccess) return (int)ej;
       }
-      if (fork && hipEventRecord(fork->join, fork->s2) != hipSuccess) return MM_E_ARG;
+      if (rcs) return rcs;
     }
 #undef MM_PAIRVEC_ARGS
   }
@@ -1374,7 +1392,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
   // small f64 models: both kinds of pairs in one launch (mm_f64.hip) -- the two sweeps then run side by side on the device
   bool both = false;
   if (sizeof(T) == 8 && !generic && wl.Po > 0 && (stages & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG)) == (MM_STAGE_DIAG | MM_STAGE_OFFDIAG)) {
-    if (mm_fork_join_wait(s)) return MM_E_ARG;       // (it reads the off-diagonal operands too)
+    if (const int rj = mm_fork_join_wait(s)) return rj;     // (it reads the off-diagonal operands too)
     const int rc = mm_launch_qred_f64_both((const double*)(packed + ml.Zc64), ml.Kz, Cm, (const double*)(packed + ml.beta64), M, L,
                                            wl.Mp, d, wl.P, wl.NS, wl.Po, B, (flags & MM_FORCE_WORST_TIER) ? 1 : 0,
                                            (const double*)(ws + wl.qhR), (const double*)(ws + wl.qhC), (const double*)(ws + wl.rowD),
@@ -1402,7 +1420,9 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
     }
   }
   // (the off-diagonal pairs' operands and the moment chain may still be on the q stage's side stream)
-  if (wl.Po > 0 && (stages & (MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE)) && mm_fork_join_wait(s)) return MM_E_ARG;
+  if (wl.Po > 0 && (stages & (MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE))) {
+    if (const int rj = mm_fork_join_wait(s)) return rj;
+  }
   // (2) off-diagonal pairs in T
   if (!both && wl.Po > 0 && (stages & MM_STAGE_OFFDIAG)) {
     if (use_mfma32) {
@@ -1459,7 +1479,10 @@ static int mm_moment_match_t(const char* packed, size_t packed_bytes, int L, int
   if (ws_bytes < wl.total) return MM_E_WORKSPACE;
   int rc = 0;
   if (do_q) {
-    rc = mm_q_forward_t<T, DK>(packed, ml, ws, wl, L, M, d, B, mu, Sigma, flags, f1, cross, q_out, status, s, do_Q);
+    // the q stage forks only where the Q stage of this very call joins: every stage requested (MM_STAGE_* all set or none)
+    const int st = flags & (MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE);
+    const bool joins = do_Q && (st == 0 || (st & (MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE)) != 0);
+    rc = mm_q_forward_t<T, DK>(packed, ml, ws, wl, L, M, d, B, mu, Sigma, flags, f1, cross, q_out, status, s, joins);
     if (rc) return rc;
   }
   if (do_Q) rc = mm_Q_reduce_t<T, DK>(packed, ml, has_C, ws, wl, L, M, d, B, flags, jitter, Sff, status, s);

@@ -124,7 +124,7 @@ extern "C" int mm_route_estimates(const void* packed, size_t packed_bytes, int L
   if (workspace_bytes < wl.total || packed_bytes < ml.Cm) return MM_E_WORKSPACE;
   if (wl.Po <= 0) return 0;
   const char* ws = (const char*)workspace;
-  if (mm_fork_join_wait((hipStream_t)stream)) return MM_E_ARG;
+  if (const int rj = mm_fork_join_wait((hipStream_t)stream)) return rj;
   hipLaunchKernelGGL(k_route_report, dim3(B), dim3(64), 0, (hipStream_t)stream, (const float*)(ws + wl.estO),
                      (wl.Mp + MM_PANEL_ROWS - 1) / MM_PANEL_ROWS, (const double*)(ws + wl.s12), (const double*)(ws + wl.f1raw),
                      (const unsigned int*)(ws + wl.amax), (const double*)((const char*)packed + ml.zmax2), L, wl.Po, out,
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
 int mm_launch_route(const char* packed, const MMModelLayout& ml, char* ws, const MMWorkspaceLayout& wl, int B, int L, int M,
                     int d, int flags, int agg, double* out, int32_t* status, hipStream_t stream) {
   if (wl.Po <= 0 || (flags & MM_NO_ROUTE)) return 0;
-  if (mm_fork_join_wait(stream)) return MM_E_ARG;   // s12 (the decision's scale) may still be on the q stage's side stream
+  if (const int rj = mm_fork_join_wait(stream)) return rj;   // s12 (the decision's scale) may still be on the q stage's side stream
   const int npanel = (wl.Mp + MM_PANEL_ROWS - 1) / MM_PANEL_ROWS;
   int* rlist = (int*)(ws + wl.rlist);
   int* rcount = (int*)(ws + wl.rcount);

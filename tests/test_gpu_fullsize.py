@@ -56,6 +56,32 @@ def test_full_size_against_fused_restatement(name, device):
   assert scale_err(Sffg, Sff[:2].double().cpu().numpy()) < tol2
 
 
+def test_c2_as_stated_batch_64(device):
+  """BASELINE configs[1] exactly as stated -- N = 1000, d = 5 -> D = 4, B = 64, fp64 (what `bench.py --config c2` times: the
+  step on H independent draws, d != D has no closed rollout): three elements (first, middle, last of the batch) against the
+  literal fp64 oracle's algebraic twin (oracle/mm_fused_ref.py), shard invariance of the last element (the tail of every
+  grid), symmetry, positive definiteness, and the deterministic limit's exact zeros on the off-diagonal pairs."""
+  L, M, d, B = 4, 1000, 5, 64
+  syn = make_svgp(L, M, d, seed=1001, device=str(device), ls_bounds=(0.7, 3.0))
+  po = oracle_params(syn)
+  mu, Sigma = make_inputs(B, d, seed=2000 + 1001, scale=0.1, lo=0.3, hi=0.7)
+  beta, C = fr.precompute(po)
+  sel = [0, 31, 63]
+  f1o, Sffo, cro = fr.moment_match(mu[sel], Sigma[sel], po, beta, C)
+  pm = syn.to_model(device).packed(torch.float64, True, device)
+  mu_t, S_t = to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64)
+  f1, Sff, cross = ops.moment_match(pm, mu_t, S_t)
+  pm.check_status(B)
+  assert scale_err(f1[sel], f1o) < 1e-8 and scale_err(cross[sel], cro) < 1e-8
+  assert scale_err(Sff[sel], Sffo) < 5e-5                  # (two fp64 routes to C: see CONFIGS above)
+  off, dia = contract_err(Sff[sel], Sffo)
+  assert off < 1e-9, off                                   # the off-diagonal pairs carry no C: fp64 to rounding
+  f1s, Sffs, crs = ops.moment_match(pm, mu_t[63:].contiguous(), S_t[63:].contiguous())
+  assert torch.equal(f1s, f1[63:]) and torch.equal(Sffs, Sff[63:]) and torch.equal(crs, cross[63:])
+  assert torch.equal(Sff, Sff.transpose(1, 2))
+  assert torch.linalg.eigvalsh(Sff).min() > 0
+
+
 def test_c3_rollout_stays_in_regime_and_matches_f64_mode(device):
   """10 closed-rollout steps at C3 size: f32 mode tracks the f64 mode of the same kernels."""
   L = d = 8
@@ -226,3 +252,45 @@ def test_c3_backward_on_the_f32_pack_matches_the_f64_pack(recipe, device):
   gm_a, gS_a = ops.moment_match_backward(pm32, mu32[2:5].contiguous(), S32[2:5].contiguous(), g1[2:5], g2[2:5], g3[2:5])
   assert float((gm_a - gm32[2:5]).abs().amax()) <= 1e-12 * float(gm32.abs().amax())
   assert float((gS_a - gS32[2:5]).abs().amax()) <= 1e-12 * float(gS32.abs().amax())
+
+
+def test_c3_backward_on_the_f32_pack_matches_cpu_autograd_of_the_materialised_evaluation(device):
+  """Row f-1 at C3's own sizes against the ORACLE side, not against another HIP path: one batch element of the BASELINE recipe,
+  float64 torch autograd on the CPU through the materialised [P, M, M] evaluation (autodiff.moment_match_torch: the
+  transliteration of models.py:200-299 -- what the reference's GradientTape differentiates, utils/optimizers.py:51-56), against
+  the f32 pack's gradient on the same f32-rounded state, for both routes: the two-pass backward (forward's sweeps, then
+  mm_moment_match_backward's) and value-and-gradient from one pair of sweeps (mm_moment_match_with_sums + the chain rule).
+  bench.py --config c3_grad measures 8e-7 of the gradient's scale on this element; asserted at 1e-5."""
+  from gpflowpilco_amd import autodiff
+  L, M, d = 8, 2000, 8
+  syn = make_svgp(L, M, d, seed=1002, device=str(device), ls_bounds=(0.3, 3.0), stable=False)
+  model = syn.to_model(device)
+  pm32 = model.packed(torch.float32, True, device)
+  mu, S = make_inputs(1, d, seed=3002, scale=0.1, lo=0.0, hi=1.0)
+  mu32, S32 = to_dev(mu, device, torch.float32), to_dev(S, device, torch.float32)
+  g = torch.Generator(device="cpu").manual_seed(5)
+  g1 = torch.randn(1, L, generator=g, dtype=torch.float64)
+  g2 = torch.randn(1, L, L, generator=g, dtype=torch.float64)
+  g3 = torch.randn(1, d, L, generator=g, dtype=torch.float64)
+  # CPU float64 autograd at the f32-rounded state
+  Z, ls, var, beta, Cm, mc = (None if t is None else t.detach().cpu() for t in model.precompute(device))
+  mu_c = mu32.double().cpu().requires_grad_(True)
+  S_c = S32.double().cpu().requires_grad_(True)
+  f1c, Sffc, crc = autodiff.moment_match_torch(mu_c, S_c, Z, ls, var, beta, Cm, mc, True, True)
+  ((g1 * f1c).sum() + (g2 * Sffc).sum() + (g3 * crc).sum()).backward()
+  gmu_c, gS_c = mu_c.grad, 0.5 * (S_c.grad + S_c.grad.transpose(1, 2))
+  rel = lambda x, y: float((x.cpu() - y).abs().amax() / y.abs().amax())
+  gd = [t.to(device) for t in (g1, g2, g3)]
+  # (i) two passes
+  f1, Sff, cross = ops.moment_match(pm32, mu32, S32)
+  gm, gS = ops.moment_match_backward(pm32, mu32, S32, *gd)
+  pm32.check_status(1)
+  assert rel(gm, gmu_c) < 1e-5 and rel(gS, gS_c) < 1e-5, (rel(gm, gmu_c), rel(gS, gS_c))
+  # the value of that element against the same evaluation (f32 outputs)
+  assert scale_err(Sff, Sffc.detach().numpy()) < 2e-5 and scale_err(f1, f1c.detach().numpy()) < 2e-6
+  # (ii) value and gradient from one pair of sweeps
+  f1s, Sffs, crs, sums, gen = ops.moment_match_with_sums(pm32, mu32, S32)
+  gm2, gS2 = ops.moment_match_backward(pm32, mu32, S32, *gd, forward_generation=gen, sums=sums)
+  pm32.check_status(1)
+  assert rel(gm2, gmu_c) < 1e-5 and rel(gS2, gS_c) < 1e-5, (rel(gm2, gmu_c), rel(gS2, gS_c))
+  assert scale_err(Sffs, Sffc.detach().numpy()) < 2e-5

@@ -189,3 +189,63 @@ def test_forward_with_the_side_stream_replays_from_a_hip_graph(dtype, device):
   f1, cross, _ = ops.q_forward(pm, mu, S, flags)
   Sff = ops.Q_reduce_forward(pm, B, flags)
   assert torch.equal(f1, want[0]) and torch.equal(Sff, want[1]) and torch.equal(cross, want[2])
+
+
+def test_two_caller_streams_share_nothing(device):
+  """The side stream and its fork / join events belong to the CALLER'S stream (csrc/mm_fork.h; round 4 kept one triple per device
+  under a process-wide mutex).  Two packed models with their own workspaces, driven from two streams: (i) interleaved eager calls
+  give, bit for bit, what each gives alone; (ii) one stream under HIP-graph capture while the other keeps running eagerly -- the
+  capture must neither pick up the other stream's events nor leak its own work -- and the replayed graph returns the eager result."""
+  L, M, d = 6, 300, 8
+  mods = []
+  for seed, B in ((61, 32), (67, 40)):                           # P B = 672 / 840: both calls fork
+    syn = make_svgp(L, M, d, seed=seed, device=str(device), ls_bounds=(0.5, 2.5))
+    pm = syn.to_model(device).packed(torch.float32, True, device)
+    mu, S = make_inputs(B, d, seed=seed + 1, scale=0.1, lo=0.2, hi=0.8)
+    mu, S = to_dev(mu, device, torch.float32), to_dev(S, device, torch.float32)
+    want = [t.clone() for t in ops.moment_match(pm, mu, S)]
+    pm.check_status(B)
+    mods.append((pm, mu, S, want, B))
+  sa, sb = torch.cuda.Stream(device), torch.cuda.Stream(device)
+  cur = torch.cuda.current_stream(device)
+  sa.wait_stream(cur); sb.wait_stream(cur)
+  # (i) interleaved eager calls from the two streams
+  outs = [[], []]
+  for _ in range(6):
+    for k, st in enumerate((sa, sb)):
+      pm, mu, S, _, _ = mods[k]
+      with torch.cuda.stream(st):
+        outs[k].append(ops.moment_match(pm, mu, S))
+  torch.cuda.synchronize()
+  for k in range(2):
+    mods[k][0].check_status(mods[k][4])
+    for o in outs[k]:
+      for got, ref in zip(o, mods[k][3]):
+        assert torch.equal(got, ref)
+  # (ii) stream A under capture, stream B eager in the middle of it
+  pmA, muA, SA, wantA, BA = mods[0]
+  pmB, muB, SB, wantB, BB = mods[1]
+  msA, SsA = muA.clone(), SA.clone()
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.graph(graph, stream=sa, capture_error_mode="relaxed"):
+    o1 = ops.moment_match(pmA, msA, SsA)
+    with torch.cuda.stream(sb):                                  # not part of the capture: runs now
+      eager_mid = ops.moment_match(pmB, muB, SB)
+    o2 = ops.moment_match(pmA, msA, SsA)
+  torch.cuda.synchronize()
+  for got, ref in zip(eager_mid, wantB):
+    assert torch.equal(got, ref)
+  msA.copy_(muA * 0.9); SsA.copy_(SA * 1.2)
+  graph.replay()
+  msA.copy_(muA); SsA.copy_(SA)
+  with torch.cuda.stream(sb):                                    # and while the graph replays
+    eager_during = ops.moment_match(pmB, muB, SB)
+  graph.replay()
+  torch.cuda.synchronize()
+  pmA.check_status(BA); pmB.check_status(BB)
+  for got, ref in zip(o1, wantA):
+    assert torch.equal(got, ref)
+  for got, ref in zip(o2, wantA):
+    assert torch.equal(got, ref)
+  for got, ref in zip(eager_during, wantB):
+    assert torch.equal(got, ref)
