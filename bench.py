@@ -1401,7 +1401,16 @@ def pathwise_extras(args, dev, c, paths, x0, dtype):
     fo = pw.eval_paths(pths, po, xc)
     par[nm] = {"one_evaluation_max_abs_err": float(np.abs(f1 - fo).max()), "one_evaluation_max_abs": float(np.abs(fo).max()),
                "rollout_max_abs_err": float(np.abs(tg.double().cpu().numpy() - trajo).max()), "rollout_max_abs": float(np.abs(trajo).max())}
+    # what the kernel itself says about these values (mm_pathwise_eval_bound: the pass with the sum of the absolute terms)
+    fb, errb = gpp.eval_with_bound(torch.tensor(xc, dtype=dt_, device=dev))
+    par[nm]["rounding_bound_max"] = float(errb.max())
+    par[nm]["worst_error_over_bound"] = float((np.abs(fb.double().cpu().numpy() - fo) / errb.double().cpu().numpy()).max())
   res["parity"] = par
+  # the timed f32 paths themselves: how many (sample, latent) values of ONE evaluation the bound flags at 1e-3 of max|f|
+  _, _, nflag = paths.flagged(x0, 1e-3)
+  par["f32_values_flagged_at_1e-3_of_max_f"] = {"flagged": nflag, "of": int(paths.num_samples * L),
+                                                "note": "rounding bound of the f32 weight stream > 1e-3 max|f| (all of them at M = 2000: "
+                                                        "the f64 mode is the accurate path)"}
   # ---- f64 mode of the headline rollout (the accurate mode: 2 x the bytes per weight)
   S = paths.num_samples
   S64 = min(S, 16384)

@@ -112,6 +112,7 @@ SIGNATURES = {
     "mm_pathwise_eval": (C.c_int, [C.c_int] * 6 + [C.c_void_p] * 12),
     "mm_pathwise_rollout": (C.c_int, [C.c_int] * 7 + [C.c_double] + [C.c_void_p] * 13),
     "mm_pathwise_eval_jac": (C.c_int, [C.c_int] * 6 + [C.c_void_p] * 13),
+    "mm_pathwise_eval_bound": (C.c_int, [C.c_int] * 6 + [C.c_void_p] * 13),
     "mm_pathwise_tape_bytes": (C.c_size_t, [C.c_int] * 6),
     "mm_pathwise_policy_rollout": (C.c_int, [C.c_int] * 5 + [C.c_double, C.c_int, C.c_int] + [C.c_void_p] * 10
                                    + [C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_double]

@@ -463,16 +463,19 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
   double* qb64 = q64 + ((size_t)b * L + a) * Mp;
   double* r1 = rho1 + ((size_t)b * L + a) * Mp;
   double* lqb = lq + ((size_t)b * L + a) * Mp;
-  for (int m = tid; m < Mp; m += 256) {
+  // two operand sets: the next chunk's loads (dimension-major table: coalesced over m; index-clamped, so unconditional) are in
+  // flight while this chunk is computed -- the loop used to issue its 8 + 1 loads and wait for them in every one of its 8 chunks
+  auto loadz = [&](int m, double (&z)[DK], double& bt) {
+    const int mc = m < M ? m : M - 1;
+#pragma unroll
+    for (int k = 0; k < DK; ++k) z[k] = Zt64[((size_t)a * d + (k < d ? k : 0)) * Mp + mc];
+    bt = beta64[(size_t)a * M + mc];
+  };
+  auto chunk = [&](int m, double (&z)[DK], double bt) __attribute__((always_inline)) {
     double wv = 0.0, qv = 0.0, rv = 0.0, lqv = -1.0e30;
     if (m < M) {
-      double z[DK];
-#pragma unroll
-      for (int k = 0; k < DK; ++k)                           // dimension-major table: coalesced over m
-        z[k] = Zt64[((size_t)a * d + (k < d ? k : 0)) * Mp + m];
 #pragma unroll
       for (int k = 0; k < DK; ++k) {
-        // index-clamped loads, made opaque: sunk under `k < d` each becomes a branch + s_waitcnt vmcnt(0)
         asm volatile("" : "+v"(z[k]));
         z[k] = (k < d) ? z[k] - mub[k] : 0.0;
       }
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
       }
       lqv = lognorm - 0.5 * maha;
       qv = exp(lqv);
-      wv = beta64[(size_t)a * M + m] * qv;
+      wv = bt * qv;
       acc_f += wv;
 #pragma unroll
       for (int k = 0; k < DK; ++k) acc_s[k] += wv * z[k];
@@ -517,6 +520,17 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
     qb64[m] = qv;
     r1[m] = rv;
     lqb[m] = lqv;
+  };
+  {
+    double zA[DK], zB[DK], bA, bB;
+    loadz(tid, zA, bA);
+    for (int m = tid; m < Mp; m += 512) {
+      loadz(m + 256 < Mp ? m + 256 : m, zB, bB);
+      chunk(m, zA, bA);
+      if (m + 256 >= Mp) break;
+      loadz(m + 512 < Mp ? m + 512 : m + 256, zA, bA);
+      chunk(m + 256, zB, bB);
+    }
   }
   // the DK + 1 workgroup sums together: wave butterflies, one LDS stage, one barrier (fixed order: reproducible)
   __shared__ double red9[4][DK + 1];

@@ -104,7 +104,9 @@ __device__ __forceinline__ float pw_wave_sum63(float v) {
 // cross-lane step is one shuffle reduction per (latent, sample) -- no LDS, no barriers.  The weight
 // loads are software-pipelined two passes ahead (PMC: 71 % of wave cycles were s_waitcnt with one
 // pass in flight).  EULER != 0: x_out = x + dt f (needs d == L), else f_out = f.
-template <typename T, int DK, bool JAC>
+// CND: the pass also accumulates the ABSOLUTE terms, abs[s,a] = scale_a sum_k |w cos| + var_a sum_m |v 2^arg| -- what the rounding of
+// a T-typed weight stream and T-typed basis values does to f[s,a] is within ~2 eps_T of it (mm_pathwise_eval_bound).
+template <typename T, int DK, bool JAC, bool CND>
 __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, int d,
                                                   const T* __restrict__ x,        // [S,d]
                                                   const T* __restrict__ omega,    // [L,d,K] revolutions
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
                                                   T* __restrict__ out,            // [S,L] (f or x_next)
                                                   T* __restrict__ traj,           // optional [S,L]
                                                   T* __restrict__ jac,            // JAC: [S,L,d]
+                                                  T* __restrict__ cnd,            // CND: [S,L]
                                                   int euler, double dt) {
   typedef typename PwVec<T>::type VT;
   constexpr int W = PwVec<T>::W, NS = MM_PW_NS, BT = 64 * W;     // BT terms per pass of a wave
@@ -139,10 +142,10 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
   }
 
   for (int a = wv; a < L; a += 4) {
-    T accp[NS], accu[NS], accJ[NS][NJ];
+    T accp[NS], accu[NS], accJ[NS][NJ], absp[NS], absu[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      accp[s] = (T)0; accu[s] = (T)0;
+      accp[s] = (T)0; accu[s] = (T)0; absp[s] = (T)0; absu[s] = (T)0;
 #pragma unroll
       for (int k = 0; k < NJ; ++k) accJ[s][k] = (T)0;
     }
@@ -190,6 +193,10 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
               const T t = wv4[s][j] * sn;
 #pragma unroll
               for (int k = 0; k < DK; ++k) accJ[s][k] += t * cv[k][j];
+            } else if constexpr (CND) {
+              const T c = PW_COS(arg);
+              accp[s] += wv4[s][j] * c;                       // (the plain pass's own expression: the value stays bit-equal)
+              absp[s] += fabs(wv4[s][j]) * fabs(c);
             } else {
               accp[s] += wv4[s][j] * PW_COS(arg);
             }
@@ -258,8 +265,10 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
             T arg = -hv[j] - hx[s];
 #pragma unroll
             for (int k = 0; k < DK; ++k) arg += cv[k][j] * xsc[s][k];
-            const T t = vv[s][j] * PW_EXP(arg);
+            const T e = PW_EXP(arg);
+            const T t = vv[s][j] * e;
             accu[s] += t;
+            if constexpr (CND) absu[s] += fabs(vv[s][j]) * e;
             if constexpr (JAC) {
 #pragma unroll
               for (int k = 0; k < DK; ++k) accJ[s][k] += t * cv[k][j];
@@ -292,6 +301,10 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
         out[(size_t)(s0 + s) * L + a] = (T)f;
         if (traj) traj[(size_t)(s0 + s) * L + a] = (T)f;
       }
+      if constexpr (CND) {
+        const double ab = pw_wave_sum63(ps * (double)absp[s] + vr * (double)absu[s]);
+        if (lane == 63 && s0 + s < S) cnd[(size_t)(s0 + s) * L + a] = (T)ab;
+      }
       if constexpr (JAC) {
 #pragma unroll
         for (int k = 0; k < DK; ++k) {
@@ -308,7 +321,7 @@ __global__ __launch_bounds__(256) void k_pathwise(int S, int L, int M, int K, in
 // and then streams many sample groups through it, so the only global traffic in the loop is the
 // weight stream itself (operand re-reads through L2 cost 39 % of the plain kernel's time).
 // grid = L * nW workgroups; wave w of workgroup (a, i) handles sample groups i*8 + w, + nW*8, ...
-template <typename T, int DK, bool JAC>
+template <typename T, int DK, bool JAC, bool CND>
 __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L, int M, int K, int d, int nW,
                                                       const T* __restrict__ x, const T* __restrict__ omega,
                                                       const T* __restrict__ phase, const T* __restrict__ zs,
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
                                                       const double* __restrict__ pscale, const double* __restrict__ var,
                                                       const double* __restrict__ meanc, const T* __restrict__ wb,
                                                       T* __restrict__ out, T* __restrict__ traj, T* __restrict__ jac,
-                                                      int euler, double dt) {
+                                                      T* __restrict__ cnd, int euler, double dt) {
   typedef typename PwVec<T>::type VT;
   constexpr int W = PwVec<T>::W, NS = MM_PW_NS, BT = 64 * W, NWAVE = PW_LDS_WAVES;
   constexpr int NJ = JAC ? DK : 1;
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
     else if (ld_g + g_stride < ngroups) { ld_g += g_stride; ld_tb = 0; }
   };
   int cg = g_first, ctb = 0;                            // block being consumed
-  T xr[NS][DK], hx[NS], accp[NS], accu[NS], accJ[NS][NJ];
+  T xr[NS][DK], hx[NS], accp[NS], accu[NS], accJ[NS][NJ], absp[NS], absu[NS];
   auto consume = [&](const VT (&q)[NS]) {
     const int s0 = cg * NS;
     if (ctb == 0) {                                     // new group: its NS states (wave-uniform loads)
@@ -391,7 +404,7 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
           h += xs * xs;
         }
         hx[s] = (T)0.5 * h;
-        accp[s] = (T)0; accu[s] = (T)0;
+        accp[s] = (T)0; accu[s] = (T)0; absp[s] = (T)0; absu[s] = (T)0;
 #pragma unroll
         for (int k = 0; k < NJ; ++k) accJ[s][k] = (T)0;
       }
@@ -418,6 +431,10 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
             const T t = wv4[s][j] * sn;
 #pragma unroll
             for (int k = 0; k < DK; ++k) accJ[s][k] += t * cv[k][j];
+          } else if constexpr (CND) {
+            const T c = PW_COS(arg);
+            accp[s] += wv4[s][j] * c;                         // (the plain pass's own expression: the value stays bit-equal)
+            absp[s] += fabs(wv4[s][j]) * fabs(c);
           } else {
             accp[s] += wv4[s][j] * PW_COS(arg);
           }
@@ -442,8 +459,10 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
           T arg = -sv[j] - hx[s];
 #pragma unroll
           for (int k = 0; k < DK; ++k) arg += cv[k][j] * xr[s][k];
-          const T t = wv4[s][j] * PW_EXP(arg);
+          const T e = PW_EXP(arg);
+          const T t = wv4[s][j] * e;
           accu[s] += t;
+          if constexpr (CND) absu[s] += fabs(wv4[s][j]) * e;
           if constexpr (JAC) {
 #pragma unroll
             for (int k = 0; k < DK; ++k) accJ[s][k] += t * cv[k][j];
@@ -461,6 +480,10 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
           if (euler) f = (double)x[(size_t)(s0 + s) * d + a] + dt * f;
           out[(size_t)(s0 + s) * L + a] = (T)f;
           if (traj) traj[(size_t)(s0 + s) * L + a] = (T)f;
+        }
+        if constexpr (CND) {
+          const double ab = pw_wave_sum63(ps * (double)absp[s] + vr * (double)absu[s]);
+          if (lane == 63 && s0 + s < S) cnd[(size_t)(s0 + s) * L + a] = (T)ab;
         }
         if constexpr (JAC) {
           // update rows carry c = z xscale^2 and arg = c . x - hz - hx: d arg / d x_k = c_k - xscale_k^2 x_k
@@ -493,7 +516,8 @@ template <typename T>
 static int pw_launch(int S, int L, int M, int K, int d, const T* x, const T* omega, const T* phase, const T* zs,
                      const T* hz, const double* xscale, const double* pscale, const double* var,
                      const double* meanc, const T* wb, T* out, T* traj, int euler, double dt, hipStream_t s,
-                     T* jac = nullptr) {
+                     T* jac = nullptr, T* cnd = nullptr) {
+  if (jac && cnd) return MM_E_ARG;                  // (one extra output per pass)
   if (jac && d > 8) return MM_E_DIM;               // the Jacobian pass keeps (1 + d) accumulators per sample: d <= 8
   // LDS-resident operands when one latent's (d + 1) x (K + M) block fits (<= 144 KB)
   const int dk = d <= 4 ? 4 : d <= 8 ? 8 : d <= 16 ? 16 : 32;
@@ -502,7 +526,7 @@ static int pw_launch(int S, int L, int M, int K, int d, const T* x, const T* ome
     const int ngroups = (S + MM_PW_NS - 1) / MM_PW_NS;
     int nW = 256 / L; if (nW < 1) nW = 1;                           // ~ one workgroup per CU
     while (nW > 1 && (nW - 1) * PW_LDS_WAVES >= ngroups) --nW;                 // no idle workgroups on small S
-#define PW_LAUNCH_LDS_(DK_, JAC_)                                                                   \
+#define PW_LAUNCH_LDS_(DK_, JAC_, CND_)                                                             \
     do {                                                                                            \
       /* raise the dynamic-LDS limit once per instantiation and device (the call is slow: not per launch) */ \
       static std::atomic<unsigned long long> lds_set{0ull};                                         \
@@ -510,32 +534,36 @@ static int pw_launch(int S, int L, int M, int K, int d, const T* x, const T* ome
       if (hipGetDevice(&dev_) != hipSuccess) dev_ = 64;                                             \
       const unsigned long long bit_ = (dev_ >= 0 && dev_ < 64) ? (1ull << dev_) : 0ull;             \
       if (!bit_ || !(lds_set.load() & bit_)) {                                                      \
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pathwise_lds<T, DK_, JAC_>), \
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pathwise_lds<T, DK_, JAC_, CND_>), \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); \
         if (ea != hipSuccess) return (int)ea;                                                       \
         lds_set.fetch_or(bit_);                                                                     \
       }                                                                                             \
-      hipLaunchKernelGGL((k_pathwise_lds<T, DK_, JAC_>), dim3(L * nW), dim3(64 * PW_LDS_WAVES), lds_bytes, s, S, L, M, K, d, nW, \
-                         x, omega, phase, zs, hz, xscale, pscale, var, meanc, wb, out, traj, jac, euler, dt); \
+      hipLaunchKernelGGL((k_pathwise_lds<T, DK_, JAC_, CND_>), dim3(L * nW), dim3(64 * PW_LDS_WAVES), lds_bytes, s, S, L, M, K, d, nW, \
+                         x, omega, phase, zs, hz, xscale, pscale, var, meanc, wb, out, traj, jac, cnd, euler, dt); \
     } while (0)
-#define PW_LAUNCH_LDS(DK_) do { if (jac) PW_LAUNCH_LDS_(DK_, true); else PW_LAUNCH_LDS_(DK_, false); } while (0)
+#define PW_LAUNCH_LDS(DK_) do { if (jac) PW_LAUNCH_LDS_(DK_, true, false); else if (cnd) PW_LAUNCH_LDS_(DK_, false, true); else PW_LAUNCH_LDS_(DK_, false, false); } while (0)
+#define PW_LAUNCH_LDS_NJ(DK_) do { if (cnd) PW_LAUNCH_LDS_(DK_, false, true); else PW_LAUNCH_LDS_(DK_, false, false); } while (0)
     if (d <= 4) PW_LAUNCH_LDS(4);
     else if (d <= 8) PW_LAUNCH_LDS(8);
-    else if (d <= 16) PW_LAUNCH_LDS_(16, false);
-    else PW_LAUNCH_LDS_(32, false);
+    else if (d <= 16) PW_LAUNCH_LDS_NJ(16);
+    else PW_LAUNCH_LDS_NJ(32);
+#undef PW_LAUNCH_LDS_NJ
 #undef PW_LAUNCH_LDS
 #undef PW_LAUNCH_LDS_
     hipError_t el = hipGetLastError();
     return el == hipSuccess ? 0 : (int)el;
   }
   dim3 grid((S + MM_PW_NS - 1) / MM_PW_NS);
-#define PW_LAUNCH_(DK_, JAC_) hipLaunchKernelGGL((k_pathwise<T, DK_, JAC_>), grid, dim3(256), 0, s, S, L, M, K, d, x, omega, phase, \
-                                                zs, hz, xscale, pscale, var, meanc, wb, out, traj, jac, euler, dt)
-#define PW_LAUNCH(DK_) do { if (jac) PW_LAUNCH_(DK_, true); else PW_LAUNCH_(DK_, false); } while (0)
+#define PW_LAUNCH_(DK_, JAC_, CND_) hipLaunchKernelGGL((k_pathwise<T, DK_, JAC_, CND_>), grid, dim3(256), 0, s, S, L, M, K, d, x, omega, phase, \
+                                                zs, hz, xscale, pscale, var, meanc, wb, out, traj, jac, cnd, euler, dt)
+#define PW_LAUNCH(DK_) do { if (jac) PW_LAUNCH_(DK_, true, false); else if (cnd) PW_LAUNCH_(DK_, false, true); else PW_LAUNCH_(DK_, false, false); } while (0)
+#define PW_LAUNCH_NJ(DK_) do { if (cnd) PW_LAUNCH_(DK_, false, true); else PW_LAUNCH_(DK_, false, false); } while (0)
   if (d <= 4) PW_LAUNCH(4);
   else if (d <= 8) PW_LAUNCH(8);
-  else if (d <= 16) PW_LAUNCH_(16, false);
-  else PW_LAUNCH_(32, false);
+  else if (d <= 16) PW_LAUNCH_NJ(16);
+  else PW_LAUNCH_NJ(32);
+#undef PW_LAUNCH_NJ
 #undef PW_LAUNCH
 #undef PW_LAUNCH_
   hipError_t e = hipGetLastError();
@@ -568,6 +596,25 @@ extern "C" int mm_pathwise_eval(int S, int L, int M, int K, int d, int dtype,
   return pw_launch<float>(S, L, M, K, d, (const float*)x, (const float*)omega_t, (const float*)phase,
                           (const float*)zs_t, (const float*)hz, x_scale, prior_scale, variance, mean_c,
                           (const float*)wb, (float*)f_out, nullptr, 0, 0.0, s);
+}
+
+extern "C" int mm_pathwise_eval_bound(int S, int L, int M, int K, int d, int dtype,
+                                      const void* x, const void* omega_t, const void* phase, const void* zs_t,
+                                      const void* hz, const double* x_scale, const double* prior_scale,
+                                      const double* variance, const double* mean_c, const void* wb, void* f_out,
+                                      void* abs_out, void* stream) {
+  int rc = pw_check(S, L, M, K, d, dtype);
+  if (rc) return rc;
+  if (!x || !omega_t || !phase || !zs_t || !hz || !x_scale || !prior_scale || !variance || !wb || !f_out || !abs_out)
+    return MM_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MM_F64)
+    return pw_launch<double>(S, L, M, K, d, (const double*)x, (const double*)omega_t, (const double*)phase,
+                             (const double*)zs_t, (const double*)hz, x_scale, prior_scale, variance, mean_c,
+                             (const double*)wb, (double*)f_out, nullptr, 0, 0.0, s, nullptr, (double*)abs_out);
+  return pw_launch<float>(S, L, M, K, d, (const float*)x, (const float*)omega_t, (const float*)phase,
+                          (const float*)zs_t, (const float*)hz, x_scale, prior_scale, variance, mean_c,
+                          (const float*)wb, (float*)f_out, nullptr, 0, 0.0, s, nullptr, (float*)abs_out);
 }
 
 // one evaluation f [S,L] (and, jac != NULL, d f / d x [S,L,d]) for the other translation units (mm_pathwise_policy.hip)

@@ -25,6 +25,9 @@ from .models import DEFAULT_FLOAT, DEFAULT_JITTER, SVGP, Constant, Zero, _stack_
 from .ops import _dtype_code, _ptr, _require_device, _stream, check
 
 
+BOUND_ULPS = 8.0      # Paths.eval_with_bound: rounding bound = BOUND_ULPS x unit roundoff x the sum of the absolute terms
+
+
 def _pad_last(t: torch.Tensor, mult: int) -> torch.Tensor:
   n = t.shape[-1]
   pad = (-n) % mult
@@ -88,6 +91,34 @@ class Paths:
                                          out.data_ptr(), jac.data_ptr(), _stream(x.device))
     check(rc, "mm_pathwise_eval_jac")
     return out, jac
+
+  def eval_with_bound(self, x: torch.Tensor):
+    """f_s(x_s) and a bound on what this dtype's rounding did to it: x [S, d] -> (f [S, L], err [S, L]) from ONE pass over the
+    weight stream (``mm_pathwise_eval_bound``).  err = BOUND_ULPS u (scale sum_k |w cos| + var sum_m |v k|): the update weights
+    v = Kuu^-1 (u - Phi w) cancel 1e5 .. 1e7-fold in sum_m v_m k(x, z_m) at M = 2000, so a float32 sample's value can have lost
+    its digits (C5 shard: ~2e-2 of max |f|) -- this is where the caller sees it; float64 paths are the accurate mode."""
+    _require_device(x, self.wb)
+    S, L, Mp, Kp, d = self._dims()
+    if x.shape != (S, d) or x.dtype != self.dtype:
+      raise ValueError(f"expected x [{S},{d}] of {self.dtype}, got {tuple(x.shape)} {x.dtype}")
+    x = x.contiguous()
+    out = torch.empty(S, L, dtype=self.dtype, device=x.device)
+    ab = torch.empty(S, L, dtype=self.dtype, device=x.device)
+    rc = _lib.lib().mm_pathwise_eval_bound(S, L, Mp, Kp, d, _dtype_code(self.dtype), x.data_ptr(), self.omega.data_ptr(),
+                                           self.phase.data_ptr(), self.zs.data_ptr(), self.hz.data_ptr(),
+                                           self.lengthscales.data_ptr(), self.prior_scale.data_ptr(),
+                                           self.variance.data_ptr(), _ptr(self.mean_c), self.wb.data_ptr(),
+                                           out.data_ptr(), ab.data_ptr(), _stream(x.device))
+    check(rc, "mm_pathwise_eval_bound")
+    # unit roundoff u = finfo.eps / 2; v and the basis value each carry ~u, the exponent's own rounding (|arg| up to ~20 at the
+    # C5 shape) a few u more: BOUND_ULPS u covers the measured worst case with a factor ~2 in hand (tests/test_pathwise.py)
+    return out, ab * (BOUND_ULPS * 0.5 * torch.finfo(self.dtype).eps)
+
+  def flagged(self, x: torch.Tensor, tol: float):
+    """(f, mask [S, L], count): the (sample, latent) values whose rounding bound exceeds ``tol`` x max |f| of the batch."""
+    f, err = self.eval_with_bound(x)
+    mask = err > tol * f.abs().amax()
+    return f, mask, int(mask.sum().item())
 
   def rollout(self, x0: torch.Tensor, num_steps: int, dt: float = 1.0, keep_trajectory: bool = False):
     """Drift-only Euler rollout of all S paths (d == L): x <- x + dt f(x), H steps in one ABI call."""

@@ -305,6 +305,15 @@ int mm_pathwise_eval(int S, int L, int M, int K, int d, int dtype,
                      const double* x_scale, const double* prior_scale, const double* variance,
                      const double* mean_c, const void* wb, void* f_out, void* stream);
 
+/* The same evaluation that also emits, in the same pass, abs_out [S,L] T = scale_a sum_k |w cos(.)| + var_a sum_m |v 2^(.)|: the sum
+ * of the ABSOLUTE terms of f[s,a].  A T-typed weight stream and T-typed basis values leave an error of at most ~2 eps_T abs_out in
+ * f[s,a] (eps_f32 = 6e-8: v = Kuu^-1 (u - Phi w) cancels 1e5 .. 1e7-fold in sum_m v_m k(x, z_m) at M = 2000, so an f32 sample's
+ * value can have lost its digits -- the caller sees it here instead of not at all; the f64 mode is the accurate path). */
+int mm_pathwise_eval_bound(int S, int L, int M, int K, int d, int dtype,
+                           const void* x, const void* omega_t, const void* phase, const void* zs_t, const void* hz,
+                           const double* x_scale, const double* prior_scale, const double* variance,
+                           const double* mean_c, const void* wb, void* f_out, void* abs_out, void* stream);
+
 /* Euler.step folded H times on the sample paths (dynamics/solvers.py:50-65, no diffusion; d == L):
  * x <- x + dt f(x).  x is updated in place (x_tmp: scratch of the same size); traj [H,S,d] optional. */
 int mm_pathwise_rollout(int S, int L, int M, int K, int d, int dtype, int H, double dt,

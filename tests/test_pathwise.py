@@ -50,6 +50,8 @@ def test_gpu_eval_and_rollout_match_oracle(shape, dtype, device):
   # and evaluating exp in f32 leaves ~3e-4 relative error (measured), f64 is exact to 1e-12
   tol = 1e-11 if dtype == torch.float64 else 2e-3
   assert scale_err(gp_paths(xt), fo) < tol
+  fb, err = gp_paths.eval_with_bound(xt)                        # the rounding bound of this dtype holds for every value
+  assert np.all(np.abs(fb.double().cpu().numpy() - fo) <= err.double().cpu().numpy() + 1e-300)
   if L == d:
     xo, traj = pw.rollout(paths, po, x, 4, dt=0.5, keep=True)
     xg, tg = gp_paths.rollout(xt, 4, dt=0.5, keep_trajectory=True)
@@ -106,6 +108,22 @@ def test_c5_shard_shape_against_oracle_on_a_slice_of_samples(device):
   # cancel in sum_m v_m k(x, z_m); storing v in f32 leaves 1.8e-2 of max|f| (measured) -- the price of the config's
   # fp32 weight stream.  The same kernel in f64 on the same tensors is exact to 1e-9 (below).
   assert scale_err(fg[torch.tensor(sel, device=device)], fo) < 4e-2
+  # ... and the caller is TOLD: the same pass with the sum of the absolute terms (mm_pathwise_eval_bound).  (i) the bound holds on
+  # the checked slice; (ii) the (sample, latent) values it does not flag at 1e-3 of max|f| are within 1e-3; (iii) the count of
+  # flagged values is reported (bench.py --config c5 prints it beside `parity`) -- at this shape nearly every value is flagged:
+  # that is the honest statement about an f32 weight stream at M = 2000
+  fb, err = gp_paths.eval_with_bound(xt)
+  seld = torch.tensor(sel, device=device)
+  adiff = np.abs(fb[seld].double().cpu().numpy() - fo)
+  eb = err[seld].double().cpu().numpy()
+  assert np.all(adiff <= eb), float((adiff / eb).max())
+  assert float((adiff / eb).max()) > 0.02                       # ... and it is not vacuous: within 50 x of the worst error
+  fmax = float(fb.abs().amax())
+  _, mask, nflag = gp_paths.flagged(xt, 1e-3)
+  ok = ~mask[seld].cpu().numpy()
+  assert np.all(adiff[ok] <= 1e-3 * fmax)
+  assert 0 <= nflag <= S * L
+  print(f"C5 shard f32: {nflag} of {S * L} (sample, latent) values flagged at 1e-3 of max|f|; worst error / bound {float((adiff / eb).max()):.3f}")
   xo, traj = pw.rollout(sub, po, x[sel], 3, dt=0.5, keep=True)
   xg, tg = gp_paths.rollout(xt, 3, dt=0.5, keep_trajectory=True)
   assert scale_err(tg[:, torch.tensor(sel, device=device)], traj) < 4e-2
