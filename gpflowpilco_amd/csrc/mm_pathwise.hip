@@ -32,6 +32,8 @@
 #define PW_EXP(x_) pw_exp(x_)
 #endif
 
+typedef float pwf2 __attribute__((ext_vector_type(2)));
+#define PW_B2(x_) ((pwf2){(float)(x_), (float)(x_)})
 template <typename T> struct PwVec;
 template <> struct PwVec<float> { typedef float4 type; static constexpr int W = 4; };
 template <> struct PwVec<double> { typedef double2 type; static constexpr int W = 2; };
@@ -389,6 +391,13 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
   };
   int cg = g_first, ctb = 0;                            // block being consumed
   T xr[NS][DK], hx[NS], accp[NS], accu[NS], accJ[NS][NJ], absp[NS], absu[NS];
+  // PK (the Jacobian pass of an f32 stream): the NS samples of a group in PAIRS -- every per-(term, sample) operation of the pass
+  // (the d FMAs of the argument, the d FMAs of the Jacobian sums, the weight product, the sums) is one v_pk_*_f32 over a sample
+  // pair with the shared operand (omega_k / c_k of the term) broadcast: half the FMA-class instructions of a pass that is
+  // VALU-bound.  Pairs over SAMPLES need no extra accumulators (pairs over terms did: 256 VGPRs + scratch)
+  constexpr bool PK = JAC && sizeof(T) == 4 && NS % 2 == 0;
+  constexpr int NP = PK ? NS / 2 : 1, NJP = PK ? DK : 1;
+  pwf2 xr2[NP][NJP], hx2[NP], accp2[NP], accu2[NP], accJ2[NP][NJP];
   auto consume = [&](const VT (&q)[NS]) {
     const int s0 = cg * NS;
     if (ctb == 0) {                                     // new group: its NS states (wave-uniform loads)
@@ -408,6 +417,18 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
 #pragma unroll
         for (int k = 0; k < NJ; ++k) accJ[s][k] = (T)0;
       }
+      if constexpr (PK) {
+#pragma unroll
+        for (int sp = 0; sp < NP; ++sp) {
+          hx2[sp] = (pwf2){(float)hx[2 * sp], (float)hx[2 * sp + 1]};
+          accp2[sp] = (pwf2){0.0f, 0.0f}; accu2[sp] = (pwf2){0.0f, 0.0f};
+#pragma unroll
+          for (int k = 0; k < DK; ++k) {
+            xr2[sp][k] = (pwf2){(float)xr[2 * sp][k], (float)xr[2 * sp + 1][k]};
+            accJ2[sp][k] = (pwf2){0.0f, 0.0f};
+          }
+        }
+      }
     }
     T wv4[NS][W], cv[DK][W], sv[W];
 #pragma unroll
@@ -416,7 +437,49 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
 #pragma unroll
     for (int k = 0; k < DK; ++k) pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)k * KT + col), cv[k]);
     pw_unpack<T>(*reinterpret_cast<const VT*>(op + (size_t)DK * KT + col), sv);
-    if (ctb < nbK) {                                    // wave-uniform: prior block
+    if (PK && ctb < nbK) {                              // prior block, sample pairs
+      if constexpr (PK) {
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+          for (int sp = 0; sp < NP; ++sp) {
+            pwf2 arg = PW_B2(sv[j]);
+#pragma unroll
+            for (int k = 0; k < DK; ++k) arg = __builtin_elementwise_fma(PW_B2(cv[k][j]), xr2[sp][k], arg);
+            float c0, s0f, c1, s1f;
+            pw_sincos(arg[0], c0, s0f); pw_sincos(arg[1], c1, s1f);
+            const pwf2 w2 = {(float)wv4[2 * sp][j], (float)wv4[2 * sp + 1][j]};
+            accp2[sp] = __builtin_elementwise_fma(w2, (pwf2){c0, c1}, accp2[sp]);
+            const pwf2 t2 = w2 * (pwf2){s0f, s1f};
+#pragma unroll
+            for (int k = 0; k < DK; ++k) accJ2[sp][k] = __builtin_elementwise_fma(t2, PW_B2(cv[k][j]), accJ2[sp][k]);
+          }
+        if (ctb == nbK - 1) {
+          const double den = 0.6931471805599453 * vr;
+          const float fj = den != 0.0 ? (float)(-6.283185307179586 * ps / den) : 0.0f;
+#pragma unroll
+          for (int sp = 0; sp < NP; ++sp)
+#pragma unroll
+            for (int k = 0; k < DK; ++k) accJ2[sp][k] = accJ2[sp][k] * PW_B2(fj);
+        }
+      }
+    } else if (PK) {                                    // update block, sample pairs
+      if constexpr (PK) {
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+#pragma unroll
+          for (int sp = 0; sp < NP; ++sp) {
+            pwf2 arg = PW_B2(-(float)sv[j]) - hx2[sp];
+#pragma unroll
+            for (int k = 0; k < DK; ++k) arg = __builtin_elementwise_fma(PW_B2(cv[k][j]), xr2[sp][k], arg);
+            const pwf2 e2 = {pw_exp(arg[0]), pw_exp(arg[1])};
+            const pwf2 t2 = (pwf2){(float)wv4[2 * sp][j], (float)wv4[2 * sp + 1][j]} * e2;
+            accu2[sp] = accu2[sp] + t2;
+#pragma unroll
+            for (int k = 0; k < DK; ++k) accJ2[sp][k] = __builtin_elementwise_fma(t2, PW_B2(cv[k][j]), accJ2[sp][k]);
+          }
+      }
+    } else if (ctb < nbK) {                             // wave-uniform: prior block
 #pragma unroll
       for (int j = 0; j < W; ++j)
 #pragma unroll
@@ -470,6 +533,16 @@ __global__ __launch_bounds__(64 * PW_LDS_WAVES) void k_pathwise_lds(int S, int L
         }
     }
     if (ctb == NB - 1) {                                // group done: reduce, Euler update, store
+      if constexpr (PK) {
+#pragma unroll
+        for (int sp = 0; sp < NP; ++sp)
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            accp[2 * sp + hh] = (T)accp2[sp][hh]; accu[2 * sp + hh] = (T)accu2[sp][hh];
+#pragma unroll
+            for (int k = 0; k < DK; ++k) accJ[2 * sp + hh][PK ? k : 0] = (T)accJ2[sp][k][hh];
+          }
+      }
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
         const double t = pw_wave_sum63(ps * (double)accp[s] + vr * (double)accu[s]);
