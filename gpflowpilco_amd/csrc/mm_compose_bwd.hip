@@ -137,7 +137,11 @@ __global__ void k_check_workspace_current(const T* __restrict__ mu, const double
                                           int code) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * d) return;
-  if ((double)mu[i] != mu64[i]) { atomicMax(status, B - i / d); status[1] = code; }
+  // a NaN state (the documented result of a non-PD step earlier in a rollout) is not a stale workspace: NaN on both sides
+  // matches; and a failure already recorded in status[0] (the non-PD element itself) is never replaced by this code
+  const double a = (double)mu[i], bq = mu64[i];
+  const bool same = (a == bq) || (a != a && bq != bq);
+  if (!same && atomicCAS(status, 0, B - i / d) == 0) status[1] = code;
 }
 template <typename T>
 __global__ void k_stamp_state(const T* __restrict__ mu, double* __restrict__ stamp, int n) {
