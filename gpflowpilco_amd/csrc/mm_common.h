@@ -45,7 +45,10 @@ static inline size_t mm_rank_table_entries(int d) {
 static inline int mm_moment_cols(int d) { return mm_round_up_int(mm_mono_offset(mm_moment_deg(d) + 1, d), 16); }
 // degree-5 and degree-6 monomials (d <= 8: the collapse's bf16 tables, mm_moments6.hip): degree 5 first, then degree 6, colex
 // inside a degree; rounded up to the 128-column tile of the bf16 GEMM.  0 for d > 8 (no collapse).
-static inline int mm_moment56_cols(int d) { return d <= 8 ? mm_round_up_int(mm_mono_count(5, d) + mm_mono_count(6, d), 128) : 0; }
+// Layout: [degree 5 | pad to 128][degree 6 | pad to 128] -- a 128-column block of the GEMM holds one degree only, so that the
+// degree-6 blocks can be formed for the rows that need them alone (MM_C6_X5_2 below).
+static inline int mm_moment56_off6(int d) { return d <= 8 ? mm_round_up_int(mm_mono_count(5, d), 128) : 0; }
+static inline int mm_moment56_cols(int d) { return d <= 8 ? mm_moment56_off6(d) + mm_round_up_int(mm_mono_count(6, d), 128) : 0; }
 // Index tables of the degree-5/6 contraction (k_spoly56, mm_moments6.hip; functions of d alone, written at pack time), with
 // sym(k) = mm_mono_count(k, d) sorted index tuples of length k in colex rank order:
 //   ins  [m = 0..5][J < sym(m)][8] i16: rank inside sym(m + 1) of the tuple J with the index j inserted (0 for j >= d)
@@ -150,6 +153,16 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 #ifndef MM_COLLAPSE_BOUND2
 #define MM_COLLAPSE_BOUND2 0.25f
 #endif
+// ... and not every collapsed item needs every order: with the item's Cauchy-Schwarz bound X on |b|, dropping the degree-6 term
+// of p6 leaves C3 X^6 <= 8.3e-11 at X = 1/16, dropping degrees 5 and 6 C2 X^5 + C3 X^6 <= 8.2e-11 at X = 1/40 -- below the
+// polynomial's own 5.8e-10.  k_wmom_perm orders a latent's rows [degree 6 | degree 5 only | degree 4 only | not collapsed], the
+// bf16 GEMM forms the degree-5 column blocks for the first two classes and the degree-6 blocks for the first, k_spoly56 contracts
+// what exists.  (The pilco recipe's items sit at X <= 0.05: without this the degree-5/6 work -- all of it useless there -- took
+// the step from 5.0 to 6.2 ms.)
+#define MM_C6_X5_2 (1.0f / 256.0f)      /* X <= 1/16: no degree-6 term */
+#define MM_C6_X4_2 (1.0f / 1600.0f)     /* X <= 1/40: neither degree 5 nor 6 (the f64 degree-3/4 moments only).  (At 1/32 the dropped
+                                           C2 X^5, priced like p6's own error in the route estimate, sent 0.6 % of the pilco recipe's
+                                           items -- |what| |what'| ~ 1e7 x the covariance scale there -- to the f64 re-reduce: +0.5 ms) */
 #define MM_C6_MAX 0.25f
 #define MM_C6_C0 1.666663289e-01f
 #define MM_C6_C1 4.166659713e-02f
@@ -255,8 +268,9 @@ struct MMWorkspaceLayout {
   size_t mom;      // [B][Po][2][MM_MOM_SPLIT][KMp] f64  partial sums over m of what_m zc_m^alpha (all monomials of the
                    //                  table): row side, column side; MM_MOM_SPLIT slices of the m range
   size_t amax;     // [B][Po] u32  bits of max_i |A_i|^2 (f32, >= 0: ordered like the integer), zeroed by k_prep
-  size_t gperm;    // [L][(L-1) B] i32 + [L] i32 (f32 mode): per latent the rows of its moment GEMM with the COLLAPSED (b, pair) items
-                   //              first (stable), and their count -- the cubic / quartic column blocks are formed for those only
+  size_t gperm;    // [L][(L-1) B] i32 + [3][L] i32 (f32 mode): per latent the rows of its moment GEMM ordered [collapsed to degree 6 |
+                   //              to degree 5 | to degree 4 | not collapsed], and the counts {collapsed, needing degree 5, needing
+                   //              degree 6} -- every column block of the GEMMs is formed for the rows that read it only
   size_t s12;      // [B][Po] f64  the polynomial part of the off-diagonal sums from the moments:
                    //              orders 0..2 always, orders 3 and 4 as well where the (b, pair) is collapsed
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
@@ -316,7 +330,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.whC = off;     off = mm_align_up(off + nwh * 8, A);
   o.mom = off;     off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * 2 * MM_MOM_SPLIT * mm_moment_cols(d) * 8), A);
   o.amax = off;    off = mm_align_up(off + (size_t)B * o.Po * 4, A);
-  o.gperm = off;   off = mm_align_up(off + (dtype == MM_F64 || L < 2 ? 0 : ((size_t)L * (L - 1) * B + L) * 4), A);
+  o.gperm = off;   off = mm_align_up(off + (dtype == MM_F64 || L < 2 ? 0 : ((size_t)L * (L - 1) * B + 3 * L) * 4), A);
   o.s12 = off;     off = mm_align_up(off + (size_t)B * o.Po * 8, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);
   o.partC = off;   off = mm_align_up(off + (size_t)B * L * o.NS * 8, A);

@@ -176,41 +176,77 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // ---------------------------------------------------------------------------------------------
 // k_wmom_perm: grid L, 1024 threads.  gperm[a][0 .. R) = the rows r of latent a's GEMM (R = (L - 1) B; row -> (partner, b) as in
-// k_wmom_gemm) with the collapsed (b, pair) items first (in their natural order; the others behind them, from the back);
-// gperm[L R + a] = the number of collapsed rows.  One pass, 1024 rows at a time.
+// k_wmom_gemm) ordered by collapse class (mm_common.h: MM_C6_X5_2), the collapsed classes first in their natural order, the others
+// behind them from the back; three counts behind the permutations.  Two passes (class totals, placement), 1024 rows at a time.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_wmom_perm(const unsigned int* __restrict__ amax, const double* __restrict__ zmax2, int L, int B,
                                                     int Po, int* __restrict__ gperm) {
+  // classes by the item's bound X^2 (mm_common.h): 0: collapsed, X > 1/16 (degrees 3..6); 1: 1/32 < X <= 1/16 (3..5); 2: X <= 1/32
+  // (3, 4); 3: not collapsed.  Classes 0..2 from the front in this order (stable inside a class), class 3 from the back.
   const int a = blockIdx.x, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   const int R = (L - 1) * B;
-  __shared__ int wsum[16];
-  int ofs_c = 0, ofs_n = 0;                                            // collapsed rows so far / other rows so far
+  __shared__ int wsum[3][16];
+  __shared__ int tot[3];
   int* out = gperm + (size_t)a * R;
+  // pass 1: class totals (the front classes' start offsets)
+  int cnt[3] = {0, 0, 0};
+  auto cls_of = [&](int r) {
+    const int which = r / B, b = r - which * B;
+    const int ap = which < a ? which : which + 1;
+    const int lo = ap < a ? ap : a, hi = ap < a ? a : ap;
+    const int po = lo * (L - 1) - lo * (lo - 1) / 2 + (hi - lo - 1);
+    const float x2 = mm_collapse_bound2(amax[(size_t)b * Po + po], zmax2[hi]);
+    return x2 > MM_COLLAPSE_BOUND2 ? 3 : (x2 > MM_C6_X5_2 ? 0 : (x2 > MM_C6_X4_2 ? 1 : 2));
+  };
+  for (int r = tid; r < R; r += 1024) { const int c = cls_of(r); if (c < 3) ++cnt[c]; }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt[c] += __shfl_down(cnt[c], off, 64);
+    if (lane == 0) wsum[c][wv] = cnt[c];
+  }
+  __syncthreads();
+  if (tid < 3) { int t = 0; for (int w = 0; w < 16; ++w) t += wsum[tid][w]; tot[tid] = t; }
+  __syncthreads();
+  int ofs[3] = {0, tot[0], tot[0] + tot[1]};                          // next free slot of each front class
+  int ofs_n = 0;                                                      // rows of class 3 so far (filled from the back)
+  // pass 2: stable placement, 1024 rows at a time
   for (int r0 = 0; r0 < R; r0 += 1024) {
     const int r = r0 + tid;
     const bool in = r < R;
-    bool c = false;
-    if (in) {
-      const int which = r / B, b = r - which * B;
-      const int ap = which < a ? which : which + 1;
-      const int lo = ap < a ? ap : a, hi = ap < a ? a : ap;
-      const int po = lo * (L - 1) - lo * (lo - 1) / 2 + (hi - lo - 1);
-      c = mm_collapse_bound2(amax[(size_t)b * Po + po], zmax2[hi]) <= MM_COLLAPSE_BOUND2;
-    }
-    const unsigned long long bal = __ballot(c);
-    const int before = __popcll(bal & ((1ull << lane) - 1ull));        // collapsed rows of this wave before the lane
+    const int c = in ? cls_of(r) : 4;
+    int before[3], ctot[3];
     __syncthreads();                                                   // (the previous chunk's wsum has been read)
-    if (lane == 0) wsum[wv] = __popcll(bal);
-    __syncthreads();
-    int wbefore = 0, ctot = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) { if (w < wv) wbefore += wsum[w]; ctot += wsum[w]; }
-    const int pc = wbefore + before;                                   // collapsed rows of the chunk before this one
-    if (in) out[c ? ofs_c + pc : R - 1 - (ofs_n + (tid - pc))] = r;
+    for (int k = 0; k < 3; ++k) {
+      const unsigned long long bal = __ballot(c == k);
+      before[k] = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wsum[k][wv] = __popcll(bal);
+    }
+    __syncthreads();
+    int nfront_before = 0, nfront_tot = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      int wb = 0, ct = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) { if (w < wv) wb += wsum[k][w]; ct += wsum[k][w]; }
+      before[k] += wb; ctot[k] = ct;
+      nfront_before += before[k]; nfront_tot += ct;
+    }
+    if (in) {
+      if (c < 3) out[ofs[c] + before[c]] = r;
+      else out[R - 1 - (ofs_n + (tid - nfront_before))] = r;
+    }
     const int nin = R - r0 < 1024 ? R - r0 : 1024;
-    ofs_c += ctot; ofs_n += nin - ctot;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ofs[k] += ctot[k];
+    ofs_n += nin - nfront_tot;
   }
-  if (tid == 0) gperm[(size_t)L * R + a] = ofs_c;
+  if (tid == 0) {
+    gperm[(size_t)L * R + a] = tot[0] + tot[1] + tot[2];               // collapsed rows
+    gperm[(size_t)L * R + L + a] = tot[0] + tot[1];                    // rows that need the degree-5 moments
+    gperm[(size_t)L * R + 2 * L + a] = tot[0];                         // rows that need the degree-6 moments
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -38,12 +38,13 @@ __global__ __launch_bounds__(256) void k_pack_zm56(char* packed, MMModelLayout l
                                                    const double* __restrict__ Z) {
   const int c = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
   const int n5 = mm_binom_i(d + 4, 5), n6 = mm_binom_i(d + 5, 6);
+  const int off6 = ((n5 + 127) / 128) * 128;            // mm_moment56_off6(d): a 128-column block holds one degree only
   const double* zbar = (const double*)(packed + lay.zbar) + (size_t)a * d;
   unsigned short* oh = (unsigned short*)(packed + lay.Zm56) + (((size_t)a * 2 + 0) * N56p + c) * lay.Mp;
   unsigned short* om = (unsigned short*)(packed + lay.Zm56) + (((size_t)a * 2 + 1) * N56p + c) * lay.Mp;
   int n = 0, k[6] = {0, 0, 0, 0, 0, 0};
   if (c < n5) { n = 5; mm_mono_unrank(c, 5, k); }
-  else if (c < n5 + n6) { n = 6; mm_mono_unrank(c - n5, 6, k); }
+  else if (c >= off6 && c < off6 + n6) { n = 6; mm_mono_unrank(c - off6, 6, k); }
   for (int m = tid; m < lay.Mp; m += 256) {
     float vf = 0.0f;
     if (n && m < M) {
@@ -123,7 +124,7 @@ int mm_launch_pack56(char* packed, const MMModelLayout& lay, int L, int M, int d
 #define MM6_STAGE_BYTES 32768
 
 __global__ __launch_bounds__(256, 2) void k_wmom56_gemm(const unsigned short* __restrict__ wsp, const unsigned short* __restrict__ Zm56,
-                                                        int N56p, int L, int Mp, int B, int Po, int nrb, int ncb, int nwork,
+                                                        int N56p, int L, int Mp, int B, int Po, int nrb, int ncb, int nwork, int ncb5,
                                                         const int* __restrict__ gperm, float* __restrict__ mom56) {
   // work item -> (latent, column block, row block), row block fastest: the workgroups that run together on an XCD share a table
   // column block (and, across column blocks, the latent's weight rows)
@@ -135,7 +136,9 @@ __global__ __launch_bounds__(256, 2) void k_wmom56_gemm(const unsigned short* __
   const int cb = wi % ncb; wi /= ncb;
   const int a = wi;
   const int R = (L - 1) * B;
-  const int ncoll = gperm[(size_t)L * R + a];          // collapsed rows of this latent's GEMM (k_wmom_perm: they come first)
+  // rows of this latent's GEMM that read this column block (k_wmom_perm: they come first): the degree-5 blocks [0, ncb5) are read
+  // by the items collapsed to degree >= 5, the degree-6 blocks by those collapsed to degree 6
+  const int ncoll = gperm[(size_t)L * R + (cb < ncb5 ? 1 : 2) * L + a];
   if (rb * MM6_TB >= ncoll) return;
   const int* perm = gperm + (size_t)a * R;
   extern __shared__ __align__(1024) char lds[];        // 2 stages x 32 KB, then 128 ints
@@ -254,30 +257,44 @@ __global__ __launch_bounds__(256, 2) void k_wmom56_gemm(const unsigned short* __
 // MODE 0: store T_{k+1}; 1: X's last step (k = 2 -> 3): store mult3(I3) multJ(J') value, row stride xs; 2: Y's last step fused
 // with the dot against X (acc += value * X[J'][row])
 #ifndef MM6_THREADS
-#define MM6_THREADS 768       // 12 waves = 3 per SIMD: 168 VGPRs (G alone is 64; 1024 threads spilled at 128)
+#define MM6_THREADS 512       // 8 waves = 2 per SIMD: 256 VGPRs (G alone is 64, two chunks' gathers, sums and offsets 64 more)
 #endif
 #define MM6_WAVES (MM6_THREADS / 64)
+// NC: chunks of 64 values of J' per work unit (lane handles J' = c 64 NC + lane + 64 q, q < NC): the unit's scalar work -- its
+// decode, the tuple's largest index, the per-i branches and row offsets -- is shared by the NC chunks, and their FMA chains
+// interleave (measured: the pass is bound by instructions per unit, ~180 of which ~32 are the packed FMAs)
+#ifndef MM6_NC
+#define MM6_NC 2
+#endif
 template <int K, bool TRANSG, int MODE>
 __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin, int nI, float* __restrict__ Tout, int nJp,
                                          const short* __restrict__ ins, int d, const float (&G)[64], const float* __restrict__ multJ,
                                          int xs, float& acc, int wave, int lane) {
-  const int chunks = (nJp + 63) >> 6;
+  constexpr int NC = MM6_NC;
+  const int chunks = (nJp + 64 * NC - 1) / (64 * NC);
   // the outputs i = I0 .. 7 of one (I, J'): eight-term dot products of the gathered v with G's rows (columns: TRANSG), the
-  // chains interleaved (one chain per i inside its own branch ran at the FMA's latency, not its issue rate: 4x slower)
-  auto dots = [&](auto i0c, const float (&v)[8], float (&s)[8]) __attribute__((always_inline)) {
+  // chains interleaved (one chain per i inside its own branch ran at the FMA's latency, not its issue rate)
+  auto dots = [&](auto i0c, const float (&v)[NC][8], float (&s)[NC][8]) __attribute__((always_inline)) {
     constexpr int I0 = decltype(i0c)::value;
 #pragma unroll
-    for (int i = I0; i < 8; ++i) s[i] = (TRANSG ? G[0 * 8 + i] : G[i * 8 + 0]) * v[0];
+    for (int q = 0; q < NC; ++q)
+#pragma unroll
+      for (int i = I0; i < 8; ++i) s[q][i] = (TRANSG ? G[0 * 8 + i] : G[i * 8 + 0]) * v[q][0];
 #pragma unroll
     for (int j = 1; j < 8; ++j)
 #pragma unroll
-      for (int i = I0; i < 8; ++i) s[i] = fmaf(TRANSG ? G[j * 8 + i] : G[i * 8 + j], v[j], s[i]);
-  };
-  auto body = [&](int I, int t, int Jp, const int (&off)[8], float mj) __attribute__((always_inline)) {
-    const float* tin = Tin + I * nJin;
-    float v[8], s[8];
+      for (int q = 0; q < NC; ++q)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = tin[off[j]];
+        for (int i = I0; i < 8; ++i) s[q][i] = fmaf(TRANSG ? G[j * 8 + i] : G[i * 8 + j], v[q][j], s[q][i]);
+  };
+  // lanes past the end of J' (of chunk q) gather a valid (clamped) entry and store / add nothing
+  auto body = [&](int I, int t, const int (&Jp)[NC], const bool (&jv)[NC], const int (&off)[NC][8], const float (&mj)[NC]) __attribute__((always_inline)) {
+    const float* tin = Tin + I * nJin;
+    float v[NC][8], s[NC][8];
+#pragma unroll
+    for (int q = 0; q < NC; ++q)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[q][j] = tin[off[q][j]];
     // only i >= t (the largest index of I) is needed; t is wave-uniform: three variants of the product
     if (t < 4) dots(std::integral_constant<int, 0>{}, v, s);
     else if (t < 6) dots(std::integral_constant<int, 4>{}, v, s);
@@ -286,42 +303,47 @@ __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin
     for (int i = 0; i < 8; ++i) {
       if (i >= t && i < d) {                             // scalar compare: t, d are wave-uniform
         const int orow = I + mm_binom_i(i + K, K + 1);   // rank of I with i appended (colex)
-        if constexpr (MODE == 0) {
-          Tout[orow * nJp + Jp] = s[i];
-        } else if constexpr (MODE == 1) {
+        float m3 = 1.0f;
+        if constexpr (MODE == 1) {
           // I = (a, t) with a = I - C(t + 1, 2): multinomial of the sorted triple (a, t, i)
           const int a = I - ((t * (t + 1)) >> 1);
-          const float m3 = a == t ? (i == t ? 1.0f : 3.0f) : (i == t ? 3.0f : 6.0f);
-          Tout[orow * xs + Jp] = (m3 * mj) * s[i];
-        } else {
-          acc = fmaf(s[i], Tout[Jp * xs + orow], acc);   // (Tout = X here)
+          m3 = a == t ? (i == t ? 1.0f : 3.0f) : (i == t ? 3.0f : 6.0f);
+        }
+#pragma unroll
+        for (int q = 0; q < NC; ++q) {
+          if constexpr (MODE == 0) { if (jv[q]) Tout[orow * nJp + Jp[q]] = s[q][i]; }
+          else if constexpr (MODE == 1) { if (jv[q]) Tout[orow * xs + Jp[q]] = (m3 * mj[q]) * s[q][i]; }
+          else { if (jv[q]) acc = fmaf(s[q][i], Tout[Jp[q] * xs + orow], acc); }   // (Tout = X here)
         }
       }
     }
   };
-  auto load_off = [&](int Jc, int (&off)[8]) {
-    const short4 ia = *reinterpret_cast<const short4*>(ins + (size_t)Jc * 8);
-    const short4 ib = *reinterpret_cast<const short4*>(ins + (size_t)Jc * 8 + 4);
-    off[0] = ia.x; off[1] = ia.y; off[2] = ia.z; off[3] = ia.w; off[4] = ib.x; off[5] = ib.y; off[6] = ib.z; off[7] = ib.w;
-  };
-  // work unit = (chunk c of 64 values of J', I), I fastest: the waves take units round robin (the chunk's gather offsets are
-  // reloaded when c changes: one 16-byte load)
+  // work unit = (chunk group c of 64 NC values of J', I), I fastest: the waves take units round robin (the group's gather offsets
+  // are reloaded when c changes: one 16-byte load per chunk)
   const int nunit = chunks * nI;
   const float rnI = 1.0f / (float)nI;
-  int cprev = -1, off[8], Jc = 0;
-  bool jv = false;
-  float mj = 0.0f;
+  int cprev = -1, off[NC][8], Jc[NC];
+  bool jv[NC];
+  float mj[NC];
+#pragma unroll
+  for (int q = 0; q < NC; ++q) { Jc[q] = 0; jv[q] = false; mj[q] = 0.0f; }
   for (int u = wave; u < nunit; u += MM6_WAVES) {
     int c = K == 0 ? u : (int)(((float)u + 0.5f) * rnI);   // u / nI (exact: u < 2^20)
     c = __builtin_amdgcn_readfirstlane(c);
     const int I = K == 0 ? 0 : __builtin_amdgcn_readfirstlane(u - c * nI);
     if (c != cprev) {
       cprev = c;
-      const int Jp = c * 64 + lane;
-      jv = Jp < nJp;
-      Jc = jv ? Jp : nJp - 1;
-      load_off(Jc, off);
-      if constexpr (MODE == 1) mj = multJ[Jc];
+#pragma unroll
+      for (int q = 0; q < NC; ++q) {
+        const int Jp = (c * NC + q) * 64 + lane;
+        jv[q] = Jp < nJp;
+        Jc[q] = jv[q] ? Jp : nJp - 1;
+        const short4 ia = *reinterpret_cast<const short4*>(ins + (size_t)Jc[q] * 8);
+        const short4 ib = *reinterpret_cast<const short4*>(ins + (size_t)Jc[q] * 8 + 4);
+        off[q][0] = ia.x; off[q][1] = ia.y; off[q][2] = ia.z; off[q][3] = ia.w;
+        off[q][4] = ib.x; off[q][5] = ib.y; off[q][6] = ib.z; off[q][7] = ib.w;
+        if constexpr (MODE == 1) mj[q] = multJ[Jc[q]];
+      }
     }
     // largest index of the K-tuple of rank I: the tuples whose largest index is t have ranks [C(t + K - 1, K), C(t + K, K))
     int t = 0;
@@ -329,7 +351,7 @@ __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin
 #pragma unroll
       for (int q = 1; q < 8; ++q) t += (I >= mm_binom_i(q + K - 1, K)) ? 1 : 0;
     }
-    if (jv) body(I, t, Jc, off, mj);                      // (lanes past the end of J' sit the unit out: one exec mask per unit)
+    if (jv[0]) body(I, t, Jc, jv, off, mj);              // (chunk 0 of a group is never wholly past the end: jv[0] is a lane mask)
   }
 }
 
@@ -356,6 +378,8 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   for (int k = 0; k < 7; ++k) sy[k] = mm_binom_i(d + k - 1, k);
   // LDS (floats): nq [2][sy5 + sy6] | X [sy3][sy3 + 1] | A [sy2 sy4] | Bf [sy1 sy5] | red
   const int n56 = sy[5] + sy[6];
+  const int off6 = ((sy[5] + 127) / 128) * 128;         // mm_moment56_off6(d): first column of the degree-6 block in mom56
+  const bool need5 = bound2 > MM_C6_X4_2, need6 = bound2 > MM_C6_X5_2;   // (mm_common.h: what the item's bound leaves negligible)
   const int xs = sy[3] + 1;                              // X's row stride: odd at d = 8 (121): the fused dot reads it along a column
   float* nq = sm6;
   float* X = nq + 2 * n56;
@@ -364,7 +388,10 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   float* red = sm6 + ((2 * n56 + sy[3] * xs + sy[2] * sy[4] + sy[1] * sy[5] + 1) & ~1);   // [MM6_WAVES][3] doubles (8-byte aligned)
   for (int idx = tid; idx < 2 * n56; idx += MM6_THREADS) {
     const int side = idx >= n56, c = idx - side * n56;
-    nq[idx] = mom56[(item * 2 + side) * N56p + c];
+    const bool six = c >= sy[5];
+    float v = 0.0f;
+    if (six ? need6 : need5) v = mom56[(item * 2 + side) * N56p + (six ? off6 + (c - sy[5]) : c)];
+    nq[idx] = v;
   }
   // G in VECTOR registers (through LDS): as 64 scalar registers beside the loop's own scalars it spilled to VGPR lanes
   // (780 v_readlane / v_writelane in the kernel, 47 per work unit)
@@ -393,7 +420,7 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   const float* mult3 = (const float*)(tab + (size_t)tb.n_i16 * 2) + tb.mult3;
   float acc5 = 0.0f, acc6 = 0.0f, dummy = 0.0f;
   // ---- n = 6: X = three indices of Q_6 (column side of nq) through G; Y = three indices of N_6 through G^T, fused dot
-  {
+  if (need6) {
     const float* Q6 = nq + n56 + sy[5];
     const float* N6 = nq + sy[5];
     mm6_step<0, false, 0>(Q6, sy[6], 1, Bf, sy[5], tabi + tb.ins[5], d, G, nullptr, 0, dummy, wave, lane);
@@ -410,7 +437,7 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
     __syncthreads();
   }
   // ---- n = 5: X [sym3][sym2] = three indices of Q_5 through G; Y = two indices of N_5 through G^T, fused dot
-  {
+  if (need5) {
     const float* Q5 = nq + n56;
     const float* N5 = nq;
     mm6_step<0, false, 0>(Q5, sy[5], 1, Bf, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
@@ -437,8 +464,13 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
     s56[item] = t;
     // |p6 - r| equioscillates with amplitude 5.8e-10 on [-1/4, 1/4]; near 0 it is the perturbation of the leading
     // coefficient, (1/6 - C0) |x|^3 = 3.4e-7 |x|^3: an item whose bound X is far inside 1/4 leaves out (4 X)^3 of the amplitude
-    const double f3 = fmin(1.0, 64.0 * (double)bound2 * sqrt((double)bound2));
-    estS[item] = (float)fmin((double)MM_C6_SYS2 * (f3 * f3) * r2 * c2, 3.0e38);
+    // an item that leaves degree 6 (and 5) out adds C3 X^6 (+ C2 X^5) per entry, with the same cancellation under the weights
+    // (a smooth function of b): 1e-10 / 5.8e-10 of the amplitude, as for p6 itself
+    const double X = sqrt((double)bound2), X3 = X * X * X;
+    double amp = fmin(1.0, 64.0 * X3);                                               // in units of 1e-10
+    if (!need6) amp += (double)MM_C6_C3 * X3 * X3 / 5.8e-10;
+    if (!need5) amp += (double)MM_C6_C2 * X3 * X * X / 5.8e-10;
+    estS[item] = (float)fmin((double)MM_C6_SYS2 * (amp * amp) * r2 * c2, 3.0e38);
   }
 }
 
@@ -463,6 +495,7 @@ int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, c
     }
     hipLaunchKernelGGL(k_wmom56_gemm, dim3((int)nwork_ll), dim3(256), shm, stream, (const unsigned short*)(ws + wl.wsp),
                        (const unsigned short*)(packed + ml.Zm56), N56p, L, wl.Mp, B, wl.Po, nrb, ncb, (int)nwork_ll,
+                       mm_moment56_off6(d) / MM6_TB,
                        (const int*)(ws + wl.gperm), (float*)(ws + wl.mom56));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
