@@ -9,20 +9,21 @@
 //     sum_ij what_i what'_j b_ij^n = < M_n , G^{(x)n} Q_n >,
 //     Q_n = sum_j what'_j zc'_j^{(x)n},   M_n = sum_i what_i (zc_i - dmu)^{(x)n}.
 // Orders 0..2 (1 + b + b^2/2) are ALWAYS taken this way: in f32 it is the rounding of the linear term that
-// costs the digits of S (DESIGN.md "fp32 error budget").  For d <= 8 the tables go to degree 4, and a (b, pair)
-// whose Cauchy-Schwarz bound max_i |A_i| max_j |zc'_j| is <= 0.15 (MM_COLLAPSE_BOUND2) is COLLAPSED: the cubic and quartic
-// terms c0 x^3 + c1 x^4 -- the tile kernel's own first-tier approximant of the remainder, valid to 9e-9 |x| on
-// |x| <= 1/20 -- come from the moments too, the tile kernel skips every tile inside that tier after a one-MFMA
-// screening product and reduces only the correction r(x) - c0 x^3 - c1 x^4 on the others.
+// costs the digits of S (DESIGN.md "fp32 error budget").  For d <= 8 a (b, pair) whose Cauchy-Schwarz bound
+// max_i |A_i| max_j |zc'_j| is <= 1/2 (MM_COLLAPSE_BOUND2) is COLLAPSED (mm_common.h): the polynomial p6(x) = x^3 (C0 + .. + C3 x^3) --
+// the tile kernel's own degree-3 tier of the remainder, |p6 - r| <= 5.8e-10 on |x| <= 1/4 -- comes from moments too: its cubic and
+// quartic terms from the f64 tables of THIS file (degree <= 4, 495 columns at d = 8), its degree-5 and degree-6 terms from bf16
+// split tables on the matrix pipe (mm_moments6.hip).  The tile kernel skips every wave tile with max|b| <= 1/4 after a one-MFMA
+// screening product and reduces only the correction r(x) - p6(x) on the others.
 //
-//   k_wmom_perm : per latent the rows of its GEMM with the collapsed (b, pair) items first (the cubic / quartic column
-//                 blocks are formed for those rows only);
+//   k_wmom_perm : per latent the rows of its GEMMs ordered by collapse class (degree 6 | 5 | 4 | not collapsed): every column block of
+//                 either GEMM is formed for the rows that read it only;
 //   k_wmom_gemm : mom[(b, pair, side)][:] = sum_m what_m Zm[latent(side)][m][:]   -- an f64 GEMM
 //                 [rows = B per (pair, side)] x [K = Mp] x [N = KMp columns] on v_mfma_f64_16x16x4_f64:
 //                 64 x 128 output tile per workgroup (4 waves x 64 x 32), K-blocks of 32 staged through LDS
 //                 (bank-conflict-free strides), next block's global loads in flight during the MFMAs,
 //                 split-K over MM_MOM_SPLIT slices, XCD-aware 1-D grid (tiles sharing a table slice share an L2);
-//   k_spoly     : per (b, pair) the d^n contractions above for n = 0..2 (or 0..4), one workgroup each.
+//   k_spoly     : per (b, pair) the d^n contractions above for n = 0..2 (or 0..4), one workgroup each (n = 5, 6: k_spoly56).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"

@@ -13,11 +13,12 @@
  *   - the caller owns every buffer including the workspace (size from *_bytes queries);
  *   - calls only enqueue work (no allocation, no synchronisation; graph-capturable) in the order of `stream` (a hipStream_t
  *     passed as void*): when `stream` reaches the end of a call's work, everything the call enqueued is complete.  Some calls
- *     (mm_moment_match, the rollouts, mm_moment_match_with_sums / _backward) run independent latency-bound kernel chains on ONE
- *     library-owned side stream per device beside a long sweep and join it to `stream` before they return (fork / join by events;
- *     under stream capture the side stream joins the capture).  The only process-wide state is that stream and its two events
- *     (created on first use, shared by the device's callers, their enqueue order serialised by a mutex); the stage API
- *     (mm_q_forward, mm_Q_reduce_forward) never leaves work on it;
+ *     (mm_moment_match, the rollouts, mm_moment_match_with_sums / _backward) run independent latency-bound kernel chains on a
+ *     library-owned side stream beside a long sweep and join it to `stream` before they return (fork / join by events; under
+ *     stream capture the side stream joins the capture).  That side stream and its two events belong to the CALLER'S stream: one
+ *     triple per (device, caller stream), created on first use and kept for the process -- calls on different streams share
+ *     nothing and may run concurrently, one of them under HIP-graph capture (ABI users: one enqueuing thread per stream at a time,
+ *     as for any stream-ordered API).  The stage API (mm_q_forward, mm_Q_reduce_forward) never leaves work on a side stream;
  *   - return value: 0 ok, <0 bad argument (MM_E_*), >0 a hipError_t;
  *   - `status` (device int32[4], zeroed by the caller, may be NULL): [0] = B - b for the smallest
  *     batch index b whose (Sigma + V) Cholesky was not positive definite (0 = all fine; outputs
