@@ -9,7 +9,7 @@
 # hash of the kernel sources it was measured on): profiles/<round>_pmc_<tag>.json  via tools/pmc_summary.py.
 set -euo pipefail
 tag="$1"; shift
-round="${ROUND:-r03}"
+round="${ROUND:-r05}"
 root="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
 out="${root}/gpurun_out/${round}/pmc_${tag}"
 rm -rf "${out}"; mkdir -p "${out}"
