@@ -533,7 +533,7 @@ extern "C" int mm_backward_pair_aggregates(const void* packed, size_t packed_byt
   if (scratch_bytes < mm_backward_pair_aggregates_bytes(B, L, M, d, flags)) return MM_E_WORKSPACE;
   if (pagg_bytes < (size_t)B * wl.Po * mma_pair_agg_len(d) * sizeof(double)) return MM_E_WORKSPACE;
   char* ws = (char*)workspace;
-  int rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, ws + wl.f1s, ws + wl.crs, nullptr,
+  int rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags | MM_ISTAGE_NO_M56, ws + wl.f1s, ws + wl.crs, nullptr,
                         workspace, workspace_bytes, status, stream);
   if (rc) return rc;
   return mm_launch_bwd_offdiag_f32((const char*)packed, ml, ws, wl, B, L, M, d, flags, (const float*)mu, (double*)scratch,

@@ -14,6 +14,10 @@ static inline size_t mm_elem_size(int dtype) { return dtype == MM_F64 ? 8 : 4; }
 // can be split off the remainder sweep (it then runs on the side stream with the aggregate chain, mm_compose_bwd.hip)
 #define MM_ISTAGE_NO_ROUTE (1 << 20)      /* with MM_STAGE_OFFDIAG: the sweep alone */
 #define MM_ISTAGE_ROUTE (1 << 21)         /* the route decision + the f64 re-reduce of the routed items alone */
+// q stage of a call that will NOT run the forward's off-diagonal reduce on this workspace (the backward's own q stage, the
+// value-and-gradient call: their sums come from the backward's sweeps): the degree-5/6 moment chain (1.4 ms at C3) is skipped and
+// s56 is poisoned with NaN, so that a forward reduce run on such a workspace by mistake fails loudly instead of reading stale sums
+#define MM_ISTAGE_NO_M56 (1 << 22)
 
 static inline int mm_num_pairs(int L, int flags) {
   return (flags & MM_FULL_OUTPUT_COV) ? L * (L + 1) / 2 : L;

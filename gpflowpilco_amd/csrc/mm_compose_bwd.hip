@@ -233,7 +233,7 @@ static int mm_moment_match_backward_impl(const void* packed, size_t packed_bytes
   hipStream_t s = (hipStream_t)stream;
   int rc = 0;
   if (!workspace_is_current) {
-    rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, bw + bl.f1, bw + bl.cross, nullptr,
+    rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags | MM_ISTAGE_NO_M56, bw + bl.f1, bw + bl.cross, nullptr,
                       workspace, workspace_bytes, status, stream);
     if (rc) return rc;
   } else if (status && mode != MMB_MODE_SWEEPS && verify_sums) {   // (SWEEPS: mm_moment_match_with_sums has just run the q stage itself;
@@ -417,8 +417,8 @@ int mm_moment_match_with_sums_impl(const void* packed, size_t packed_bytes, int 
   if (dtype != MM_F64 && dtype != MM_F32) return MM_E_DTYPE;
   if (dtype == MM_F32 && !mm_bwd_f32_supported(d)) return MM_E_DTYPE;
   flags &= ~(MM_STAGE_DIAG | MM_STAGE_OFFDIAG | MM_STAGE_FINALIZE | MM_WORKSPACE_CURRENT | MM_SUMS_CURRENT);
-  int rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, f1, cross_pre, nullptr, workspace, workspace_bytes,
-                        status, stream);
+  int rc = mm_q_forward(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags | MM_ISTAGE_NO_M56, f1, cross_pre, nullptr, workspace,
+                        workspace_bytes, status, stream);
   if (rc) return rc;
   rc = mm_moment_match_backward_impl(packed, packed_bytes, L, M, d, dtype, B, mu, Sigma, flags, nullptr, nullptr, nullptr, nullptr,
                                      nullptr, 0, workspace, workspace_bytes, bwd_ws, bwd_ws_bytes, status, stream, true, false,

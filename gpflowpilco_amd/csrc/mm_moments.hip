@@ -427,7 +427,9 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
   const int nwork = (int)nwork_ll;
   const int deg = mm_moment_deg(d);
   // collapse: not with the forced worst tier (bench.py --recipe worst times the dense path)
-  const int allow = (flags & MM_FORCE_WORST_TIER) ? 0 : 1;
+  // ... nor where no forward reduce follows (MM_ISTAGE_NO_M56: s12 is then only the scale of the backward's route decision, for
+  // which orders 0..2 are ample)
+  const int allow = (flags & (MM_FORCE_WORST_TIER | MM_ISTAGE_NO_M56)) ? 0 : 1;
   const int col_deg3 = mm_mono_offset(3, d);                // first column of a cubic monomial
   // rows of every latent's GEMM ordered with the collapsed items first (none collapse: no cubic / quartic block at all)
   const bool some = allow && deg >= 4;
@@ -459,6 +461,12 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
 #undef MM_SPOLY
   e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
+  if (flags & MM_ISTAGE_NO_M56) {
+    // (mm_common.h: no forward reduce follows on this workspace) -- poison instead of compute: all-ones doubles are NaN
+    if (mm_moment56_cols(d) <= 0 || wl.Po <= 0) return 0;
+    const hipError_t em = hipMemsetAsync(ws + wl.s56, 0xFF, (size_t)B * wl.Po * sizeof(double), stream);
+    return em == hipSuccess ? 0 : (int)em;
+  }
   // orders 5 and 6 of the collapsed items (f32 moments on the bf16 matrix pipe: mm_moments6.hip) -> s56, estS
   return mm_launch_moments56(packed, ml, ws, wl, B, L, d, some ? 1 : 0, stream);
 }
