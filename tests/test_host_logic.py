@@ -245,3 +245,30 @@ def test_workspace_generation_counts_every_request():
   pm.workspace(5, fl)
   assert pm.workspace_generation(4, fl) == 2 and pm.workspace_generation(5, fl) == 1            # per batch size
   assert pm.workspace_generation(4, ops.make_flags(False, True)) == 0                           # per pair layout
+
+
+def test_partially_symmetric_contraction_of_the_degree_5_6_moments():
+  """The algorithm of csrc/mm_moments6.hip:k_spoly56 restated in numpy (tools/spoly56_proto.py): <N_n, G^{(x)n} Q_n> from PACKED
+  symmetric moments -- G applied one index at a time with the colex rank arithmetic and the insertion tables the kernel reads,
+  sequentially and meeting in the middle (three indices from the column side, n - 3 from the row side, both multinomials) --
+  against the double sum  sum_ij w_i w'_j (zc_i^T G zc'_j)^n.  (The kernel itself is checked end to end on the GPU; this pins the
+  index tables and the identity it relies on.)"""
+  import importlib.util, os
+  import numpy as np
+  spec = importlib.util.spec_from_file_location("spoly56_proto", os.path.join(os.path.dirname(__file__), "..", "tools", "spoly56_proto.py"))
+  sp = importlib.util.module_from_spec(spec); spec.loader.exec_module(sp)
+  rng = np.random.default_rng(7)
+  for d in (8, 3):
+    ins, last, mult = sp.build_tables(d)
+    M = 25
+    zc, zc2 = rng.standard_normal((M, d)), rng.standard_normal((M, d))
+    w, w2 = rng.standard_normal(M), rng.standard_normal(M)
+    G = rng.standard_normal((d, d)) * 0.3
+    bij = zc @ G @ zc2.T
+    for n in (5, 6):
+      ts = sp.tuples(n, d)
+      mono = lambda z: np.stack([np.prod(z[:, list(t)], axis=1) for t in ts], axis=1)
+      Nn, Qn = w @ mono(zc), w2 @ mono(zc2)
+      ref = float(w @ bij ** n @ w2)
+      assert abs(sp.contract(Nn, Qn, G, n, d, ins, last, mult) - ref) <= 1e-9 * max(abs(ref), 1.0)
+      assert abs(sp.contract_mitm(Nn, Qn, G, n, d, ins, last) - ref) <= 1e-9 * max(abs(ref), 1.0)
