@@ -250,15 +250,14 @@ __global__ __launch_bounds__(256, 2) void k_wmom56_gemm(const unsigned short* __
 // lane -- and the WAVE's I, its largest index and the output row are scalars: no per-lane predicate, no integer division, the
 // tuple-rank arithmetic on the scalar unit.  Measured at C3, BASELINE recipe (6400 collapsed items, tools/q_stage_kernels.py): one
 // flat loop over (I, J') pairs with per-lane bounds 1.19 ms; this form with G in 64 scalar registers (spilled to VGPR lanes)
-// 1.11 ms; G in vector registers, 12 waves 0.88 ms (8 waves 1.03) -- of which 0.16 ms are the loads and the launch of 7168
-// workgroups.  It runs at ~800 cycles per 64-lane work unit and SIMD: the unit's serial chain (decode, gathers, 8-deep FMA chains,
-// branchy stores), not its instruction count.
+// 1.11 ms; G in vector registers, 12 waves 0.88 ms (8 waves 1.03); G output-fastest per side (aligned register pairs for the packed
+// FMAs: 90 -> 27 moves per step, 202 -> 138 VGPRs) 0.83 ms -- of which 0.16 ms are the loads and the launch of 7168 workgroups.
 // ---------------------------------------------------------------------------------------------
 // MODE 0: store T_{k+1}; 1: X's last step (k = 2 -> 3): store mult3(I3) multJ(J') value, row stride xs; 2: Y's last step fused
 // with the dot against X (acc += value * X[J'][row])
 #ifndef MM6_THREADS
-#define MM6_THREADS 512       // 8 waves = 2 per SIMD: 256 VGPRs (G alone is 64, two chunks' gathers, sums and offsets 64 more)
-#endif
+#define MM6_THREADS 768       // 12 waves = 3 per SIMD (138 VGPRs with two chunks per unit).  Measured: 8 waves 0.94 ms, 12 waves 0.83,
+#endif                        // 16 waves with one chunk per unit 0.83
 #define MM6_WAVES (MM6_THREADS / 64)
 // NC: chunks of 64 values of J' per work unit (lane handles J' = c 64 NC + lane + 64 q, q < NC): the unit's scalar work -- its
 // decode, the tuple's largest index, the per-i branches and row offsets -- is shared by the NC chunks, and their FMA chains
@@ -272,20 +271,22 @@ __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin
                                          int xs, float& acc, int wave, int lane) {
   constexpr int NC = MM6_NC;
   const int chunks = (nJp + 64 * NC - 1) / (64 * NC);
-  // the outputs i = I0 .. 7 of one (I, J'): eight-term dot products of the gathered v with G's rows (columns: TRANSG), the
-  // chains interleaved (one chain per i inside its own branch ran at the FMA's latency, not its issue rate)
+  // the outputs i = I0 .. 7 of one (I, J'): eight-term dot products of the gathered v with the matrix the caller loaded into G as
+  // G[j * 8 + i] = (coefficient of v_j in output i) -- output index fastest, so that the packed FMA over an output pair (i, i + 1)
+  // reads an aligned register pair (row-major, the X side needed a v_mov pair per packed FMA: 90 of them per step) -- the chains
+  // interleaved (one chain per i inside its own branch ran at the FMA's latency, not its issue rate)
   auto dots = [&](auto i0c, const float (&v)[NC][8], float (&s)[NC][8]) __attribute__((always_inline)) {
     constexpr int I0 = decltype(i0c)::value;
 #pragma unroll
     for (int q = 0; q < NC; ++q)
 #pragma unroll
-      for (int i = I0; i < 8; ++i) s[q][i] = (TRANSG ? G[0 * 8 + i] : G[i * 8 + 0]) * v[q][0];
+      for (int i = I0; i < 8; ++i) s[q][i] = G[0 * 8 + i] * v[q][0];
 #pragma unroll
     for (int j = 1; j < 8; ++j)
 #pragma unroll
       for (int q = 0; q < NC; ++q)
 #pragma unroll
-        for (int i = I0; i < 8; ++i) s[q][i] = fmaf(TRANSG ? G[j * 8 + i] : G[i * 8 + j], v[q][j], s[q][i]);
+        for (int i = I0; i < 8; ++i) s[q][i] = fmaf(G[j * 8 + i], v[q][j], s[q][i]);
   };
   // lanes past the end of J' (of chunk q) gather a valid (clamped) entry and store / add nothing
   auto body = [&](int I, int t, const int (&Jp)[NC], const bool (&jv)[NC], const int (&off)[NC][8], const float (&mj)[NC]) __attribute__((always_inline)) {
@@ -399,7 +400,9 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   if (tid < 64) {
     const int i = tid >> 3, j = tid & 7;
     const double* pm = pairmat + ((size_t)b * P + (L + po)) * (d * d + 1);
-    Gl[tid] = (i < d && j < d) ? (float)pm[i * d + j] : 0.0f;
+    const float g = (i < d && j < d) ? (float)pm[i * d + j] : 0.0f;
+    Gl[tid] = g;                                         // row-major: the Y side's (G^T applied: output j' takes G[m][j'])
+    Gl[64 + j * 8 + i] = g;                              // transposed: the X side's (output i takes G[i][j])
   }
   // what the skipped tiles leave out, in the units of the sweep's error estimate (mm_common.h: MM_C6_SYS2)
   double s2r = 0.0, s2c = 0.0;
@@ -410,11 +413,13 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   }
   __syncthreads();
   float G[64];
+  auto load_G = [&](int transposed) __attribute__((always_inline)) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const float4 g4 = *reinterpret_cast<const float4*>(Gl + 4 * q);
-    G[4 * q] = g4.x; G[4 * q + 1] = g4.y; G[4 * q + 2] = g4.z; G[4 * q + 3] = g4.w;
-  }
+    for (int q = 0; q < 16; ++q) {
+      const float4 g4 = *reinterpret_cast<const float4*>(Gl + 64 * transposed + 4 * q);
+      G[4 * q] = g4.x; G[4 * q + 1] = g4.y; G[4 * q + 2] = g4.z; G[4 * q + 3] = g4.w;
+    }
+  };
   const short* tabi = (const short*)tab;
   const float* mult2 = (const float*)(tab + (size_t)tb.n_i16 * 2) + tb.mult2;
   const float* mult3 = (const float*)(tab + (size_t)tb.n_i16 * 2) + tb.mult3;
@@ -423,12 +428,14 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   if (need6) {
     const float* Q6 = nq + n56 + sy[5];
     const float* N6 = nq + sy[5];
+    load_G(1);
     mm6_step<0, false, 0>(Q6, sy[6], 1, Bf, sy[5], tabi + tb.ins[5], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
     mm6_step<1, false, 0>(Bf, sy[5], sy[1], A, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
     mm6_step<2, false, 1>(A, sy[4], sy[2], X, sy[3], tabi + tb.ins[3], d, G, mult3, xs, dummy, wave, lane);
     __syncthreads();
+    load_G(0);
     mm6_step<0, true, 0>(N6, sy[6], 1, Bf, sy[5], tabi + tb.ins[5], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
     mm6_step<1, true, 0>(Bf, sy[5], sy[1], A, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
@@ -440,12 +447,14 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   if (need5) {
     const float* Q5 = nq + n56;
     const float* N5 = nq;
+    load_G(1);
     mm6_step<0, false, 0>(Q5, sy[5], 1, Bf, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
     mm6_step<1, false, 0>(Bf, sy[4], sy[1], A, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
     mm6_step<2, false, 1>(A, sy[3], sy[2], X, sy[2], tabi + tb.ins[2], d, G, mult2, xs, dummy, wave, lane);
     __syncthreads();
+    load_G(0);
     mm6_step<0, true, 0>(N5, sy[5], 1, Bf, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
     mm6_step<1, true, 2>(Bf, sy[4], sy[1], X, sy[3], tabi + tb.ins[3], d, G, nullptr, xs, acc5, wave, lane);
@@ -502,7 +511,7 @@ int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, c
   }
   int sy[7];
   for (int k = 0; k < 7; ++k) sy[k] = mm_mono_count(k, d);
-  size_t nfl = (size_t)2 * (sy[5] + sy[6]) + (size_t)sy[3] * (sy[3] + 1) + (size_t)sy[2] * sy[4] + (size_t)sy[1] * sy[5] + 6 * MM6_WAVES + 64 + 16;
+  size_t nfl = (size_t)2 * (sy[5] + sy[6]) + (size_t)sy[3] * (sy[3] + 1) + (size_t)sy[2] * sy[4] + (size_t)sy[1] * sy[5] + 6 * MM6_WAVES + 128 + 16;
   nfl = (nfl + 1) & ~(size_t)1;                           // (the f64 reduction scratch behind it stays 8-byte aligned)
   const size_t shm = nfl * sizeof(float);
   static bool attr2_done[64] = {};
