@@ -15,13 +15,14 @@
 //                   both operands are read 8 consecutive m per lane (what is [row][m], the table [monomial][m]): no transposes;
 //   k_spoly56     : s56[b][po] = C2 <N_5, G^{(x)5} Q_5> + C3 <N_6, G^{(x)6} Q_6> from the PACKED symmetric moments, G applied one
 //                   index at a time on tensors symmetric in the transformed and in the untransformed indices separately
-//                   (tools/spoly56_proto.py: 0.54 M FMA per item at d = 8 against 15 M for full tensors), f32, one 1024-thread
+//                   (tools/spoly56_proto.py: 0.54 M FMA per item at d = 8 against 15 M for full tensors), f32, one MM6_THREADS-thread
 //                   workgroup per collapsed (b, pair); also estS (mm_common.h: MM_C6_SYS2).
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include "mm_common.h"
 #include "mm_mono.h"
 #include "mm_f32_tile.h"
+#include <atomic>
 #include <type_traits>
 
 __device__ __forceinline__ void mm6_decode_pair_o(int lp, int L, int& a, int& a2) {
@@ -496,11 +497,15 @@ int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, c
     // (offsets inside wsp / Zm56 are 32-bit element counts)
     if ((size_t)B * wl.Po * 4 * wl.Mp >= 0xffffffffull || (size_t)L * 2 * N56p * wl.Mp >= 0xffffffffull) return MM_E_DIM;
     const size_t shm = 2 * MM6_STAGE_BYTES + MM6_TB * sizeof(int);
-    static bool attr_done[64] = {};
+    // (raise the dynamic-LDS limit once per device: the call is slow)
+    static std::atomic<unsigned long long> attr_done{0ull};
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr_done[dev]) {
-      if (hipFuncSetAttribute((const void*)k_wmom56_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess) return MM_E_ARG;
-      attr_done[dev] = true;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+    if (!bit || !(attr_done.load() & bit)) {
+      const hipError_t ea = hipFuncSetAttribute((const void*)k_wmom56_gemm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+      if (ea != hipSuccess) return (int)ea;
+      attr_done.fetch_or(bit);
     }
     hipLaunchKernelGGL(k_wmom56_gemm, dim3((int)nwork_ll), dim3(256), shm, stream, (const unsigned short*)(ws + wl.wsp),
                        (const unsigned short*)(packed + ml.Zm56), N56p, L, wl.Mp, B, wl.Po, nrb, ncb, (int)nwork_ll,
@@ -514,11 +519,14 @@ int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, c
   size_t nfl = (size_t)2 * (sy[5] + sy[6]) + (size_t)sy[3] * (sy[3] + 1) + (size_t)sy[2] * sy[4] + (size_t)sy[1] * sy[5] + 6 * MM6_WAVES + 128 + 16;
   nfl = (nfl + 1) & ~(size_t)1;                           // (the f64 reduction scratch behind it stays 8-byte aligned)
   const size_t shm = nfl * sizeof(float);
-  static bool attr2_done[64] = {};
+  static std::atomic<unsigned long long> attr2_done{0ull};
   int dev = 0;
-  if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 && !attr2_done[dev]) {
-    if (hipFuncSetAttribute((const void*)k_spoly56, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return MM_E_ARG;
-    attr2_done[dev] = true;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 64;
+  const unsigned long long bit2 = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+  if (!bit2 || !(attr2_done.load() & bit2)) {
+    const hipError_t ea = hipFuncSetAttribute((const void*)k_spoly56, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (ea != hipSuccess) return (int)ea;
+    attr2_done.fetch_or(bit2);
   }
   hipLaunchKernelGGL(k_spoly56, dim3(wl.Po, B), dim3(MM6_THREADS), shm, stream, (const float*)(ws + wl.mom56), N56p,
                      (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zmax2), (const unsigned int*)(ws + wl.amax),
