@@ -249,3 +249,29 @@ def test_two_caller_streams_share_nothing(device):
     assert torch.equal(got, ref)
   for got, ref in zip(eager_during, wantB):
     assert torch.equal(got, ref)
+
+
+def test_a_forward_reduce_on_a_value_and_gradient_workspace_fails_loudly(device):
+  """mm_moment_match_with_sums runs a q stage WITHOUT the forward-only part of the moment chain (csrc/mm_common.h:
+  MM_ISTAGE_NO_M56: the value comes from the backward's sweeps) and poisons the degree-5/6 sums on the workspace: a forward reduce
+  run on that workspace by mistake (the stage API lets a caller do it) must not return stale numbers silently -- every
+  off-diagonal entry of a collapsed pair comes back NaN -- while the value-and-gradient call itself is unaffected."""
+  L, M, d, B = 3, 300, 4, 4
+  syn = make_svgp(L, M, d, seed=4242, device=str(device), ls_bounds=(0.7, 2.0))
+  pm = syn.to_model(device).packed(torch.float32, True, device)
+  mu, S = make_inputs(B, d, seed=11, scale=0.12, lo=0.3, hi=0.7)
+  mu, S = to_dev(mu, device, torch.float32), to_dev(S, device, torch.float32)
+  want = [t.clone() for t in ops.moment_match(pm, mu, S)]
+  flags = ops.make_flags(True, True)
+  collapsed, total, _ = ops.offdiag_stats(pm, B, flags)
+  assert collapsed == total > 0                                   # (narrow state: every off-diagonal item is collapsed)
+  f1, Sff, cross, sums, gen = ops.moment_match_with_sums(pm, mu, S)
+  assert torch.isfinite(Sff).all()
+  assert float((Sff - want[1]).abs().max()) < 2e-5 * float(want[1].abs().max())
+  bad = ops.Q_reduce_forward(pm, B, flags)                        # the mistake
+  off = ~torch.eye(L, dtype=torch.bool, device=device)
+  assert torch.isnan(bad[:, off]).all() and torch.isfinite(torch.diagonal(bad, dim1=-2, dim2=-1)).all()
+  # a fresh forward puts the workspace right again
+  again = ops.moment_match(pm, mu, S)
+  for got, ref in zip(again, want):
+    assert torch.equal(got, ref)
