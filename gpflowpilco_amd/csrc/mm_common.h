@@ -51,7 +51,10 @@ static inline int mm_moment_cols(int d) { return mm_round_up_int(mm_mono_offset(
 // inside a degree; rounded up to the 128-column tile of the bf16 GEMM.  0 for d > 8 (no collapse).
 // Layout: [degree 5 | pad to 128][degree 6 | pad to 128] -- a 128-column block of the GEMM holds one degree only, so that the
 // degree-6 blocks can be formed for the rows that need them alone (MM_C6_X5_2 below).
-static inline int mm_moment56_off6(int d) { return d <= 8 ? mm_round_up_int(mm_mono_count(5, d), 128) : 0; }
+// (the table also carries the degree-4 monomials, in front: [degree 4 | pad][degree 5 | pad][degree 6 | pad] -- the quartic term of
+// p6 comes from the bf16 GEMM too; the names keep their "56")
+static inline int mm_moment56_off5(int d) { return d <= 8 ? mm_round_up_int(mm_mono_count(4, d), 128) : 0; }
+static inline int mm_moment56_off6(int d) { return d <= 8 ? mm_moment56_off5(d) + mm_round_up_int(mm_mono_count(5, d), 128) : 0; }
 static inline int mm_moment56_cols(int d) { return d <= 8 ? mm_moment56_off6(d) + mm_round_up_int(mm_mono_count(6, d), 128) : 0; }
 // Index tables of the degree-5/6 contraction (k_spoly56, mm_moments6.hip; functions of d alone, written at pack time), with
 // sym(k) = mm_mono_count(k, d) sorted index tuples of length k in colex rank order:
@@ -143,7 +146,7 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 // THE MOMENT COLLAPSE (d <= 8; round 5: to degree 6).  For a collapsed (b, pair) the polynomial
 //     p6(x) = x^3 (C0 + C1 x + C2 x^2 + C3 x^3)  ~  r(x) = e^x - 1 - x - x^2/2     on |x| <= MM_C6_MAX = 1/4
 // (near-minimax, |p6 - r| <= 5.8e-10 there: it IS the tile kernel's degree-3 tier, MMRem<3>) is taken from weight moments
-// against model-constant monomial tables -- degrees <= 4 in f64 (k_wmom_gemm, k_spoly), degrees 5 and 6 from a bf16 2-way
+// against model-constant monomial tables -- degrees <= 3 in f64 (k_wmom_gemm, k_spoly), degrees 4, 5 and 6 from a bf16 2-way
 // split GEMM on the matrix pipe with f32 accumulation and a partially-symmetric f32 contraction (mm_moments6.hip) -- and the
 // tile kernel skips every wave tile whose max|b| <= 1/4 after a one-MFMA screening product, reducing the correction r - p6 on
 // the others.  Round 4 stopped at degree 4 (first tier |b| <= 1/20): on the BASELINE recipe 9 % of the wave tiles could be
@@ -164,7 +167,7 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
 // what exists.  (The pilco recipe's items sit at X <= 0.05: without this the degree-5/6 work -- all of it useless there -- took
 // the step from 5.0 to 6.2 ms.)
 #define MM_C6_X5_2 (1.0f / 256.0f)      /* X <= 1/16: no degree-6 term */
-#define MM_C6_X4_2 (1.0f / 1600.0f)     /* X <= 1/40: neither degree 5 nor 6 (the f64 degree-3/4 moments only).  (At 1/32 the dropped
+#define MM_C6_X4_2 (1.0f / 1600.0f)     /* X <= 1/40: neither degree 5 nor 6 (the f64 cubic and the bf16 quartic moments only).  (At 1/32 the dropped
                                            C2 X^5, priced like p6's own error in the route estimate, sent 0.6 % of the pilco recipe's
                                            items -- |what| |what'| ~ 1e7 x the covariance scale there -- to the f64 re-reduce: +0.5 ms) */
 #define MM_C6_MAX 0.25f
@@ -276,7 +279,7 @@ struct MMWorkspaceLayout {
                    //              to degree 5 | to degree 4 | not collapsed], and the counts {collapsed, needing degree 5, needing
                    //              degree 6} -- every column block of the GEMMs is formed for the rows that read it only
   size_t s12;      // [B][Po] f64  the polynomial part of the off-diagonal sums from the moments:
-                   //              orders 0..2 always, orders 3 and 4 as well where the (b, pair) is collapsed
+                   //              orders 0..2 always, order 3 as well where the (b, pair) is collapsed (orders 4..6: s56)
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
   size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i expm1(delta_ij) q_j  (+ q^T C q)
   size_t mu64;     // [B][d] f64    the state mean as the q stage read it (mm_route.hip re-derives A_i = G^T (z_i - mu) in f64)
@@ -290,8 +293,8 @@ struct MMWorkspaceLayout {
   size_t mom56;    // [B][Po][2][N56p] f32: sum_m what_m zc_m^alpha over the degree-5 and degree-6 monomials (collapsed items)
   size_t estS;     // [B][Po] f32: MM_C6_SYS2 sum what^2 sum what'^2 of a collapsed item (0 otherwise): what its skipped tiles leave
                    //              out, in the units of the sweep's error estimate estO (k_spoly56 writes, k_route_decide adds)
-  size_t s56;      // [B][Po] f64: C2 <N_5, G^5 Q_5> + C3 <N_6, G^6 Q_6> of a collapsed item (0 otherwise): the degree-5/6 part of p6 from the
-                   //              f32 moments.  Kept apart from s12: an item the accuracy contract re-reduces in f64 (mm_route.hip) takes
+  size_t s56;      // [B][Po] f64: C1 <N_4, G^4 Q_4> + C2 <N_5, G^5 Q_5> + C3 <N_6, G^6 Q_6> of a collapsed item (0 otherwise): the degree-4..6
+                   //              part of p6 from the f32 moments.  Kept apart from s12: an item the accuracy contract re-reduces in f64 (mm_route.hip) takes
                    //              those two orders from the re-reduce instead (k_finalize skips s56 where rflag is set)
   size_t f1s;      // [B][L] T      rollout scratch outputs
   size_t Sffs;     // [B][L][L] T

@@ -11,9 +11,9 @@
 // Orders 0..2 (1 + b + b^2/2) are ALWAYS taken this way: in f32 it is the rounding of the linear term that
 // costs the digits of S (DESIGN.md "fp32 error budget").  For d <= 8 a (b, pair) whose Cauchy-Schwarz bound
 // max_i |A_i| max_j |zc'_j| is <= 1/2 (MM_COLLAPSE_BOUND2) is COLLAPSED (mm_common.h): the polynomial p6(x) = x^3 (C0 + .. + C3 x^3) --
-// the tile kernel's own degree-3 tier of the remainder, |p6 - r| <= 5.8e-10 on |x| <= 1/4 -- comes from moments too: its cubic and
-// quartic terms from the f64 tables of THIS file (degree <= 4, 495 columns at d = 8), its degree-5 and degree-6 terms from bf16
-// split tables on the matrix pipe (mm_moments6.hip).  The tile kernel skips every wave tile with max|b| <= 1/4 after a one-MFMA
+// the tile kernel's own degree-3 tier of the remainder, |p6 - r| <= 5.8e-10 on |x| <= 1/4 -- comes from moments too: its cubic
+// term from the f64 tables of THIS file (the forward forms the columns to degree 3; the table goes to degree 4, 495 columns at
+// d = 8, for the backward's aggregates), its degree-4, -5 and -6 terms from bf16 split tables on the matrix pipe (mm_moments6.hip).  The tile kernel skips every wave tile with max|b| <= 1/4 after a one-MFMA
 // screening product and reduces only the correction r(x) - p6(x) on the others.
 //
 //   k_wmom_perm : per latent the rows of its GEMMs ordered by collapse class (degree 6 | 5 | 4 | not collapsed): every column block of
@@ -313,9 +313,9 @@ __global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, i
     if (tid < DK) dmu[tid] = (tid < d && !rcen) ? (double)mu[(size_t)b * d + tid] - zbar[a * d + tid] : 0.0;
   }
   __syncthreads();
-  const bool coll = allow_collapse && deg >= 4 &&
+  const bool coll = allow_collapse && deg >= 3 &&
                     mm_collapse_bound2(amax[(size_t)b * Po + po], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
-  const int nmax = coll ? 4 : 2;
+  const int nmax = coll ? deg : 2;                         // (deg = 3: the quartic term is mm_moments6.hip's)
   double Gr[DK == 8 ? 64 : 1];
   if constexpr (DK == 8) {
 #pragma unroll
@@ -421,18 +421,22 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
   const double* Zm = (const double*)(packed + ml.Zm);
   double* mom = (double*)(ws + wl.mom);
   // per latent a GEMM with (L - 1) B rows (k_wmom_gemm): row blocks, column blocks, k slices
-  const int nrb = ((L - 1) * B + MM_GEMM_RB - 1) / MM_GEMM_RB, ncb = (ml.KMp + MM_GEMM_NB - 1) / MM_GEMM_NB;
+  // (the forward reads the f64 moments to degree 3 only: the quartic term of a collapsed item comes from the bf16 GEMM with the
+  // degree-5/6 ones, mm_moments6.hip -- emulated on the BASELINE recipe it costs <= 4.7e-7 of the covariance scale there, where the
+  // CUBIC term would cost 1e-5; the backward's full GEMM, mm_launch_wmom_full, still forms every column)
+  const int deg = mm_moment_deg(d) >= 4 ? 3 : mm_moment_deg(d);
+  const int ncol_fwd = mm_mono_offset(deg + 1, d);
+  const int nrb = ((L - 1) * B + MM_GEMM_RB - 1) / MM_GEMM_RB, ncb = (ncol_fwd + MM_GEMM_NB - 1) / MM_GEMM_NB;
   const long long nwork_ll = (long long)L * ncb * MM_MOM_SPLIT * nrb;
   if (nwork_ll <= 0 || nwork_ll > 0x7fffffffLL) return MM_E_DIM;
   const int nwork = (int)nwork_ll;
-  const int deg = mm_moment_deg(d);
   // collapse: not with the forced worst tier (bench.py --recipe worst times the dense path)
   // ... nor where no forward reduce follows (MM_ISTAGE_NO_M56: s12 is then only the scale of the backward's route decision, for
   // which orders 0..2 are ample)
   const int allow = (flags & (MM_FORCE_WORST_TIER | MM_ISTAGE_NO_M56)) ? 0 : 1;
   const int col_deg3 = mm_mono_offset(3, d);                // first column of a cubic monomial
   // rows of every latent's GEMM ordered with the collapsed items first (none collapse: no cubic / quartic block at all)
-  const bool some = allow && deg >= 4;
+  const bool some = allow && mm_moment_deg(d) >= 4;
   if (some) {
     hipLaunchKernelGGL(k_wmom_perm, dim3(L), dim3(1024), 0, stream, (const unsigned int*)(ws + wl.amax),
                        (const double*)(packed + ml.zmax2), L, B, wl.Po, (int*)(ws + wl.gperm));

@@ -1,11 +1,12 @@
-// Degree-5 and degree-6 weight moments of the collapsed f32 off-diagonal pairs and their contraction (gfx950, d <= 8).
+// Degree-4, -5 and -6 weight moments of the collapsed f32 off-diagonal pairs and their contraction (gfx950, d <= 8).
 //
 // mm_common.h ("THE MOMENT COLLAPSE"): a collapsed (b, pair) takes p6(x) = x^3 (C0 + C1 x + C2 x^2 + C3 x^3) ~ r(x) on |x| <= 1/4
-// from weight moments.  Degrees <= 4 are f64 (mm_moments.hip).  Degrees 5 and 6 contribute <= ~3e-4 of the batch element's
-// covariance scale on the items that are collapsed, so f32 accuracy is ample -- and an f64 GEMM over their 792 + 1716 columns
-// (d = 8) would cost 5x the whole f64 moment GEMM.  Here:
+// from weight moments.  Degrees <= 3 are f64 (mm_moments.hip).  Degrees 5 and 6 contribute <= ~3e-4 of the batch element's
+// covariance scale on the items that are collapsed, degree 4 <= 6e-3, so f32 accuracy is ample -- emulated on the BASELINE recipe the
+// 2-way split's rounding is <= 1.1e-8 (degrees 5, 6) and <= 4.7e-7 (degree 4) of that scale, where the CUBIC term would cost 1.1e-5
+// (it stays f64) -- and an f64 GEMM over their 330 + 792 + 1716 columns (d = 8) would cost 6x the f64 moment GEMM that is left.  Here:
 //
-//   k_pack_zm56   : the monomials of zc of degree 5 and 6, bf16 2-way split (h, m), monomial-major [L][2][N56p][Mp], and the
+//   k_pack_zm56   : the monomials of zc of degree 4, 5 and 6, bf16 2-way split (h, m), monomial-major [L][2][N56p][Mp], and the
 //                   contraction's index tables (MMTab56) -- pack time;
 //   k_wmom56_gemm : mom56[(b, pair, side)][c] = sum_m what_m zc_m^alpha(c) over the COLLAPSED rows of every latent's GEMM
 //                   (k_wmom_perm puts them first): the three products hh + hm + mh on v_mfma_f32_32x32x16_bf16 with f32
@@ -13,7 +14,7 @@
 //                   128 x 128 output tile per workgroup (4 waves x 64 x 64), K blocks of 32 through a double-buffered LDS image
 //                   filled by global_load_lds_dwordx4 (XOR-swizzled on the source side: conflict-free ds_read_b128 fragments);
 //                   both operands are read 8 consecutive m per lane (what is [row][m], the table [monomial][m]): no transposes;
-//   k_spoly56     : s56[b][po] = C2 <N_5, G^{(x)5} Q_5> + C3 <N_6, G^{(x)6} Q_6> from the PACKED symmetric moments, G applied one
+//   k_spoly56     : s56[b][po] = C1 <N_4, G^{(x)4} Q_4> + C2 <N_5, G^{(x)5} Q_5> + C3 <N_6, G^{(x)6} Q_6> from the PACKED symmetric moments, G applied one
 //                   index at a time on tensors symmetric in the transformed and in the untransformed indices separately
 //                   (tools/spoly56_proto.py: 0.54 M FMA per item at d = 8 against 15 M for full tensors), f32, one MM6_THREADS-thread
 //                   workgroup per collapsed (b, pair); also estS (mm_common.h: MM_C6_SYS2).
@@ -38,13 +39,15 @@ __device__ __forceinline__ void mm6_decode_pair_o(int lp, int L, int& a, int& a2
 __global__ __launch_bounds__(256) void k_pack_zm56(char* packed, MMModelLayout lay, int L, int M, int d, int N56p,
                                                    const double* __restrict__ Z) {
   const int c = blockIdx.x, a = blockIdx.y, tid = threadIdx.x;
-  const int n5 = mm_binom_i(d + 4, 5), n6 = mm_binom_i(d + 5, 6);
-  const int off6 = ((n5 + 127) / 128) * 128;            // mm_moment56_off6(d): a 128-column block holds one degree only
+  const int n4 = mm_binom_i(d + 3, 4), n5 = mm_binom_i(d + 4, 5), n6 = mm_binom_i(d + 5, 6);
+  const int off5 = ((n4 + 127) / 128) * 128;            // mm_moment56_off5 / _off6 (d): a 128-column block holds one degree only
+  const int off6 = off5 + ((n5 + 127) / 128) * 128;
   const double* zbar = (const double*)(packed + lay.zbar) + (size_t)a * d;
   unsigned short* oh = (unsigned short*)(packed + lay.Zm56) + (((size_t)a * 2 + 0) * N56p + c) * lay.Mp;
   unsigned short* om = (unsigned short*)(packed + lay.Zm56) + (((size_t)a * 2 + 1) * N56p + c) * lay.Mp;
   int n = 0, k[6] = {0, 0, 0, 0, 0, 0};
-  if (c < n5) { n = 5; mm_mono_unrank(c, 5, k); }
+  if (c < n4) { n = 4; mm_mono_unrank(c, 4, k); }
+  else if (c >= off5 && c < off5 + n5) { n = 5; mm_mono_unrank(c - off5, 5, k); }
   else if (c >= off6 && c < off6 + n6) { n = 6; mm_mono_unrank(c - off6, 6, k); }
   for (int m = tid; m < lay.Mp; m += 256) {
     float vf = 0.0f;
@@ -125,7 +128,7 @@ int mm_launch_pack56(char* packed, const MMModelLayout& lay, int L, int M, int d
 #define MM6_STAGE_BYTES 32768
 
 __global__ __launch_bounds__(256, 2) void k_wmom56_gemm(const unsigned short* __restrict__ wsp, const unsigned short* __restrict__ Zm56,
-                                                        int N56p, int L, int Mp, int B, int Po, int nrb, int ncb, int nwork, int ncb5,
+                                                        int N56p, int L, int Mp, int B, int Po, int nrb, int ncb, int nwork, int cb5, int cb6,
                                                         const int* __restrict__ gperm, float* __restrict__ mom56) {
   // work item -> (latent, column block, row block), row block fastest: the workgroups that run together on an XCD share a table
   // column block (and, across column blocks, the latent's weight rows)
@@ -137,9 +140,9 @@ __global__ __launch_bounds__(256, 2) void k_wmom56_gemm(const unsigned short* __
   const int cb = wi % ncb; wi /= ncb;
   const int a = wi;
   const int R = (L - 1) * B;
-  // rows of this latent's GEMM that read this column block (k_wmom_perm: they come first): the degree-5 blocks [0, ncb5) are read
-  // by the items collapsed to degree >= 5, the degree-6 blocks by those collapsed to degree 6
-  const int ncoll = gperm[(size_t)L * R + (cb < ncb5 ? 1 : 2) * L + a];
+  // rows of this latent's GEMM that read this column block (k_wmom_perm: they come first): the degree-4 blocks [0, cb5) are read by
+  // every collapsed item, the degree-5 blocks [cb5, cb6) by those collapsed to degree >= 5, the degree-6 blocks by those to degree 6
+  const int ncoll = gperm[(size_t)L * R + (cb < cb5 ? 0 : (cb < cb6 ? 1 : 2)) * L + a];
   if (rb * MM6_TB >= ncoll) return;
   const int* perm = gperm + (size_t)a * R;
   extern __shared__ __align__(1024) char lds[];        // 2 stages x 32 KB, then 128 ints
@@ -306,10 +309,12 @@ __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin
       if (i >= t && i < d) {                             // scalar compare: t, d are wave-uniform
         const int orow = I + mm_binom_i(i + K, K + 1);   // rank of I with i appended (colex)
         float m3 = 1.0f;
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 1 && K == 2) {
           // I = (a, t) with a = I - C(t + 1, 2): multinomial of the sorted triple (a, t, i)
           const int a = I - ((t * (t + 1)) >> 1);
           m3 = a == t ? (i == t ? 1.0f : 3.0f) : (i == t ? 3.0f : 6.0f);
+        } else if constexpr (MODE == 1 && K == 1) {
+          m3 = i == t ? 1.0f : 2.0f;                     // I = (t): multinomial of the sorted pair (t, i)
         }
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
@@ -379,8 +384,9 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
 #pragma unroll
   for (int k = 0; k < 7; ++k) sy[k] = mm_binom_i(d + k - 1, k);
   // LDS (floats): nq [2][sy5 + sy6] | X [sy3][sy3 + 1] | A [sy2 sy4] | Bf [sy1 sy5] | red
-  const int n56 = sy[5] + sy[6];
-  const int off6 = ((sy[5] + 127) / 128) * 128;         // mm_moment56_off6(d): first column of the degree-6 block in mom56
+  const int n56 = sy[4] + sy[5] + sy[6];                // (degrees 4, 5, 6 of one side)
+  const int off5 = ((sy[4] + 127) / 128) * 128;         // mm_moment56_off5 / _off6 (d): first columns of the degree-5 / -6 blocks in mom56
+  const int off6 = off5 + ((sy[5] + 127) / 128) * 128;
   const bool need5 = bound2 > MM_C6_X4_2, need6 = bound2 > MM_C6_X5_2;   // (mm_common.h: what the item's bound leaves negligible)
   const int xs = sy[3] + 1;                              // X's row stride: odd at d = 8 (121): the fused dot reads it along a column
   float* nq = sm6;
@@ -390,14 +396,17 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   float* red = sm6 + ((2 * n56 + sy[3] * xs + sy[2] * sy[4] + sy[1] * sy[5] + 1) & ~1);   // [MM6_WAVES][3] doubles (8-byte aligned)
   for (int idx = tid; idx < 2 * n56; idx += MM6_THREADS) {
     const int side = idx >= n56, c = idx - side * n56;
-    const bool six = c >= sy[5];
+    const int dg = c < sy[4] ? 4 : (c < sy[4] + sy[5] ? 5 : 6);
+    const int col = dg == 4 ? c : (dg == 5 ? off5 + (c - sy[4]) : off6 + (c - sy[4] - sy[5]));
     float v = 0.0f;
-    if (six ? need6 : need5) v = mom56[(item * 2 + side) * N56p + (six ? off6 + (c - sy[5]) : c)];
+    if (dg == 4 || (dg == 5 ? need5 : need6)) v = mom56[(item * 2 + side) * N56p + col];
     nq[idx] = v;
   }
   // G in VECTOR registers (through LDS): as 64 scalar registers beside the loop's own scalars it spilled to VGPR lanes
   // (780 v_readlane / v_writelane in the kernel, 47 per work unit)
-  float* Gl = sm6 + ((2 * n56 + sy[3] * xs + sy[2] * sy[4] + sy[1] * sy[5] + 6 * MM6_WAVES + 2 + 3) & ~3);   // [64], 16-byte aligned
+  float* Gl = sm6 + ((2 * n56 + sy[3] * xs + sy[2] * sy[4] + sy[1] * sy[5] + 6 * MM6_WAVES + 2 + 3) & ~3);   // [128], 16-byte aligned
+  float* Bf4 = Gl + 128;                                 // n = 4: T_1 [sym1][sym3]
+  float* X4 = Bf4 + sy[1] * sy[3];                       //        X [sym2][sym2 + 1]
   if (tid < 64) {
     const int i = tid >> 3, j = tid & 7;
     const double* pm = pairmat + ((size_t)b * P + (L + po)) * (d * d + 1);
@@ -427,8 +436,8 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   float acc5 = 0.0f, acc6 = 0.0f, dummy = 0.0f;
   // ---- n = 6: X = three indices of Q_6 (column side of nq) through G; Y = three indices of N_6 through G^T, fused dot
   if (need6) {
-    const float* Q6 = nq + n56 + sy[5];
-    const float* N6 = nq + sy[5];
+    const float* Q6 = nq + n56 + sy[4] + sy[5];
+    const float* N6 = nq + sy[4] + sy[5];
     load_G(1);
     mm6_step<0, false, 0>(Q6, sy[6], 1, Bf, sy[5], tabi + tb.ins[5], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
@@ -444,23 +453,36 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
     mm6_step<2, true, 2>(A, sy[4], sy[2], X, sy[3], tabi + tb.ins[3], d, G, nullptr, xs, acc6, wave, lane);
     __syncthreads();
   }
-  // ---- n = 5: X [sym3][sym2] = three indices of Q_5 through G; Y = two indices of N_5 through G^T, fused dot
-  if (need5) {
-    const float* Q5 = nq + n56;
-    const float* N5 = nq;
+  // ---- n = 5 (X [sym3][sym2] = three indices of Q_5 through G; Y = two indices of N_5 through G^T, fused dot) and n = 4 (every
+  // collapsed item: X4 [sym2][sym2] = two indices of Q_4; Y = two indices of N_4) in the SAME barrier phases: the n = 4 steps are
+  // 1 / 8 / 1 / 8 work units on buffers of their own (Bf4, X4: 9 KB) -- as a pass of its own they cost four nearly empty rounds
+  // per item (0.15 ms at C3); merged, a few waves take one more unit per phase
+  float acc4 = 0.0f;
+  {
+    const float* Q5 = nq + n56 + sy[4];
+    const float* N5 = nq + sy[4];
+    const float* Q4 = nq + n56;
+    const float* N4 = nq;
+    const int xs4 = sy[2] + 1;
     load_G(1);
-    mm6_step<0, false, 0>(Q5, sy[5], 1, Bf, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
+    if (need5) mm6_step<0, false, 0>(Q5, sy[5], 1, Bf, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
+    mm6_step<0, false, 0>(Q4, sy[4], 1, Bf4, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
-    mm6_step<1, false, 0>(Bf, sy[4], sy[1], A, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
+    if (need5) mm6_step<1, false, 0>(Bf, sy[4], sy[1], A, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
+    mm6_step<1, false, 1>(Bf4, sy[3], sy[1], X4, sy[2], tabi + tb.ins[2], d, G, mult2, xs4, dummy, wave, lane);
     __syncthreads();
-    mm6_step<2, false, 1>(A, sy[3], sy[2], X, sy[2], tabi + tb.ins[2], d, G, mult2, xs, dummy, wave, lane);
-    __syncthreads();
+    if (need5) {
+      mm6_step<2, false, 1>(A, sy[3], sy[2], X, sy[2], tabi + tb.ins[2], d, G, mult2, xs, dummy, wave, lane);
+      __syncthreads();
+    }
     load_G(0);
-    mm6_step<0, true, 0>(N5, sy[5], 1, Bf, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
+    if (need5) mm6_step<0, true, 0>(N5, sy[5], 1, Bf, sy[4], tabi + tb.ins[4], d, G, nullptr, 0, dummy, wave, lane);
+    mm6_step<0, true, 0>(N4, sy[4], 1, Bf4, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
-    mm6_step<1, true, 2>(Bf, sy[4], sy[1], X, sy[3], tabi + tb.ins[3], d, G, nullptr, xs, acc5, wave, lane);
+    if (need5) mm6_step<1, true, 2>(Bf, sy[4], sy[1], X, sy[3], tabi + tb.ins[3], d, G, nullptr, xs, acc5, wave, lane);
+    mm6_step<1, true, 2>(Bf4, sy[3], sy[1], X4, sy[2], tabi + tb.ins[2], d, G, nullptr, xs4, acc4, wave, lane);
   }
-  double tot = (double)MM_C6_C2 * (double)acc5 + (double)MM_C6_C3 * (double)acc6;
+  double tot = (double)MM_C6_C1 * (double)acc4 + (double)MM_C6_C2 * (double)acc5 + (double)MM_C6_C3 * (double)acc6;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     tot += __shfl_down(tot, off, 64); s2r += __shfl_down(s2r, off, 64); s2c += __shfl_down(s2c, off, 64);
@@ -509,14 +531,15 @@ int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, c
     }
     hipLaunchKernelGGL(k_wmom56_gemm, dim3((int)nwork_ll), dim3(256), shm, stream, (const unsigned short*)(ws + wl.wsp),
                        (const unsigned short*)(packed + ml.Zm56), N56p, L, wl.Mp, B, wl.Po, nrb, ncb, (int)nwork_ll,
-                       mm_moment56_off6(d) / MM6_TB,
+                       mm_moment56_off5(d) / MM6_TB, mm_moment56_off6(d) / MM6_TB,
                        (const int*)(ws + wl.gperm), (float*)(ws + wl.mom56));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
   int sy[7];
   for (int k = 0; k < 7; ++k) sy[k] = mm_mono_count(k, d);
-  size_t nfl = (size_t)2 * (sy[5] + sy[6]) + (size_t)sy[3] * (sy[3] + 1) + (size_t)sy[2] * sy[4] + (size_t)sy[1] * sy[5] + 6 * MM6_WAVES + 128 + 16;
+  size_t nfl = (size_t)2 * (sy[4] + sy[5] + sy[6]) + (size_t)sy[3] * (sy[3] + 1) + (size_t)sy[2] * sy[4] + (size_t)sy[1] * sy[5] + 6 * MM6_WAVES + 128 + 16
+               + (size_t)sy[1] * sy[3] + (size_t)sy[2] * (sy[2] + 1);
   nfl = (nfl + 1) & ~(size_t)1;                           // (the f64 reduction scratch behind it stays 8-byte aligned)
   const size_t shm = nfl * sizeof(float);
   static std::atomic<unsigned long long> attr2_done{0ull};

@@ -221,9 +221,9 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
     bool coll = false;
     if (!AGG && allow_collapse && zmax2 != nullptr && d <= 8)
       coll = mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
-    // (orders 3 and 4 of p6 stay with the f64 moments; orders 5 and 6 -- s56, from f32 moments -- are dropped for a routed item by
-    // k_finalize, so the re-reduce keeps them: r - C0 x^3 - C1 x^4)
-    const double sub0 = coll ? (double)MM_C6_C0 : 0.0, sub1 = coll ? (double)MM_C6_C1 : 0.0;
+    // (order 3 of p6 stays with the f64 moments; orders 4, 5, 6 -- s56, from f32 moments -- are dropped for a routed item by
+    // k_finalize, so the re-reduce keeps them: r - C0 x^3)
+    const double sub0 = coll ? (double)MM_C6_C0 : 0.0, sub1 = 0.0;
     const double* zc = Zc64 + (size_t)a2 * Mp * Kz;         // wave-uniform from here on: scalar loads
     const double* wc = whC + ((size_t)b * Po + lp) * Mp;
     double B0 = 0.0, B1[AGG ? DK : 1], B2[NB2];
