@@ -44,6 +44,7 @@ SIGNATURES = {
     "mm_packed_model_bytes": (C.c_size_t, [C.c_int] * 5),
     "mm_pack_model": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int]
                       + [C.c_void_p] * 6 + [C.c_void_p]),
+    "mm_pack_perm": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "mm_workspace_bytes": (C.c_size_t, [C.c_int] * 6),
     "mm_moment_match": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                   C.c_void_p, C.c_void_p, C.c_int, C.c_double,

@@ -75,6 +75,14 @@ def small_algebra(Sigma: torch.Tensor, ls2: torch.Tensor, var: torch.Tensor, ia,
   return Pa, lognorm, G, Dr, Dc, const
 
 
+def _packed_order(pm: ops.PackedModel, pre):
+  """``pre`` with the inducing points in the pack's own order (``PackedModel.perm``): the per-point sums of
+  ``mm_backward_sums`` are in that order, and everything below multiplies them with Z and beta point by point."""
+  Z, ls, var, beta, C, mean_c = pre
+  perm = pm.perm()
+  return (Z.gather(1, perm[..., None].expand(-1, -1, Z.shape[-1])), ls, var, beta.gather(1, perm), C, mean_c)
+
+
 def _backward_sums(pm: ops.PackedModel, mu: torch.Tensor, L: int, M: int, d: int, B: int, flags: int,
                    full_output_cov: bool):
   """``mm_backward_sums`` -> Ksum, csum, cC [B,P,M], Usum [B,P,M,d], Rsum, rsum [B,P,M]."""
@@ -113,13 +121,14 @@ def moment_match_backward(pm: ops.PackedModel, pre, mu: torch.Tensor, Sigma: tor
   ``moment_match_backward_reference`` is the autograd version it is tested against)."""
   if pm.dtype != torch.float64:
     raise NotImplementedError("the backward sums are taken on a float64 pack (see MomentMatchFunction)")
-  Z, ls, var, beta, _, mean_c = pre
+  Z, ls, var, beta, _, mean_c = _packed_order(pm, pre)
   L, M, d = Z.shape
   B = mu.shape[0]
   dev = mu.device
   flags = ops.make_flags(full_output_cov, model_uncertainty)
   with torch.no_grad():
     _, _, q = ops.q_forward(pm, mu, Sigma, flags, want_q=True)              # [B,L,M]; fills the workspace the sums read
+    q = q.gather(2, pm.perm()[None].expand(B, L, M))                        # (q_forward's q is in the caller's order)
   Ksum, csum, cC, Usum, Rsum, rsum = _backward_sums(pm, mu, L, M, d, B, flags, full_output_cov)
   ia, ib = pair_indices(L, full_output_cov, dev)
   if full_output_cov:
@@ -213,7 +222,7 @@ def moment_match_backward_reference(pm: ops.PackedModel, pre, mu: torch.Tensor, 
   ops.q_forward(pm, mu, Sigma, ops.make_flags(full_output_cov, model_uncertainty))
   if pm.dtype != torch.float64:
     raise NotImplementedError("the backward pass is built for float64 models only (first version)")
-  Z, ls, var, beta, _, mean_c = pre
+  Z, ls, var, beta, _, mean_c = _packed_order(pm, pre)
   L, M, d = Z.shape
   B = mu.shape[0]
   dev = mu.device

@@ -324,17 +324,7 @@ __device__ __forceinline__ void mmb_mfma_body(const double* __restrict__ Zc, int
         acc[rt][ct] = c;
       }
     if (PFB) load_first(it + 1 < nt ? it + 1 : it, arow_n, rinit_n);
-    unsigned int mxh = 0u;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double av = acc[rt][ct][r];                  // (see mm_f64.hip: bit_cast on a vector element miscompiles)
-          const unsigned int ah = (unsigned int)__double2hiint(av) & 0x7fffffffu;
-          mxh = ah > mxh ? ah : mxh;
-        }
+    const unsigned int mxh = mm_absmax_hi32(acc);                      // (mm_exp_f64.h)
 #define MMB_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))
     // Taylor degree by range (absolute truncation |x|^(D+1)/(D+1)! <= 2e-18): 1/64 -> 7, 1/32 -> 8, 1/16 -> 9,
     // 1/8 -> 10, 1/4 -> 12, 1/2 -> 15; the half steps as in mm_f64.hip (most tiles of a rollout sit in them)
@@ -637,17 +627,7 @@ __global__ __launch_bounds__(256, (NU >= 2 ? 1 : (KS4 <= 2 ? MMB_DIAG_WAVES : 2)
           for (int s = 0; s < KS4; ++s) c = __builtin_amdgcn_mfma_f64_16x16x4f64(arow[rt][s], bfix[e][ct][s], c, 0, 0, 0);
           acc[rt][ct] = c;
         }
-      unsigned int mxh = 0u;
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double av = acc[rt][ct][r];
-            const unsigned int ah = (unsigned int)__double2hiint(av) & 0x7fffffffu;
-            mxh = ah > mxh ? ah : mxh;
-          }
+      const unsigned int mxh = mm_absmax_hi32(acc);
 #define MMB_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))
       const int tier = !__any(mxh >= MMB_HI32(0.015625)) ? 0 : !__any(mxh >= MMB_HI32(0.03125)) ? 1
                      : !__any(mxh >= MMB_HI32(0.0625)) ? 2 : !__any(mxh >= MMB_HI32(0.125)) ? 3

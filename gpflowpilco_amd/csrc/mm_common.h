@@ -100,10 +100,20 @@ struct MMModelLayout {
   size_t Zm56;    // [L][2 (h, m)][N56p][Mp] bf16 (f32 mode, d <= 8): the degree-5 and degree-6 monomials of zc, 2-way split, one
                   // monomial's Mp values contiguous (the B operand of k_wmom56_gemm reads 8 consecutive m per lane)
   size_t tab56;   // index tables of k_spoly56 (MMTab56; f32 mode, d <= 8): i16 block, then the f32 multinomials
+  size_t perm;    // [L][Mp] int32: the caller's index of the inducing point at packed position m (identity beyond M and for packs
+                  // of M <= MM_SORT_MIN_M points).  Every packed array is in PACKED order: per latent the points are sorted by
+                  // |(z - zbar) / lengthscale| (mm_kernels.hip: k_pack_key / k_pack_rank) -- the outputs are sums over the points
+                  // and do not depend on it, but |b_ij| <= |G| |zeta_i| |zeta_j|, so tiles of sorted points are homogeneous and the
+                  // reduce kernels' per-tile range tiers (and the f32 sweep's screening) see smaller maxima; q_out is written
+                  // through perm in the caller's order
+  size_t skey;    // [L][Mp] f64 scratch of the pack: the sort keys
   size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
                   // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
 };
+// packs of at most this many inducing points keep the caller's order (four 64-point tiles: nothing to gain, and the policy
+// packs of the composed rollout -- M <= 256 -- return gradients per packed centre: include/gpflowpilco_mm.h g_policy)
+#define MM_SORT_MIN_M 256
 
 static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int with_C) {
   MMModelLayout o;
@@ -135,6 +145,8 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   if (dtype != MM_F64 && d <= 8) off = mm_align_up(off + (size_t)L * 2 * mm_moment56_cols(d) * o.Mp * 2, A);
   o.tab56 = off;
   if (dtype != MM_F64 && d <= 8) off = mm_align_up(off + mm_tab56(d).bytes, A);
+  o.perm = off;   off = mm_align_up(off + (size_t)L * o.Mp * 4, A);
+  o.skey = off;   off = mm_align_up(off + (size_t)L * o.Mp * 8, A);
   o.Cm = off;
   if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;

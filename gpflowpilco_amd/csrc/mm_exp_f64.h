@@ -54,3 +54,23 @@ __device__ __forceinline__ double mm_exp_f64(double x) {
   return fma(s, q * r, s);                      // 2^k (1 + expm1(r))
 }
 
+// max |x| over the 16 entries of a wave's 2 x 2 accumulator tiles, as the bit pattern of the HIGH DWORD with the sign cleared
+// (ordered like |x| for doubles; the callers compare it with the high dword of their power-of-two limits).  Read as an f32
+// the high dword keeps that order for every finite double below 2^1017 (sign | the exponent's top 8 bits as the f32 exponent
+// | the rest as mantissa; doubles below 2^-1015 may read as 0), so the max runs as ONE v_max3_f32 |a|, |b|, m per entry PAIR
+// on two chains -- 10 instructions per batch element and wave where v_and + v_max3_u32 took 24.
+// (__double2hiint, not bit_cast<u64>(vec[r]) >> 32: on a vector element the latter compiles to a test of element 0 only with
+// this toolchain -- tools/bitcast_repro.hip)
+typedef double mm_f64x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned int mm_absmax_hi32(const mm_f64x4_t (&acc)[2][2]) {
+  float m0 = 0.0f, m1 = 0.0f;
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const mm_f64x4_t cv = acc[rt][ct];
+      m0 = fmaxf(fmaxf(m0, fabsf(__int_as_float(__double2hiint(cv[0])))), fabsf(__int_as_float(__double2hiint(cv[1]))));
+      m1 = fmaxf(fmaxf(m1, fabsf(__int_as_float(__double2hiint(cv[2])))), fabsf(__int_as_float(__double2hiint(cv[3]))));
+    }
+  return __float_as_uint(fmaxf(m0, m1));
+}

@@ -266,20 +266,7 @@ __device__ __forceinline__ void mmq_f64_body(const double* __restrict__ Zc, int 
     // wave-uniform choice of the expm1 form.  |x| is ordered like its high dword (sign cleared) as an
     // unsigned integer, so the range test runs on 32-bit integer max; comparing against the high
     // dword of the (power-of-two) limits with >= errs to the higher-degree side at the boundary.
-    unsigned int mxh = 0u;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // (__double2hiint, not bit_cast<u64>(vec[r]) >> 32: on a vector element the latter compiles to a test of
-          // element 0 only with this toolchain -- tools/bitcast_repro.hip)
-          const double cv = cacc[rt][ct][r];
-          const unsigned int hi = (unsigned int)__double2hiint(cv);
-          const unsigned int ah = hi & 0x7fffffffu;
-          mxh = ah > mxh ? ah : mxh;
-        }
+    unsigned int mxh = mm_absmax_hi32(cacc);                       // (mm_exp_f64.h: one v_max3_f32 per entry pair)
 #define MM_HI32(x_) ((unsigned int)(__builtin_bit_cast(unsigned long long, (double)(x_)) >> 32))
     if (force_worst) mxh = 0x7ff00000u;                          // MM_FORCE_WORST_TIER: wave-uniform override
     double sv = 0.0;

@@ -106,19 +106,79 @@ __device__ __forceinline__ float mm_expm1(float x) { return expm1f(x); }
 __device__ __forceinline__ double mm_expm1(double x) { return expm1(x); }
 
 // ---------------------------------------------------------------------------------------------
+// Pack order (MMModelLayout::perm): per latent the inducing points are sorted by the norm of (z - zbar) / lengthscale.
+// Every sum of the path runs over all points of a latent, so the order is free; |b_ij| <= |G| |zeta_i| |zeta_j| makes tiles of
+// sorted points homogeneous: along the C3 rollout the mean degree of the diagonal sweep's tier polynomial falls from 9.8 to
+// 8.1 FMAs per entry (with the column recentring of k_pairvec_reg), and 83 % instead of 32 % of the dense off-diagonal wave
+// tiles have max|b| <= 1/4 (scratch study).
+//   k_pack_key   : keys (one workgroup per latent)
+//   k_pack_rank  : rank by counting, ties by index (a permutation for ANY keys; non-finite keys sort last) -> perm
+//   k_pack_gather: Z64, beta64 in packed order; the other pack kernels read THOSE
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pack_key(char* packed, MMModelLayout lay, int M, int d, const double* __restrict__ Z,
+                                                  const double* __restrict__ ls) {
+  const int a = blockIdx.x, tid = threadIdx.x;
+  __shared__ double red[4];
+  __shared__ double zb[MM_DMAX];
+  for (int k = 0; k < d; ++k) {
+    double s = 0.0;
+    for (int m = tid; m < M; m += 256) s += Z[((size_t)a * M + m) * d + k];
+    s = mm_block_sum256(s, red);
+    if (tid == 0) zb[k] = s / (double)M;
+    __syncthreads();
+  }
+  double* key = (double*)(packed + lay.skey) + (size_t)a * lay.Mp;
+  for (int m = tid; m < M; m += 256) {
+    double s2 = 0.0;
+    for (int k = 0; k < d; ++k) { const double v = (Z[((size_t)a * M + m) * d + k] - zb[k]) / ls[a * d + k]; s2 = fma(v, v, s2); }
+    key[m] = (s2 == s2 && s2 < 1.0e300) ? s2 : 1.0e300;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pack_rank(char* packed, MMModelLayout lay, int M, int sorted) {
+  // grid (Mp / 256, L)
+  const int a = blockIdx.y, tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  int* perm = (int*)(packed + lay.perm) + (size_t)a * lay.Mp;
+  if (!sorted) { if (i < lay.Mp) perm[i] = i; return; }
+  const double* key = (const double*)(packed + lay.skey) + (size_t)a * lay.Mp;
+  __shared__ double kj[256];
+  const double ki = i < M ? key[i] : 0.0;
+  int r = 0;
+  for (int j0 = 0; j0 < M; j0 += 256) {
+    __syncthreads();
+    kj[tid] = j0 + tid < M ? key[j0 + tid] : 0.0;
+    __syncthreads();
+    const int n = M - j0 < 256 ? M - j0 : 256;
+    for (int t = 0; t < n; ++t) { const double k2 = kj[t]; r += (k2 < ki || (k2 == ki && j0 + t < i)) ? 1 : 0; }
+  }
+  if (i < M) perm[r] = i;
+  else if (i < lay.Mp) perm[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_pack_gather(char* packed, MMModelLayout lay, int M, int d, const double* __restrict__ Z,
+                                                     const double* __restrict__ beta) {
+  // grid (ceil(M / 256), L)
+  const int a = blockIdx.y, m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= M) return;
+  const int src = ((const int*)(packed + lay.perm))[(size_t)a * lay.Mp + m];
+  double* Z64 = (double*)(packed + lay.Z64) + ((size_t)a * M + m) * d;
+  for (int k = 0; k < d; ++k) Z64[k] = Z[((size_t)a * M + src) * d + k];
+  ((double*)(packed + lay.beta64))[(size_t)a * M + m] = beta[(size_t)a * M + src];
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_pack_model: raw f64 model -> packed buffer (centred/padded T copies for the reduce kernels)
 // ---------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, int d,
-                               const double* __restrict__ Z, const double* __restrict__ ls,
-                               const double* __restrict__ var, const double* __restrict__ beta,
+                               const double* __restrict__ ls,
+                               const double* __restrict__ var,
                                const double* __restrict__ mean_c) {
-  // one workgroup per latent a
+  // one workgroup per latent a; Z: the inducing inputs in PACKED order (k_pack_gather wrote Z64 and beta64)
   const int a = blockIdx.x, tid = threadIdx.x;
-  double* Z64 = (double*)(packed + lay.Z64) + (size_t)a * M * d;
+  const double* Z = (const double*)(packed + lay.Z64);
   double* zbar = (double*)(packed + lay.zbar) + (size_t)a * d;
   double* ls2 = (double*)(packed + lay.ls2) + (size_t)a * d;
-  double* b64 = (double*)(packed + lay.beta64) + (size_t)a * M;
   double* Zc64 = (double*)(packed + lay.Zc64) + (size_t)a * lay.Mp * lay.Kz;
   T* Zc = (T*)(packed + lay.Zc) + (size_t)a * lay.Mp * lay.Kz;
   __shared__ double red[4];
@@ -135,7 +195,6 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
     ((double*)(packed + lay.var))[a] = var[a];
     ((double*)(packed + lay.meanc))[a] = mean_c ? mean_c[a] : 0.0;
   }
-  for (int idx = tid; idx < M * d; idx += 256) Z64[idx] = Z[(size_t)a * M * d + idx];
   {
     double* Zt = (double*)(packed + lay.Zt64) + (size_t)a * d * lay.Mp;
     for (int idx = tid; idx < d * lay.Mp; idx += 256) {
@@ -143,7 +202,6 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
       Zt[idx] = m < M ? Z[((size_t)a * M + m) * d + k] : 0.0;
     }
   }
-  for (int m = tid; m < M; m += 256) b64[m] = beta[(size_t)a * M + m];
   for (int idx = tid; idx < lay.Mp * lay.Kz; idx += 256) {
     const int m = idx / lay.Kz, k = idx - m * lay.Kz;
     double v = 0.0;
@@ -188,6 +246,8 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
         base += sz;
       }
     }
+  }
+  {
     // max_m |zc_m|^2 (the column side of the Cauchy-Schwarz bound on |b_ij|)
     double zm2 = 0.0;
     for (int m = tid; m < M; m += 256) {
@@ -258,12 +318,13 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
 }
 
 __global__ void k_pack_C(char* packed, MMModelLayout lay, int L, int M, const double* __restrict__ C) {
-  // grid (Mp/256, Mp, L): zero-padded f64 copy of C
+  // grid (Mp/256, Mp, L): zero-padded f64 copy of C in packed order (rows and columns)
   const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, a = blockIdx.z;
   if (j >= lay.Mp) return;
   double* Cm = (double*)(packed + lay.Cm) + ((size_t)a * lay.Mp + i) * lay.Mp;
+  const int* pm = (const int*)(packed + lay.perm) + (size_t)a * lay.Mp;   // packed position -> the caller's index
   double v = 0.0;
-  if (i < M && j < M) v = C[((size_t)a * M + i) * M + j];
+  if (i < M && j < M) v = C[((size_t)a * M + pm[i]) * M + pm[j]];
   Cm[j] = v;
 }
 
@@ -415,7 +476,8 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
                                               double* __restrict__ w64, double* __restrict__ q64, T* __restrict__ w,
                                               double* __restrict__ f1raw, double* __restrict__ rho1,
                                               T* __restrict__ f1, T* __restrict__ cross, T* __restrict__ q_out,
-                                              double* __restrict__ mu64, double* __restrict__ lq) {
+                                              double* __restrict__ mu64, double* __restrict__ lq,
+                                              const int* __restrict__ perm) {
   const int a = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   // P_a = (Sigma + Lambda_a)^-1 and E_a, zero padded to DK x DK: compile-time LDS offsets (wide broadcast reads)
   __shared__ double Pa[DK * DK], Ea[DK * DK];
@@ -514,7 +576,7 @@ __global__ __launch_bounds__(256) void k_qvec(const double* __restrict__ Zt64, c
       acc_f += wv;
 #pragma unroll
       for (int k = 0; k < DK; ++k) acc_s[k] += wv * z[k];
-      if (q_out) q_out[((size_t)b * L + a) * M + m] = (T)qv;
+      if (q_out) q_out[((size_t)b * L + a) * M + perm[(size_t)a * Mp + m]] = (T)qv;   // the caller's order (MMModelLayout::perm)
     }
     wb64[m] = wv;
     qb64[m] = qv;
@@ -825,6 +887,31 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
   }
   __syncthreads();
   bool recentred = true;
+  if constexpr (MODE == 0) {
+    // DIAGONAL pairs: the A operand of the sweep is zeta_i = z_i - zbar_a (model constant); the column operand was g_j = G (z_j - mu),
+    // so b_ij = zeta_i . g_j kept the state's offset from the centroid on the column side.  Recentred there too,
+    //     g'_j = G zeta_j = g_j + h,   h = G (mu - zbar_a) = t0 / Lam_a,   delta_ij = (rho_i - zeta_i . h) + gamma'_j + zeta_i . g'_j:
+    // the row-only term joins rho_i (one more term in the row weight's single exponential), b'_ij = zeta_i G zeta_j is smaller
+    // on average (lower range tiers in the sweeps; with the pack's norm order the mean tier degree of the C3 rollout falls from
+    // 9.8 to 8.1 FMAs per entry) and every consumer of (rowD, colD, qhR, qhC) evaluates the same delta_ij.  Taken where the
+    // moved exponent is harmless, |h| max|zeta| <= MM_RECENTRE_CMAX, else the operands stay as they were.
+    double h2 = 0.0, t0[DK];
+#pragma unroll
+    for (int i = 0; i < DK; ++i) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < DK; ++k) t = fma(Tr[tsym(i, k)], vecs[4][k], t);
+      t0[i] = t;
+      const double hi = t * vecs[1][i];
+      h2 = fma(hi, hi, h2);
+    }
+    recentred = h2 * zmax2[a] <= MM_RECENTRE_CMAX * MM_RECENTRE_CMAX;
+    if (tid == 0) {
+#pragma unroll
+      for (int i = 0; i < DK; ++i) vecs[5][i] = recentred ? t0[i] : 0.0;
+    }
+    __syncthreads();
+  }
   if constexpr (MODE == 1) {
     // rows recentred at zbar_a (mm_mono.h): t0 = T (mu - zbar_a) / Lam_a, A_i = (u_i + t0_i) / Lam_a',i, and the column weight
     // takes e^{-c_j}, c_j = sum_k t0_k zc'_jk / Lam_a',k.  Every thread forms t0 (workgroup-uniform), thread 0 publishes it.
@@ -870,7 +957,7 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
         double sv[DK];
 #pragma unroll
         for (int k = 0; k < DK; ++k) sv[k] = (o.zr[k] - vl[k]) * vl[DK + k];
-        double tq = 0.0, corr = 0.0;
+        double tq = 0.0, corr = 0.0, zh = 0.0;
 #pragma unroll
         for (int i = 0; i < DK; ++i) {
           double u = 0.0;
@@ -878,11 +965,13 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
           for (int k = 0; k < DK; ++k) u = fma(Tr[tsym(i, k)], sv[k], u);
           tq = fma(sv[i], u, tq);
           corr = fma(vl[4 * DK + i], u, corr);               // (mu - zbar_a) . g
-          cbD[rowi(i) + m] = u * vl[DK + i];                 // g_i
+          zh = fma(sv[i] + vl[4 * DK + i], vl[5 * DK + i], zh);   // zeta . h  (t0 = 0 where the pair stays as it was)
+          cbD[rowi(i) + m] = (u + vl[5 * DK + i]) * vl[DK + i];   // g'_i = (G zeta)_i
         }
-        // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j
-        const double rowv = -0.5 * (o.r1r - tq);
-        const double colv = rowv + cst - corr;
+        // gamma' = gamma + const - (mu - zbar_a)^T g   so that   delta = rho_i + gamma'_j + zc_i . g_j  (= rho_i - zeta_i . h + gamma'_j + zeta_i . g'_j)
+        const double row0 = -0.5 * (o.r1r - tq);
+        const double rowv = row0 - zh;
+        const double colv = row0 + cst - corr;
         // factored weights of the f64 MFMA reduce (mm_f64.hip): e^{delta_ij} = e^{rho_i} e^{gamma'_j} e^{zc_i . g_j};
         // u = q with model uncertainty (the fused sum runs over q_i q_j D_ij e^{delta}), w without
         const double uw = with_unc ? 1.0 : o.br;             // the weight of the fused sum is q with model uncertainty, else w = beta q
@@ -1265,10 +1354,19 @@ template <typename T>
 static int mm_pack_model_t(char* packed, const MMModelLayout& lay, int L, int M, int d,
                            const double* Z, const double* ls, const double* var, const double* beta,
                            const double* C, const double* mean_c, hipStream_t s) {
-  hipLaunchKernelGGL((k_pack_vectors<T>), dim3(L), dim3(256), 0, s, packed, lay, L, M, d, Z, ls, var, beta, mean_c);
+  const int sorted = M > MM_SORT_MIN_M ? 1 : 0;
+  if (sorted) {
+    hipLaunchKernelGGL(k_pack_key, dim3(L), dim3(256), 0, s, packed, lay, M, d, Z, ls);
+    MM_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(k_pack_rank, dim3((lay.Mp + 255) / 256, L), dim3(256), 0, s, packed, lay, M, sorted);
+  MM_CHECK_LAUNCH();
+  hipLaunchKernelGGL(k_pack_gather, dim3((M + 255) / 256, L), dim3(256), 0, s, packed, lay, M, d, Z, beta);
+  MM_CHECK_LAUNCH();
+  hipLaunchKernelGGL((k_pack_vectors<T>), dim3(L), dim3(256), 0, s, packed, lay, L, M, d, ls, var, mean_c);
   MM_CHECK_LAUNCH();
   if (sizeof(T) == 4 && d <= 8) {
-    const int rc = mm_launch_pack56(packed, lay, L, M, d, Z, s);
+    const int rc = mm_launch_pack56(packed, lay, L, M, d, (const double*)(packed + lay.Z64), s);
     if (rc) return rc;
   }
   if (C) {
@@ -1289,6 +1387,17 @@ extern "C" int mm_pack_model(void* packed, size_t packed_bytes, int L, int M, in
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MM_F64) return mm_pack_model_t<double>((char*)packed, lay, L, M, d, Z, lengthscales, variance, beta, C, mean_c, s);
   return mm_pack_model_t<float>((char*)packed, lay, L, M, d, Z, lengthscales, variance, beta, C, mean_c, s);
+}
+
+extern "C" int mm_pack_perm(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int32_t* perm, void* stream) {
+  int rc = mm_check_common(packed, L, M, d, dtype, 1);
+  if (rc) return rc;
+  if (!perm) return MM_E_ARG;
+  const MMModelLayout lay = mm_model_layout(L, M, d, dtype, 0);       // (perm lies before C: the offset does not depend on with_C)
+  if (packed_bytes < lay.total) return MM_E_WORKSPACE;
+  const hipError_t e = hipMemcpy2DAsync(perm, (size_t)M * 4, (const char*)packed + lay.perm, (size_t)lay.Mp * 4, (size_t)M * 4, (size_t)L,
+                                        hipMemcpyDeviceToDevice, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : (int)e;
 }
 
 template <typename T, int DK>
@@ -1318,7 +1427,8 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
   hipLaunchKernelGGL((k_qvec<T, DK>), dim3(L, B), dim3(256), 0, s,
                      (const double*)(packed + ml.Zt64), (const double*)(packed + ml.beta64), (const double*)(packed + ml.meanc),
                      L, M, wl.Mp, d, mu, latmat, (double*)(ws + wl.w64), (double*)(ws + wl.q64), (T*)(ws + wl.w),
-                     (double*)(ws + wl.f1raw), (double*)(ws + wl.rho1), f1, cross, q_out, (double*)(ws + wl.mu64), (double*)(ws + wl.lq));
+                     (double*)(ws + wl.f1raw), (double*)(ws + wl.rho1), f1, cross, q_out, (double*)(ws + wl.mu64), (double*)(ws + wl.lq),
+                     (const int*)(packed + ml.perm));
   MM_CHECK_LAUNCH();
   {
     // The streamed operands of the reduces, one launch per kind of pair: the diagonal pairs' first (all the diagonal sweep needs),

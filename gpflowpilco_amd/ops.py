@@ -61,6 +61,7 @@ class PackedModel:
   _ws_gen: Dict[Tuple[int, int], int] = field(default_factory=dict, repr=False)
   _status: Optional[torch.Tensor] = field(default=None, repr=False)
   _keep: Optional[tuple] = field(default=None, repr=False)
+  _perm: Optional[torch.Tensor] = field(default=None, repr=False)
 
   @property
   def device(self):
@@ -88,6 +89,17 @@ class PackedModel:
   def workspace_generation(self, B: int, flags: int) -> int:
     """Counter of the requests for this workspace: unchanged since a forward <=> that forward's q stage is still on it."""
     return self._ws_gen.get((B, flags & (MM_FULL_OUTPUT_COV | MM_MODEL_UNCERTAINTY)), 0)
+
+  def perm(self) -> torch.Tensor:
+    """[L, M] int64: the caller's index of the inducing point at packed position m (``mm_pack_perm``: packs of M > 256 points
+    are sorted per latent by |(z - mean z) / lengthscale|).  ``q_forward``'s q is in the caller's order; the per-point sums of
+    ``mm_backward_sums`` are in packed order."""
+    if self._perm is None:
+      p32 = torch.empty(self.L, self.M, dtype=torch.int32, device=self.device)
+      check(lib().mm_pack_perm(self.buf.data_ptr(), self.nbytes, self.L, self.M, self.d, _dtype_code(self.dtype),
+                               p32.data_ptr(), _stream(self.device)), "mm_pack_perm")
+      self._perm = p32.long()
+    return self._perm
 
   def status(self) -> torch.Tensor:
     if self._status is None:

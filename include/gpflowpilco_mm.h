@@ -106,6 +106,14 @@ int mm_pack_model(void* packed, size_t packed_bytes,
                   const double* mean_c,       /* [L] Constant mean, or NULL (Zero)         */
                   void* stream);
 
+/* Order of the inducing points inside the pack.  The outputs of the path are sums over a latent's inducing points, so the pack
+ * is free to store them in an order of its own: packs of M > 256 points are sorted per latent by |(z - mean z) / lengthscale|
+ * (tiles of the M x M reduces then hold points of similar norm: lower per-tile range tiers); smaller packs -- in particular
+ * every policy pack of the composed rollout, whose g_policy is per packed centre -- keep the caller's order.
+ * perm [L][M] (device, int32): the caller's index of the point at packed position m.  q_out (mm_q_forward) is written in the
+ * CALLER's order; the per-point sums of mm_backward_sums are in PACKED order. */
+int mm_pack_perm(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int32_t* perm, void* stream);
+
 /* ---- one moment match: (mu, Sigma) -> (f1, Sff, Sigma^-1 Cov(x,f)) --------------------
  * Replaces _mm_gauss_svgp_mo / _so / _mm_gauss_gpr up to (not including) the
  * LinearCoregionalization mixing (models.py:279-286), which stays on the host. */
@@ -239,7 +247,8 @@ int mm_rollout_composed_backward(const void* drift_packed, size_t drift_bytes, i
  * The M x M part of d(f1, Sff, cross)/d(mu, Sigma) reduced to M-sized sums (see csrc/mm_backward.hip);
  * gpflowpilco_amd/autodiff.py finishes the chain rule.  Must follow mm_moment_match / mm_q_forward +
  * mm_Q_reduce_forward with the same (mu, Sigma, flags) on the same workspace.
- * out: [B][P][3+d][Mp] column sums (Ksum, csum, cC, Usum[d]) then [B][P-L][2][Mp] row sums (Rsum, rsum). */
+ * out: [B][P][3+d][Mp] column sums (Ksum, csum, cC, Usum[d]) then [B][P-L][2][Mp] row sums (Rsum, rsum), the inducing points
+ * in PACKED order (mm_pack_perm). */
 size_t mm_backward_bytes(int B, int L, int M, int d, int flags);
 int mm_backward_sums(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B,
                      const void* mu, int flags, const void* workspace, size_t workspace_bytes,

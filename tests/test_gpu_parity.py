@@ -611,3 +611,40 @@ def test_disjoint_active_dims_under_a_diagonal_covariance(dtype, device):
   got01 = Sff[:, 0, 1].double().cpu().numpy()
   assert np.abs(want01).max() < 1e-8 * max(scale, 1.0)    # the shortcut: independent outputs (beta carries cond(Kuu) eps)
   assert np.abs(got01 - want01).max() < tol["Sff"] * scale and torch.equal(Sff[:, 0, 1], Sff[:, 1, 0])
+
+
+def test_pack_order_is_internal(device):
+  """Packs of M > 256 points are sorted per latent by |(z - mean z) / lengthscale| (csrc/mm_kernels.hip: k_pack_key / k_pack_rank;
+  include/gpflowpilco_mm.h: mm_pack_perm); smaller packs keep the caller's order.  perm is a permutation in key order, q comes
+  back in the CALLER's order, and the outputs do not depend on the order the caller listed the points in."""
+  L, M, d, B = 3, 300, 5, 3
+  syn = make_svgp(L, M, d, seed=33, ls_bounds=(0.6, 2.0))
+  po = oracle_params(syn)
+  mu, Sigma = make_inputs(B, d, seed=4, scale=0.15)
+  model = syn.to_model(device)
+  flags = ops.make_flags(True, True)
+  for dtype in (torch.float64, torch.float32):
+    pm = model.packed(dtype, True, device)
+    perm = pm.perm().cpu().numpy()
+    Z = np.broadcast_to(np.asarray(po.Z), (L, M, d))
+    for a in range(L):
+      assert sorted(perm[a].tolist()) == list(range(M))
+      key = ((((Z[a] - Z[a].mean(0)) / np.asarray(po.lengthscales)[a]) ** 2).sum(1))[perm[a]]
+      assert np.all(np.diff(key) >= -1e-12 * key.max())
+    mu_t, S_t = to_dev(mu, device, dtype), to_dev(Sigma, device, dtype)
+    _, _, q = ops.q_forward(pm, mu_t, S_t, flags, want_q=True)
+    eKfu = mo.eKfu_list(mu_t.double().cpu().numpy(), S_t.double().cpu().numpy(), po.Z, po.lengthscales, po.variance)   # [B,M,L]
+    assert scale_err(q.double().transpose(1, 2), eKfu) < (1e-12 if dtype == torch.float64 else 2e-6)
+  small = make_svgp(2, 200, 4, seed=5).to_model(device).packed(torch.float64, True, device)
+  assert torch.equal(small.perm(), torch.arange(200, device=device)[None].expand(2, 200))
+  # the same model with its points listed in another order
+  pre = model._cache._pre
+  Zt, ls, var, beta, C, mean_c = pre
+  sh = torch.randperm(M, generator=torch.Generator().manual_seed(1)).to(device)
+  pm1 = ops.pack_model(Zt, ls, var, beta, C, mean_c, dtype=torch.float64)
+  pm2 = ops.pack_model(Zt[:, sh], ls, var, beta[:, sh], C[:, sh][:, :, sh], mean_c, dtype=torch.float64)
+  mu_t, S_t = to_dev(mu, device, torch.float64), to_dev(Sigma, device, torch.float64)
+  o1 = ops.moment_match(pm1, mu_t, S_t)
+  o2 = ops.moment_match(pm2, mu_t, S_t)
+  for x, y in zip(o1, o2):
+    assert float((x - y).abs().max()) <= 1e-9 * float(x.abs().max())
