@@ -678,12 +678,14 @@ def main():
       torch.cuda.synchronize()
     # regime of the off-diagonal reduce over one (untimed) rollout: its kernels' time depends on it
     collapsed = [0, 0, 0]
+    groups = [0, 0, 0]
     routed = 0
     if f32_mode and not args.pmc_run:
       state["h"] = 0
       for _ in range(H):
         one_step(False)
         collapsed = [x + y for x, y in zip(collapsed, ops.offdiag_stats(pm, B, base))]
+        groups = [x + y for x, y in zip(groups, ops.offdiag_row_groups(pm, B, base))]
         routed += ops.offdiag_routed(pm, B, base)               # items the accuracy contract re-reduced in f64 (csrc/mm_route.hip)
     if cfg["closed"] and not torch.isfinite(state["S"]).all():
       raise SystemExit(f"non-finite state in the timed rollout (recipe {recipe_name})")
@@ -743,7 +745,8 @@ def main():
         "rollouts_timed": rollouts_timed, "collectives_timed": collectives_timed if world > 1 else 0,
         "segments_ms": {k: round(v, 4) for k, v in seg.items()},
         "offdiag_items_one_rollout": {"collapsed": collapsed[0], "wholly_inside": collapsed[2], "total": collapsed[1],
-                                      "routed_to_f64": routed},
+                                      "routed_to_f64": routed, "partly_collapsed": groups[0],
+                                      "collapsed_row_groups": groups[1], "row_groups": groups[2]},
         "roofline": roofs[dominant], "roofline_other": roofs["diag" if dominant == "offdiag" else "offdiag"],
         "roofline_step": roof_step, "roofline_q_stage": qroof,
     }
@@ -821,10 +824,11 @@ def main():
                  "steps_requested": args.steps,
                  "diag_pairs": "f64", "offdiag_pairs": cfg["dtype"],
                  "offdiag_items_one_rollout": dict(pr["offdiag_items_one_rollout"],
-                                                   meaning="(b, off-diagonal pair, step) items of one rollout; collapsed: cubic + quartic "
-                                                           "remainder terms from f64 moments (items with Cauchy-Schwarz bound <= 0.15), tiles with max|b| <= 1/20 skipped after a "
-                                                           "screening MFMA; wholly_inside: the Cauchy-Schwarz bound alone puts every |b| <= 1/20, "
-                                                           "no tile work (csrc/mm_moments.hip, mm_mfma.hip); routed_to_f64: items whose f32 "
+                                                   meaning="(b, off-diagonal pair, step) items of one rollout; collapsed: the degree-3..6 polynomial "
+                                                           "p6 of the remainder from weight moments for EVERY row (Cauchy-Schwarz bound <= 1/2), tiles with max|b| <= 1/4 skipped after a "
+                                                           "screening MFMA; partly_collapsed: the same for some 64-row groups of the item (collapsed_row_groups of row_groups over "
+                                                           "all items), the other groups reduced densely; wholly_inside: the Cauchy-Schwarz bound alone puts every |b| <= 1/4, "
+                                                           "no tile work (csrc/mm_moments.hip, mm_moments6.hip, mm_mfma.hip); routed_to_f64: items whose f32 "
                                                            "rounding-error estimate exceeded MM_ROUTE_TOL = 3e-4 of the covariance block's scale and "
                                                            "were re-reduced in f64 inside the timed off-diagonal segment (csrc/mm_route.hip)")},
       "segments_ms": pr["segments_ms"],

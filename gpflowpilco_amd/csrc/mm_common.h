@@ -107,6 +107,9 @@ struct MMModelLayout {
                   // reduce kernels' per-tile range tiers (and the f32 sweep's screening) see smaller maxima; q_out is written
                   // through perm in the caller's order
   size_t skey;    // [L][Mp] f64 scratch of the pack: the sort keys
+  size_t zt2;     // [L][Mp/32] f32: max |zc_m|^2 over the 32 points of a column tile, rounded up (with the pack in norm order nearly
+                  // ascending): the f32 sweep skips the column tiles whose Cauchy-Schwarz bound with the wave's own rows is inside
+                  // the collapsed range without touching them (mm_mfma.hip)
   size_t Cm;      // [L][Mp][Mp] f64 Kuu^-1 S Kuu^-1 - Kuu^-1, zero padded (absent: == total).
                   // Always f64: with Kuu jitter 1e-6 its norm reaches 1e6.
   size_t total;
@@ -147,6 +150,7 @@ static inline MMModelLayout mm_model_layout(int L, int M, int d, int dtype, int 
   if (dtype != MM_F64 && d <= 8) off = mm_align_up(off + mm_tab56(d).bytes, A);
   o.perm = off;   off = mm_align_up(off + (size_t)L * o.Mp * 4, A);
   o.skey = off;   off = mm_align_up(off + (size_t)L * o.Mp * 8, A);
+  o.zt2 = off;    off = mm_align_up(off + (size_t)L * (o.Mp / 32) * 4, A);
   o.Cm = off;
   if (with_C) off = mm_align_up(off + (size_t)L * o.Mp * o.Mp * 8, A);
   o.total = off;
@@ -287,6 +291,12 @@ struct MMWorkspaceLayout {
   size_t mom;      // [B][Po][2][MM_MOM_SPLIT][KMp] f64  partial sums over m of what_m zc_m^alpha (all monomials of the
                    //                  table): row side, column side; MM_MOM_SPLIT slices of the m range
   size_t amax;     // [B][Po] u32  bits of max_i |A_i|^2 (f32, >= 0: ordered like the integer), zeroed by k_prep
+  size_t amaxc;    // [B][Po] u32  the same over the rows of the COLLAPSED row groups alone (0: none), zeroed by k_prep (== amax + 4 B Po)
+  size_t gflag;    // [B][Po][Mp/64] u8 (f32 mode, d <= 8): 1 = the 64-row group is collapsed -- orders 4, 5, 6 of its rows' p6 come from
+                   //              the f32 moments (k_pairvec_reg writes zero bf16 row weights for the other groups), the sweep screens /
+                   //              corrects its tiles; 0 = the sweep reduces r(b) on every tile of the group -- minus the cubic term
+                   //              C0 b^3 where the item has collapsed groups at all: the f64 moments then carry that term for EVERY
+                   //              row (mm_mono.h: MM_GROUP_ROWS)
   size_t gperm;    // [L][(L-1) B] i32 + [3][L] i32 (f32 mode): per latent the rows of its moment GEMM ordered [collapsed to degree 6 |
                    //              to degree 5 | to degree 4 | not collapsed], and the counts {collapsed, needing degree 5, needing
                    //              degree 6} -- every column block of the GEMMs is formed for the rows that read it only
@@ -348,7 +358,9 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.whR = off;     off = mm_align_up(off + nwh * 8, A);
   o.whC = off;     off = mm_align_up(off + nwh * 8, A);
   o.mom = off;     off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * 2 * MM_MOM_SPLIT * mm_moment_cols(d) * 8), A);
-  o.amax = off;    off = mm_align_up(off + (size_t)B * o.Po * 4, A);
+  o.amax = off;    off = off + (size_t)B * o.Po * 4;
+  o.amaxc = off;   off = mm_align_up(off + (size_t)B * o.Po * 4, A);
+  o.gflag = off;   off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * (o.Mp / 64)), A);
   o.gperm = off;   off = mm_align_up(off + (dtype == MM_F64 || L < 2 ? 0 : ((size_t)L * (L - 1) * B + 3 * L) * 4), A);
   o.s12 = off;     off = mm_align_up(off + (size_t)B * o.Po * 8, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);

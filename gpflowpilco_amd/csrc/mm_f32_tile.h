@@ -16,6 +16,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct mm_true { static constexpr bool value = true; };
 struct mm_false { static constexpr bool value = false; };
+template <int V> struct mm_int { static constexpr int value = V; };
 
 __device__ __forceinline__ unsigned int mm_f2bf(float x) {
   const __bf16 b = (__bf16)x;                                  // v_cvt_pk_bf16_f32, round to nearest even

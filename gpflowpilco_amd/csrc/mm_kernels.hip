@@ -262,6 +262,19 @@ __global__ void k_pack_vectors(char* packed, MMModelLayout lay, int L, int M, in
     __syncthreads();
     if (tid == 0) ((double*)(packed + lay.zmax2))[a] = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
     __syncthreads();
+    // the same per 32-point column tile (MMModelLayout::zt2)
+    float* zt2 = (float*)(packed + lay.zt2) + (size_t)a * (lay.Mp / 32);
+    for (int t = tid; t < lay.Mp / 32; t += 256) {
+      double mx = 0.0;
+      for (int j = 0; j < 32; ++j) {
+        const int m = t * 32 + j;
+        if (m >= M) break;
+        double s2 = 0.0;
+        for (int k = 0; k < d; ++k) { const double v = Z[((size_t)a * M + m) * d + k] - zb[k]; s2 += v * v; }
+        mx = s2 > mx ? s2 : mx;
+      }
+      zt2[t] = (float)(mx * 1.000001);
+    }
   }
   if (sizeof(T) != 8) {
     // bf16 3-way split of the centred inputs for the f32 MFMA kernel, tile-and-part major:
@@ -404,7 +417,10 @@ __global__ __launch_bounds__(192) void k_prep(const double* __restrict__ ls2, co
   } else {
     int a, a2;
     mm_decode_pair(item, L, a, a2);
-    if (amax && item >= L && tid == 0) amax[(size_t)b * (P - L) + (item - L)] = 0u;   // k_pairvec max-es |A_i|^2 into it
+    if (amax && item >= L && tid == 0) {                    // k_pairvec max-es |A_i|^2 into both: amax, and amaxc right behind it
+      amax[(size_t)b * (P - L) + (item - L)] = 0u;
+      amax[((size_t)gridDim.y + b) * (P - L) + (item - L)] = 0u;
+    }
     const double* la = ls2 + a * d;
     const double* lb = ls2 + a2 * d;
     for (int idx = tid; idx < d * d; idx += nt) {
@@ -638,7 +654,8 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
                                                  const double* __restrict__ q64, double* __restrict__ qhR,
                                                  double* __restrict__ qhC, int with_unc, int nblk,
                                                  const double* __restrict__ lq, const double* __restrict__ beta64,
-                                                 const double* __restrict__ zmax2, unsigned short* __restrict__ /* wsp: d <= 8 only */, int p0) {
+                                                 const double* __restrict__ zmax2, unsigned short* __restrict__ /* wsp: d <= 8 only */,
+                                                 unsigned char* __restrict__ /* gflag */, int /* allow */, int p0) {
   static_assert(DK > 8, "d <= 8 takes k_pairvec_reg");
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
   // pair's matrix is fetched once per workgroup, not once per chunk
@@ -823,7 +840,7 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
                                                     double* __restrict__ qhC, int with_unc, int nblk, int a, int a2,
                                                     double (*vecs)[DK], const double* __restrict__ lq,
                                                     const double* __restrict__ beta64, int p, const double* __restrict__ zmax2,
-                                                    unsigned short* __restrict__ wsp) {
+                                                    unsigned short* __restrict__ wsp, unsigned char* __restrict__ gflag, int allow) {
   constexpr bool diag = MODE == 0;
   const int b = blockIdx.z, tid = threadIdx.x;
   const int Po = P - L;
@@ -936,6 +953,9 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
   }
   const double cst = pm[d * d];
   float a2max = 0.0f;                                         // max_i |A_i|^2 over this thread's rows (f32 off-diagonal pairs)
+  float a2cmax = 0.0f, a2in = 0.0f;                           // ... over the rows of COLLAPSED groups alone (mm_mono.h: row-group collapse)
+  const bool cancoll = MODE == 1 && allow && recentred;       // no group is collapsed where the caller rules it out or the rows stay at mu
+  const double zm2c = MODE == 1 ? zmax2[a2] : 0.0;
   typedef const __attribute__((address_space(3))) double* lds_cptr;
   // rows i >= d of a (d + 1)-row operand do not exist: their (zero) value goes to row d, which the chunk's last
   // store overwrites -- no branch per row, and no extra store at all when d == DK
@@ -991,6 +1011,8 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
       T* cO = colO + ((size_t)b * Po + (p - L)) * Mp;
       double* hR = whR + ((size_t)b * Po + (p - L)) * Mp;
       double* hC = whC + ((size_t)b * Po + (p - L)) * Mp;
+      double whr = 0.0, whc = 0.0;
+      bool rowok = true;                                     // (padding rows: A_i = 0)
       if (live) {
         double sr[DK], sc[DK];
         double cj = vl[6 * DK];                              // c_j = t0 . (zc'_j / Lam_a'): the row shift's column factor
@@ -1017,27 +1039,32 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
           corrA = fma(vl[3 * DK + i], u, corrA);
           rO[rowi(i) + m] = (T)av;
         }
-        a2max = fmaxf(a2max, (float)asq * 1.000001f);        // rounded up: the bound must not be under-estimated
-        const double whr = o.br * exp(fmin(o.wr - 0.5 * (o.r1r - tA) + cst - corrA, (double)MM_EXP_CAP_F32));
-        const double whc = o.bc * exp(fmin(o.wc - 0.5 * (o.r1c - tg) - cj, (double)MM_EXP_CAP_F32));
-        rO[rowd + m] = (T)whr; cO[m] = (T)whc; hR[m] = whr; hC[m] = whc;
-        if (wsp) {
-          // bf16 2-way split of both weights: the A operand of the degree-5/6 moment GEMM (mm_moments6.hip), [side][h, m][Mp]
-          unsigned short* sp = wsp + ((size_t)b * Po + (p - L)) * 4 * (size_t)Mp + m;
-          const float fr = (float)whr, fc = (float)whc;
-          const __bf16 rh = (__bf16)fr, ch = (__bf16)fc;
-          const __bf16 rm = (__bf16)(fr - (float)rh), cm = (__bf16)(fc - (float)ch);
-          sp[0] = __builtin_bit_cast(unsigned short, rh); sp[Mp] = __builtin_bit_cast(unsigned short, rm);
-          sp[2 * (size_t)Mp] = __builtin_bit_cast(unsigned short, ch); sp[3 * (size_t)Mp] = __builtin_bit_cast(unsigned short, cm);
-        }
+        const float a2row = (float)asq * 1.000001f;          // rounded up: the bound must not be under-estimated
+        a2max = fmaxf(a2max, a2row);
+        rowok = mm_collapse_bound2(__float_as_uint(a2row), zm2c) <= MM_COLLAPSE_BOUND2;
+        a2in = a2row;
+        whr = o.br * exp(fmin(o.wr - 0.5 * (o.r1r - tA) + cst - corrA, (double)MM_EXP_CAP_F32));
+        whc = o.bc * exp(fmin(o.wc - 0.5 * (o.r1c - tg) - cj, (double)MM_EXP_CAP_F32));
       } else {
 #pragma unroll
         for (int i = 0; i < DK; ++i) rO[rowi(i) + m] = (T)0;  // zero rows: b = 0 in the padding
-        rO[rowd + m] = (T)0; cO[m] = (T)0; hR[m] = 0.0; hC[m] = 0.0;
-        if (wsp) {
-          unsigned short* sp = wsp + ((size_t)b * Po + (p - L)) * 4 * (size_t)Mp + m;
-          sp[0] = 0; sp[Mp] = 0; sp[2 * (size_t)Mp] = 0; sp[3 * (size_t)Mp] = 0;
-        }
+        a2in = 0.0f;
+      }
+      rO[rowd + m] = (T)whr; cO[m] = (T)whc; hR[m] = whr; hC[m] = whc;
+      if (wsp) {
+        // ROW-GROUP COLLAPSE (mm_mono.h): this wave's 64 rows are one group; collapsed when every row's own Cauchy-Schwarz
+        // bound is <= 1/2.  (the lanes are converged here: m < Mp is wave-uniform, Mp % 128 == 0)
+        const bool inner = cancoll && __all(rowok);
+        if ((tid & 63) == 0) gflag[((size_t)b * Po + (p - L)) * (size_t)(Mp / MM_GROUP_ROWS) + (m >> 6)] = inner ? 1 : 0;
+        if (inner) a2cmax = fmaxf(a2cmax, a2in);
+        // bf16 2-way split of both weights: the A operand of the degree-4/5/6 moment GEMM (mm_moments6.hip), [side][h, m][Mp];
+        // the ROW weight of a group that is not collapsed is zero there
+        unsigned short* sp = wsp + ((size_t)b * Po + (p - L)) * 4 * (size_t)Mp + m;
+        const float fr = inner ? (float)whr : 0.0f, fc = (float)whc;
+        const __bf16 rh = (__bf16)fr, ch = (__bf16)fc;
+        const __bf16 rm = (__bf16)(fr - (float)rh), cm = (__bf16)(fc - (float)ch);
+        sp[0] = __builtin_bit_cast(unsigned short, rh); sp[Mp] = __builtin_bit_cast(unsigned short, rm);
+        sp[2 * (size_t)Mp] = __builtin_bit_cast(unsigned short, ch); sp[3 * (size_t)Mp] = __builtin_bit_cast(unsigned short, cm);
       }
     } else {
       // off-diagonal pair of the f64 mode: rho_i (row), g_j and gamma'_j (column)
@@ -1087,6 +1114,10 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
     for (int off = 32; off > 0; off >>= 1) a2max = fmaxf(a2max, __shfl_down(a2max, off, 64));
     // rows left centred at mu: marked (mm_mono.h), which also keeps the item out of every collapse predicate
     if ((tid & 63) == 0) atomicMax(amax + (size_t)b * Po + (p - L), recentred ? __float_as_uint(a2max) : MM_AMAX_NOT_RECENTRED);
+    // amaxc ([B][Po] right behind amax): the same over the collapsed groups
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a2cmax = fmaxf(a2cmax, __shfl_down(a2cmax, off, 64));
+    if ((tid & 63) == 0 && a2cmax > 0.0f) atomicMax(amax + ((size_t)gridDim.z + b) * Po + (p - L), __float_as_uint(a2cmax));
   }
 }
 
@@ -1102,7 +1133,8 @@ __global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict
                                                         const double* __restrict__ q64, double* __restrict__ qhR,
                                                         double* __restrict__ qhC, int with_unc, int nblk,
                                                         const double* __restrict__ lq, const double* __restrict__ beta64,
-                                                        const double* __restrict__ zmax2, unsigned short* __restrict__ wsp, int p0) {
+                                                        const double* __restrict__ zmax2, unsigned short* __restrict__ wsp,
+                                                        unsigned char* __restrict__ gflag, int allow, int p0) {
   // (grid.y = the pairs [p0, p0 + gridDim.y): the q stage launches the diagonal pairs' operands first -- the diagonal sweep needs
   // nothing else -- and the off-diagonal pairs' on the side stream beside that sweep)
   static_assert(DK <= 8, "register form: d <= 8");
@@ -1113,7 +1145,7 @@ __global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict
   mm_decode_pair(p, L, a, a2);
 #define MM_PV_BODY(MODE_)                                                                                           \
   mm_pairvec_reg_body<T, DK, MODE_>(Zt64, zbar, ls2, L, M, Mp, d, P, mu, pairmat, rho1, rowD, colD, rowO, colO, w64, \
-                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64, p, zmax2, wsp)
+                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64, p, zmax2, wsp, gflag, allow)
   if (p < L) MM_PV_BODY(0);
   else if (sizeof(T) == 4) MM_PV_BODY(1);
   else MM_PV_BODY(2);
@@ -1134,7 +1166,8 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
                                                       const T* __restrict__ w, const T* __restrict__ q,
                                                       const T* __restrict__ rowA, const T* __restrict__ colB,
                                                       double* __restrict__ partB, double* __restrict__ partC,
-                                                      const unsigned int* __restrict__ amax, const double* __restrict__ zmax2) {
+                                                      const unsigned char* __restrict__ gflag, const unsigned int* __restrict__ amaxc,
+                                                      const double* __restrict__ zmax2) {
   const int cbk = blockIdx.x % ncb, rbk = blockIdx.x / ncb;
   const int lp = blockIdx.y, np = gridDim.y, p = p0 + lp, b = blockIdx.z, tid = threadIdx.x;
   int a, a2;
@@ -1166,10 +1199,12 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
   const int i1 = (i0 + MM_GEN_ROWS < Mp) ? i0 + MM_GEN_ROWS : Mp;
   T accB = (T)0;
   double sumB = 0.0, sumC = 0.0;
-  // ROWVEC: a collapsed (b, pair) has p6 (mm_common.h) of the remainder in the moments (mm_moments.hip, mm_moments6.hip)
-  const bool coll = ROWVEC && amax != nullptr && zmax2 != nullptr &&
-                    mm_collapse_bound2(amax[(size_t)b * np + lp], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
+  // ROWVEC: the rows of a COLLAPSED row group (mm_mono.h) have p6 (mm_common.h) of the remainder in the moments (mm_moments.hip,
+  // mm_moments6.hip); the other rows of an item with such a group the cubic term C0 b^3 alone
+  const unsigned char* gf = (ROWVEC && gflag != nullptr && zmax2 != nullptr) ? gflag + ((size_t)b * np + lp) * (size_t)(Mp / MM_GROUP_ROWS) : nullptr;
+  const bool icoll = gf != nullptr && mm_item_collapsed(amaxc[(size_t)b * np + lp]);
   for (int i = i0; i < i1; ++i) {
+    const bool coll = icoll && gf[i >> 6] != 0;
     T delta = ROWVEC ? (T)0 : ra[i] + gam;
 #pragma unroll
     for (int k = 0; k < DK; ++k)
@@ -1177,7 +1212,7 @@ __global__ __launch_bounds__(256) void k_qred_generic(const T* __restrict__ Zc, 
     // ROWVEC (f32 off-diagonal pairs): only the remainder expm1(b) - b - b^2/2 is reduced here, the
     // rest comes from the f64 weight moments (k_spoly); evaluated in f64 (portable cross-check kernel)
     const double dd = fmin((double)delta, sizeof(T) == 8 ? MM_EXP_CAP_F64 : (double)MM_EXP_CAP_F32);   // (mm_common.h: exponent caps)
-    const T e = ROWVEC ? (T)(expm1(dd) - dd - 0.5 * dd * dd - (coll ? MM_C6_POLY_F64(dd) : 0.0))
+    const T e = ROWVEC ? (T)(expm1(dd) - dd - 0.5 * dd * dd - (coll ? MM_C6_POLY_F64(dd) : (icoll ? (double)MM_C6_C0 * dd * dd * dd : 0.0)))
                        : (T)expm1(dd);
     accB += (ROWVEC ? ra[(size_t)d * Mp + i] : wr[i]) * e;
     if (withC) {
@@ -1449,7 +1484,8 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     (const double*)(ws + wl.w64), (double*)(ws + wl.whR), (double*)(ws + wl.whC), amax,                                      \
     (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC), (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk, \
     (const double*)(ws + wl.lq), (const double*)(packed + ml.beta64), (const double*)(packed + ml.zmax2),                       \
-    ((sizeof(T) == 4 && d <= 8) ? (unsigned short*)(ws + wl.wsp) : (unsigned short*)nullptr)
+    ((sizeof(T) == 4 && d <= 8) ? (unsigned short*)(ws + wl.wsp) : (unsigned short*)nullptr),                                \
+    (unsigned char*)(ws + wl.gflag), ((flags & (MM_FORCE_WORST_TIER | MM_ISTAGE_NO_M56)) ? 0 : 1)
     auto pairvec = [&](int p0, int npairs, hipStream_t st) {
       if (npairs <= 0) return;
       if constexpr (DK <= 8) {
@@ -1531,7 +1567,7 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
                          (const double*)(packed + ml.Zc64), ml.Kz, Cm, L, wl.Mp, d, wl.P, wl.NS, ncb, 0,
                          (const double*)(ws + wl.w64), (const double*)(ws + wl.q64),
                          (const double*)(ws + wl.rowD), (const double*)(ws + wl.colD), partB, partC,
-                         (const unsigned int*)nullptr, (const double*)nullptr);
+                         (const unsigned char*)nullptr, (const unsigned int*)nullptr, (const double*)nullptr);
       MM_CHECK_LAUNCH();
     } else {
       const int rc = mm_launch_qred_f64((const double*)(packed + ml.Zc64), ml.Kz, Cm,
@@ -1569,7 +1605,8 @@ static int mm_Q_reduce_t(const char* packed, const MMModelLayout& ml, bool has_C
                          (const T*)(packed + ml.Zc), ml.Kz, (const double*)nullptr, L, wl.Mp, d, wl.P, wl.NS, ncb, L,
                          (const T*)(ws + wl.w), (const T*)nullptr, (const T*)(ws + wl.rowO),
                          (const T*)(ws + wl.colO), partB, partC,
-                         (sizeof(T) == 4 && !(flags & MM_FORCE_WORST_TIER)) ? (const unsigned int*)(ws + wl.amax) : (const unsigned int*)nullptr,
+                         (sizeof(T) == 4 && d <= 8 && !(flags & MM_FORCE_WORST_TIER)) ? (const unsigned char*)(ws + wl.gflag) : (const unsigned char*)nullptr,
+                         (const unsigned int*)(ws + wl.amaxc),
                          (sizeof(T) == 4 && mm_moment_deg(d) >= 4) ? (const double*)(packed + ml.zmax2) : (const double*)nullptr);
       MM_CHECK_LAUNCH();
     }

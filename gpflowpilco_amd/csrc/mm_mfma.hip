@@ -58,14 +58,16 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
 // CC: the (b, pair) is collapsed -- its moments already carry p6 = x^3 (C0 + C1 x + C2 x^2 + C3 x^3) (mm_common.h), which is
 // subtracted from the four leading coefficients at compile time (the corrected polynomial costs no instruction; the
 // differences are exact in f32: Sterbenz)
-template <int DEG, bool CC>
+template <int DEG, int CC>
 struct MMRemC {
+  // CC: what the moments already carry for these rows -- 0: nothing beyond order 2; 1: p6 (a collapsed row group); 2: the cubic
+  // term C0 x^3 alone (the other row groups of an item that has collapsed ones: mm_mono.h)
   static constexpr float get(int k) {
     const float c6[4] = {MM_C6_C0, MM_C6_C1, MM_C6_C2, MM_C6_C3};
-    return MMRem<DEG>::c[k] - ((CC && k < 4) ? c6[k] : 0.0f);
+    return MMRem<DEG>::c[k] - ((CC == 1 && k < 4) ? c6[k] : ((CC == 2 && k == 0) ? c6[0] : 0.0f));
   }
 };
-template <int DEG, bool CC>
+template <int DEG, int CC>
 __device__ __forceinline__ f32x2 mm_weighted_rem(const f32x2 (&xx)[16], const f32x2 (&wrow)[2][8]) {
   f32x2 parts[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   // two halves of 8 register pairs (one 32-row MFMA tile each): 8 independent chains cover the packed-FMA latency,
@@ -129,7 +131,9 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
                                                           int L, int Mp, int d, int P, int Po, int NS,
                                                           int npanel, int ppw, int nwork, int force_worst,
                                                           const unsigned int* __restrict__ amax,
-                                                          const double* __restrict__ zmax2,
+                                                          const unsigned int* __restrict__ amaxc,
+                                                          const unsigned char* __restrict__ gflag,
+                                                          const double* __restrict__ zmax2, const float* __restrict__ zt2,
                                                           const float* __restrict__ rowO,
                                                           const float* __restrict__ colO,
                                                           double* __restrict__ partB, float* __restrict__ estO,
@@ -203,18 +207,24 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     const float* wcf = colO + ((size_t)b * Po + lp) * Mp;                    // what'_j
     // pre-split centred inducing inputs of latent a': [Mp/32][3 (h,m,l)][32][8 ND8] bf16
     const unsigned short* zs = Zs3 + (size_t)a2 * Mp * (24 * ND8);
-    // collapsed (b, pair)?  Cauchy-Schwarz: |b_ij| <= |A_i| |zc_j| <= sqrt(bound2); the same predicate as k_spoly
-    const float bound2 = zmax2 ? mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) : 3.0e38f;
-    const bool coll = (ND8 == 1) && !force_worst && bound2 <= MM_COLLAPSE_BOUND2;
+    // are this wave's 64 rows a COLLAPSED row group (mm_mono.h)?  k_pairvec_reg decided, with the Cauchy-Schwarz bound of the
+    // group's rows, |b_ij| <= |A_i| |zc_j|; bound2: the bound over all collapsed groups of the item (the screening margin)
+    const float bound2 = zmax2 ? mm_collapse_bound2(amaxc[(size_t)b * Po + lp], zmax2[a2]) : 3.0e38f;
+    // icoll: the item has collapsed groups -- then the CUBIC term of every row is in the f64 moments (k_spoly), and a group that
+    // is not collapsed reduces r(b) - C0 b^3 on every tile
+    const bool icoll = (ND8 == 1) && !force_worst && zmax2 != nullptr && mm_item_collapsed(amaxc[(size_t)b * Po + lp]);
+    const bool coll = icoll && gflag[((size_t)b * Po + lp) * (size_t)(Mp / MM_GROUP_ROWS) + (row0 >> 6)] != 0;
     // a tile is skipped on the screening product alone: its error is <= 2^-9 sum_k |A_k||Z_k| <= 2^-9 sqrt(bound2)
     const float thr_skip = MM_C6_MAX - 0.00390625f * __builtin_sqrtf(bound2) - 1e-6f;
 
     // ---- stationary operands --------------------------------------------------------------
     bf16x8 a1[2][ND8], a2v[2][ND8], a3[2][ND8];
     f32x2 wrow[2][8], wc0[2][8], wc1[2][8];
+    float a2w = 0.0f;                                     // max |A_i|^2 over this wave's rows, from the operand values themselves
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int row = row0 + rt * 32 + l31;
+      float a2r = 0.0f;
 #pragma unroll
       for (int nb = 0; nb < ND8; ++nb) {
         unsigned int hh[8], mm[8], ll[8];
@@ -223,6 +233,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
           const int k = nb * 8 + j;
           const float v = ra[(size_t)(k < d ? k : d) * Mp + row];
           mm_split3(k < d ? v : 0.0f, hh[j], mm[j], ll[j]);
+          a2r = fmaf(k < d ? v : 0.0f, v, a2r);
         }
         u32x4 ph, pm, pl;
 #pragma unroll
@@ -237,6 +248,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
         a2v[rt][nb] = __builtin_bit_cast(bf16x8, h ? pl : ph);
         a3[rt][nb] = __builtin_bit_cast(bf16x8, ph);
       }
+      a2w = fmaxf(a2w, a2r);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int rr = row0 + rt * 32 + 8 * g + 4 * h;
@@ -332,20 +344,20 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // (sub0, sub1) = (c0, c1) of the first tier for a collapsed (b, pair) -- already in the moments -- else (0, 0).
     // collm (compile time): the (b, pair) is collapsed -- the moments already carry c0 x^3 + c1 x^4 of the first tier
     auto reduce_tile = [&](auto collm, const f32x16 (&acc)[2], float mx, float wc) {
-      constexpr bool CC = decltype(collm)::value;
+      constexpr int CC = decltype(collm)::value;            // 0 / 1 / 2: MMRemC
       f32x2 xx[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) xx[r] = (f32x2){acc[r >> 3][2 * (r & 7)], acc[r >> 3][2 * (r & 7) + 1]};
       f32x2 part2;
       // wave-uniform tier choice (ballots, no cross-lane reduction)
-      if (!CC && !__any(mx > MM_TIER1_MAX)) {
+      if (CC == 0 && !__any(mx > MM_TIER1_MAX)) {
         // (the folded coefficients cost 64 more VGPRs: only where the operand registers leave room, d <= 8)
         if constexpr (ND8 == 1) part2 = mm_weighted_rem1(xx, wc0, wc1);
-        else part2 = mm_weighted_rem<1, false>(xx, wrow);
+        else part2 = mm_weighted_rem<1, 0>(xx, wrow);
       } else if (!__any(mx > MM_C6_MAX)) {
-        // a collapsed (b, pair) has nothing left to add below 1/4: its moments carry this tier's own polynomial
-        if constexpr (CC) part2 = (f32x2){0.0f, 0.0f};
-        else part2 = mm_weighted_rem<3, false>(xx, wrow);
+        // a collapsed row group has nothing left to add below 1/4: its moments carry this tier's own polynomial
+        if constexpr (CC == 1) part2 = (f32x2){0.0f, 0.0f};
+        else part2 = mm_weighted_rem<3, CC>(xx, wrow);
       } else if (!__any(mx > 0.5f)) {
         part2 = mm_weighted_rem<4, CC>(xx, wrow);
       } else if (!__any(mx > 1.0f)) {
@@ -361,7 +373,8 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
             const float xs = fminf(fmaxf(x, -1.0f), 1.0f);
             const float big = (__builtin_amdgcn_exp2f(x * 1.44269504f) - 1.0f) - fmaf(0.5f * x, x, x);
             float e = (fabsf(x) <= 1.0f) ? mm_rem_p5(xs) : big;
-            if constexpr (CC) e -= (x * x) * x * fmaf(fmaf(fmaf(MM_C6_C3, x, MM_C6_C2), x, MM_C6_C1), x, MM_C6_C0);
+            if constexpr (CC == 1) e -= (x * x) * x * fmaf(fmaf(fmaf(MM_C6_C3, x, MM_C6_C2), x, MM_C6_C1), x, MM_C6_C0);
+            if constexpr (CC == 2) e -= (x * x) * (x * MM_C6_C0);
             part2[e2] = fmaf(wrow[r >> 3][r & 7][e2], e, part2[e2]);
           }
       }
@@ -400,14 +413,35 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // two-stage register ping-pong: tile ct + 1 is in flight while tile ct is reduced.  (Issuing the MFMAs
     // of tile ct + 1 interleaved with the v_max3 range check of tile ct -- a second accumulator set,
     // 182 VGPRs -- was measured: 4.27 ms against 4.25 ms; three waves per SIMD already overlap the two.)
+    // A collapsed row group skips, without touching them, the column tiles whose Cauchy-Schwarz bound with ITS rows is inside the
+    // collapsed range: max_i |A_i|^2 (this wave's rows) x max_j |zc'_j|^2 (the tile's 32 points, MMModelLayout::zt2) <=
+    // MM_INSIDE_BOUND2.  The pack's norm order makes those tiles a PREFIX: the sweep starts at the first tile that is not
+    // (BASELINE recipe: two thirds of the screened wave tiles; the screening product + range check was half the sweep's time).
+    int ct_first = 0;
+    if (coll && zt2 != nullptr) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) a2w = fmaxf(a2w, __shfl_xor(a2w, off, 64));
+      a2w *= 1.000001f;
+      const float* zt = zt2 + (size_t)a2 * nct;
+      int cf = nct;
+      for (int c0 = 0; c0 < nct; c0 += 64) {
+        const int c = c0 + lane;
+        const bool outside = c < nct && a2w * zt[c < nct ? c : 0] > MM_INSIDE_BOUND2;
+        const unsigned long long bal = __ballot(outside);
+        if (bal) { cf = c0 + (int)__builtin_ctzll(bal); break; }
+      }
+      ct_first = cf & ~1;
+    }
     auto sweep = [&](auto collc, auto collm) __attribute__((always_inline)) {
       constexpr bool CM = decltype(collc)::value;
       u32x4 zA0[ND8], zB0[ND8], zA1[ND8], zB1[ND8];
       float w0, w1;
       w0 = w1 = 0.0f;
-      load_zA(0, zA0);
+      const int ct0 = CM ? ct_first : 0;
+      if (ct0 >= nct) return;
+      load_zA(ct0, zA0);
       if constexpr (!CM) { load_zB(0, zB0); w0 = wcf[l31]; }
-      for (int ct = 0; ct < nct; ct += 2) {
+      for (int ct = ct0; ct < nct; ct += 2) {
         load_zA(ct + 1, zA1);
         if constexpr (!CM) { load_zB(ct + 1, zB1); w1 = wcf[(ct + 1) * 32 + l31]; }
         float emx0, ewc0, emx1, ewc1;
@@ -431,8 +465,10 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // tools/tile_hist_baseline.py).
     // (Two instantiations, not a run-time flag: a non-collapsed item must not pay for the collapsed coefficients -- as a flag
     // they cost the exp2 branch 4 more ops per entry: forced-worst C3 12.5 -> 16.8 ms)
-    if (coll) sweep(mm_true{}, mm_true{});
-    else sweep(mm_false{}, mm_false{});
+    // (the third: the dense row groups of an item that has collapsed ones, cubic term in the moments)
+    if (coll) sweep(mm_true{}, mm_int<1>{});
+    else if (icoll) sweep(mm_false{}, mm_int<2>{});
+    else sweep(mm_false{}, mm_int<0>{});
   }
   // workgroup reduction -> slab
   float estl;
@@ -480,7 +516,8 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
   float* estO = (float*)(ws + wl.estO);
 #define MM_LAUNCH_ND(ND_, LZ_, SH_)                                                                          \
   hipLaunchKernelGGL((k_qred_f32_mfma<ND_, LZ_>), dim3(nwork), dim3(256), SH_, stream, Zs3, L, wl.Mp, d,    \
-                     wl.P, wl.Po, wl.NS, npanel, ppw, nwork, force_worst, amax, zmax2, rowO, colO, partB, estO, (int*)(ws + wl.rcount))
+                     wl.P, wl.Po, wl.NS, npanel, ppw, nwork, force_worst, amax, (const unsigned int*)(ws + wl.amaxc), \
+                     (const unsigned char*)(ws + wl.gflag), zmax2, (const float*)(packed + ml.zt2), rowO, colO, partB, estO, (int*)(ws + wl.rcount))
   switch (ml.nd8) {
     case 1: if (ldsz) MM_LAUNCH_ND(1, true, zbytes); else MM_LAUNCH_ND(1, false, 0); break;
     case 2: MM_LAUNCH_ND(2, false, 0); break;

@@ -48,7 +48,7 @@ __device__ __forceinline__ void mm_decode_pair_m(int p, int L, int& a, int& a2) 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_wmom_gemm(const double* __restrict__ whR, const double* __restrict__ whC,
                                                       const double* __restrict__ Zm, int KMp, int L, int Mp, int B, int Po,
                                                       int nrb, int ncb, int nwork, int col_deg3,
-                                                      const unsigned int* __restrict__ amax, const double* __restrict__ zmax2,
+                                                      const unsigned int* __restrict__ amaxc, const double* __restrict__ zmax2,
                                                       const int* __restrict__ gperm, double* __restrict__ mom) {
   // The GEMM of latent a: rows = every weight vector taken against a's table -- (L - 1) B of them: for partner
   // a' > a the ROW side of pair (a, a'), for a' < a the COLUMN side of pair (a', a) -- so a 64-row block is full
@@ -89,10 +89,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     } else {
       const int r = rb * MM_GEMM_RB + lane;
       bool c = false;
-      if (amax != nullptr && r < R) {
+      if (amaxc != nullptr && r < R) {
         int b, po, side, acol;
         row_item(r, b, po, side, acol);
-        c = mm_collapse_bound2(amax[(size_t)b * Po + po], zmax2[acol]) <= MM_COLLAPSE_BOUND2;
+        c = mm_item_collapsed(amaxc[(size_t)b * Po + po]);
       }
       if (!__any(c)) return;                                // every wave evaluates the same 64 rows: uniform exit
     }
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   int ab, apo, aside, aacol;
   row_item(perm ? perm[arow] : arow, ab, apo, aside, aacol);
   const double* aptr = (aside ? whC : whR) + ((size_t)ab * Po + apo) * Mp + k_begin + ak;
+
   const int bk = tid >> 3, bc = (tid & 7) * 16;
   const int col0 = cb * MM_GEMM_NB + bc;
   const bool bvalid = col0 < KMp;                           // KMp % 16 == 0: a 16-column chunk is all in or all out
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // k_wmom_gemm) ordered by collapse class (mm_common.h: MM_C6_X5_2), the collapsed classes first in their natural order, the others
 // behind them from the back; three counts behind the permutations.  Two passes (class totals, placement), 1024 rows at a time.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_wmom_perm(const unsigned int* __restrict__ amax, const double* __restrict__ zmax2, int L, int B,
+__global__ __launch_bounds__(1024) void k_wmom_perm(const unsigned int* __restrict__ amaxc, const double* __restrict__ zmax2, int L, int B,
                                                     int Po, int* __restrict__ gperm) {
   // classes by the item's bound X^2 (mm_common.h): 0: collapsed, X > 1/16 (degrees 3..6); 1: 1/32 < X <= 1/16 (3..5); 2: X <= 1/32
   // (3, 4); 3: not collapsed.  Classes 0..2 from the front in this order (stable inside a class), class 3 from the back.
@@ -196,8 +197,10 @@ __global__ __launch_bounds__(1024) void k_wmom_perm(const unsigned int* __restri
     const int ap = which < a ? which : which + 1;
     const int lo = ap < a ? ap : a, hi = ap < a ? a : ap;
     const int po = lo * (L - 1) - lo * (lo - 1) / 2 + (hi - lo - 1);
-    const float x2 = mm_collapse_bound2(amax[(size_t)b * Po + po], zmax2[hi]);
-    return x2 > MM_COLLAPSE_BOUND2 ? 3 : (x2 > MM_C6_X5_2 ? 0 : (x2 > MM_C6_X4_2 ? 1 : 2));
+    // (amaxc: the bound of the item's COLLAPSED row groups, mm_mono.h; none: class 3)
+    const unsigned int ac = amaxc[(size_t)b * Po + po];
+    const float x2 = mm_collapse_bound2(ac, zmax2[hi]);
+    return !mm_item_collapsed(ac) ? 3 : (x2 > MM_C6_X5_2 ? 0 : (x2 > MM_C6_X4_2 ? 1 : 2));
   };
   for (int r = tid; r < R; r += 1024) { const int c = cls_of(r); if (c < 3) ++cnt[c]; }
 #pragma unroll
@@ -273,7 +276,8 @@ __device__ __forceinline__ double mm_block_sum256m(double v, double* red) {
 template <int DK, int LB>
 __global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, int KMp, const double* __restrict__ pairmat,
                                                const double* __restrict__ zbar, const double* __restrict__ zmax2,
-                                               const unsigned int* __restrict__ amax, const float* __restrict__ mu,
+                                               const unsigned int* __restrict__ amax, const unsigned int* __restrict__ amaxc,
+                                               const float* __restrict__ mu,
                                                int L, int d, int P, int deg, int allow_collapse,
                                                int off1, int off2, int off3, int off4, const short* __restrict__ rtab,
                                                double c0, double c1, double* __restrict__ s12) {
@@ -313,8 +317,10 @@ __global__ __launch_bounds__(256) void k_spoly(const double* __restrict__ mom, i
     if (tid < DK) dmu[tid] = (tid < d && !rcen) ? (double)mu[(size_t)b * d + tid] - zbar[a * d + tid] : 0.0;
   }
   __syncthreads();
-  const bool coll = allow_collapse && deg >= 3 &&
-                    mm_collapse_bound2(amax[(size_t)b * Po + po], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
+  // (an item with at least one collapsed row group, mm_mono.h: the CUBIC term C0 b^3 then comes from these f64 moments for EVERY
+  // row -- the identity is exact for any b -- and the sweep's dense row groups reduce r(b) - C0 b^3; orders 4, 5, 6, from f32
+  // moments, cover the collapsed groups alone: k_pairvec_reg writes zero bf16 row weights for the others)
+  const bool coll = allow_collapse && deg >= 3 && mm_item_collapsed(amaxc[(size_t)b * Po + po]);
   const int nmax = coll ? deg : 2;                         // (deg = 3: the quartic term is mm_moments6.hip's)
   double Gr[DK == 8 ? 64 : 1];
   if constexpr (DK == 8) {
@@ -438,14 +444,14 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
   // rows of every latent's GEMM ordered with the collapsed items first (none collapse: no cubic / quartic block at all)
   const bool some = allow && mm_moment_deg(d) >= 4;
   if (some) {
-    hipLaunchKernelGGL(k_wmom_perm, dim3(L), dim3(1024), 0, stream, (const unsigned int*)(ws + wl.amax),
+    hipLaunchKernelGGL(k_wmom_perm, dim3(L), dim3(1024), 0, stream, (const unsigned int*)(ws + wl.amaxc),
                        (const double*)(packed + ml.zmax2), L, B, wl.Po, (int*)(ws + wl.gperm));
     hipError_t ep = hipGetLastError();
     if (ep != hipSuccess) return (int)ep;
   }
   hipLaunchKernelGGL(k_wmom_gemm, dim3(nwork), dim3(256), 0, stream, (const double*)(ws + wl.whR),
                      (const double*)(ws + wl.whC), Zm, ml.KMp, L, wl.Mp, B, wl.Po, nrb, ncb, nwork, col_deg3,
-                     some ? (const unsigned int*)(ws + wl.amax) : (const unsigned int*)nullptr,
+                     some ? (const unsigned int*)(ws + wl.amaxc) : (const unsigned int*)nullptr,
                      (const double*)(packed + ml.zmax2), some ? (const int*)(ws + wl.gperm) : (const int*)nullptr, mom);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
@@ -457,7 +463,7 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
     const size_t shm_ = (size_t)(dn_ + (dn_ >> 5) + up_ + (up_ >> 5) + 2 * ml.KMp + DK_ * DK_ + DK_ + 8) * sizeof(double);      \
     hipLaunchKernelGGL((k_spoly<DK_, LB_>), dim3(wl.Po, B), dim3(256), shm_, stream, (const double*)mom, ml.KMp,                \
                        (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zbar), (const double*)(packed + ml.zmax2), \
-                       (const unsigned int*)(ws + wl.amax), (const float*)mu_f32, L, d, wl.P, deg, allow, off1, off2, off3, off4, \
+                       (const unsigned int*)(ws + wl.amax), (const unsigned int*)(ws + wl.amaxc), (const float*)mu_f32, L, d, wl.P, deg, allow, off1, off2, off3, off4, \
                        (const short*)(packed + ml.rtab),                                                                        \
                        (double)MM_C6_C0, (double)MM_C6_C1, (double*)(ws + wl.s12));                                             \
   } while (0)
@@ -477,23 +483,32 @@ int mm_launch_moments(const char* packed, const MMModelLayout& ml, char* ws, con
 
 // ---------------------------------------------------------------------------------------------
 // mm_offdiag_stats: how many (b, off-diagonal pair) items of the last mm_q_forward are collapsed (bench.py reports
-// it with the timing: the reduce kernels' time depends on the regime).  out: device int32[4] = {collapsed, total,
-// wholly inside the collapsed range (no tile work at all), 0}.
+// it with the timing: the reduce kernels' time depends on the regime).  out: device int32[6] = {collapsed in every row group
+// (overall bound <= 1/2), total, wholly inside the collapsed range (no tile work at all), routed, PARTLY collapsed (some row
+// groups: mm_mono.h), collapsed 64-row groups over all items}.
 // ---------------------------------------------------------------------------------------------
-__global__ void k_offdiag_stats(const unsigned int* __restrict__ amax, const double* __restrict__ zmax2, int L, int Po, int n,
+__global__ void k_offdiag_stats(const unsigned int* __restrict__ amax, const double* __restrict__ zmax2,
+                                const unsigned char* __restrict__ gflag, int ng, int L, int Po, int n,
                                 int32_t* __restrict__ out) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  bool c = false, in = false;
+  bool c = false, in = false, part = false;
+  int groups = 0;
   if (idx < n) {
     int a, a2;
     mm_decode_pair_m(L + idx % Po, L, a, a2);
     const float b2 = mm_collapse_bound2(amax[idx], zmax2[a2]);
     c = b2 <= MM_COLLAPSE_BOUND2;
     in = b2 <= MM_INSIDE_BOUND2;
+    part = !c && mm_item_collapsed(amax[n + idx]);          // (amaxc right behind amax: at least one collapsed row group)
+    for (int g = 0; g < ng; ++g) groups += gflag[(size_t)idx * ng + g] ? 1 : 0;
   }
-  const unsigned long long m = __ballot(c), mi = __ballot(in);
+  const unsigned long long m = __ballot(c), mi = __ballot(in), mp = __ballot(part);
   if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, (int)__popcll(m));
   if ((threadIdx.x & 63) == 0 && mi) atomicAdd(out + 2, (int)__popcll(mi));
+  if ((threadIdx.x & 63) == 0 && mp) atomicAdd(out + 4, (int)__popcll(mp));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) groups += __shfl_down(groups, off, 64);
+  if ((threadIdx.x & 63) == 0 && groups) atomicAdd(out + 5, groups);
   if (idx == 0) out[1] = n;
 }
 
@@ -504,7 +519,7 @@ extern "C" int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, 
   const MMWorkspaceLayout wl = mm_workspace_layout(B, L, M, d, dtype, flags);
   if (packed_bytes < ml.Cm || workspace_bytes < wl.total) return MM_E_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out, 0, 4 * sizeof(int32_t), s);
+  hipError_t e = hipMemsetAsync(out, 0, 6 * sizeof(int32_t), s);
   if (e != hipSuccess) return (int)e;
   if (dtype == MM_F32 && wl.Po > 0) {       // out[3]: items the last forward on this workspace re-reduced in f64 (mm_route.hip)
     e = hipMemcpyAsync(out + 3, (const char*)workspace + wl.rcount + 4, sizeof(int32_t), hipMemcpyDeviceToDevice, s);
@@ -513,7 +528,8 @@ extern "C" int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, 
   if (dtype != MM_F32 || wl.Po == 0 || mm_moment_deg(d) < 4 || (flags & MM_FORCE_WORST_TIER)) return 0;   // nothing collapses
   const int n = B * wl.Po;
   hipLaunchKernelGGL(k_offdiag_stats, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned int*)((const char*)workspace + wl.amax),
-                     (const double*)((const char*)packed + ml.zmax2), L, wl.Po, n, out);
+                     (const double*)((const char*)packed + ml.zmax2), (const unsigned char*)((const char*)workspace + wl.gflag),
+                     wl.Mp / MM_GROUP_ROWS, L, wl.Po, n, out);
   e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }

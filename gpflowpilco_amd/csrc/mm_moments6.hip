@@ -363,7 +363,8 @@ __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin
 }
 
 __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict__ mom56, int N56p, const double* __restrict__ pairmat,
-                                                 const double* __restrict__ zmax2, const unsigned int* __restrict__ amax,
+                                                 const double* __restrict__ zmax2, const unsigned int* __restrict__ amaxc,
+                                                 const unsigned char* __restrict__ gflag,
                                                  const double* __restrict__ whR, const double* __restrict__ whC,
                                                  const char* __restrict__ tab, MMTab56 tb, int L, int d, int P, int Mp, int allow,
                                                  double* __restrict__ s56, float* __restrict__ estS) {
@@ -374,8 +375,9 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   int a, a2;
   mm6_decode_pair_o(po, L, a, a2);
   const size_t item = (size_t)b * Po + po;
-  const float bound2 = mm_collapse_bound2(amax[item], zmax2[a2]);
-  const bool coll = allow && bound2 <= MM_COLLAPSE_BOUND2;
+  // (the bound of the item's COLLAPSED row groups -- mm_mono.h: the moments carry their rows alone)
+  const float bound2 = mm_collapse_bound2(amaxc[item], zmax2[a2]);
+  const bool coll = allow && mm_item_collapsed(amaxc[item]);
   if (!coll) {
     if (tid == 0) { s56[item] = 0.0; estS[item] = 0.0f; }
     return;
@@ -419,7 +421,11 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
   {
     const double* hr = whR + item * Mp;
     const double* hc = whC + item * Mp;
-    for (int m = tid; m < Mp; m += MM6_THREADS) { const double x = hr[m], y = hc[m]; s2r = fma(x, x, s2r); s2c = fma(y, y, s2c); }
+    const unsigned char* gf = gflag + item * (size_t)(Mp / MM_GROUP_ROWS);
+    for (int m = tid; m < Mp; m += MM6_THREADS) {
+      const double x = gf[m >> 6] ? hr[m] : 0.0, y = hc[m];     // (the rows of the collapsed groups)
+      s2r = fma(x, x, s2r); s2c = fma(y, y, s2c);
+    }
   }
   __syncthreads();
   float G[64];
@@ -552,8 +558,8 @@ int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, c
     attr2_done.fetch_or(bit2);
   }
   hipLaunchKernelGGL(k_spoly56, dim3(wl.Po, B), dim3(MM6_THREADS), shm, stream, (const float*)(ws + wl.mom56), N56p,
-                     (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zmax2), (const unsigned int*)(ws + wl.amax),
-                     (const double*)(ws + wl.whR), (const double*)(ws + wl.whC), packed + ml.tab56, mm_tab56(d), L, d, wl.P, wl.Mp,
+                     (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zmax2), (const unsigned int*)(ws + wl.amaxc),
+                     (const unsigned char*)(ws + wl.gflag), (const double*)(ws + wl.whR), (const double*)(ws + wl.whC), packed + ml.tab56, mm_tab56(d), L, d, wl.P, wl.Mp,
                      allow, (double*)(ws + wl.s56), (float*)(ws + wl.estS));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

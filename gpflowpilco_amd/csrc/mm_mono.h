@@ -63,3 +63,16 @@ __host__ __device__ __forceinline__ bool mm_rows_recentred(unsigned int amax_bit
 __device__ __forceinline__ float mm_collapse_bound2(unsigned int amax_bits, double zmax2) {
   return __uint_as_float(amax_bits) * ((float)zmax2 * 1.000001f);
 }
+// ROW-GROUP COLLAPSE.  The predicate is taken per group of MM_GROUP_ROWS = 64 consecutive rows (one wave of k_pairvec_reg, one
+// wave panel of the tile kernel): a group is collapsed when the bound of ITS rows, max_{i in group} |A_i|^2 max_j |zc'_j|^2, is
+// <= MM_COLLAPSE_BOUND2.  With the pack in norm order (MMModelLayout::perm) the rows of large |A_i| are the last groups, and an
+// item whose overall bound is beyond 1/2 -- "dense" before: 11 % of the BASELINE recipe's items, 70 % of the sweep's time --
+// keeps 62 % of its rows collapsed.  gflag (workspace) is the ONE record of the decision; amaxc = the max of |A_i|^2 over the
+// collapsed groups (0: no collapsed group) gives the item's collapse degree and screening margin through mm_collapse_bound2.
+// Who carries what for an item with collapsed groups: the CUBIC term C0 b^3 of every row, collapsed or not, is in the f64
+// moments (k_wmom_gemm, k_spoly: sum_ij what_i what'_j b_ij^3 = <N_3, G^(x)3 Q_3> is an identity, exact for any b; the f64
+// GEMM needs no second weight set); orders 4, 5, 6 of p6 for the rows of the collapsed groups alone (f32 moments from the bf16
+// GEMM, whose row weights k_pairvec_reg zeroes for the other groups); the sweep reduces r - p6 on the collapsed groups' tiles
+// that are not skipped and r - C0 b^3 on every tile of the others; the routed f64 re-reduce r - C0 b^3 on every row.
+#define MM_GROUP_ROWS 64
+__host__ __device__ __forceinline__ bool mm_item_collapsed(unsigned int amaxc_bits) { return amaxc_bits != 0u; }

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
                                                    const double* __restrict__ Zt64, const double* __restrict__ Zc64, int Kz,
                                                    const double* __restrict__ mu64, const double* __restrict__ pairmat,
                                                    const double* __restrict__ whR, const double* __restrict__ whC,
-                                                   const unsigned int* __restrict__ amax, const double* __restrict__ zmax2,
+                                                   const unsigned int* __restrict__ amax, const unsigned int* __restrict__ amaxc,
+                                                   const double* __restrict__ zmax2,
                                                    int allow_collapse, int L, int M, int Mp, int d, int P, int Po, int npanel,
                                                    int ncc, int NS, double* __restrict__ out) {
   constexpr int NB2 = AGG ? DK * (DK + 1) / 2 : 1;
@@ -218,9 +219,9 @@ __global__ __launch_bounds__(256) void k_route_f64(const int* __restrict__ rlist
     }
     const double wr = live ? whR[((size_t)b * Po + lp) * Mp + rr] : 0.0;
     // the forward's collapsed items carry p6 in their moments (k_spoly, k_spoly56): the same predicate, the same coefficients
+    // (an item with at least one collapsed row group has the cubic term of EVERY row in its f64 moments: mm_mono.h, k_spoly)
     bool coll = false;
-    if (!AGG && allow_collapse && zmax2 != nullptr && d <= 8)
-      coll = mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) <= MM_COLLAPSE_BOUND2;
+    if (!AGG && allow_collapse && zmax2 != nullptr && d <= 8) coll = mm_item_collapsed(amaxc[(size_t)b * Po + lp]);
     // (order 3 of p6 stays with the f64 moments; orders 4, 5, 6 -- s56, from f32 moments -- are dropped for a routed item by
     // k_finalize, so the re-reduce keeps them: r - C0 x^3)
     const double sub0 = coll ? (double)MM_C6_C0 : 0.0, sub1 = 0.0;
@@ -338,7 +339,7 @@ int mm_launch_route(const char* packed, const MMModelLayout& ml, char* ws, const
 #define MMX_ARGS                                                                                                             \
   (const int*)rlist, (const int*)rcount, (const double*)(packed + ml.Zt64), (const double*)(packed + ml.Zc64), ml.Kz,       \
   (const double*)(ws + wl.mu64), (const double*)(ws + wl.pairmat), (const double*)(ws + wl.whR), (const double*)(ws + wl.whC), \
-  (const unsigned int*)(ws + wl.amax), zmax2, allow, L, M, wl.Mp, d, wl.P, wl.Po, npanel, ncc, wl.NS, out
+  (const unsigned int*)(ws + wl.amax), (const unsigned int*)(ws + wl.amaxc), zmax2, allow, L, M, wl.Mp, d, wl.P, wl.Po, npanel, ncc, wl.NS, out
   if (agg) {
     if (d > 8) return MM_E_DIM;
     if (d <= 4) hipLaunchKernelGGL((k_route_f64<4, true>), dim3(grid), dim3(256), 0, stream, MMX_ARGS);

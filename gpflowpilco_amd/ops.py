@@ -230,12 +230,26 @@ def offdiag_stats(pm: PackedModel, B: int, flags: int):
   weight moments (Cauchy-Schwarz bound on |b| <= 1/2), all items, and collapsed items whose bound puts every |b| <= 1/4 (the
   tile kernel does nothing for them).  Synchronises."""
   ws = pm.workspace(B, flags, peek=True)
-  out = torch.zeros(4, dtype=torch.int32, device=pm.device)
+  out = torch.zeros(6, dtype=torch.int32, device=pm.device)
   rc = lib().mm_offdiag_stats(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, flags,
                               ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(pm.device))
   check(rc, "mm_offdiag_stats")
-  c, n, inside, _ = out.tolist()
+  c, n, inside, _, _, _ = out.tolist()
   return c, n, inside
+
+
+def offdiag_row_groups(pm: PackedModel, B: int, flags: int):
+  """(partly collapsed items, collapsed 64-row groups, all row groups) of the last ``q_forward`` / ``moment_match``: the collapse is
+  decided per group of 64 rows of an item (csrc/mm_mono.h); an item counted by ``offdiag_stats`` as collapsed has all its groups
+  collapsed, a partly collapsed one some.  Synchronises."""
+  ws = pm.workspace(B, flags, peek=True)
+  out = torch.zeros(6, dtype=torch.int32, device=pm.device)
+  rc = lib().mm_offdiag_stats(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, flags,
+                              ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(pm.device))
+  check(rc, "mm_offdiag_stats")
+  o = out.tolist()
+  Mp = (pm.M + _lib.MM_M_ALIGN - 1) // _lib.MM_M_ALIGN * _lib.MM_M_ALIGN
+  return o[4], o[5], o[1] * (Mp // 64)
 
 
 def offdiag_routed(pm: PackedModel, B: int, flags: int) -> int:
@@ -244,7 +258,7 @@ def offdiag_routed(pm: PackedModel, B: int, flags: int) -> int:
   if pm.dtype != torch.float32 or pm.L < 2 or not (flags & MM_FULL_OUTPUT_COV):
     return 0
   ws = pm.workspace(B, flags, peek=True)
-  out = torch.zeros(4, dtype=torch.int32, device=pm.device)
+  out = torch.zeros(6, dtype=torch.int32, device=pm.device)
   rc = lib().mm_offdiag_stats(pm.buf.data_ptr(), pm.nbytes, pm.L, pm.M, pm.d, _dtype_code(pm.dtype), B, flags,
                               ws.data_ptr(), ws.numel(), out.data_ptr(), _stream(pm.device))
   check(rc, "mm_offdiag_stats")

@@ -171,9 +171,11 @@ int mm_expected_cost(int N, int d, int dtype, const void* mean, const void* cov,
 /* Diagnostic: after mm_q_forward (f32 model, d <= 8), how many (batch element, off-diagonal pair) items take the
  * moment collapse of csrc/mm_moments.hip / mm_moments6.hip (the degree-3..6 polynomial p6 of the remainder from weight
  * moments, wave tiles with max |b| <= 1/4 skipped: Cauchy-Schwarz bound <= 1/2), and for how many of those the bound alone puts
- * every |b| <= 1/4 (no tile work at all).  out: device int32[4] = {collapsed, total, wholly inside, routed}; the first three are zeros where
- * the collapse does not apply; routed = the items the last mm_moment_match / mm_Q_reduce_forward on this workspace
- * re-reduced in f64 (csrc/mm_route.hip; meaningful only after such a call on an MM_F32 pack). */
+ * every |b| <= 1/4 (no tile work at all).  The collapse is decided per GROUP OF 64 ROWS of an item (the pack's norm order puts the
+ * rows of large |A_i| last): out: device int32[6] = {collapsed in every row group, total, wholly inside, routed, partly collapsed
+ * (some row groups), collapsed row groups over all items (of total * ceil(M / 128) * 2)}; zeros where the collapse does not
+ * apply; routed = the items the last mm_moment_match / mm_Q_reduce_forward on this workspace re-reduced in f64
+ * (csrc/mm_route.hip; meaningful only after such a call on an MM_F32 pack). */
 int mm_offdiag_stats(const void* packed, size_t packed_bytes, int L, int M, int d, int dtype, int B, int flags,
                      const void* workspace, size_t workspace_bytes, int32_t* out, void* stream);
 

@@ -488,14 +488,20 @@ def test_offdiag_regimes_inside_collapsed_dense(device):
       _, Sffo, _ = mo.mm_gauss_svgp_mo(mu, Sigma, oracle_params(syn))
       _, Sff, _ = ops.moment_match(pm, to_dev(mu, device, torch.float32), to_dev(Sigma, device, torch.float32))
       collapsed, total, inside = ops.offdiag_stats(pm, B, flags)
-      assert total == n and inside <= collapsed <= total
-      seen.append((collapsed, inside))
+      partly, groups, all_groups = ops.offdiag_row_groups(pm, B, flags)
+      assert total == n and inside <= collapsed <= total and collapsed + partly <= total
+      # (Mp = 384: six 64-row groups, the last one padding alone -- flagged whatever the item is, and read by nobody)
+      assert all_groups == n * 6 and collapsed * 6 + partly <= groups <= collapsed * 6 + partly * 5 + (n - collapsed - partly)
+      seen.append((collapsed, inside, partly))
       off, dia = contract_err(Sff, Sffo)
-      assert off < 3e-4 and dia < 2e-5, (ls_bounds, scale, collapsed, inside, off, dia)
-  assert seen[0] == (n, n), seen                                  # narrow: every item wholly inside
-  assert any(c == n and i < n for c, i in seen), seen             # collapsed, tiles screened
-  assert any(0 < c < n for c, i in seen), seen                    # collapsed and dense items in one call
-  assert any(c == 0 for c, i in seen), seen                       # every item reduced densely
+      assert off < 3e-4 and dia < 2e-5, (ls_bounds, scale, collapsed, inside, partly, off, dia)
+  assert seen[0][:2] == (n, n), seen                              # narrow: every item wholly inside
+  assert any(c == n and i < n for c, i, _ in seen), seen          # collapsed, tiles screened
+  assert any(0 < c < n for c, i, _ in seen), seen                 # items collapsed in every row group and others in one call
+  assert any(c == 0 for c, i, _ in seen), seen                    # no item collapsed in every row group
+  # the collapse is decided per 64-row group (csrc/mm_mono.h): with the pack in norm order an item beyond the bound keeps the
+  # groups of its small rows collapsed
+  assert any(pt > 0 for _, _, pt in seen), seen
 
 
 @pytest.mark.parametrize("dtype", [torch.float64, torch.float32], ids=["f64", "f32"])
