@@ -302,6 +302,9 @@ struct MMWorkspaceLayout {
                    //              degree 6} -- every column block of the GEMMs is formed for the rows that read it only
   size_t s12;      // [B][Po] f64  the polynomial part of the off-diagonal sums from the moments:
                    //              orders 0..2 always, order 3 as well where the (b, pair) is collapsed (orders 4..6: s56)
+  size_t gmax2;    // [B][Po][Mp/64] f32 (f32 mode, d <= 8): max_i |A_i|^2 over the rows of the group, rounded up (k_pairvec_reg): the
+                   //              sweep's Cauchy-Schwarz skipping reads it instead of the rows (a collapsed group all of whose
+                   //              tiles are inside the collapsed range loads nothing at all)
   size_t partB;    // [B][P][NS] f64 partial sums of w_i expm1(delta_ij) w_j
   size_t partC;    // [B][L][NS] f64 partial sums of C_ij q_i expm1(delta_ij) q_j  (+ q^T C q)
   size_t mu64;     // [B][d] f64    the state mean as the q stage read it (mm_route.hip re-derives A_i = G^T (z_i - mu) in f64)
@@ -361,6 +364,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.amax = off;    off = off + (size_t)B * o.Po * 4;
   o.amaxc = off;   off = mm_align_up(off + (size_t)B * o.Po * 4, A);
   o.gflag = off;   off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * (o.Mp / 64)), A);
+  o.gmax2 = off;   off = mm_align_up(off + (dtype == MM_F64 ? 0 : (size_t)B * o.Po * (o.Mp / 64) * 4), A);
   o.gperm = off;   off = mm_align_up(off + (dtype == MM_F64 || L < 2 ? 0 : ((size_t)L * (L - 1) * B + 3 * L) * 4), A);
   o.s12 = off;     off = mm_align_up(off + (size_t)B * o.Po * 8, A);
   o.partB = off;   off = mm_align_up(off + (size_t)B * o.P * o.NS * 8, A);

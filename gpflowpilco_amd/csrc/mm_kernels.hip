@@ -655,7 +655,7 @@ __global__ __launch_bounds__(256) void k_pairvec(const double* __restrict__ Zt64
                                                  double* __restrict__ qhC, int with_unc, int nblk,
                                                  const double* __restrict__ lq, const double* __restrict__ beta64,
                                                  const double* __restrict__ zmax2, unsigned short* __restrict__ /* wsp: d <= 8 only */,
-                                                 unsigned char* __restrict__ /* gflag */, int /* allow */, int p0) {
+                                                 unsigned char* __restrict__ /* gflag */, float* __restrict__ /* gmax2 */, int /* allow */, int p0) {
   static_assert(DK > 8, "d <= 8 takes k_pairvec_reg");
   // a workgroup owns the 256-row chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one (b, pair): the
   // pair's matrix is fetched once per workgroup, not once per chunk
@@ -840,7 +840,8 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
                                                     double* __restrict__ qhC, int with_unc, int nblk, int a, int a2,
                                                     double (*vecs)[DK], const double* __restrict__ lq,
                                                     const double* __restrict__ beta64, int p, const double* __restrict__ zmax2,
-                                                    unsigned short* __restrict__ wsp, unsigned char* __restrict__ gflag, int allow) {
+                                                    unsigned short* __restrict__ wsp, unsigned char* __restrict__ gflag, float* __restrict__ gmax2,
+                                                    int allow) {
   constexpr bool diag = MODE == 0;
   const int b = blockIdx.z, tid = threadIdx.x;
   const int Po = P - L;
@@ -1055,7 +1056,14 @@ __device__ __forceinline__ void mm_pairvec_reg_body(const double* __restrict__ Z
         // ROW-GROUP COLLAPSE (mm_mono.h): this wave's 64 rows are one group; collapsed when every row's own Cauchy-Schwarz
         // bound is <= 1/2.  (the lanes are converged here: m < Mp is wave-uniform, Mp % 128 == 0)
         const bool inner = cancoll && __all(rowok);
-        if ((tid & 63) == 0) gflag[((size_t)b * Po + (p - L)) * (size_t)(Mp / MM_GROUP_ROWS) + (m >> 6)] = inner ? 1 : 0;
+        float g2 = a2in;                                     // the group's max |A_i|^2 (MMWorkspaceLayout::gmax2)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) g2 = fmaxf(g2, __shfl_xor(g2, off, 64));
+        if ((tid & 63) == 0) {
+          const size_t gi = ((size_t)b * Po + (p - L)) * (size_t)(Mp / MM_GROUP_ROWS) + (m >> 6);
+          gflag[gi] = inner ? 1 : 0;
+          gmax2[gi] = g2;
+        }
         if (inner) a2cmax = fmaxf(a2cmax, a2in);
         // bf16 2-way split of both weights: the A operand of the degree-4/5/6 moment GEMM (mm_moments6.hip), [side][h, m][Mp];
         // the ROW weight of a group that is not collapsed is zero there
@@ -1134,7 +1142,7 @@ __global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict
                                                         double* __restrict__ qhC, int with_unc, int nblk,
                                                         const double* __restrict__ lq, const double* __restrict__ beta64,
                                                         const double* __restrict__ zmax2, unsigned short* __restrict__ wsp,
-                                                        unsigned char* __restrict__ gflag, int allow, int p0) {
+                                                        unsigned char* __restrict__ gflag, float* __restrict__ gmax2, int allow, int p0) {
   // (grid.y = the pairs [p0, p0 + gridDim.y): the q stage launches the diagonal pairs' operands first -- the diagonal sweep needs
   // nothing else -- and the off-diagonal pairs' on the side stream beside that sweep)
   static_assert(DK <= 8, "register form: d <= 8");
@@ -1145,7 +1153,7 @@ __global__ __launch_bounds__(256, 2) void k_pairvec_reg(const double* __restrict
   mm_decode_pair(p, L, a, a2);
 #define MM_PV_BODY(MODE_)                                                                                           \
   mm_pairvec_reg_body<T, DK, MODE_>(Zt64, zbar, ls2, L, M, Mp, d, P, mu, pairmat, rho1, rowD, colD, rowO, colO, w64, \
-                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64, p, zmax2, wsp, gflag, allow)
+                                    whR, whC, amax, q64, qhR, qhC, with_unc, nblk, a, a2, vecs, lq, beta64, p, zmax2, wsp, gflag, gmax2, allow)
   if (p < L) MM_PV_BODY(0);
   else if (sizeof(T) == 4) MM_PV_BODY(1);
   else MM_PV_BODY(2);
@@ -1485,7 +1493,7 @@ static int mm_q_forward_t(const char* packed, const MMModelLayout& ml, char* ws,
     (const double*)(ws + wl.q64), (double*)(ws + wl.qhR), (double*)(ws + wl.qhC), (flags & MM_MODEL_UNCERTAINTY) ? 1 : 0, nblk, \
     (const double*)(ws + wl.lq), (const double*)(packed + ml.beta64), (const double*)(packed + ml.zmax2),                       \
     ((sizeof(T) == 4 && d <= 8) ? (unsigned short*)(ws + wl.wsp) : (unsigned short*)nullptr),                                \
-    (unsigned char*)(ws + wl.gflag), ((flags & (MM_FORCE_WORST_TIER | MM_ISTAGE_NO_M56)) ? 0 : 1)
+    (unsigned char*)(ws + wl.gflag), (float*)(ws + wl.gmax2), ((flags & (MM_FORCE_WORST_TIER | MM_ISTAGE_NO_M56)) ? 0 : 1)
     auto pairvec = [&](int p0, int npairs, hipStream_t st) {
       if (npairs <= 0) return;
       if constexpr (DK <= 8) {

@@ -42,9 +42,10 @@ __device__ __forceinline__ void mm_decode_pair_o(int p, int L, int& a, int& a2) 
 // LDS-staged sweep: workgroups per (b, pair), each paying the 64 KB fill for its share of the row panels.  Measured
 // at C3 (off-diagonal segment, pilco / BASELINE recipe): 1 -> 0.574 / 6.66 ms, 2 -> 0.444 / 6.27, 4 -> 0.380 / 6.19,
 // 8 -> 0.420 / 6.31: with most (b, pair) items leaving at once (wholly inside the collapsed range) the few that sweep
-// are the grid's tail, and finer items balance it
+// are the grid's tail, and finer items balance it.  Round 5, with a workgroup's panels interleaved over the (norm-ordered) rows
+// and the Cauchy-Schwarz skipping (BASELINE recipe): 1 -> 1.135, 2 -> 0.99, 4 -> 1.03, 8 -> 1.09 ms
 #ifndef MM_F32_PPW_DIV
-#define MM_F32_PPW_DIV 4
+#define MM_F32_PPW_DIV 2
 #endif
 // 0: the sweep without its rounding-error estimate (A/B measurement of what the accuracy contract costs: nothing is ever routed)
 #ifndef MM_ROUTE_EST
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
                                                           int npanel, int ppw, int nwork, int force_worst,
                                                           const unsigned int* __restrict__ amax,
                                                           const unsigned int* __restrict__ amaxc,
-                                                          const unsigned char* __restrict__ gflag,
+                                                          const unsigned char* __restrict__ gflag, const float* __restrict__ gmax2,
                                                           const double* __restrict__ zmax2, const float* __restrict__ zt2,
                                                           const float* __restrict__ rowO,
                                                           const float* __restrict__ colO,
@@ -160,11 +161,37 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // Cauchy-Schwarz already bounds every |b_ij| of this (b, pair) by MM_C6_MAX: the remainder is p6 everywhere, which the
     // moments carry (k_spoly, k_spoly56) -- every tile would be skipped: no sweep at all
     if (!force_worst && zmax2 && mm_collapse_bound2(amax[(size_t)b * Po + lp], zmax2[a2]) <= MM_INSIDE_BOUND2) {
-      for (int panel = pgrp * ppw + (int)threadIdx.x; panel < npanel && panel < (pgrp + 1) * ppw; panel += 256) {
+      for (int panel = (int)threadIdx.x; panel < npanel; panel += 256) {
+        if (panel % npw != pgrp) continue;                   // (this workgroup's panels: pgrp, pgrp + npw, ...)
         partB[((size_t)b * P + p) * NS + panel] = 0.0;
         if (estO) estO[((size_t)b * Po + lp) * npanel + panel] = 0.0f;        // exact (f64 moments): nothing to estimate
       }
       return;
+    }
+  }
+  // Row-group collapse (mm_mono.h): does any wave of this workgroup have a tile to visit?  A collapsed group whose Cauchy-Schwarz
+  // bound with the column latent's LARGEST point is inside the collapsed range has none (gmax2: its rows' max |A_i|^2 from
+  // k_pairvec_reg) -- with the pack in norm order those are the first panels of most items; a workgroup of such groups alone
+  // writes its zero partials and leaves before the 64 KB fill
+  const bool icoll_wg = (ND8 == 1) && !force_worst && zmax2 != nullptr && zt2 != nullptr && gmax2 != nullptr &&
+                        mm_item_collapsed(amaxc[(size_t)b * Po + lp]);
+  const size_t grp0 = ((size_t)b * Po + lp) * (size_t)(Mp / MM_GROUP_ROWS);
+  if constexpr (ND8 == 1) {
+    if (icoll_wg) {
+      bool need = false;
+      for (int panel = pgrp; panel < npanel; panel += npw) {
+        const int g = (panel * MM_PANEL_ROWS + wv * 64) >> 6;
+        if (g < Mp / MM_GROUP_ROWS)
+          need = need || !(gflag[grp0 + g] != 0 && mm_collapse_bound2(__float_as_uint(gmax2[grp0 + g]), zmax2[a2]) <= MM_INSIDE_BOUND2);
+      }
+      if (!__syncthreads_or(need ? 1 : 0)) {
+        for (int panel = (int)threadIdx.x; panel < npanel; panel += 256) {
+          if (panel % npw != pgrp) continue;
+          partB[((size_t)b * P + p) * NS + panel] = 0.0;
+          if (estO) estO[((size_t)b * Po + lp) * npanel + panel] = 0.0f;
+        }
+        return;
+      }
     }
   }
   extern __shared__ __align__(16) char zlds[];     // LDSZ: [Mp/32 tiles][2 parts (h, m)][32 columns][16 ND8 bytes]
@@ -194,7 +221,9 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
   }
   __shared__ double red[4];
   __shared__ float redf[4];
-  for (int panel = pgrp * ppw; panel < npanel && panel < (pgrp + 1) * ppw; ++panel) {
+  // the workgroup's panels are INTERLEAVED (pgrp, pgrp + npw, ...): with the pack in norm order the rows of large |A_i| -- the
+  // tiles that are not skipped -- are the last panels, and consecutive panels would give one workgroup of four all of an item's work
+  for (int panel = pgrp; panel < npanel; panel += npw) {
   const int row0 = panel * MM_PANEL_ROWS + wv * 64;
   double sum = 0.0;
   // running estimate of the sweep's own rounding error (mm_common.h: MM_ROUTE_TOL; mm_route.hip): per lane -- one column,
@@ -202,29 +231,30 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
   // of squares and the (1 + X + X^2) factor of rho (X = the lane's largest |b|: one v_max3 per tile pair) once per sweep
   f32x2 est2 = {0.0f, 0.0f};
   float rowsq = 0.0f, xall = 0.0f;
-  if (row0 < Mp) {   // Mp % 128 == 0, so a wave's 64 rows are all inside or all outside
+  // icoll: the item has collapsed groups -- then the CUBIC term of every row is in the f64 moments (k_spoly), and a group that
+  // is not collapsed reduces r(b) - C0 b^3 on every tile.  coll: this wave's 64 rows are a COLLAPSED row group (mm_mono.h:
+  // k_pairvec_reg decided, with the Cauchy-Schwarz bound of the group's rows, |b_ij| <= |A_i| |zc_j|); g2: its rows' max |A_i|^2
+  const bool icoll = icoll_wg;
+  const bool coll = icoll && row0 < Mp && gflag[grp0 + (row0 >> 6)] != 0;
+  const float g2 = coll ? gmax2[grp0 + (row0 >> 6)] : 0.0f;
+  // (a collapsed group with every tile inside the collapsed range: nothing to load, nothing to add)
+  const bool wave_inside = coll && mm_collapse_bound2(__float_as_uint(g2), zmax2[a2]) <= MM_INSIDE_BOUND2;
+  if (row0 < Mp && !wave_inside) {   // Mp % 128 == 0, so a wave's 64 rows are all inside or all outside
     const float* ra = rowO + ((size_t)b * Po + lp) * (size_t)(d + 1) * Mp;   // [d+1][Mp]: A_i, what_i
     const float* wcf = colO + ((size_t)b * Po + lp) * Mp;                    // what'_j
     // pre-split centred inducing inputs of latent a': [Mp/32][3 (h,m,l)][32][8 ND8] bf16
     const unsigned short* zs = Zs3 + (size_t)a2 * Mp * (24 * ND8);
-    // are this wave's 64 rows a COLLAPSED row group (mm_mono.h)?  k_pairvec_reg decided, with the Cauchy-Schwarz bound of the
-    // group's rows, |b_ij| <= |A_i| |zc_j|; bound2: the bound over all collapsed groups of the item (the screening margin)
+    // bound2: the bound over all collapsed groups of the item (the screening margin)
     const float bound2 = zmax2 ? mm_collapse_bound2(amaxc[(size_t)b * Po + lp], zmax2[a2]) : 3.0e38f;
-    // icoll: the item has collapsed groups -- then the CUBIC term of every row is in the f64 moments (k_spoly), and a group that
-    // is not collapsed reduces r(b) - C0 b^3 on every tile
-    const bool icoll = (ND8 == 1) && !force_worst && zmax2 != nullptr && mm_item_collapsed(amaxc[(size_t)b * Po + lp]);
-    const bool coll = icoll && gflag[((size_t)b * Po + lp) * (size_t)(Mp / MM_GROUP_ROWS) + (row0 >> 6)] != 0;
     // a tile is skipped on the screening product alone: its error is <= 2^-9 sum_k |A_k||Z_k| <= 2^-9 sqrt(bound2)
     const float thr_skip = MM_C6_MAX - 0.00390625f * __builtin_sqrtf(bound2) - 1e-6f;
 
     // ---- stationary operands --------------------------------------------------------------
     bf16x8 a1[2][ND8], a2v[2][ND8], a3[2][ND8];
     f32x2 wrow[2][8], wc0[2][8], wc1[2][8];
-    float a2w = 0.0f;                                     // max |A_i|^2 over this wave's rows, from the operand values themselves
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
       const int row = row0 + rt * 32 + l31;
-      float a2r = 0.0f;
 #pragma unroll
       for (int nb = 0; nb < ND8; ++nb) {
         unsigned int hh[8], mm[8], ll[8];
@@ -233,7 +263,6 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
           const int k = nb * 8 + j;
           const float v = ra[(size_t)(k < d ? k : d) * Mp + row];
           mm_split3(k < d ? v : 0.0f, hh[j], mm[j], ll[j]);
-          a2r = fmaf(k < d ? v : 0.0f, v, a2r);
         }
         u32x4 ph, pm, pl;
 #pragma unroll
@@ -248,7 +277,6 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
         a2v[rt][nb] = __builtin_bit_cast(bf16x8, h ? pl : ph);
         a3[rt][nb] = __builtin_bit_cast(bf16x8, ph);
       }
-      a2w = fmaxf(a2w, a2r);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int rr = row0 + rt * 32 + 8 * g + 4 * h;
@@ -418,10 +446,8 @@ __global__ __launch_bounds__(256, (ND8 >= 4 ? 1 : MM_F32_WAVES)) void k_qred_f32
     // MM_INSIDE_BOUND2.  The pack's norm order makes those tiles a PREFIX: the sweep starts at the first tile that is not
     // (BASELINE recipe: two thirds of the screened wave tiles; the screening product + range check was half the sweep's time).
     int ct_first = 0;
-    if (coll && zt2 != nullptr) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) a2w = fmaxf(a2w, __shfl_xor(a2w, off, 64));
-      a2w *= 1.000001f;
+    if (coll) {
+      const float a2w = g2 * 1.000001f;                     // (gmax2 is rounded up from f64; the f32-rounded operands add < 2e-7)
       const float* zt = zt2 + (size_t)a2 * nct;
       int cf = nct;
       for (int c0 = 0; c0 < nct; c0 += 64) {
@@ -517,7 +543,7 @@ int mm_launch_qred_mfma(const char* packed, const MMModelLayout& ml, char* ws, c
 #define MM_LAUNCH_ND(ND_, LZ_, SH_)                                                                          \
   hipLaunchKernelGGL((k_qred_f32_mfma<ND_, LZ_>), dim3(nwork), dim3(256), SH_, stream, Zs3, L, wl.Mp, d,    \
                      wl.P, wl.Po, wl.NS, npanel, ppw, nwork, force_worst, amax, (const unsigned int*)(ws + wl.amaxc), \
-                     (const unsigned char*)(ws + wl.gflag), zmax2, (const float*)(packed + ml.zt2), rowO, colO, partB, estO, (int*)(ws + wl.rcount))
+                     (const unsigned char*)(ws + wl.gflag), (const float*)(ws + wl.gmax2), zmax2, (const float*)(packed + ml.zt2), rowO, colO, partB, estO, (int*)(ws + wl.rcount))
   switch (ml.nd8) {
     case 1: if (ldsz) MM_LAUNCH_ND(1, true, zbytes); else MM_LAUNCH_ND(1, false, 0); break;
     case 2: MM_LAUNCH_ND(2, false, 0); break;

@@ -269,11 +269,10 @@ __global__ __launch_bounds__(256, 2) void k_wmom56_gemm(const unsigned short* __
 #ifndef MM6_NC
 #define MM6_NC 2
 #endif
-template <int K, bool TRANSG, int MODE>
+template <int K, bool TRANSG, int MODE, int NC = MM6_NC>
 __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin, int nI, float* __restrict__ Tout, int nJp,
                                          const short* __restrict__ ins, int d, const float (&G)[64], const float* __restrict__ multJ,
                                          int xs, float& acc, int wave, int lane) {
-  constexpr int NC = MM6_NC;
   const int chunks = (nJp + 64 * NC - 1) / (64 * NC);
   // the outputs i = I0 .. 7 of one (I, J'): eight-term dot products of the gathered v with the matrix the caller loaded into G as
   // G[j * 8 + i] = (coefficient of v_j in output i) -- output index fastest, so that the packed FMA over an output pair (i, i + 1)
@@ -475,10 +474,10 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
     mm6_step<0, false, 0>(Q4, sy[4], 1, Bf4, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
     if (need5) mm6_step<1, false, 0>(Bf, sy[4], sy[1], A, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
-    mm6_step<1, false, 1>(Bf4, sy[3], sy[1], X4, sy[2], tabi + tb.ins[2], d, G, mult2, xs4, dummy, wave, lane);
+    mm6_step<1, false, 1, 1>(Bf4, sy[3], sy[1], X4, sy[2], tabi + tb.ins[2], d, G, mult2, xs4, dummy, wave, lane);   // (J' = sym2 <= 36: one chunk)
     __syncthreads();
     if (need5) {
-      mm6_step<2, false, 1>(A, sy[3], sy[2], X, sy[2], tabi + tb.ins[2], d, G, mult2, xs, dummy, wave, lane);
+      mm6_step<2, false, 1, 1>(A, sy[3], sy[2], X, sy[2], tabi + tb.ins[2], d, G, mult2, xs, dummy, wave, lane);
       __syncthreads();
     }
     load_G(0);
@@ -486,7 +485,7 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
     mm6_step<0, true, 0>(N4, sy[4], 1, Bf4, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
     __syncthreads();
     if (need5) mm6_step<1, true, 2>(Bf, sy[4], sy[1], X, sy[3], tabi + tb.ins[3], d, G, nullptr, xs, acc5, wave, lane);
-    mm6_step<1, true, 2>(Bf4, sy[3], sy[1], X4, sy[2], tabi + tb.ins[2], d, G, nullptr, xs4, acc4, wave, lane);
+    mm6_step<1, true, 2, 1>(Bf4, sy[3], sy[1], X4, sy[2], tabi + tb.ins[2], d, G, nullptr, xs4, acc4, wave, lane);
   }
   double tot = (double)MM_C6_C1 * (double)acc4 + (double)MM_C6_C2 * (double)acc5 + (double)MM_C6_C3 * (double)acc6;
 #pragma unroll
