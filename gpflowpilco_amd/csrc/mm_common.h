@@ -318,6 +318,9 @@ struct MMWorkspaceLayout {
   size_t mom56;    // [B][Po][2][N56p] f32: sum_m what_m zc_m^alpha over the degree-5 and degree-6 monomials (collapsed items)
   size_t estS;     // [B][Po] f32: MM_C6_SYS2 sum what^2 sum what'^2 of a collapsed item (0 otherwise): what its skipped tiles leave
                    //              out, in the units of the sweep's error estimate estO (k_spoly56 writes, k_route_decide adds)
+  size_t ilist;    // i32 [4] counts {items collapsed to degree 6, to degree 5, to degree 4, 0} + [B Po] item indices: the degree-6 and
+                   //              degree-5 items from the front (in that order), the degree-4 items from the back (k_item_classes:
+                   //              the work lists of k_spoly56 / k_spoly4, mm_moments6.hip)
   size_t s56;      // [B][Po] f64: C1 <N_4, G^4 Q_4> + C2 <N_5, G^5 Q_5> + C3 <N_6, G^6 Q_6> of a collapsed item (0 otherwise): the degree-4..6
                    //              part of p6 from the f32 moments.  Kept apart from s12: an item the accuracy contract re-reduces in f64 (mm_route.hip) takes
                    //              those two orders from the re-reduce instead (k_finalize skips s56 where rflag is set)
@@ -380,6 +383,7 @@ static inline MMWorkspaceLayout mm_workspace_layout(int B, int L, int M, int d, 
   o.mom56 = off;   off = mm_align_up(off + n56 * 2 * mm_moment56_cols(d) * 4, A);
   o.estS = off;    off = mm_align_up(off + n56 * 4, A);
   o.s56 = off;     off = mm_align_up(off + n56 * 8, A);
+  o.ilist = off;   off = mm_align_up(off + n56 * 4 + 16, A);
   o.f1s = off;     off = mm_align_up(off + (size_t)B * L * es, A);
   o.Sffs = off;    off = mm_align_up(off + (size_t)B * L * L * es, A);
   o.crs = off;     off = mm_align_up(off + (size_t)B * d * L * es, A);

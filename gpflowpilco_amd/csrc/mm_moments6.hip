@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void k_wmom56_gemm(const unsigned short* __
 #ifndef MM6_NC
 #define MM6_NC 2
 #endif
-template <int K, bool TRANSG, int MODE, int NC = MM6_NC>
+template <int K, bool TRANSG, int MODE, int NC = MM6_NC, int NW = MM6_WAVES>
 __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin, int nI, float* __restrict__ Tout, int nJp,
                                          const short* __restrict__ ins, int d, const float (&G)[64], const float* __restrict__ multJ,
                                          int xs, float& acc, int wave, int lane) {
@@ -333,7 +333,7 @@ __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin
   float mj[NC];
 #pragma unroll
   for (int q = 0; q < NC; ++q) { Jc[q] = 0; jv[q] = false; mj[q] = 0.0f; }
-  for (int u = wave; u < nunit; u += MM6_WAVES) {
+  for (int u = wave; u < nunit; u += NW) {
     int c = K == 0 ? u : (int)(((float)u + 0.5f) * rnI);   // u / nI (exact: u < 2^20)
     c = __builtin_amdgcn_readfirstlane(c);
     const int I = K == 0 ? 0 : __builtin_amdgcn_readfirstlane(u - c * nI);
@@ -361,26 +361,71 @@ __device__ __forceinline__ void mm6_step(const float* __restrict__ Tin, int nJin
   }
 }
 
+// Work lists by collapse degree (MMWorkspaceLayout::ilist): the contractions run over the items that need them, the degree-6/5 ones
+// in workgroups of MM6_THREADS threads with 160 KB of LDS (one per CU), the degree-4 ones -- every item of the pilco recipe --
+// in workgroups of 256 threads with 13 KB (k_spoly4): as ONE grid over all (b, pair) a degree-4 item cost a 768-thread, whole-CU
+// workgroup of its own (pilco recipe: 0.53 ms for 0.03 ms of arithmetic).  An item without a collapsed row group gets its zeros here.
+__global__ __launch_bounds__(256) void k_item_classes(const unsigned int* __restrict__ amaxc, const double* __restrict__ zmax2,
+                                                      int L, int Po, int n, int allow, int* __restrict__ ilist,
+                                                      double* __restrict__ s56, float* __restrict__ estS) {
+  const int idx = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  int cls = 3;
+  if (idx < n) {
+    int a, a2;
+    mm6_decode_pair_o(idx % Po, L, a, a2);
+    const unsigned int ac = amaxc[idx];
+    const float x2 = mm_collapse_bound2(ac, zmax2[a2]);
+    cls = (!allow || !mm_item_collapsed(ac)) ? 3 : (x2 > MM_C6_X5_2 ? 0 : (x2 > MM_C6_X4_2 ? 1 : 2));
+    if (cls == 3) { s56[idx] = 0.0; estS[idx] = 0.0f; }
+  }
+  // slots: class 0 and 1 items from the front of two separate runs is not possible without the totals, so: class 0/1 items are
+  // appended at the FRONT cursor (count[0] + count[1] grows; the kernel reads each item's class again from its bound), class 2
+  // items at the BACK cursor
+  const unsigned long long b01 = __ballot(cls == 0 || cls == 1), b2 = __ballot(cls == 2);
+  int base01 = 0, base2 = 0;
+  if (lane == 0) {
+    if (b01) base01 = atomicAdd(ilist + 0, (int)__popcll(b01));
+    if (b2) base2 = atomicAdd(ilist + 2, (int)__popcll(b2));
+  }
+  base01 = __shfl(base01, 0, 64); base2 = __shfl(base2, 0, 64);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  if (cls == 0 || cls == 1) ilist[4 + base01 + __popcll(b01 & below)] = idx;
+  if (cls == 2) ilist[4 + n - 1 - (base2 + __popcll(b2 & below))] = idx;
+}
+
+// what the skipped tiles of a collapsed item leave out, in the units of the sweep's error estimate (mm_common.h: MM_C6_SYS2):
+// |p6 - r| equioscillates with amplitude 5.8e-10 on [-1/4, 1/4]; near 0 it is the perturbation of the leading coefficient,
+// (1/6 - C0) |x|^3 = 3.4e-7 |x|^3: an item whose bound X is far inside 1/4 leaves out (4 X)^3 of the amplitude; an item that
+// leaves degree 6 (and 5) out adds C3 X^6 (+ C2 X^5) per entry, with the same cancellation under the weights (a smooth function
+// of b): 1e-10 / 5.8e-10 of the amplitude, as for p6 itself
+__device__ __forceinline__ float mm6_estS(float bound2, bool need5, bool need6, double r2, double c2) {
+  const double X = sqrt((double)bound2), X3 = X * X * X;
+  double amp = fmin(1.0, 64.0 * X3);                                                 // in units of 1e-10
+  if (!need6) amp += (double)MM_C6_C3 * X3 * X3 / 5.8e-10;
+  if (!need5) amp += (double)MM_C6_C2 * X3 * X * X / 5.8e-10;
+  return (float)fmin((double)MM_C6_SYS2 * (amp * amp) * r2 * c2, 3.0e38);
+}
+
+// grid: persistent over the degree-6 / degree-5 items of ilist (any size; one workgroup per CU fits)
 __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict__ mom56, int N56p, const double* __restrict__ pairmat,
                                                  const double* __restrict__ zmax2, const unsigned int* __restrict__ amaxc,
                                                  const unsigned char* __restrict__ gflag,
                                                  const double* __restrict__ whR, const double* __restrict__ whC,
-                                                 const char* __restrict__ tab, MMTab56 tb, int L, int d, int P, int Mp, int allow,
+                                                 const char* __restrict__ tab, MMTab56 tb, int L, int d, int P, int Mp,
+                                                 const int* __restrict__ ilist,
                                                  double* __restrict__ s56, float* __restrict__ estS) {
   extern __shared__ __align__(16) float sm6[];
-  const int po = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int Po = P - L;
+  const int nitems = __builtin_amdgcn_readfirstlane(ilist[0]);
+  for (int li = blockIdx.x; li < nitems; li += gridDim.x) {
+  const size_t item = (size_t)__builtin_amdgcn_readfirstlane(ilist[4 + li]);
+  const int b = (int)(item / Po), po = (int)(item - (size_t)b * Po);
   int a, a2;
   mm6_decode_pair_o(po, L, a, a2);
-  const size_t item = (size_t)b * Po + po;
   // (the bound of the item's COLLAPSED row groups -- mm_mono.h: the moments carry their rows alone)
   const float bound2 = mm_collapse_bound2(amaxc[item], zmax2[a2]);
-  const bool coll = allow && mm_item_collapsed(amaxc[item]);
-  if (!coll) {
-    if (tid == 0) { s56[item] = 0.0; estS[item] = 0.0f; }
-    return;
-  }
   int sy[7];
 #pragma unroll
   for (int k = 0; k < 7; ++k) sy[k] = mm_binom_i(d + k - 1, k);
@@ -499,15 +544,103 @@ __global__ __launch_bounds__(MM6_THREADS) void k_spoly56(const float* __restrict
     double t = 0.0, r2 = 0.0, c2 = 0.0;
     for (int w = 0; w < MM6_WAVES; ++w) { t += redd[w * 3]; r2 += redd[w * 3 + 1]; c2 += redd[w * 3 + 2]; }
     s56[item] = t;
-    // |p6 - r| equioscillates with amplitude 5.8e-10 on [-1/4, 1/4]; near 0 it is the perturbation of the leading
-    // coefficient, (1/6 - C0) |x|^3 = 3.4e-7 |x|^3: an item whose bound X is far inside 1/4 leaves out (4 X)^3 of the amplitude
-    // an item that leaves degree 6 (and 5) out adds C3 X^6 (+ C2 X^5) per entry, with the same cancellation under the weights
-    // (a smooth function of b): 1e-10 / 5.8e-10 of the amplitude, as for p6 itself
-    const double X = sqrt((double)bound2), X3 = X * X * X;
-    double amp = fmin(1.0, 64.0 * X3);                                               // in units of 1e-10
-    if (!need6) amp += (double)MM_C6_C3 * X3 * X3 / 5.8e-10;
-    if (!need5) amp += (double)MM_C6_C2 * X3 * X * X / 5.8e-10;
-    estS[item] = (float)fmin((double)MM_C6_SYS2 * (amp * amp) * r2 * c2, 3.0e38);
+    estS[item] = mm6_estS(bound2, need5, need6, r2, c2);
+  }
+  __syncthreads();                                       // (the next item of this workgroup reuses the LDS image)
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_spoly4: the degree-4 items (bound X <= 1/40: orders 5 and 6 are below p6's own error) -- s56 = C1 <N_4, G^{(x)4} Q_4>, the n = 4
+// steps of k_spoly56 alone: 256 threads, 13 KB of LDS, persistent over the back part of ilist
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_spoly4(const float* __restrict__ mom56, int N56p, const double* __restrict__ pairmat,
+                                                const double* __restrict__ zmax2, const unsigned int* __restrict__ amaxc,
+                                                const unsigned char* __restrict__ gflag,
+                                                const double* __restrict__ whR, const double* __restrict__ whC,
+                                                const char* __restrict__ tab, MMTab56 tb, int L, int d, int P, int Mp, int ntotal,
+                                                const int* __restrict__ ilist,
+                                                double* __restrict__ s56, float* __restrict__ estS) {
+  extern __shared__ __align__(16) float sm4[];
+  constexpr int NW = 4;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int Po = P - L;
+  int sy[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) sy[k] = mm_binom_i(d + k - 1, k);
+  const int xs4 = sy[2] + 1;
+  // LDS (floats): nq [2][sy4] | Bf4 [sy1][sy3] | X4 [sy2][sy2 + 1] | Gl [128] (16-byte aligned) | red [NW][3] doubles
+  float* nq = sm4;
+  float* Bf4 = nq + 2 * sy[4];
+  float* X4 = Bf4 + sy[1] * sy[3];
+  float* Gl = sm4 + ((2 * sy[4] + sy[1] * sy[3] + sy[2] * xs4 + 3) & ~3);
+  double* redd = reinterpret_cast<double*>(Gl + 128);
+  const short* tabi = (const short*)tab;
+  const float* mult2 = (const float*)(tab + (size_t)tb.n_i16 * 2) + tb.mult2;
+  const int nitems = __builtin_amdgcn_readfirstlane(ilist[2]);
+  for (int li = blockIdx.x; li < nitems; li += gridDim.x) {
+    const size_t item = (size_t)__builtin_amdgcn_readfirstlane(ilist[4 + ntotal - 1 - li]);
+    const int b = (int)(item / Po), po = (int)(item - (size_t)b * Po);
+    int a, a2;
+    mm6_decode_pair_o(po, L, a, a2);
+    const float bound2 = mm_collapse_bound2(amaxc[item], zmax2[a2]);
+    for (int idx = tid; idx < 2 * sy[4]; idx += 256) {
+      const int side = idx >= sy[4], c = idx - side * sy[4];
+      nq[idx] = mom56[(item * 2 + side) * N56p + c];       // (the degree-4 block: the first columns of mom56)
+    }
+    if (tid < 64) {
+      const int i = tid >> 3, j = tid & 7;
+      const double* pm = pairmat + ((size_t)b * P + (L + po)) * (d * d + 1);
+      const float g = (i < d && j < d) ? (float)pm[i * d + j] : 0.0f;
+      Gl[tid] = g;                                         // row-major: the Y side's
+      Gl[64 + j * 8 + i] = g;                              // transposed: the X side's
+    }
+    double s2r = 0.0, s2c = 0.0;
+    {
+      const double* hr = whR + item * Mp;
+      const double* hc = whC + item * Mp;
+      const unsigned char* gf = gflag + item * (size_t)(Mp / MM_GROUP_ROWS);
+      for (int m = tid; m < Mp; m += 256) {
+        const double x = gf[m >> 6] ? hr[m] : 0.0, y = hc[m];
+        s2r = fma(x, x, s2r); s2c = fma(y, y, s2c);
+      }
+    }
+    __syncthreads();
+    float G[64];
+    auto load_G = [&](int transposed) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float4 g4 = *reinterpret_cast<const float4*>(Gl + 64 * transposed + 4 * q);
+        G[4 * q] = g4.x; G[4 * q + 1] = g4.y; G[4 * q + 2] = g4.z; G[4 * q + 3] = g4.w;
+      }
+    };
+    float acc4 = 0.0f, dummy = 0.0f;
+    const float* Q4 = nq + sy[4];
+    const float* N4 = nq;
+    load_G(1);
+    mm6_step<0, false, 0, MM6_NC, NW>(Q4, sy[4], 1, Bf4, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<1, false, 1, 1, NW>(Bf4, sy[3], sy[1], X4, sy[2], tabi + tb.ins[2], d, G, mult2, xs4, dummy, wave, lane);
+    __syncthreads();
+    load_G(0);
+    mm6_step<0, true, 0, MM6_NC, NW>(N4, sy[4], 1, Bf4, sy[3], tabi + tb.ins[3], d, G, nullptr, 0, dummy, wave, lane);
+    __syncthreads();
+    mm6_step<1, true, 2, 1, NW>(Bf4, sy[3], sy[1], X4, sy[2], tabi + tb.ins[2], d, G, nullptr, xs4, acc4, wave, lane);
+    double tot = (double)MM_C6_C1 * (double)acc4;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      tot += __shfl_down(tot, off, 64); s2r += __shfl_down(s2r, off, 64); s2c += __shfl_down(s2c, off, 64);
+    }
+    if (lane == 0) { redd[wave * 3 + 0] = tot; redd[wave * 3 + 1] = s2r; redd[wave * 3 + 2] = s2c; }
+    __syncthreads();
+    if (tid == 0) {
+      double t = 0.0, r2 = 0.0, c2 = 0.0;
+      for (int w = 0; w < NW; ++w) { t += redd[w * 3]; r2 += redd[w * 3 + 1]; c2 += redd[w * 3 + 2]; }
+      s56[item] = t;
+      estS[item] = mm6_estS(bound2, false, false, r2, c2);
+    }
+    __syncthreads();
   }
 }
 
@@ -541,6 +674,20 @@ int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, c
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
+  // work lists by collapse degree (k_item_classes; the items without a collapsed group get their zeros there)
+  const int nitem = B * wl.Po;
+  int* ilist = (int*)(ws + wl.ilist);
+  {
+    const hipError_t em = hipMemsetAsync(ilist, 0, 16, stream);
+    if (em != hipSuccess) return (int)em;
+  }
+  hipLaunchKernelGGL(k_item_classes, dim3((nitem + 255) / 256), dim3(256), 0, stream, (const unsigned int*)(ws + wl.amaxc),
+                     (const double*)(packed + ml.zmax2), L, wl.Po, nitem, allow, ilist, (double*)(ws + wl.s56), (float*)(ws + wl.estS));
+  {
+    const hipError_t ec = hipGetLastError();
+    if (ec != hipSuccess) return (int)ec;
+  }
+  if (!allow) return 0;
   int sy[7];
   for (int k = 0; k < 7; ++k) sy[k] = mm_mono_count(k, d);
   size_t nfl = (size_t)2 * (sy[4] + sy[5] + sy[6]) + (size_t)sy[3] * (sy[3] + 1) + (size_t)sy[2] * sy[4] + (size_t)sy[1] * sy[5] + 6 * MM6_WAVES + 128 + 16
@@ -548,18 +695,36 @@ int mm_launch_moments56(const char* packed, const MMModelLayout& ml, char* ws, c
   nfl = (nfl + 1) & ~(size_t)1;                           // (the f64 reduction scratch behind it stays 8-byte aligned)
   const size_t shm = nfl * sizeof(float);
   static std::atomic<unsigned long long> attr2_done{0ull};
+  static std::atomic<int> ncu_cached[64];
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 64;
   const unsigned long long bit2 = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+  int ncu = bit2 ? ncu_cached[dev].load() : 0;
   if (!bit2 || !(attr2_done.load() & bit2)) {
     const hipError_t ea = hipFuncSetAttribute((const void*)k_spoly56, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (ea != hipSuccess) return (int)ea;
-    attr2_done.fetch_or(bit2);
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev < 64 ? dev : 0) != hipSuccess || v <= 0) v = 256;
+    ncu = v;
+    if (bit2) { ncu_cached[dev].store(v); attr2_done.fetch_or(bit2); }
   }
-  hipLaunchKernelGGL(k_spoly56, dim3(wl.Po, B), dim3(MM6_THREADS), shm, stream, (const float*)(ws + wl.mom56), N56p,
+  if (ncu <= 0) ncu = 256;
+  // persistent grids over the lists: one 160 KB workgroup per CU for the degree-6/5 items, eight small ones for the degree-4 items
+  const int g56 = nitem < ncu ? nitem : ncu, g4 = nitem < 8 * ncu ? nitem : 8 * ncu;
+  hipLaunchKernelGGL(k_spoly56, dim3(g56), dim3(MM6_THREADS), shm, stream, (const float*)(ws + wl.mom56), N56p,
                      (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zmax2), (const unsigned int*)(ws + wl.amaxc),
-                     (const unsigned char*)(ws + wl.gflag), (const double*)(ws + wl.whR), (const double*)(ws + wl.whC), packed + ml.tab56, mm_tab56(d), L, d, wl.P, wl.Mp,
-                     allow, (double*)(ws + wl.s56), (float*)(ws + wl.estS));
+                     (const unsigned char*)(ws + wl.gflag), (const double*)(ws + wl.whR), (const double*)(ws + wl.whC),
+                     packed + ml.tab56, mm_tab56(d), L, d, wl.P, wl.Mp, (const int*)ilist, (double*)(ws + wl.s56), (float*)(ws + wl.estS));
+  {
+    const hipError_t e5 = hipGetLastError();
+    if (e5 != hipSuccess) return (int)e5;
+  }
+  const size_t shm4 = (size_t)(((2 * sy[4] + sy[1] * sy[3] + sy[2] * (sy[2] + 1) + 3) & ~3) + 128 + 2 * 3 * 4 + 8) * sizeof(float);
+  hipLaunchKernelGGL(k_spoly4, dim3(g4), dim3(256), shm4, stream, (const float*)(ws + wl.mom56), N56p,
+                     (const double*)(ws + wl.pairmat), (const double*)(packed + ml.zmax2), (const unsigned int*)(ws + wl.amaxc),
+                     (const unsigned char*)(ws + wl.gflag), (const double*)(ws + wl.whR), (const double*)(ws + wl.whC),
+                     packed + ml.tab56, mm_tab56(d), L, d, wl.P, wl.Mp, nitem, (const int*)ilist, (double*)(ws + wl.s56),
+                     (float*)(ws + wl.estS));
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;
 }
