@@ -731,10 +731,10 @@ def main():
     if step_tf > step_peak:
       roof_step["frac_null_reason"] = "exceeds the peak: the step does not execute 8d's per-entry work in this data regime (see roofline.frac_null_reason)"
     # q stage: HBM-bound operand producers: bytes from the counters / the HIP-event segment is the whole stage
-    qroof = {"bound": "hbm", "kernels": "k_prep + k_qvec + k_pairvec (+ k_wmom_gemm [f64 MFMA GEMM] + k_spoly + k_wmom56_gemm [bf16 MFMA GEMM] + k_spoly56)", "segment_ms": round(seg["q_stage"], 4),
+    qroof = {"bound": "hbm", "kernels": "k_prep + k_qvec + k_pairvec (+ k_wmom_gemm [f64 MFMA GEMM] + k_spoly + k_wmom56_gemm [bf16 MFMA GEMM] + k_item_classes + k_spoly56 + k_spoly4)", "segment_ms": round(seg["q_stage"], 4),
              "peak": PEAK_HBM_GBS, "unit": "GB/s", "per_kernel": {}}
     if pmc is not None:
-      for pre in ("k_qvec", "k_pairvec", "k_wmom_gemm", "k_spoly<", "k_wmom56_gemm", "k_spoly56"):
+      for pre in ("k_qvec", "k_pairvec", "k_wmom_gemm", "k_spoly<", "k_wmom56_gemm", "k_spoly56", "k_spoly4"):
         got = pmc_kernel(pmc, pre)
         if got and "hbm_bytes" in got[1]["counters"]:
           qroof["per_kernel"][got[0]] = {"hbm_bytes": got[1]["counters"]["hbm_bytes"] * pscale}
